@@ -1,0 +1,134 @@
+/* trx2_model.h -- constants that DEFINE the fold's energy model and protocol.
+ *
+ * Shared (as data, not code) by the HIP product path (trrosettax2-dynamics_amd/csrc) and by the CPU
+ * oracle (oracle/trx2_oracle.c) so that both evaluate the same function.  Plain C, no dependencies.
+ *
+ * Provenance of every number:
+ *  - restraint-table parameters: /root/reference/folding/data/params.json:1-16 and
+ *    folding/utils_ros/utils_ros.py:18-31,55-61,82,125 (gen_rst)
+ *  - score-function weights: folding/data/scorefxn{,1,_vdw,_cart}.wts (quoted in SURVEY.md 3.2)
+ *  - selection thresholds: folding/utils_ros/utils_ros.py:719-723 (add_rst)
+ *  - random start table: folding/utils_ros/utils_ros.py:667-696 (random_dihedral)
+ *  - minimiser settings: folding/folding.py:91-104 (tolerance 1e-4, max_iter 1000/500, RepeatMover 3)
+ *  - ideal backbone geometry and soft-sphere radii: measured on the reference's 8 committed PyRosetta
+ *    decoys (example/output/seq/pred_pdb/conf_*.pdb) by tools/derive_constants.py, because the Rosetta
+ *    database (ICOOR ideals, AtomVDW, Rama tables) is not in the reference tree.
+ */
+#ifndef TRX2_MODEL_H
+#define TRX2_MODEL_H
+
+/* ---- atoms per residue, in storage order ------------------------------------------------------- */
+#define TRX2_NATOM 5 /* N, CA, C, O, CB */
+#define TRX2_AT_N 0
+#define TRX2_AT_CA 1
+#define TRX2_AT_C 2
+#define TRX2_AT_O 3
+#define TRX2_AT_CB 4
+#define TRX2_RES_STRIDE 16 /* floats per residue in device buffers: 5 atoms x 3 + 1 pad = 64 B */
+
+/* ---- distogram / table geometry (reference bins) -------------------------------- */
+#define TRX2_ND_BINS 37 /* dist  npz last dim */
+#define TRX2_NO_BINS 25 /* omega, theta */
+#define TRX2_NP_BINS 13 /* phi */
+#define TRX2_KD 35      /* knots of the distance spline: 3 repulsive + 32 contact bins (utils_ros.py:60-64) */
+#define TRX2_KO 28      /* knots of omega / theta splines: 24 + 4 wrap-pad (utils_ros.py:81-87)          */
+#define TRX2_KP 16      /* knots of phi spline: 12 + 4 mirror-pad (utils_ros.py:124-130)                */
+#define TRX2_KTOT (TRX2_KD + TRX2_KO + TRX2_KO + TRX2_KP) /* 107 knots per ordered pair */
+#define TRX2_GEN_PCUT 0.05 /* utils_ros.py:18 (literal, ignores -pd) */
+
+/* selection mask bits per ORDERED pair (a,b) */
+#define TRX2_M_DIST 1
+#define TRX2_M_OMEGA 2
+#define TRX2_M_THETA 4
+#define TRX2_M_PHI 8
+
+/* ---- ideal backbone geometry (tools/derive_constants.py on the reference decoys) --------------- */
+#define TRX2_B_N_CA 1.458
+#define TRX2_B_CA_C 1.524
+#define TRX2_B_C_N 1.334
+#define TRX2_B_C_O 1.232
+#define TRX2_A_N_CA_C 111.4  /* degrees */
+#define TRX2_A_CA_C_N 117.0
+#define TRX2_A_C_N_CA 121.0
+#define TRX2_A_CA_C_O 120.4
+/* CB = CA + KA*(b x c) + KB*b + KC*c with b = CA-N, c = C-CA (same construction as the reference's
+ * virtual CB, utils_trX2dy/utils.py:132-135; coefficients refitted to the decoys' real CB) */
+#define TRX2_CB_KA (-0.58433326)
+#define TRX2_CB_KB (0.57201293)
+#define TRX2_CB_KC (-0.53795593)
+
+/* ---- energy terms ------------------------------------------------------------------------------- */
+enum {
+  TRX2_E_DIST = 0, /* atom_pair_constraint : CB-CB spline               */
+  TRX2_E_OMEGA,    /* dihedral_constraint  : CA CB CB CA                */
+  TRX2_E_THETA,    /* dihedral_constraint  : N CA CB CB                 */
+  TRX2_E_PHI,      /* angle_constraint     : CA CB CB                   */
+  TRX2_E_VDW,      /* soft-sphere repulsion (surrogate of centroid vdw) */
+  TRX2_E_RAMA,     /* -ln mixture over the reference's 6 basins         */
+  TRX2_E_OMEGA_BB, /* peptide-bond planarity tether (Rosetta "omega")   */
+  TRX2_E_CART,     /* harmonic bonded geometry (Cartesian stage only)   */
+  TRX2_NTERMS
+};
+/* weight vector layout: w[0]=atom_pair, w[1]=dihedral (omega & theta), w[2]=angle (phi), w[3]=vdw,
+ * w[4]=rama, w[5]=omega_bb, w[6]=cart_bonded, w[7]=unused */
+#define TRX2_NW 8
+
+/* soft-sphere: E = VDW_SCALE * sum_{|i-j|>=VDW_MINSEP} max(0, r0^2 - d^2)^2 / r0^2 */
+#define TRX2_VDW_SCALE 0.8
+#define TRX2_VDW_MINSEP 3
+#define TRX2_VDW_CUT2 (10.0 * 10.0) /* skip residue pairs with |CA-CA|^2 above this (max r0 + 2*|CA-X| < 10) */
+/* r0 by atom-type pair, order N CA C O CB (0.1-percentile closest approach, |i-j|>=3, in the decoys) */
+#define TRX2_VDW_R0_INIT                                                                               \
+  {                                                                                                    \
+    {4.28, 4.14, 3.49, 2.80, 3.72}, {4.14, 4.67, 4.23, 3.36, 4.02}, {3.49, 4.23, 4.42, 3.38, 3.97},    \
+        {2.80, 3.36, 3.38, 3.01, 3.25}, {                                                              \
+      3.72, 4.02, 3.97, 3.25, 4.15                                                                     \
+    }                                                                                                  \
+  }
+
+/* rama surrogate: E_i = -ln( (sum_k p_k exp(KAPPA (cos(phi-phi_k) + cos(psi-psi_k) - 2)) + FLOOR) / P_REF )
+ * for residues 2..L-1; basins = the reference's start table (utils_ros.py:667-673), degrees */
+#define TRX2_RAMA_NB 6
+#define TRX2_RAMA_INIT                                                                                 \
+  {                                                                                                    \
+    {-140.0, 153.0, 0.135}, {-72.0, 145.0, 0.155}, {-122.0, 117.0, 0.073}, {-82.0, -14.0, 0.122},      \
+        {-61.0, -41.0, 0.497}, {                                                                       \
+      57.0, 39.0, 0.018                                                                                \
+    }                                                                                                  \
+  }
+#define TRX2_RAMA_KAPPA 8.0
+#define TRX2_RAMA_FLOOR 1.0e-3
+#define TRX2_RAMA_PREF 0.497
+/* cumulative thresholds of random_dihedral (utils_ros.py:678-695): r<=t[k] picks basin k */
+#define TRX2_RAND_CUM_INIT {0.135, 0.29, 0.363, 0.485, 0.982, 2.0}
+
+/* omega_bb: E = OMEGA_K * (wrap(omega - 180 deg) in degrees)^2 */
+#define TRX2_OMEGA_K 0.05
+
+/* cart_bonded surrogate: harmonic around the ideal values above */
+#define TRX2_CART_KLEN 300.0 /* per A^2   */
+#define TRX2_CART_KANG 80.0  /* per rad^2 */
+
+/* ---- minimiser (own design; Rosetta's lbfgs_armijo_nonmonotone is not in the tree) --------------- */
+#define TRX2_LBFGS_M 12
+#define TRX2_LS_PAST 3       /* non-monotone window */
+#define TRX2_LS_C1 1.0e-4
+#define TRX2_LS_SHRINK 0.5
+#define TRX2_LS_MAXTRIAL 20
+#define TRX2_MIN_TOL 1.0e-6  /* folding.py:91 fractional tolerance: 2|f0-f1| <= tol (|f0|+|f1|+eps) */
+#define TRX2_CLASH_BREAK 10.0 /* utils_ros.py:701 */
+#define TRX2_MAX_RUNS 32
+
+/* one minimiser run of the staged protocol (folding.py:119,164-171; utils_ros.py:699-703) */
+typedef struct trx2_run {
+  float w[TRX2_NW]; /* score-function weights                                                  */
+  int max_iter;     /* MinMover.max_iter                                                       */
+  int sep_lo;       /* restraints with sep_lo <= |a-b| < sep_hi are active (add_rst)           */
+  int sep_hi;
+  int precheck;     /* 1: before running, if rama+vdw (raw) < CLASH_BREAK jump to skip_to      */
+  int skip_to;      /* run index to continue with when the precheck fires                      */
+  int cartesian;    /* 1: minimise Cartesian coordinates (MinMover.cartesian(True))            */
+  int pad0, pad1;
+} trx2_run;
+
+#endif

@@ -1,0 +1,220 @@
+"""ctypes front-end of the CPU oracle (oracle/trx2_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by the product
+package.  The library is compiled on demand with -march=native for the host it runs on (the .so name carries
+a hash of the CPU flags so a build made in one container is not reused on a different CPU).
+"""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NTERMS = 8
+NW = 8
+KD, KO, KP = 35, 28, 16
+
+
+class Run(C.Structure):
+    """mirror of trx2_run (include/trx2_model.h)"""
+    _fields_ = [("w", C.c_float * NW), ("max_iter", C.c_int), ("sep_lo", C.c_int), ("sep_hi", C.c_int),
+                ("precheck", C.c_int), ("skip_to", C.c_int), ("cartesian", C.c_int), ("pad0", C.c_int),
+                ("pad1", C.c_int)]
+
+
+class FoldStats(C.Structure):
+    _fields_ = [("n_evals", C.c_int), ("n_iters", C.c_int), ("runs_done", C.c_int), ("status", C.c_int),
+                ("e_final", C.c_double * NTERMS), ("f_final", C.c_double)]
+
+
+def _cpu_tag():
+    try:
+        txt = [l for l in open("/proc/cpuinfo") if l.startswith(("model name", "flags"))][:2]
+    except OSError:
+        txt = []
+    return hashlib.sha1("".join(txt).encode()).hexdigest()[:10]
+
+
+def build(force=False):
+    out = os.path.join(_HERE, "_build", f"libtrx2oracle-{_cpu_tag()}.so")
+    src = os.path.join(_HERE, "trx2_oracle.c")
+    hdr = os.path.join(_HERE, "..", "include", "trx2_model.h")
+    if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        tmp = out + f".{os.getpid()}.tmp"
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-fopenmp", "-shared", "-o", tmp, src, "-lm"])
+        os.replace(tmp, out)
+    return out
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        dp, fp, vp = C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_void_p
+        L.orc_build_tables.restype = vp
+        L.orc_build_tables.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_double]
+        L.orc_tables_free.argtypes = [vp]
+        L.orc_tables_ptr.restype = dp
+        L.orc_tables_ptr.argtypes = [vp, C.c_int]
+        L.orc_tables_prob.restype = fp
+        L.orc_tables_prob.argtypes = [vp, C.c_int]
+        L.orc_tables_mask.restype = C.POINTER(C.c_ubyte)
+        L.orc_tables_mask.argtypes = [vp, C.c_int]
+        L.orc_spline_y2.argtypes = [C.c_int, vp, vp, vp]
+        L.orc_spline_eval.argtypes = [C.c_int, vp, vp, vp, C.c_double, dp, dp]
+        L.orc_dihedral.restype = C.c_double
+        L.orc_dihedral.argtypes = [vp, vp, vp, vp, vp]
+        L.orc_angle.restype = C.c_double
+        L.orc_angle.argtypes = [vp, vp, vp, vp]
+        L.orc_nerf.argtypes = [C.c_int, vp, vp]
+        L.orc_eval.restype = C.c_double
+        L.orc_eval.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
+        L.orc_energy_cart.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+        L.orc_uniform.restype = C.c_double
+        L.orc_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+        L.orc_random_torsions.argtypes = [C.c_int, C.c_uint64, C.c_uint32, vp]
+        L.orc_fold.restype = C.c_int
+        L.orc_fold.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+DEFAULT_PARAMS = dict(EBASE=-0.5, EREP=[10.0, 3.0, 0.5], DREP=[0.0, 2.0, 3.5], MEFF=1e-4, DCUT=19.5, ALPHA=1.57,
+                      DSTEP=0.5, ASTEP=15.0)
+
+
+def params_vec(p=None):
+    p = {**DEFAULT_PARAMS, **(p or {})}
+    return np.array([p["EBASE"], *p["EREP"], *p["DREP"], p["MEFF"], p["DCUT"], p["ALPHA"], p["DSTEP"], p["ASTEP"]],
+                    dtype=np.float64)
+
+
+class Tables:
+    """orc_build_tables: gen_rst + add_rst selection, dense."""
+
+    def __init__(self, dist, omega=None, theta=None, phi=None, params=None, pcut=0.05):
+        self.L = int(dist.shape[0])
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) if a is not None else None for a in (dist, omega, theta, phi)]
+        self._keep = arrs
+        self.use_orient = all(a is not None for a in arrs)
+        self.h = lib().orc_build_tables(self.L, *[_p(a) for a in arrs], _p(params_vec(params)), float(pcut))
+
+    def __del__(self):
+        try:
+            lib().orc_tables_free(self.h)
+        except Exception:
+            pass
+
+    def _arr(self, which, shape):
+        ptr = lib().orc_tables_ptr(self.h, which)
+        return np.ctypeslib.as_array(ptr, shape=shape).copy()
+
+    def knots(self):
+        return dict(dist=self._arr(8, (KD,)), omega=self._arr(9, (KO,)), theta=self._arr(10, (KO,)), phi=self._arr(11, (KP,)))
+
+    def y(self, ch):
+        k = {"dist": (0, KD), "omega": (2, KO), "theta": (4, KO), "phi": (6, KP)}[ch]
+        return self._arr(k[0], (self.L, self.L, k[1]))
+
+    def y2(self, ch):
+        k = {"dist": (1, KD), "omega": (3, KO), "theta": (5, KO), "phi": (7, KP)}[ch]
+        return self._arr(k[0], (self.L, self.L, k[1]))
+
+    def prob(self, ch):
+        i = ["dist", "omega", "theta", "phi"].index(ch)
+        return np.ctypeslib.as_array(lib().orc_tables_prob(self.h, i), shape=(self.L, self.L)).copy()
+
+    def mask(self, selected=True):
+        return np.ctypeslib.as_array(lib().orc_tables_mask(self.h, 1 if selected else 0), shape=(self.L, self.L)).copy()
+
+
+def spline_y2(x, y):
+    x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+    y2 = np.zeros_like(y)
+    lib().orc_spline_y2(len(x), _p(x), _p(y), _p(y2))
+    return y2
+
+
+def spline_eval(x, y, y2, xq):
+    e, de = C.c_double(), C.c_double()
+    x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64); y2 = np.ascontiguousarray(y2, np.float64)
+    lib().orc_spline_eval(len(x), _p(x), _p(y), _p(y2), float(xq), C.byref(e), C.byref(de))
+    return e.value, de.value
+
+
+def dihedral(p1, p2, p3, p4, grad=False):
+    ps = [np.ascontiguousarray(p, np.float64) for p in (p1, p2, p3, p4)]
+    g = np.zeros(12) if grad else None
+    v = lib().orc_dihedral(*[_p(p) for p in ps], _p(g))
+    return (v, g.reshape(4, 3)) if grad else v
+
+
+def angle(p1, p2, p3, grad=False):
+    ps = [np.ascontiguousarray(p, np.float64) for p in (p1, p2, p3)]
+    g = np.zeros(9) if grad else None
+    v = lib().orc_angle(*[_p(p) for p in ps], _p(g))
+    return (v, g.reshape(3, 3)) if grad else v
+
+
+def nerf(tors):
+    tors = np.ascontiguousarray(tors, np.float64)
+    L = tors.shape[0]
+    xyz = np.zeros((L, 5, 3))
+    lib().orc_nerf(L, _p(tors), _p(xyz))
+    return xyz
+
+
+def evaluate(tab, tors, w, sep_lo=1, sep_hi=None, grad=True):
+    """returns (total, terms[8], grad[L,3] or None, xyz[L,5,3])"""
+    tors = np.ascontiguousarray(tors, np.float64)
+    w = np.ascontiguousarray(w, np.float64)
+    L = tab.L
+    e = np.zeros(NTERMS); g = np.zeros((L, 3)) if grad else None; xyz = np.zeros((L, 5, 3))
+    f = lib().orc_eval(tab.h, _p(tors), _p(w), int(sep_lo), int(sep_hi if sep_hi is not None else L), _p(e), _p(g), _p(xyz))
+    return f, e, g, xyz
+
+
+def energy_cart(tab, xyz, w, sep_lo=1, sep_hi=None):
+    xyz = np.ascontiguousarray(xyz, np.float64); w = np.ascontiguousarray(w, np.float64)
+    e = np.zeros(NTERMS); gx = np.zeros_like(xyz)
+    lib().orc_energy_cart(tab.h, _p(xyz), _p(w), int(sep_lo), int(sep_hi if sep_hi is not None else tab.L), _p(e), _p(gx))
+    return e, gx
+
+
+def random_torsions(L, seed, decoy):
+    t = np.zeros((L, 3))
+    lib().orc_random_torsions(L, int(seed), int(decoy), _p(t))
+    return t
+
+
+def make_runs(runs):
+    """runs: list of dicts(w=[8], max_iter, sep_lo, sep_hi, precheck, skip_to, cartesian)"""
+    arr = (Run * len(runs))()
+    for i, r in enumerate(runs):
+        for k in range(NW):
+            arr[i].w[k] = float(r["w"][k])
+        arr[i].max_iter = int(r["max_iter"]); arr[i].sep_lo = int(r["sep_lo"]); arr[i].sep_hi = int(r["sep_hi"])
+        arr[i].precheck = int(r.get("precheck", 0)); arr[i].skip_to = int(r.get("skip_to", 0))
+        arr[i].cartesian = int(r.get("cartesian", 0))
+    return arr
+
+
+def fold(tab, tors0, runs, max_evals=200000):
+    """fold one decoy; returns (torsions, xyz, stats dict)"""
+    tors = np.ascontiguousarray(tors0, np.float64).copy()
+    arr = make_runs(runs)
+    st = FoldStats()
+    xyz = np.zeros((tab.L, 5, 3))
+    lib().orc_fold(tab.h, _p(tors), arr, len(runs), int(max_evals), C.byref(st), _p(xyz))
+    return tors, xyz, dict(n_evals=st.n_evals, n_iters=st.n_iters, runs_done=st.runs_done, status=st.status,
+                           e_final=np.array(st.e_final[:]), f_final=st.f_final)

@@ -1,0 +1,58 @@
+"""Staged minimisation protocol of the reference fold script, as a flat list of minimiser runs.
+
+Mirrors /root/reference/folding/folding.py:74-104 (four score functions, four MinMovers, RepeatMover 3),
+:118-119 (random start + declash), :125-186 (modes 0-3) and folding/utils_ros/utils_ros.py:699-703
+(remove_clash: at most 5 x { if sf_vdw(pose) < 10: break; mover.apply(pose) }).
+
+Weight vector layout (include/trx2_model.h): [atom_pair, dihedral, angle, vdw, rama, omega, cart_bonded, -].
+Weights are the reference's folding/data/*.wts files; cen_hb / hbond_* have no surrogate yet.
+"""
+
+# folding/data/scorefxn.wts
+SF = [5.0, 4.0, 4.0, 1.0, 1.0, 0.5, 0.0, 0.0]
+# folding/data/scorefxn1.wts
+SF1 = [3.0, 1.0, 1.0, 3.0, 1.0, 0.5, 0.0, 0.0]
+# folding/data/scorefxn_vdw.wts
+SF_VDW = [0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0]
+# folding/data/scorefxn_cart.wts
+SF_CART = [5.0, 4.0, 4.0, 0.5, 1.0, 0.5, 0.1, 0.0]
+
+MAX_ITER = 1000      # folding.py:92,95,101
+MAX_ITER_VDW = 500   # folding.py:98
+N_REPEAT = 3         # folding.py:104
+N_DECLASH = 5        # utils_ros.py:700
+
+
+def _run(w, max_iter, sep_lo, sep_hi, precheck=0, skip_to=0, cartesian=0):
+    return dict(w=list(w), max_iter=max_iter, sep_lo=sep_lo, sep_hi=sep_hi, precheck=precheck, skip_to=skip_to,
+                cartesian=cartesian)
+
+
+def _declash(runs, w, max_iter, sep_lo, sep_hi):
+    """remove_clash(sf_vdw, mover, pose): every round is guarded by the rama+vdw < 10 test."""
+    end = len(runs) + N_DECLASH
+    for _ in range(N_DECLASH):
+        runs.append(_run(w, max_iter, sep_lo, sep_hi, precheck=1, skip_to=end))
+
+
+def build_runs(L, mode=2, cartesian_stage=False):
+    """Run list for `-m mode` (folding/utils_ros/arguments.py:12).  Mode 3 needs the npz 'idr' mask and is
+    not reachable from run_inference.py: not built."""
+    runs = []
+    # folding.py:119  remove_clash(sf_vdw, min_mover_vdw, pose) -- no restraints loaded yet
+    _declash(runs, SF_VDW, MAX_ITER_VDW, 0, 0)
+    if mode == 0:
+        stages = [(1, 12), (1, 24), (1, L)]      # add_rst accumulates: folding.py:129,136,143
+    elif mode == 1:
+        stages = [(3, 24), (3, L)]               # folding.py:152,159
+    elif mode == 2:
+        stages = [(1, L)]                        # folding.py:168
+    else:
+        raise ValueError("mode 3 (idr mask) is not supported")
+    for lo, hi in stages:
+        for _ in range(N_REPEAT):                # repeat_mover.apply
+            runs.append(_run(SF, MAX_ITER, lo, hi))
+        # min_mover_cart.apply: Cartesian-space L-BFGS on sf_cart
+        runs.append(_run(SF_CART, MAX_ITER, lo, hi, cartesian=1 if cartesian_stage else 0))
+        _declash(runs, SF1, MAX_ITER, lo, hi)    # remove_clash(sf_vdw, min_mover1, pose)
+    return runs
