@@ -1,0 +1,98 @@
+/* trx2fold.h -- C ABI of libtrx2fold.so, the MI355X-native replacement of the trRosettaX2-Dynamics folding
+ * hot path (one PyRosetta process per decoy -> one batched on-device fold per distogram).
+ *
+ * Drop-in boundary.  The reference has no FFI for this path: it shells out
+ *     python ./folding/folding.py -NPZ .. -FASTA .. -OUT .. {options}
+ * once per decoy (/root/reference/utils_trX2dy/utils.py:484-505).  The entry points below are what a binding
+ * for that path needs; each cites the reference code it replaces.  Plain pointers and sizes only; all
+ * pointers are HOST pointers owned by the caller unless the name says _device.
+ *
+ * Threading: one ctx = one GPU stream + one distogram ("map").  A ctx is not thread-safe; distinct ctxs may
+ * be used concurrently (the NMR and X-ray chains of run_inference.py:310-318 run as two ctxs).  No global
+ * state.  Every function returns 0 on success, non-zero on error with text in trx2_last_error(ctx).
+ */
+#ifndef TRX2FOLD_H
+#define TRX2FOLD_H
+
+#include <stdint.h>
+
+#include "trx2_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct trx2_ctx trx2_ctx;
+
+/* folding/data/params.json + the -pd flag (folding/utils_ros/arguments.py:11) */
+typedef struct trx2_params {
+  double ebase;     /* EBASE */
+  double erep[3];   /* EREP  */
+  double drep[3];   /* DREP  */
+  double meff;      /* MEFF  */
+  double dcut;      /* DCUT  */
+  double alpha;     /* ALPHA */
+  double dstep;     /* DSTEP */
+  double astep_deg; /* ASTEP */
+  double pcut;      /* PCUT / -pd : add_rst selection threshold (utils_ros.py:707) */
+} trx2_params;
+
+/* per-decoy status codes */
+#define TRX2_OK 0
+#define TRX2_DIVERGED 1 /* non-finite energy or coordinates */
+#define TRX2_MAXEVAL 2  /* evaluation budget exhausted before the protocol finished */
+
+int trx2_abi_version(void);
+
+/* replaces pyrosetta.init + process start-up (folding/folding.py:48): binds a GPU and creates a stream */
+int trx2_ctx_create(int device, trx2_ctx** out);
+void trx2_ctx_destroy(trx2_ctx* ctx);
+const char* trx2_last_error(const trx2_ctx* ctx);
+
+/* replaces np.load(NPZ) + gen_rst + add_rst selection (folding/folding.py:56-63; utils_ros.py:6-146,706-723).
+ * dist[L][L][37], omega[L][L][25], theta[L][L][25], phi[L][L][13] float32 row-major; omega/theta/phi NULL
+ * <=> --no-orient.  seq[L] one-letter codes.  Builds the spline tables on the device (kernel K2); they stay
+ * resident for every later fold/eval on this ctx. */
+int trx2_set_map(trx2_ctx* ctx, int L, const char* seq, const float* dist, const float* omega, const float* theta,
+                 const float* phi, const trx2_params* prm);
+/* same with DEVICE pointers (in-memory hand-off from the trX2 front-end, utils_trX2dy/utils.py:783-796) */
+int trx2_set_map_device(trx2_ctx* ctx, int L, const char* seq, const float* dist_dev, const float* omega_dev,
+                        const float* theta_dev, const float* phi_dev, const trx2_params* prm);
+
+/* read the tables back (parity tests).  channel 0 dist, 1 omega, 2 theta, 3 phi.
+ * y_y2: [L][L][K][2] float (value, second derivative), K = 35/28/28/16; knots: [K]; prob: [L][L];
+ * gen, sel: [L][L] bit masks (TRX2_M_*).  Any output pointer may be NULL. */
+int trx2_get_tables(trx2_ctx* ctx, int channel, float* y_y2, float* knots, float* prob, unsigned char* gen,
+                    unsigned char* sel);
+
+/* one energy+gradient evaluation of B decoys through the fold's own kernels (K1 NeRF, K3/K4 pair terms,
+ * K5 torsion gradient) -- what one ScoreFunction(pose) + derivative call does (folding/folding.py:74-84).
+ * tors[B][L][3] (phi, psi, omega; radians); w[TRX2_NW]; restraints with sep_lo <= |a-b| < sep_hi.
+ * Outputs (each may be NULL): e_terms[B][TRX2_NTERMS] raw energies, f_total[B] weighted sum,
+ * grad[B][L][3], xyz[B][L][5][3] (N CA C O CB). */
+int trx2_eval_batch(trx2_ctx* ctx, int B, const float* tors, const float* w, int sep_lo, int sep_hi,
+                    double* e_terms, double* f_total, float* grad, float* xyz);
+
+/* replaces `repeat` runs of folding.py (set_random_dihedral .. remove_clash, folding/folding.py:109-171):
+ * folds B decoys of the current map with the staged protocol runs[nruns] (trx2_run, trx2_model.h).
+ * Start torsions: tors0[B][L][3] if non-NULL, else the reference's random table drawn from (seed, decoy0+i).
+ * Outputs (each may be NULL): tors_out[B][L][3], xyz_out[B][L][5][3], e_terms[B][TRX2_NTERMS] and f_final[B]
+ * under the last run's weights, status[B], n_evals[B], n_iters[B]. */
+int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint64_t seed, uint32_t decoy0,
+                    const float* tors0, int max_evals, float* tors_out, float* xyz_out, double* e_terms,
+                    double* f_final, int* status, int* n_evals, int* n_iters);
+
+/* measurement helper (bench.py roofline leg): replays the pair-energy kernel n_rep times on the ctx stream
+ * for the coordinates of the last eval/fold batch and returns the average launch duration in milliseconds
+ * measured with hipEvents on that stream, plus the number of selected term-evaluations per launch. */
+int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int sep_lo, int sep_hi, int n_rep, double* ms_avg,
+                          double* term_evals);
+
+/* seconds spent inside the last trx2_fold_batch between first launch and results on host, and the number of
+ * pair-kernel launches it made */
+int trx2_last_fold_stats(trx2_ctx* ctx, double* seconds, int* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,114 @@
+// trx2_device.h -- small device-side math helpers shared by the trx2fold kernels (gfx950 / wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define TRX2_PI_F 3.14159265358979323846f
+#define TRX2_DEG_F (TRX2_PI_F / 180.0f)
+
+struct f3 {
+  float x, y, z;
+};
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3& operator+=(f3& a, f3 b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ f3 cross(f3 a, f3 b) {
+  return f3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ f3 fma3(f3 a, float s, f3 acc) {  // acc + a*s
+  return f3{fmaf(a.x, s, acc.x), fmaf(a.y, s, acc.y), fmaf(a.z, s, acc.z)};
+}
+__device__ __forceinline__ f3 unit(f3 a) { return a * rsqrtf(dot(a, a)); }
+
+// ---- rigid transform x -> R x + t (row-major R) ----------------------------------------------------------
+struct Xf {
+  float r[9];
+  float t[3];
+};
+__device__ __forceinline__ Xf xf_identity() { return Xf{{1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0}}; }
+__device__ __forceinline__ f3 xf_apply(const Xf& A, f3 p) {
+  return f3{fmaf(A.r[0], p.x, fmaf(A.r[1], p.y, fmaf(A.r[2], p.z, A.t[0]))),
+            fmaf(A.r[3], p.x, fmaf(A.r[4], p.y, fmaf(A.r[5], p.z, A.t[1]))),
+            fmaf(A.r[6], p.x, fmaf(A.r[7], p.y, fmaf(A.r[8], p.z, A.t[2])))};
+}
+// (A o B)(x) = A(B(x))
+__device__ __forceinline__ Xf xf_compose(const Xf& A, const Xf& B) {
+  Xf C;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+      C.r[i * 3 + j] = fmaf(A.r[i * 3], B.r[j], fmaf(A.r[i * 3 + 1], B.r[3 + j], A.r[i * 3 + 2] * B.r[6 + j]));
+    C.t[i] = fmaf(A.r[i * 3], B.t[0], fmaf(A.r[i * 3 + 1], B.t[1], fmaf(A.r[i * 3 + 2], B.t[2], A.t[i])));
+  }
+  return C;
+}
+// frame with origin at CA, ex along CA->C, ey towards N in the N-CA-C plane, ez = ex x ey
+__device__ __forceinline__ Xf xf_from_atoms(f3 N, f3 CA, f3 C) {
+  f3 ex = unit(C - CA);
+  f3 v = N - CA;
+  f3 ey = unit(v - ex * dot(v, ex));
+  f3 ez = cross(ex, ey);
+  return Xf{{ex.x, ey.x, ez.x, ex.y, ey.y, ez.y, ex.z, ey.z, ez.z}, {CA.x, CA.y, CA.z}};
+}
+__device__ __forceinline__ Xf xf_shfl_up(const Xf& v, int off) {
+  Xf o;
+#pragma unroll
+  for (int i = 0; i < 9; i++) o.r[i] = __shfl_up(v.r[i], off, 64);
+#pragma unroll
+  for (int i = 0; i < 3; i++) o.t[i] = __shfl_up(v.t[i], off, 64);
+  return o;
+}
+
+// place atom d: |cd| = len, angle(b,c,d) = ang, dihedral(a,b,c,d) = tor   (cs = cos/sin of ang, tor)
+__device__ __forceinline__ f3 place_atom(f3 a, f3 b, f3 c, float len, float cang, float sang, float ctor, float stor) {
+  f3 bc = unit(c - b);
+  f3 n = unit(cross(b - a, bc));
+  f3 m = cross(n, bc);
+  return c + bc * (-len * cang) + m * (len * sang * ctor) + n * (len * sang * stor);
+}
+
+// IUPAC dihedral p1-p2-p3-p4 and its gradient with respect to the four points
+__device__ __forceinline__ float dihedral_grad(f3 p1, f3 p2, f3 p3, f3 p4, f3& d1, f3& d2, f3& d3, f3& d4) {
+  f3 F = p1 - p2, G = p2 - p3, H = p4 - p3;
+  f3 A = cross(F, G), B = cross(H, G);
+  float G2 = dot(G, G);
+  float iGn = rsqrtf(G2), Gn = G2 * iGn;
+  float iA2 = 1.0f / fmaxf(dot(A, A), 1e-12f), iB2 = 1.0f / fmaxf(dot(B, B), 1e-12f);
+  float cosv = dot(A, B), sinv = dot(cross(B, A), G) * iGn;
+  float ang = atan2f(sinv, cosv);
+  float ca = dot(F, G) * iA2 * iGn, cb = dot(H, G) * iB2 * iGn;
+  float ga = Gn * iA2, gb = Gn * iB2;
+  d1 = A * (-ga);
+  d4 = B * gb;
+  d2 = A * (ga + ca) - B * cb;
+  d3 = B * (cb - gb) - A * ca;
+  return ang;
+}
+
+// planar angle p1-p2-p3 in [0,pi] and gradient
+__device__ __forceinline__ float angle_grad(f3 p1, f3 p2, f3 p3, f3& d1, f3& d2, f3& d3) {
+  f3 v = p1 - p2, w = p3 - p2;
+  float ivn = rsqrtf(dot(v, v)), iwn = rsqrtf(dot(w, w));
+  f3 vh = v * ivn, wh = w * iwn;
+  float c = fminf(1.0f, fmaxf(-1.0f, dot(vh, wh)));
+  float ang = acosf(c);
+  float is = -1.0f / fmaxf(sqrtf(1.0f - c * c), 1e-8f);
+  d1 = (wh - vh * c) * (is * ivn);
+  d3 = (vh - wh * c) * (is * iwn);
+  d2 = (d1 + d3) * -1.0f;
+  return ang;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

@@ -1,0 +1,1350 @@
+// trx2fold.hip -- MI355X (gfx950, wave64) kernels + C ABI of the restraint-guided batched fold.
+//
+// Replaces the per-decoy PyRosetta process of /root/reference/folding/folding.py (+ folding/utils_ros) by a
+// device-resident batched minimiser.  Kernel inventory ("native work-list"):
+//   K2 k_build_tables : gen_rst + add_rst selection -> dense (y, y'') spline tables  (utils_ros.py:6-146,706-723)
+//   K3/K4 k_pair<BW>  : CB-CB distance / omega / theta / phi spline restraints + soft-sphere repulsion,
+//                       energy and Cartesian gradient, lane = decoy                 (folding.py:74-84 score terms)
+//   K1/K5/K6 k_chain  : per decoy: gradient slabs -> torsion gradient (suffix scan of force/torque), rama/omega
+//                       terms, non-monotone Armijo L-BFGS state machine over the staged protocol, new trial
+//                       torsions -> backbone by a parallel rigid-transform scan (NeRF) (folding.py:86-119,164-171)
+// Data layout in HBM: see DESIGN.md.  No CPU fallback exists: every entry point runs on the GPU or fails.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/trx2fold.h"
+#include "trx2_device.h"
+
+#define KD TRX2_KD
+#define KO TRX2_KO
+#define KP TRX2_KP
+#define LBM TRX2_LBFGS_M
+#define CHAIN_THREADS 256
+#define PAIR_THREADS 256
+#define PAIR_WAVES (PAIR_THREADS / 64)
+
+__constant__ float c_vdw_r0sq[25];
+__constant__ float c_rama[TRX2_RAMA_NB * 3];  // phi_k, psi_k (rad), p_k
+
+// =================================================================================================
+// K2: restraint tables
+// =================================================================================================
+struct BuildArgs {
+  int L, use_orient;
+  const float *dist, *omega, *theta, *phi;
+  double ebase, erep[3], meff, pcut;
+  double bkgr[32];      // background (bins_k/DCUT)^ALPHA per contact bin; computed on the host: a device f64
+                        // pow() with a runtime exponent sends the gfx950 backend into a >10 min compile
+  const double* knots;  // [107] rounded knot positions: d(35) o(28) t(28) p(16)
+  float2 *Td, *To, *Tt, *Tp;
+  float *pd, *po, *pt, *pp;
+  unsigned char *gen, *sel;
+};
+
+__device__ float np_sum_f32_dev(const float* a, int n) {  // numpy pairwise_sum for 8 <= n <= 128
+  float r[8];
+  _Pragma("unroll 1") for (int j = 0; j < 8; j++) r[j] = a[j];
+  int i;
+  _Pragma("unroll 1") for (i = 8; i < n - (n % 8); i += 8)
+    _Pragma("unroll 1") for (int j = 0; j < 8; j++) r[j] += a[i + j];
+  float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  _Pragma("unroll 1") for (; i < n; i++) res += a[i];
+  return res;
+}
+
+// clamped cubic spline (end slopes 0) second derivatives, then store (y, y'') as float2
+__device__ __noinline__ void spline_store(int n, const double* x, const double* y, float2* out) {
+  double y2[KD], u[KD];
+  y2[0] = -0.5;
+  u[0] = (3.0 / (x[1] - x[0])) * ((y[1] - y[0]) / (x[1] - x[0]));
+  _Pragma("unroll 1") for (int i = 1; i < n - 1; i++) {
+    double sig = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
+    double p = sig * y2[i - 1] + 2.0;
+    y2[i] = (sig - 1.0) / p;
+    double t = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - (y[i] - y[i - 1]) / (x[i] - x[i - 1]);
+    u[i] = (6.0 * t / (x[i + 1] - x[i - 1]) - sig * u[i - 1]) / p;
+  }
+  double un = (3.0 / (x[n - 1] - x[n - 2])) * (0.0 - (y[n - 1] - y[n - 2]) / (x[n - 1] - x[n - 2]));
+  y2[n - 1] = (un - 0.5 * u[n - 2]) / (0.5 * y2[n - 2] + 1.0);
+  _Pragma("unroll 1") for (int k = n - 2; k >= 0; k--) y2[k] = y2[k] * y2[k + 1] + u[k];
+  _Pragma("unroll 1") for (int k = 0; k < n; k++) out[k] = make_float2((float)y[k], (float)y2[k]);
+}
+
+__device__ __forceinline__ double round_dp(double v, double scale) { return rint(v * scale) / scale; }
+
+__global__ void k_build_tables(BuildArgs A) {
+  const int L = A.L;
+  size_t ab = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ab >= (size_t)L * L) return;
+  int a = (int)(ab / L), b = (int)(ab % L);
+  unsigned char gen = 0, sel = 0;
+  const float meff32 = (float)A.meff;
+  double y[KD];
+  {  // ---- dist (utils_ros.py:54-75)
+    const float* row = A.dist + ab * TRX2_ND_BINS;
+    float p = np_sum_f32_dev(row + 5, 32);
+    A.pd[ab] = p;
+    if ((double)p > TRX2_GEN_PCUT && b > a) {
+      double attr0 = 0;
+      _Pragma("unroll 1") for (int k = 0; k < 32; k++) {
+        double bk = A.bkgr[k];  // (bins_k / DCUT)^ALPHA, host libm pow like numpy (utils_ros.py:57)
+        float num = row[5 + k] + meff32;
+        double den = (double)row[36] * bk + 1e-6;
+        double at = -log((double)num / den) + A.ebase;
+        if (k == 0) attr0 = at;
+        y[3 + k] = round_dp(at, 1e3);
+      }
+      double rep0 = attr0 > 0.0 ? attr0 : 0.0;
+      _Pragma("unroll 1") for (int k = 0; k < 3; k++) y[k] = round_dp(rep0 + A.erep[k], 1e3);
+      spline_store(KD, A.knots, y, A.Td + ab * KD);
+      gen |= TRX2_M_DIST;
+      if ((double)p >= A.pcut) sel |= TRX2_M_DIST;
+    }
+  }
+  if (A.use_orient) {
+    _Pragma("unroll 1") for (int ch = 0; ch < 2; ch++) {  // ---- omega, theta (utils_ros.py:81-119), float32 like numpy
+      const float* row = (ch == 0 ? A.omega : A.theta) + ab * TRX2_NO_BINS;
+      float p = np_sum_f32_dev(row + 1, 24);
+      (ch == 0 ? A.po : A.pt)[ab] = p;
+      bool ok = (double)p > TRX2_GEN_PCUT && (ch == 0 ? b > a : b != a);
+      if (!ok) continue;
+      float v[TRX2_NO_BINS];
+      float den = row[24] + meff32;
+      _Pragma("unroll 1") for (int k = 0; k < TRX2_NO_BINS; k++) v[k] = -(float)log((double)((row[k] + meff32) / den));
+      double sc = ch == 0 ? 1e5 : 1e3;
+      y[0] = round_dp(v[23], sc);
+      y[1] = round_dp(v[24], sc);
+      _Pragma("unroll 1") for (int k = 1; k <= 24; k++) y[1 + k] = round_dp(v[k], sc);
+      y[26] = round_dp(v[1], sc);
+      y[27] = round_dp(v[2], sc);
+      spline_store(KO, A.knots + (ch == 0 ? KD : KD + KO), y, (ch == 0 ? A.To : A.Tt) + ab * KO);
+      unsigned char bit = ch == 0 ? TRX2_M_OMEGA : TRX2_M_THETA;
+      gen |= bit;
+      if ((double)p >= A.pcut + 0.5) sel |= bit;
+    }
+    {  // ---- phi (utils_ros.py:124-144)
+      const float* row = A.phi + ab * TRX2_NP_BINS;
+      float p = np_sum_f32_dev(row + 1, 12);
+      A.pp[ab] = p;
+      if ((double)p > TRX2_GEN_PCUT && a != b) {
+        float v[TRX2_NP_BINS];
+        float den = row[12] + meff32;
+        _Pragma("unroll 1") for (int k = 0; k < TRX2_NP_BINS; k++) v[k] = -(float)log((double)((row[k] + meff32) / den));
+        y[0] = round_dp(v[2], 1e3);
+        y[1] = round_dp(v[1], 1e3);
+        _Pragma("unroll 1") for (int k = 1; k <= 12; k++) y[1 + k] = round_dp(v[k], 1e3);
+        y[14] = round_dp(v[12], 1e3);
+        y[15] = round_dp(v[11], 1e3);
+        spline_store(KP, A.knots + KD + 2 * KO, y, A.Tp + ab * KP);
+        gen |= TRX2_M_PHI;
+        if ((double)p >= A.pcut + 0.6) sel |= TRX2_M_PHI;
+      }
+    }
+  }
+  A.gen[ab] = gen;
+  A.sel[ab] = sel;
+}
+
+// =================================================================================================
+// K3/K4: pair terms.  Workgroup = (row residue a, b-range split, decoy group); lane = decoy (BW decoys per
+// wave, 64/BW residues b per wave step).  Each ORDERED pair (a,b) is visited from a's row and only the
+// gradient on a's atoms is kept -> no atomics, no cross-workgroup reduction, deterministic.
+// =================================================================================================
+struct PairArgs {
+  int L, B, nsplit, Bpad;
+  const float4* xyzT;  // [ngrp][L][4][BW] float4 : residue record (N CA C O CB + pad), decoy-minor
+  const float2 *Td, *To, *Tt, *Tp;
+  const unsigned char* mask;  // [L][L] selected bits, ordered pair
+  const float* knots;         // [107] float
+  const float* wcur;          // [Bpad][8] : w_ap w_dih w_ang w_vdw sep_lo sep_hi active -
+  float* fpart;               // [nsplit][Bpad][L][16] gradient on N CA C O CB (+pad)
+  float* epart;               // [nsplit][Bpad][L][8]  raw energies dist omega theta phi vdw
+};
+
+__device__ __forceinline__ void spline_eval_dev(const float2* __restrict__ row, const float* kn, int K, int idx, float x,
+                                                float& e, float& de) {
+  // idx is a guess; fix up against the (rounded, slightly non-uniform) knots
+  idx = max(0, min(K - 2, idx));
+  if (x < kn[idx]) idx = max(0, idx - 1);
+  else if (x >= kn[idx + 1]) idx = min(K - 2, idx + 1);
+  float lo = kn[idx], hi = kn[idx + 1];
+  float2 k0 = row[idx], k1 = row[idx + 1];
+  float h = hi - lo, ih = 1.0f / h;
+  float a = (hi - x) * ih, b = (x - lo) * ih;
+  bool inside = (x > kn[0]) && (x < kn[K - 1]);
+  float h26 = h * h * (1.0f / 6.0f);
+  float ev = a * k0.x + b * k1.x + ((a * a * a - a) * k0.y + (b * b * b - b) * k1.y) * h26;
+  float dv = (k1.x - k0.x) * ih + ((3.0f * b * b - 1.0f) * k1.y - (3.0f * a * a - 1.0f) * k0.y) * (h * (1.0f / 6.0f));
+  // outside the knot range: constant end value, zero slope (SplineFunc)
+  e = inside ? ev : (x <= kn[0] ? row[0].x : row[K - 1].x);
+  de = inside ? dv : 0.0f;
+}
+
+template <int BW>
+__global__ __launch_bounds__(PAIR_THREADS) void k_pair(PairArgs A) {
+  constexpr int PW = 64 / BW;
+  const int L = A.L;
+  const int a = blockIdx.x, split = blockIdx.y, grp = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = lane % BW, h = lane / BW;
+  const int dec = grp * BW + d;
+  const bool live = dec < A.B;
+
+  __shared__ float s_kn[TRX2_KTOT];
+  __shared__ float s_red[PAIR_WAVES * 64 * 20];
+  for (int i = threadIdx.x; i < TRX2_KTOT; i += PAIR_THREADS) s_kn[i] = A.knots[i];
+  __syncthreads();
+  const float* knd = s_kn;
+  const float* kno = s_kn + KD;
+  const float* knt = s_kn + KD + KO;
+  const float* knp = s_kn + KD + 2 * KO;
+  const float inv_o = 1.0f / (kno[1] - kno[0]), inv_p = 1.0f / (knp[1] - knp[0]);
+
+  float w_ap = 0, w_dih = 0, w_ang = 0, w_vdw = 0;
+  int sep_lo = 0, sep_hi = 0;
+  bool active = false;
+  if (live) {
+    const float4* wp = reinterpret_cast<const float4*>(A.wcur + (size_t)dec * 8);
+    float4 w0 = wp[0], w1 = wp[1];
+    w_ap = w0.x; w_dih = w0.y; w_ang = w0.z; w_vdw = w0.w;
+    sep_lo = (int)w1.x; sep_hi = (int)w1.y;
+    active = w1.z != 0.0f;
+  }
+
+  // residue a
+  const float4* xa = A.xyzT + ((size_t)(grp * L + a) * 4) * BW + d;
+  float4 q0 = xa[0], q1 = xa[BW], q2 = xa[2 * BW], q3 = xa[3 * BW];
+  const f3 Na = mk3(q0.x, q0.y, q0.z), CAa = mk3(q0.w, q1.x, q1.y), Ca = mk3(q1.z, q1.w, q2.x),
+           Oa = mk3(q2.y, q2.z, q2.w), CBa = mk3(q3.x, q3.y, q3.z);
+
+  f3 gN = mk3(0, 0, 0), gCA = gN, gC = gN, gO = gN, gCB = gN;
+  float e_d = 0, e_o = 0, e_t = 0, e_p = 0, e_v = 0;
+
+  const int chunk = (L + A.nsplit - 1) / A.nsplit;
+  const int b_lo = split * chunk, b_hi = min(L, b_lo + chunk);
+
+  for (int b0 = b_lo + wave * PW; b0 < b_hi; b0 += PAIR_WAVES * PW) {
+    const int b = b0 + h;
+    const bool valid = live && active && b < b_hi && b != a;
+    const int bc = min(b, L - 1);
+    const int sep = abs(a - bc);
+    unsigned m_ab = 0, m_ba = 0;
+    if (valid && sep >= sep_lo && sep < sep_hi) {
+      m_ab = A.mask[(size_t)a * L + bc];
+      m_ba = A.mask[(size_t)bc * L + a];
+    }
+    const unsigned msym = (a < bc) ? m_ab : m_ba;  // DIST / OMEGA bits live on the (min,max) row
+    const bool dovdw = valid && sep >= TRX2_VDW_MINSEP && w_vdw != 0.0f;
+    if (!__any((int)(m_ab | m_ba | (unsigned)dovdw))) continue;
+
+    const float4* xb = A.xyzT + ((size_t)(grp * L + bc) * 4) * BW + d;
+    float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW];
+    const f3 Nb = mk3(r0.x, r0.y, r0.z), CAb = mk3(r0.w, r1.x, r1.y), Cb = mk3(r1.z, r1.w, r2.x),
+             Ob = mk3(r2.y, r2.z, r2.w), CBb = mk3(r3.x, r3.y, r3.z);
+    const size_t iab = (size_t)a * L + bc, iba = (size_t)bc * L + a;
+    const size_t isym = (a < bc) ? iab : iba;
+    const bool first = a < bc;  // symmetric energies are counted from the lower row only
+
+    if (msym & TRX2_M_DIST) {
+      f3 u = CBa - CBb;
+      float d2 = dot(u, u), id = rsqrtf(d2), dd = d2 * id;
+      int idx = dd < 2.0f ? 0 : (dd < 3.5f ? 1 : (dd < 4.25f ? 2 : 3 + (int)((dd - 4.25f) * 2.0f)));
+      float ev, de;
+      spline_eval_dev(A.Td + isym * KD, knd, KD, idx, dd, ev, de);
+      if (first) e_d += ev;
+      gCB = fma3(u, w_ap * de * id, gCB);
+    }
+    if (msym & TRX2_M_OMEGA) {
+      f3 d1, d2, d3, d4;
+      float x = dihedral_grad(CAa, CBa, CBb, CAb, d1, d2, d3, d4);
+      float ev, de;
+      spline_eval_dev(A.To + isym * KO, kno, KO, (int)((x - kno[0]) * inv_o), x, ev, de);
+      if (first) e_o += ev;
+      float s = w_dih * de;
+      gCA = fma3(d1, s, gCA);
+      gCB = fma3(d2, s, gCB);
+    }
+    if (m_ab & TRX2_M_THETA) {
+      f3 d1, d2, d3, d4;
+      float x = dihedral_grad(Na, CAa, CBa, CBb, d1, d2, d3, d4);
+      float ev, de;
+      spline_eval_dev(A.Tt + iab * KO, knt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
+      e_t += ev;
+      float s = w_dih * de;
+      gN = fma3(d1, s, gN);
+      gCA = fma3(d2, s, gCA);
+      gCB = fma3(d3, s, gCB);
+    }
+    if (m_ba & TRX2_M_THETA) {  // theta(b,a): only its gradient on CB_a (4th point)
+      f3 d1, d2, d3, d4;
+      float x = dihedral_grad(Nb, CAb, CBb, CBa, d1, d2, d3, d4);
+      float ev, de;
+      spline_eval_dev(A.Tt + iba * KO, knt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
+      gCB = fma3(d4, w_dih * de, gCB);
+    }
+    if (m_ab & TRX2_M_PHI) {
+      f3 d1, d2, d3;
+      float x = angle_grad(CAa, CBa, CBb, d1, d2, d3);
+      float ev, de;
+      spline_eval_dev(A.Tp + iab * KP, knp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
+      e_p += ev;
+      float s = w_ang * de;
+      gCA = fma3(d1, s, gCA);
+      gCB = fma3(d2, s, gCB);
+    }
+    if (m_ba & TRX2_M_PHI) {  // phi(b,a): only its gradient on CB_a (3rd point)
+      f3 d1, d2, d3;
+      float x = angle_grad(CAb, CBb, CBa, d1, d2, d3);
+      float ev, de;
+      spline_eval_dev(A.Tp + iba * KP, knp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
+      gCB = fma3(d3, w_ang * de, gCB);
+    }
+    if (dovdw) {
+      f3 dca = CAa - CAb;
+      if (dot(dca, dca) < (float)TRX2_VDW_CUT2) {
+        const f3 pa[5] = {Na, CAa, Ca, Oa, CBa};
+        const f3 pb[5] = {Nb, CAb, Cb, Ob, CBb};
+        f3 ga[5] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
+        float ev = 0;
+#pragma unroll
+        for (int p = 0; p < 5; p++)
+#pragma unroll
+          for (int q = 0; q < 5; q++) {
+            f3 u = pa[p] - pb[q];
+            float r02 = c_vdw_r0sq[p * 5 + q];
+            float c = fmaxf(r02 - dot(u, u), 0.0f);
+            float ir = 1.0f / r02;
+            ev = fmaf(c * c, ir, ev);
+            ga[p] = fma3(u, -4.0f * c * ir, ga[p]);
+          }
+        const float s = w_vdw * (float)TRX2_VDW_SCALE;
+        if (first) e_v += (float)TRX2_VDW_SCALE * ev;
+        gN = fma3(ga[0], s, gN);
+        gCA = fma3(ga[1], s, gCA);
+        gC = fma3(ga[2], s, gC);
+        gO = fma3(ga[3], s, gO);
+        gCB = fma3(ga[4], s, gCB);
+      }
+    }
+  }
+
+  // ---- reduce over waves and over the PW residue sub-lanes; write decoy-major records
+  {
+    const int slot = wave * PW + h;  // PAIR_WAVES*PW slots, each [20][BW]
+    float* s = s_red + (size_t)slot * 20 * BW + d;
+    const float vals[20] = {gN.x, gN.y, gN.z, gCA.x, gCA.y, gCA.z, gC.x, gC.y, gC.z, gO.x,
+                            gO.y, gO.z, gCB.x, gCB.y, gCB.z, e_d, e_o, e_t, e_p, e_v};
+#pragma unroll
+    for (int k = 0; k < 20; k++) s[k * BW] = vals[k];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 20 * BW; t += PAIR_THREADS) {
+    const int dd = t / 20, k = t % 20;
+    const int dc = grp * BW + dd;
+    if (dc >= A.B) continue;
+    float acc = 0;
+    for (int sl = 0; sl < PAIR_WAVES * PW; sl++) acc += s_red[(size_t)sl * 20 * BW + k * BW + dd];
+    const size_t rec = ((size_t)split * A.Bpad + dc) * L + a;
+    if (k < 15) A.fpart[rec * 16 + k] = acc;
+    else A.epart[rec * 8 + (k - 15)] = acc;
+  }
+}
+
+// =================================================================================================
+// K1/K5/K6: per-decoy chain kernel
+// =================================================================================================
+enum { PH_START = 0, PH_LS = 1, PH_DONE = 2 };
+enum { MODE_INIT = 0, MODE_STEP = 1, MODE_FINISH = 2 };
+// integer state slots
+enum { SI_RUN = 0, SI_PHASE, SI_ITER, SI_NLS, SI_HL, SI_HH, SI_NH, SI_STATUS, SI_NEVALS, SI_NITERS, SI_N = 16 };
+// double state slots
+enum { SD_F = 0, SD_ALPHA, SD_GD, SD_FH0, SD_FH1, SD_FH2, SD_N = 8 };
+
+struct ChainArgs {
+  int L, B, Bpad, BW, nsplit, mode, nruns, max_evals;
+  const trx2_run* runs;
+  int* st_i;       // [B][SI_N]
+  double* st_d;    // [B][SD_N]
+  float* rho;      // [B][LBM]
+  float4 *X, *G, *D, *XT;  // [B][L] (phi, psi, omega, -)
+  float4 *S, *Y;           // [B][LBM][L]
+  float* xyz;              // [B][L][16] trial coordinates, decoy-major
+  float4* xyzT;            // decoy-minor copy for k_pair
+  float* wcur;             // [Bpad][8]
+  const float* fpart;      // [nsplit][Bpad][L][16]
+  const float* epart;      // [nsplit][Bpad][L][8]
+  double* e_last;          // [B][NTERMS] raw terms of the last evaluation
+  double* f_last;          // [B]
+  float* grad_out;         // [B][L][3] (MODE_FINISH)
+  int* done_count;
+};
+
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double* s_buf /* [4*K] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
+  __syncthreads();
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < K; k++) s_buf[wave * K + k] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; k++) v[k] = (s_buf[k] + s_buf[K + k]) + (s_buf[2 * K + k] + s_buf[3 * K + k]);
+}
+
+__device__ __forceinline__ float dot3(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+
+struct NerfConst {
+  float cNCAC, sNCAC, cCACN, sCACN, cCNCA, sCNCA, cCACO, sCACO;
+};
+
+// local frame of a residue: CA at origin, C on +x, N in the xy plane (y>0 side)
+__device__ __forceinline__ void local_atoms(const NerfConst& nc, f3& N, f3& CA, f3& C, f3& CB) {
+  CA = mk3(0, 0, 0);
+  C = mk3((float)TRX2_B_CA_C, 0, 0);
+  N = mk3((float)TRX2_B_N_CA * nc.cNCAC, (float)TRX2_B_N_CA * nc.sNCAC, 0);
+  f3 b = CA - N, c = C - CA, a = cross(b, c);
+  CB = CA + a * (float)TRX2_CB_KA + b * (float)TRX2_CB_KB + c * (float)TRX2_CB_KC;
+}
+
+template <int RPT>
+__global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) {
+  const int L = A.L, dec = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ double s_buf[4 * 8];
+  __shared__ float s_scan[4 * 12];
+  __shared__ float s_alpha[LBM];
+  __shared__ int s_i[SI_N];
+  __shared__ double s_d[SD_N];
+  __shared__ float s_rho[LBM];
+  __shared__ float s_phi[4 * CHAIN_THREADS + 1];
+
+  int* gi = A.st_i + (size_t)dec * SI_N;
+  double* gd_ = A.st_d + (size_t)dec * SD_N;
+  if (tid < SI_N) s_i[tid] = gi[tid];
+  if (tid < SD_N) s_d[tid] = gd_[tid];
+  if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
+  __syncthreads();
+  int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
+  if (A.mode == MODE_STEP && phase == PH_DONE) return;
+
+  const size_t vb = (size_t)dec * L;  // base of this decoy's [L] vectors
+  NerfConst nc;
+  sincosf((float)TRX2_A_N_CA_C * TRX2_DEG_F, &nc.sNCAC, &nc.cNCAC);
+  sincosf((float)TRX2_A_CA_C_N * TRX2_DEG_F, &nc.sCACN, &nc.cCACN);
+  sincosf((float)TRX2_A_C_N_CA * TRX2_DEG_F, &nc.sCNCA, &nc.cCNCA);
+  sincosf((float)TRX2_A_CA_C_O * TRX2_DEG_F, &nc.sCACO, &nc.cCACO);
+
+  float4 xt[RPT], gt[RPT];
+  bool need_nerf = true;
+
+  if (A.mode != MODE_INIT) {
+    // ------------------------------------------------------------------ consume the evaluation at XT
+    const trx2_run R = A.runs[min(run, A.nruns - 1)];
+    double esum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    f3 g2[RPT], g1[RPT];       // per-residue sums of gradient / x cross gradient
+    f3 gO_[RPT], gC_[RPT], gCB_[RPT], pN[RPT], pCA[RPT], pC[RPT], pO[RPT], pCB[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int r = k * CHAIN_THREADS + tid;
+      xt[k] = make_float4(0, 0, 0, 0);
+      gt[k] = make_float4(0, 0, 0, 0);
+      g2[k] = g1[k] = gO_[k] = gC_[k] = gCB_[k] = pN[k] = pCA[k] = pC[k] = pO[k] = pCB[k] = mk3(0, 0, 0);
+      if (r < L) {
+        xt[k] = A.XT[vb + r];
+        float g[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) g[i] = 0;
+        for (int s = 0; s < A.nsplit; s++) {
+          const size_t rec = ((size_t)s * A.Bpad + dec) * L + r;
+          const float4* fp = reinterpret_cast<const float4*>(A.fpart + rec * 16);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            float4 v = fp[q];
+            g[q * 4] += v.x; g[q * 4 + 1] += v.y; g[q * 4 + 2] += v.z; g[q * 4 + 3] += v.w;
+          }
+          const float4* ep = reinterpret_cast<const float4*>(A.epart + rec * 8);
+          float4 e0 = ep[0], e1 = ep[1];
+          esum[0] += e0.x; esum[1] += e0.y; esum[2] += e0.z; esum[3] += e0.w; esum[4] += e1.x;
+        }
+        const float4* xp = reinterpret_cast<const float4*>(A.xyz + (vb + r) * 16);
+        float4 c0 = xp[0], c1 = xp[1], c2 = xp[2], c3 = xp[3];
+        pN[k] = mk3(c0.x, c0.y, c0.z); pCA[k] = mk3(c0.w, c1.x, c1.y); pC[k] = mk3(c1.z, c1.w, c2.x);
+        pO[k] = mk3(c2.y, c2.z, c2.w); pCB[k] = mk3(c3.x, c3.y, c3.z);
+        f3 gN = mk3(g[0], g[1], g[2]), gCA = mk3(g[3], g[4], g[5]);
+        gC_[k] = mk3(g[6], g[7], g[8]); gO_[k] = mk3(g[9], g[10], g[11]); gCB_[k] = mk3(g[12], g[13], g[14]);
+        g2[k] = gN + gCA + gC_[k] + gO_[k] + gCB_[k];
+        g1[k] = cross(pN[k], gN) + cross(pCA[k], gCA) + cross(pC[k], gC_[k]) + cross(pO[k], gO_[k]) + cross(pCB[k], gCB_[k]);
+        // torsion-space terms: rama (residues 2..L-1) and omega_bb (1..L-1)
+        if (r >= 1 && r < L - 1) {
+          float s = 0, dph = 0, dps = 0;
+#pragma unroll
+          for (int j = 0; j < TRX2_RAMA_NB; j++) {
+            float sa, ca, sb, cb;
+            sincosf(xt[k].x - c_rama[j * 3], &sa, &ca);
+            sincosf(xt[k].y - c_rama[j * 3 + 1], &sb, &cb);
+            float t = c_rama[j * 3 + 2] * expf((float)TRX2_RAMA_KAPPA * (ca + cb - 2.0f));
+            s += t; dph -= t * (float)TRX2_RAMA_KAPPA * sa; dps -= t * (float)TRX2_RAMA_KAPPA * sb;
+          }
+          float inv = 1.0f / (s + (float)TRX2_RAMA_FLOOR);
+          esum[5] += -(double)logf((s + (float)TRX2_RAMA_FLOOR) * (1.0f / (float)TRX2_RAMA_PREF));
+          gt[k].x += -R.w[4] * dph * inv;
+          gt[k].y += -R.w[4] * dps * inv;
+        }
+        if (r < L - 1) {
+          float dw = xt[k].z - TRX2_PI_F;
+          dw -= 2.0f * TRX2_PI_F * rintf(dw * (0.5f / TRX2_PI_F));
+          dw *= (1.0f / TRX2_DEG_F);
+          esum[6] += (double)((float)TRX2_OMEGA_K * dw * dw);
+          gt[k].z += R.w[5] * 2.0f * (float)TRX2_OMEGA_K * dw * (1.0f / TRX2_DEG_F);
+        }
+      }
+    }
+    // ---- suffix sums over residues of (g2, g1): chunks from the end, wave shuffles + LDS wave totals
+    f3 car2 = mk3(0, 0, 0), car1 = mk3(0, 0, 0);  // sum over all residues in later chunks
+#pragma unroll
+    for (int k = RPT - 1; k >= 0; k--) {
+      float v[6] = {g2[k].x, g2[k].y, g2[k].z, g1[k].x, g1[k].y, g1[k].z};
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          float t = __shfl_down(v[i], o, 64);
+          if (lane + o < 64) v[i] += t;
+        }
+      }
+      __syncthreads();
+      if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 6; i++) s_scan[wave * 6 + i] = v[i];
+      __syncthreads();
+      float tot[6] = {0, 0, 0, 0, 0, 0}, after[6] = {0, 0, 0, 0, 0, 0};
+      for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          float t = s_scan[w * 6 + i];
+          tot[i] += t;
+          if (w > wave) after[i] += t;
+        }
+      // inclusive suffix sum for this residue = v + later waves + later chunks; exclusive = minus own
+      f3 inc2 = mk3(v[0] + after[0] + car2.x, v[1] + after[1] + car2.y, v[2] + after[2] + car2.z);
+      f3 inc1 = mk3(v[3] + after[3] + car1.x, v[4] + after[4] + car1.y, v[5] + after[5] + car1.z);
+      f3 ex2 = inc2 - g2[k], ex1 = inc1 - g1[k];  // residues > r
+      const int r = k * CHAIN_THREADS + tid;
+      if (r < L) {
+        // omega_r: axis C_r -> N_{r+1}
+        if (r + 1 < L) {
+          const float* nx = A.xyz + (vb + r + 1) * 16;
+          f3 Nn = mk3(nx[0], nx[1], nx[2]);
+          f3 n = unit(Nn - pC[k]);
+          gt[k].z += dot(n, ex1) - dot(cross(n, pC[k]), ex2);
+        }
+        {  // psi_r: axis CA -> C, moves O_r and residues > r
+          f3 h1 = ex1 + cross(pO[k], gO_[k]), h2 = ex2 + gO_[k];
+          f3 n = unit(pC[k] - pCA[k]);
+          gt[k].y += dot(n, h1) - dot(cross(n, pCA[k]), h2);
+        }
+        {  // phi_r: axis N -> CA, moves CB_r, C_r, O_r and residues > r
+          f3 h1 = ex1 + cross(pO[k], gO_[k]) + cross(pC[k], gC_[k]) + cross(pCB[k], gCB_[k]);
+          f3 h2 = ex2 + gO_[k] + gC_[k] + gCB_[k];
+          f3 n = unit(pCA[k] - pN[k]);
+          gt[k].x += dot(n, h1) - dot(cross(n, pN[k]), h2);
+        }
+      }
+      car2 = car2 + mk3(tot[0], tot[1], tot[2]);
+      car1 = car1 + mk3(tot[3], tot[4], tot[5]);
+    }
+    block_sum<8>(esum, s_buf);
+    const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] +
+                       (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6];
+    if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
+    if (tid == 0) A.f_last[dec] = f_t;
+
+    if (A.mode == MODE_FINISH) {
+      if (A.grad_out)
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          const int r = k * CHAIN_THREADS + tid;
+          if (r < L) {
+            float* go = A.grad_out + (vb + r) * 3;
+            go[0] = gt[k].x; go[1] = gt[k].y; go[2] = gt[k].z;
+          }
+        }
+      return;
+    }
+
+    // ------------------------------------------------------------------ minimiser state machine (uniform)
+    int iter = s_i[SI_ITER], nls = s_i[SI_NLS], hl = s_i[SI_HL], hh = s_i[SI_HH], nh = s_i[SI_NH];
+    int n_evals = s_i[SI_NEVALS] + 1, n_iters = s_i[SI_NITERS], status = s_i[SI_STATUS];
+    double f = s_d[SD_F], alpha = s_d[SD_ALPHA], gdir = s_d[SD_GD];
+    double fh[3] = {s_d[SD_FH0], s_d[SD_FH1], s_d[SD_FH2]};
+    float4 x[RPT], g[RPT], dv[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int r = k * CHAIN_THREADS + tid;
+      x[k] = g[k] = dv[k] = make_float4(0, 0, 0, 0);
+      if (r < L) { x[k] = A.X[vb + r]; g[k] = A.G[vb + r]; dv[k] = A.D[vb + r]; }
+    }
+    bool next_run = false, new_dir = false, steepest = false, new_trial = false;
+    const bool finite_t = isfinite(f_t);
+    if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
+    else if (phase == PH_START) {
+      if (R.precheck && esum[5] + esum[4] < (double)TRX2_CLASH_BREAK) {
+        run = R.skip_to;
+        if (run >= A.nruns) phase = PH_DONE;
+        need_nerf = false;
+      } else {
+        f = f_t;
+#pragma unroll
+        for (int k = 0; k < RPT; k++) g[k] = gt[k];
+        hl = 0; hh = 0; nh = 1; fh[0] = f; iter = 0;
+        steepest = true;
+      }
+    } else {  // PH_LS
+      double fref = fh[0];
+      for (int k = 1; k < nh; k++) fref = fmax(fref, fh[k]);
+      const bool accept = finite_t && f_t <= fref + (double)TRX2_LS_C1 * alpha * gdir;
+      if (accept) {
+        double v3[3] = {0, 0, 0};
+        float4 s[RPT], y[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          s[k] = make_float4(xt[k].x - x[k].x, xt[k].y - x[k].y, xt[k].z - x[k].z, 0);
+          y[k] = make_float4(gt[k].x - g[k].x, gt[k].y - g[k].y, gt[k].z - g[k].z, 0);
+          v3[0] += (double)dot3(s[k], y[k]); v3[1] += (double)dot3(s[k], s[k]); v3[2] += (double)dot3(y[k], y[k]);
+        }
+        block_sum<3>(v3, s_buf);
+        if (v3[0] > 1e-12 * sqrt(v3[1] * v3[2])) {
+#pragma unroll
+          for (int k = 0; k < RPT; k++) {
+            const int r = k * CHAIN_THREADS + tid;
+            if (r < L) {
+              A.S[((size_t)dec * LBM + hh) * L + r] = s[k];
+              A.Y[((size_t)dec * LBM + hh) * L + r] = y[k];
+            }
+          }
+          __syncthreads();
+          if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
+          __syncthreads();
+          hh = (hh + 1) % LBM;
+          if (hl < LBM) hl++;
+        }
+        const double fprev = f;
+#pragma unroll
+        for (int k = 0; k < RPT; k++) { x[k] = xt[k]; g[k] = gt[k]; }
+        f = f_t;
+        if (nh < TRX2_LS_PAST) fh[nh++] = f;
+        else { fh[0] = fh[1]; fh[1] = fh[2]; fh[2] = f; }
+        iter++; n_iters++;
+        const bool conv = 2.0 * fabs(fprev - f) <= (double)TRX2_MIN_TOL * (fabs(fprev) + fabs(f) + 1e-10);
+        if (conv || iter >= R.max_iter) next_run = true;
+        else new_dir = true;
+      } else {
+        nls++;
+        alpha *= (double)TRX2_LS_SHRINK;
+        if (nls > TRX2_LS_MAXTRIAL) {
+          if (hl > 0) { hl = 0; steepest = true; }
+          else next_run = true;
+        } else new_trial = true;
+      }
+    }
+    if (new_dir) {
+      // two-loop recursion over the stored pairs (A.S / A.Y are L2-resident; coalesced float4 per residue)
+      float4 q[RPT];
+#pragma unroll
+      for (int k = 0; k < RPT; k++) q[k] = g[k];
+      for (int kk = 0; kk < hl; kk++) {
+        const int j = (hh - 1 - kk + LBM) % LBM;
+        double v1[1] = {0};
+        float4 sj[RPT], yj[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          const int r = k * CHAIN_THREADS + tid;
+          sj[k] = yj[k] = make_float4(0, 0, 0, 0);
+          if (r < L) { sj[k] = A.S[((size_t)dec * LBM + j) * L + r]; yj[k] = A.Y[((size_t)dec * LBM + j) * L + r]; }
+          v1[0] += (double)dot3(sj[k], q[k]);
+        }
+        block_sum<1>(v1, s_buf);
+        const float al = s_rho[j] * (float)v1[0];
+        if (tid == 0) s_alpha[j] = al;
+#pragma unroll
+        for (int k = 0; k < RPT; k++) { q[k].x -= al * yj[k].x; q[k].y -= al * yj[k].y; q[k].z -= al * yj[k].z; }
+      }
+      if (hl > 0) {
+        const int j = (hh - 1 + LBM) % LBM;
+        double v1[1] = {0};
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          const int r = k * CHAIN_THREADS + tid;
+          if (r < L) { float4 yj = A.Y[((size_t)dec * LBM + j) * L + r]; v1[0] += (double)dot3(yj, yj); }
+        }
+        block_sum<1>(v1, s_buf);
+        const float gam = (float)(1.0 / ((double)s_rho[j] * v1[0]));
+#pragma unroll
+        for (int k = 0; k < RPT; k++) { q[k].x *= gam; q[k].y *= gam; q[k].z *= gam; }
+      }
+      __syncthreads();
+      for (int kk = hl - 1; kk >= 0; kk--) {
+        const int j = (hh - 1 - kk + LBM) % LBM;
+        double v1[1] = {0};
+        float4 sj[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          const int r = k * CHAIN_THREADS + tid;
+          sj[k] = make_float4(0, 0, 0, 0);
+          if (r < L) {
+            float4 yj = A.Y[((size_t)dec * LBM + j) * L + r];
+            sj[k] = A.S[((size_t)dec * LBM + j) * L + r];
+            v1[0] += (double)dot3(yj, q[k]);
+          }
+        }
+        block_sum<1>(v1, s_buf);
+        const float c = s_alpha[j] - s_rho[j] * (float)v1[0];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) { q[k].x += c * sj[k].x; q[k].y += c * sj[k].y; q[k].z += c * sj[k].z; }
+      }
+      double v2[2] = {0, 0};
+#pragma unroll
+      for (int k = 0; k < RPT; k++) {
+        dv[k] = make_float4(-q[k].x, -q[k].y, -q[k].z, 0);
+        v2[0] += (double)dot3(g[k], dv[k]); v2[1] += (double)dot3(g[k], g[k]);
+      }
+      block_sum<2>(v2, s_buf);
+      if (!(v2[1] > 0)) next_run = true;
+      else if (hl == 0 || !(v2[0] < 0)) { hl = 0; steepest = true; }
+      else { gdir = v2[0]; alpha = 1.0; nls = 0; new_trial = true; }
+    }
+    if (steepest) {
+      double v1[1] = {0};
+#pragma unroll
+      for (int k = 0; k < RPT; k++) { dv[k] = make_float4(-g[k].x, -g[k].y, -g[k].z, 0); v1[0] += (double)dot3(g[k], g[k]); }
+      block_sum<1>(v1, s_buf);
+      if (!(v1[0] > 0)) next_run = true;
+      else {
+        gdir = -v1[0];
+        alpha = fmin(1.0, 1.0 / sqrt(v1[0]));
+        nls = 0;
+        new_trial = true;
+      }
+    }
+    if (next_run) {
+      run++;
+      phase = (run >= A.nruns) ? PH_DONE : PH_START;
+#pragma unroll
+      for (int k = 0; k < RPT; k++) xt[k] = x[k];
+      need_nerf = true;  // XT := X (the accepted point) so that coordinates match for the next evaluation
+    }
+    if (new_trial) {
+      phase = PH_LS;
+      const float al = (float)alpha;
+#pragma unroll
+      for (int k = 0; k < RPT; k++)
+        xt[k] = make_float4(fmaf(al, dv[k].x, x[k].x), fmaf(al, dv[k].y, x[k].y), fmaf(al, dv[k].z, x[k].z), 0);
+    }
+    if (phase != PH_DONE && n_evals >= A.max_evals) { status = TRX2_MAXEVAL; phase = PH_DONE; }
+    // ---- store state
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int r = k * CHAIN_THREADS + tid;
+      if (r < L) { A.X[vb + r] = x[k]; A.G[vb + r] = g[k]; A.D[vb + r] = dv[k]; A.XT[vb + r] = xt[k]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      gi[SI_RUN] = run; gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
+      gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
+      gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
+      if (phase == PH_DONE) atomicAdd(A.done_count, 1);
+    }
+    if (tid < LBM) A.rho[(size_t)dec * LBM + tid] = s_rho[tid];
+  } else {
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int r = k * CHAIN_THREADS + tid;
+      xt[k] = (r < L) ? A.XT[vb + r] : make_float4(0, 0, 0, 0);
+    }
+  }
+
+  // ------------------------------------------------------------------ weights for the next pair launch
+  if (tid == 0) {
+    const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
+    float* w = A.wcur + (size_t)dec * 8;
+    w[0] = Rn.w[0]; w[1] = Rn.w[1]; w[2] = Rn.w[2]; w[3] = Rn.w[3];
+    w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi;
+    w[6] = (phase == PH_DONE && A.mode == MODE_STEP) ? 0.0f : 1.0f;
+    w[7] = 0;
+  }
+  if (!need_nerf) return;
+
+  // ------------------------------------------------------------------ K1: torsions XT -> backbone (NeRF scan)
+  // M_r maps frame r+1 coordinates into frame r; F_r = F_0 o M_0 o ... o M_{r-1}
+  f3 lN, lCA, lC, lCB;
+  local_atoms(nc, lN, lCA, lC, lCB);
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < RPT; k++) s_phi[k * CHAIN_THREADS + tid] = xt[k].x;
+  __syncthreads();
+  Xf carry;  // F_0: N at the origin, CA on +x, C in the xy plane (same start as the oracle)
+  {
+    f3 N0 = mk3(0, 0, 0), CA0 = mk3((float)TRX2_B_N_CA, 0, 0);
+    f3 C0 = mk3((float)TRX2_B_N_CA - (float)TRX2_B_CA_C * nc.cNCAC, (float)TRX2_B_CA_C * nc.sNCAC, 0);
+    carry = xf_from_atoms(N0, CA0, C0);
+  }
+#pragma unroll
+  for (int k = 0; k < RPT; k++) {
+    const int r = k * CHAIN_THREADS + tid;
+    Xf M = xf_identity();
+    float spsi = 0, cpsi = 1;
+    if (r < L) {
+      sincosf(xt[k].y, &spsi, &cpsi);
+      if (r + 1 < L) {
+        float so, co, sp, cp;
+        sincosf(xt[k].z, &so, &co);
+        sincosf(s_phi[r + 1], &sp, &cp);  // phi of residue r+1
+        f3 Nn = place_atom(lN, lCA, lC, (float)TRX2_B_C_N, nc.cCACN, nc.sCACN, cpsi, spsi);
+        f3 CAn = place_atom(lCA, lC, Nn, (float)TRX2_B_N_CA, nc.cCNCA, nc.sCNCA, co, so);
+        f3 Cn = place_atom(lC, Nn, CAn, (float)TRX2_B_CA_C, nc.cNCAC, nc.sNCAC, cp, sp);
+        M = xf_from_atoms(Nn, CAn, Cn);
+      }
+    }
+    // inclusive scan of M within the wave
+    Xf P = M;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      Xf t = xf_shfl_up(P, o);
+      if (lane >= o) P = xf_compose(t, P);
+    }
+    __syncthreads();
+    if (lane == 63) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) s_scan[wave * 12 + i] = P.r[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) s_scan[wave * 12 + 9 + i] = P.t[i];
+    }
+    __syncthreads();
+    Xf pre = carry;  // transform of everything before this wave
+    Xf tot = carry;
+    for (int w = 0; w < 4; w++) {
+      Xf T;
+#pragma unroll
+      for (int i = 0; i < 9; i++) T.r[i] = s_scan[w * 12 + i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) T.t[i] = s_scan[w * 12 + 9 + i];
+      if (w < wave) pre = xf_compose(pre, T);
+      tot = xf_compose(tot, T);
+    }
+    // frame of residue r = pre o (inclusive scan of the previous lane)
+    Xf prev = xf_shfl_up(P, 1);
+    Xf F = (lane == 0) ? pre : xf_compose(pre, prev);
+    carry = tot;
+    if (r < L) {
+      f3 lO = place_atom(lN, lCA, lC, (float)TRX2_B_C_O, nc.cCACO, nc.sCACO, -cpsi, -spsi);  // psi + pi
+      f3 N = xf_apply(F, lN), CA = xf_apply(F, lCA), C = xf_apply(F, lC), O = xf_apply(F, lO), CB = xf_apply(F, lCB);
+      float4 o0 = make_float4(N.x, N.y, N.z, CA.x), o1 = make_float4(CA.y, CA.z, C.x, C.y),
+             o2 = make_float4(C.z, O.x, O.y, O.z), o3 = make_float4(CB.x, CB.y, CB.z, 0);
+      float4* xo = reinterpret_cast<float4*>(A.xyz + (vb + r) * 16);
+      xo[0] = o0; xo[1] = o1; xo[2] = o2; xo[3] = o3;
+      const int grp = dec / A.BW, dd = dec % A.BW;
+      float4* xT = A.xyzT + ((size_t)(grp * L + r) * 4) * A.BW + dd;
+      xT[0] = o0; xT[A.BW] = o1; xT[2 * A.BW] = o2; xT[3 * A.BW] = o3;
+    }
+  }
+}
+
+// random start torsions: set_random_dihedral (utils_ros.py:656-696) with explicit (seed, decoy, residue) hashing
+__device__ __forceinline__ uint64_t splitmix64_dev(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ void k_init_torsions(int L, int B, uint64_t seed, uint32_t decoy0, const float* tors0, float4* X, float4* XT) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L * B) return;
+  const int dec = i / L, r = i % L;
+  float4 v;
+  if (tors0) v = make_float4(tors0[(size_t)i * 3], tors0[(size_t)i * 3 + 1], tors0[(size_t)i * 3 + 2], 0);
+  else {
+    float ph = 180.0f, ps = 180.0f;
+    if (r < L - 1) {
+      const double cum[6] = TRX2_RAND_CUM_INIT;
+      uint64_t hsh = splitmix64_dev(seed ^ splitmix64_dev(((uint64_t)(decoy0 + dec) << 32) | (uint32_t)r));
+      double u = (double)(hsh >> 11) * (1.0 / 9007199254740992.0);
+      int k = 0;
+      while (!(u <= cum[k])) k++;
+      v = make_float4(c_rama[k * 3], c_rama[k * 3 + 1], TRX2_PI_F, 0);
+    } else
+      v = make_float4(ph * TRX2_DEG_F, ps * TRX2_DEG_F, TRX2_PI_F, 0);
+  }
+  X[i] = v;
+  XT[i] = v;
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+struct trx2_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  // map
+  int L = 0, use_orient = 0;
+  std::string seq;
+  float2 *Td = nullptr, *To = nullptr, *Tt = nullptr, *Tp = nullptr;
+  float *pd = nullptr, *po = nullptr, *pt = nullptr, *pp = nullptr;
+  unsigned char *gen = nullptr, *sel = nullptr;
+  float* knots_f = nullptr;
+  double* knots_d = nullptr;
+  double knots_h[TRX2_KTOT];
+  // batch
+  int Bcap = 0, Lcap = 0, BW = 64, Bpad = 0, nsplit = 1, nsplit_cap = 0;
+  int* st_i = nullptr; double* st_d = nullptr; float* rho = nullptr;
+  float4 *X = nullptr, *G = nullptr, *D = nullptr, *XT = nullptr, *S = nullptr, *Y = nullptr;
+  float* xyz = nullptr; float4* xyzT = nullptr; float* wcur = nullptr;
+  float *fpart = nullptr, *epart = nullptr;
+  double *e_last = nullptr, *f_last = nullptr;
+  float* grad = nullptr; float* tors0 = nullptr;
+  int* done_count = nullptr;
+  trx2_run* runs = nullptr;
+  int* h_done = nullptr;  // pinned
+  double last_seconds = 0; int last_launches = 0;
+};
+
+#define HIPCHK(expr)                                                                                        \
+  do {                                                                                                      \
+    hipError_t e_ = (expr);                                                                                 \
+    if (e_ != hipSuccess) {                                                                                 \
+      ctx->err = std::string(#expr) + ": " + hipGetErrorString(e_);                                         \
+      return 1;                                                                                             \
+    }                                                                                                       \
+  } while (0)
+
+static double round_txt(double v, int dp) {
+  char buf[64];
+  snprintf(buf, sizeof buf, dp == 3 ? "%.3f" : "%.5f", v);
+  return strtod(buf, nullptr);
+}
+
+extern "C" int trx2_abi_version(void) { return 1; }
+
+extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
+  if (!out) return 1;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return 2;
+  trx2_ctx* ctx = new trx2_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return 3;
+  }
+  const double r0[5][5] = TRX2_VDW_R0_INIT;
+  float r0sq[25];
+  for (int p = 0; p < 5; p++)
+    for (int q = 0; q < 5; q++) r0sq[p * 5 + q] = (float)(r0[p][q] * r0[p][q]);
+  const double rama[TRX2_RAMA_NB][3] = TRX2_RAMA_INIT;
+  float rm[TRX2_RAMA_NB * 3];
+  for (int k = 0; k < TRX2_RAMA_NB; k++) {
+    rm[k * 3] = (float)(rama[k][0] * M_PI / 180.0);
+    rm[k * 3 + 1] = (float)(rama[k][1] * M_PI / 180.0);
+    rm[k * 3 + 2] = (float)rama[k][2];
+  }
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_vdw_r0sq), r0sq, sizeof r0sq) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(c_rama), rm, sizeof rm) != hipSuccess ||
+      hipHostMalloc((void**)&ctx->h_done, sizeof(int)) != hipSuccess) {
+    delete ctx;
+    return 4;
+  }
+  *out = ctx;
+  return 0;
+}
+
+static void free_map(trx2_ctx* c) {
+  void* p[] = {c->Td, c->To, c->Tt, c->Tp, c->pd, c->po, c->pt, c->pp, c->gen, c->sel, c->knots_f, c->knots_d};
+  for (void* q : p)
+    if (q) (void)hipFree(q);
+  c->Td = c->To = c->Tt = c->Tp = nullptr;
+  c->pd = c->po = c->pt = c->pp = nullptr;
+  c->gen = c->sel = nullptr;
+  c->knots_f = nullptr; c->knots_d = nullptr;
+  c->L = 0;
+}
+static void free_batch(trx2_ctx* c) {
+  void* p[] = {c->st_i, c->st_d, c->rho, c->X, c->G, c->D, c->XT, c->S, c->Y, c->xyz, c->xyzT, c->wcur, c->fpart,
+               c->epart, c->e_last, c->f_last, c->grad, c->tors0, c->done_count, c->runs};
+  for (void* q : p)
+    if (q) (void)hipFree(q);
+  c->st_i = nullptr; c->st_d = nullptr; c->rho = nullptr;
+  c->X = c->G = c->D = c->XT = c->S = c->Y = nullptr;
+  c->xyz = nullptr; c->xyzT = nullptr; c->wcur = nullptr; c->fpart = c->epart = nullptr;
+  c->e_last = c->f_last = nullptr; c->grad = nullptr; c->tors0 = nullptr; c->done_count = nullptr; c->runs = nullptr;
+  c->Bcap = c->Lcap = 0;
+}
+
+extern "C" void trx2_ctx_destroy(trx2_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  free_map(ctx);
+  free_batch(ctx);
+  if (ctx->h_done) (void)hipHostFree(ctx->h_done);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* trx2_last_error(const trx2_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist, const float* omega, const float* theta,
+                        const float* phi, const trx2_params* prm, bool device_ptrs) {
+  if (!ctx) return 1;
+  if (L < 4 || L > 1024 || !dist || !prm) { ctx->err = "trx2_set_map: need 4 <= L <= 1024, dist and params"; return 1; }
+  const bool orient = omega && theta && phi;
+  if (!orient && (omega || theta || phi)) { ctx->err = "trx2_set_map: omega/theta/phi must be all given or all NULL"; return 1; }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  free_map(ctx);
+  const size_t LL = (size_t)L * L;
+  ctx->L = L; ctx->use_orient = orient; ctx->seq = seq ? std::string(seq, strnlen(seq, L)) : std::string();
+  // knot positions after the reference's "%.3f" / "%.5f" text round trip (utils_ros.py:70,92,111,135)
+  double* kn = ctx->knots_h;
+  for (int k = 0; k < 3; k++) kn[k] = round_txt(prm->drep[k], 3);
+  for (int k = 0; k < 32; k++) kn[3 + k] = round_txt(4.25 + prm->dstep * k, 3);
+  const double astep = prm->astep_deg * M_PI / 180.0;
+  {
+    double start = -M_PI - 1.5 * astep, stop = M_PI + 1.5 * astep, step = (stop - start) / (KO - 1);
+    for (int k = 0; k < KO; k++) {
+      double v = (k == KO - 1) ? stop : start + k * step;
+      kn[KD + k] = round_txt(v, 5);
+      kn[KD + KO + k] = round_txt(v, 3);
+    }
+    start = -1.5 * astep; stop = M_PI + 1.5 * astep; step = (stop - start) / (KP - 1);
+    for (int k = 0; k < KP; k++) kn[KD + 2 * KO + k] = round_txt((k == KP - 1) ? stop : start + k * step, 3);
+  }
+  float knf[TRX2_KTOT];
+  for (int k = 0; k < TRX2_KTOT; k++) knf[k] = (float)kn[k];
+  HIPCHK(hipMalloc((void**)&ctx->knots_d, sizeof(double) * TRX2_KTOT));
+  HIPCHK(hipMalloc((void**)&ctx->knots_f, sizeof(float) * TRX2_KTOT));
+  HIPCHK(hipMemcpyAsync(ctx->knots_d, kn, sizeof(double) * TRX2_KTOT, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->knots_f, knf, sizeof knf, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMalloc((void**)&ctx->Td, LL * KD * sizeof(float2)));
+  HIPCHK(hipMalloc((void**)&ctx->pd, LL * 4));
+  HIPCHK(hipMalloc((void**)&ctx->gen, LL));
+  HIPCHK(hipMalloc((void**)&ctx->sel, LL));
+  HIPCHK(hipMemsetAsync(ctx->Td, 0, LL * KD * sizeof(float2), ctx->stream));
+  if (orient) {
+    HIPCHK(hipMalloc((void**)&ctx->To, LL * KO * sizeof(float2)));
+    HIPCHK(hipMalloc((void**)&ctx->Tt, LL * KO * sizeof(float2)));
+    HIPCHK(hipMalloc((void**)&ctx->Tp, LL * KP * sizeof(float2)));
+    HIPCHK(hipMalloc((void**)&ctx->po, LL * 4));
+    HIPCHK(hipMalloc((void**)&ctx->pt, LL * 4));
+    HIPCHK(hipMalloc((void**)&ctx->pp, LL * 4));
+    HIPCHK(hipMemsetAsync(ctx->To, 0, LL * KO * sizeof(float2), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->Tt, 0, LL * KO * sizeof(float2), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->Tp, 0, LL * KP * sizeof(float2), ctx->stream));
+  }
+  const float* src[4] = {dist, omega, theta, phi};
+  float* dev[4] = {nullptr, nullptr, nullptr, nullptr};
+  const int nb[4] = {TRX2_ND_BINS, TRX2_NO_BINS, TRX2_NO_BINS, TRX2_NP_BINS};
+  for (int c = 0; c < 4; c++) {
+    if (!src[c]) continue;
+    if (device_ptrs) dev[c] = const_cast<float*>(src[c]);
+    else {
+      HIPCHK(hipMalloc((void**)&dev[c], LL * nb[c] * 4));
+      HIPCHK(hipMemcpyAsync(dev[c], src[c], LL * nb[c] * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
+  BuildArgs A;
+  A.L = L; A.use_orient = orient;
+  A.dist = dev[0]; A.omega = dev[1]; A.theta = dev[2]; A.phi = dev[3];
+  A.ebase = prm->ebase; for (int k = 0; k < 3; k++) A.erep[k] = prm->erep[k];
+  A.meff = prm->meff; A.pcut = prm->pcut;
+  for (int k = 0; k < 32; k++) A.bkgr[k] = std::pow((4.25 + prm->dstep * k) / prm->dcut, prm->alpha);
+  A.knots = ctx->knots_d;
+  A.Td = ctx->Td; A.To = ctx->To; A.Tt = ctx->Tt; A.Tp = ctx->Tp;
+  A.pd = ctx->pd; A.po = ctx->po; A.pt = ctx->pt; A.pp = ctx->pp; A.gen = ctx->gen; A.sel = ctx->sel;
+  hipLaunchKernelGGL(k_build_tables, dim3((unsigned)((LL + 127) / 128)), dim3(128), 0, ctx->stream, A);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (!device_ptrs)
+    for (int c = 0; c < 4; c++)
+      if (dev[c]) HIPCHK(hipFree(dev[c]));
+  return 0;
+}
+
+extern "C" int trx2_set_map(trx2_ctx* ctx, int L, const char* seq, const float* dist, const float* omega,
+                            const float* theta, const float* phi, const trx2_params* prm) {
+  return set_map_impl(ctx, L, seq, dist, omega, theta, phi, prm, false);
+}
+extern "C" int trx2_set_map_device(trx2_ctx* ctx, int L, const char* seq, const float* dist, const float* omega,
+                                   const float* theta, const float* phi, const trx2_params* prm) {
+  return set_map_impl(ctx, L, seq, dist, omega, theta, phi, prm, true);
+}
+
+extern "C" int trx2_get_tables(trx2_ctx* ctx, int channel, float* y_y2, float* knots, float* prob, unsigned char* gen,
+                               unsigned char* sel) {
+  if (!ctx || !ctx->L) return 1;
+  if (channel < 0 || channel > 3 || (channel > 0 && !ctx->use_orient)) { ctx->err = "trx2_get_tables: bad channel"; return 1; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t LL = (size_t)ctx->L * ctx->L;
+  const int K[4] = {KD, KO, KO, KP};
+  const int off[4] = {0, KD, KD + KO, KD + 2 * KO};
+  const float2* T[4] = {ctx->Td, ctx->To, ctx->Tt, ctx->Tp};
+  const float* P[4] = {ctx->pd, ctx->po, ctx->pt, ctx->pp};
+  if (y_y2) HIPCHK(hipMemcpy(y_y2, T[channel], LL * K[channel] * sizeof(float2), hipMemcpyDeviceToHost));
+  if (knots) for (int k = 0; k < K[channel]; k++) knots[k] = (float)ctx->knots_h[off[channel] + k];
+  if (prob) HIPCHK(hipMemcpy(prob, P[channel], LL * 4, hipMemcpyDeviceToHost));
+  if (gen) HIPCHK(hipMemcpy(gen, ctx->gen, LL, hipMemcpyDeviceToHost));
+  if (sel) HIPCHK(hipMemcpy(sel, ctx->sel, LL, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+static int pick_bw(int B) {
+  int bw = 1;
+  while (bw < B && bw < 64) bw <<= 1;
+  return bw;
+}
+
+static int ensure_batch(trx2_ctx* ctx, int B) {
+  const int L = ctx->L;
+  const int BW = pick_bw(B);
+  const int ngrp = (B + BW - 1) / BW;
+  const int Bpad = ngrp * BW;
+  // b-range splits: enough workgroups (>= ~2 per CU) while every wave keeps a few residues b
+  int nsplit = 1;
+  {
+    const int PW = 64 / BW;
+    while ((long)L * nsplit * ngrp < 512 && (L / (nsplit * 2)) >= PAIR_WAVES * PW * 2 && nsplit < 16) nsplit *= 2;
+  }
+  ctx->BW = BW; ctx->Bpad = Bpad; ctx->nsplit = nsplit;
+  if (B <= ctx->Bcap && L <= ctx->Lcap && nsplit <= ctx->nsplit_cap) return 0;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  free_batch(ctx);
+  const size_t BL = (size_t)B * L;
+  HIPCHK(hipMalloc((void**)&ctx->st_i, sizeof(int) * B * SI_N));
+  HIPCHK(hipMalloc((void**)&ctx->st_d, sizeof(double) * B * SD_N));
+  HIPCHK(hipMalloc((void**)&ctx->rho, sizeof(float) * B * LBM));
+  HIPCHK(hipMalloc((void**)&ctx->X, sizeof(float4) * BL));
+  HIPCHK(hipMalloc((void**)&ctx->G, sizeof(float4) * BL));
+  HIPCHK(hipMalloc((void**)&ctx->D, sizeof(float4) * BL));
+  HIPCHK(hipMalloc((void**)&ctx->XT, sizeof(float4) * BL));
+  HIPCHK(hipMalloc((void**)&ctx->S, sizeof(float4) * BL * LBM));
+  HIPCHK(hipMalloc((void**)&ctx->Y, sizeof(float4) * BL * LBM));
+  HIPCHK(hipMalloc((void**)&ctx->xyz, sizeof(float) * BL * 16));
+  HIPCHK(hipMalloc((void**)&ctx->xyzT, sizeof(float4) * (size_t)Bpad * L * 4));
+  HIPCHK(hipMalloc((void**)&ctx->wcur, sizeof(float) * Bpad * 8));
+  HIPCHK(hipMalloc((void**)&ctx->fpart, sizeof(float) * (size_t)nsplit * Bpad * L * 16));
+  HIPCHK(hipMalloc((void**)&ctx->epart, sizeof(float) * (size_t)nsplit * Bpad * L * 8));
+  HIPCHK(hipMalloc((void**)&ctx->e_last, sizeof(double) * B * TRX2_NTERMS));
+  HIPCHK(hipMalloc((void**)&ctx->f_last, sizeof(double) * B));
+  HIPCHK(hipMalloc((void**)&ctx->grad, sizeof(float) * BL * 3));
+  HIPCHK(hipMalloc((void**)&ctx->tors0, sizeof(float) * BL * 3));
+  HIPCHK(hipMalloc((void**)&ctx->done_count, sizeof(int)));
+  HIPCHK(hipMalloc((void**)&ctx->runs, sizeof(trx2_run) * TRX2_MAX_RUNS));
+  HIPCHK(hipMemsetAsync(ctx->xyzT, 0, sizeof(float4) * (size_t)Bpad * L * 4, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->wcur, 0, sizeof(float) * Bpad * 8, ctx->stream));
+  ctx->Bcap = B; ctx->Lcap = L; ctx->nsplit_cap = nsplit;
+  return 0;
+}
+
+static PairArgs pair_args(trx2_ctx* c, int B) {
+  PairArgs P;
+  P.L = c->L; P.B = B; P.nsplit = c->nsplit; P.Bpad = c->Bpad;
+  P.xyzT = c->xyzT; P.Td = c->Td; P.To = c->To; P.Tt = c->Tt; P.Tp = c->Tp;
+  P.mask = c->sel; P.knots = c->knots_f; P.wcur = c->wcur; P.fpart = c->fpart; P.epart = c->epart;
+  return P;
+}
+static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_evals) {
+  ChainArgs A;
+  A.L = c->L; A.B = B; A.Bpad = c->Bpad; A.BW = c->BW; A.nsplit = c->nsplit; A.mode = mode; A.nruns = nruns;
+  A.max_evals = max_evals; A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho;
+  A.X = c->X; A.G = c->G; A.D = c->D; A.XT = c->XT; A.S = c->S; A.Y = c->Y; A.xyz = c->xyz; A.xyzT = c->xyzT;
+  A.wcur = c->wcur; A.fpart = c->fpart; A.epart = c->epart; A.e_last = c->e_last; A.f_last = c->f_last;
+  A.grad_out = c->grad; A.done_count = c->done_count;
+  return A;
+}
+
+static void launch_pair(trx2_ctx* c, int B) {
+  PairArgs P = pair_args(c, B);
+  dim3 grid(c->L, c->nsplit, c->Bpad / c->BW), block(PAIR_THREADS);
+  switch (c->BW) {
+    case 64: hipLaunchKernelGGL(k_pair<64>, grid, block, 0, c->stream, P); break;
+    case 32: hipLaunchKernelGGL(k_pair<32>, grid, block, 0, c->stream, P); break;
+    case 16: hipLaunchKernelGGL(k_pair<16>, grid, block, 0, c->stream, P); break;
+    case 8: hipLaunchKernelGGL(k_pair<8>, grid, block, 0, c->stream, P); break;
+    case 4: hipLaunchKernelGGL(k_pair<4>, grid, block, 0, c->stream, P); break;
+    case 2: hipLaunchKernelGGL(k_pair<2>, grid, block, 0, c->stream, P); break;
+    default: hipLaunchKernelGGL(k_pair<1>, grid, block, 0, c->stream, P); break;
+  }
+}
+static void launch_chain(trx2_ctx* c, int B, int mode, int nruns, int max_evals) {
+  ChainArgs A = chain_args(c, B, mode, nruns, max_evals);
+  dim3 grid(B), block(CHAIN_THREADS);
+  if (c->L <= CHAIN_THREADS) hipLaunchKernelGGL(k_chain<1>, grid, block, 0, c->stream, A);
+  else if (c->L <= 2 * CHAIN_THREADS) hipLaunchKernelGGL(k_chain<2>, grid, block, 0, c->stream, A);
+  else hipLaunchKernelGGL(k_chain<4>, grid, block, 0, c->stream, A);
+}
+
+static int upload_single_run(trx2_ctx* ctx, const float* w, int sep_lo, int sep_hi) {
+  trx2_run r;
+  memset(&r, 0, sizeof r);
+  for (int k = 0; k < TRX2_NW; k++) r.w[k] = w[k];
+  r.max_iter = 1; r.sep_lo = sep_lo; r.sep_hi = sep_hi;
+  HIPCHK(hipMemcpyAsync(ctx->runs, &r, sizeof r, hipMemcpyHostToDevice, ctx->stream));
+  return 0;
+}
+
+extern "C" int trx2_eval_batch(trx2_ctx* ctx, int B, const float* tors, const float* w, int sep_lo, int sep_hi,
+                               double* e_terms, double* f_total, float* grad, float* xyz) {
+  if (!ctx) return 1;
+  if (!ctx->L) { ctx->err = "trx2_eval_batch: no map set"; return 1; }
+  if (B < 1 || !tors || !w) { ctx->err = "trx2_eval_batch: bad arguments"; return 1; }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ensure_batch(ctx, B)) return 1;
+  const int L = ctx->L;
+  const size_t BL = (size_t)B * L;
+  if (upload_single_run(ctx, w, sep_lo, sep_hi)) return 1;
+  HIPCHK(hipMemcpyAsync(ctx->tors0, tors, sizeof(float) * BL * 3, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->st_i, 0, sizeof(int) * B * SI_N, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->st_d, 0, sizeof(double) * B * SD_N, ctx->stream));
+  hipLaunchKernelGGL(k_init_torsions, dim3((unsigned)((BL + 255) / 256)), dim3(256), 0, ctx->stream, L, B, 0ull, 0u,
+                     ctx->tors0, ctx->X, ctx->XT);
+  launch_chain(ctx, B, MODE_INIT, 1, 1 << 30);
+  launch_pair(ctx, B);
+  launch_chain(ctx, B, MODE_FINISH, 1, 1 << 30);
+  HIPCHK(hipGetLastError());
+  if (e_terms) HIPCHK(hipMemcpyAsync(e_terms, ctx->e_last, sizeof(double) * B * TRX2_NTERMS, hipMemcpyDeviceToHost, ctx->stream));
+  if (f_total) HIPCHK(hipMemcpyAsync(f_total, ctx->f_last, sizeof(double) * B, hipMemcpyDeviceToHost, ctx->stream));
+  if (grad) HIPCHK(hipMemcpyAsync(grad, ctx->grad, sizeof(float) * BL * 3, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<float> tmp;
+  if (xyz) {
+    tmp.resize(BL * 16);
+    HIPCHK(hipMemcpyAsync(tmp.data(), ctx->xyz, sizeof(float) * BL * 16, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (xyz)
+    for (size_t i = 0; i < BL; i++) memcpy(xyz + i * 15, tmp.data() + i * 16, 15 * sizeof(float));
+  return 0;
+}
+
+extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint64_t seed, uint32_t decoy0,
+                               const float* tors0, int max_evals, float* tors_out, float* xyz_out, double* e_terms,
+                               double* f_final, int* status, int* n_evals, int* n_iters) {
+  if (!ctx) return 1;
+  if (!ctx->L) { ctx->err = "trx2_fold_batch: no map set"; return 1; }
+  if (B < 1 || !runs || nruns < 1 || nruns > TRX2_MAX_RUNS) { ctx->err = "trx2_fold_batch: bad arguments"; return 1; }
+  for (int i = 0; i < nruns; i++)
+    if (runs[i].cartesian) { ctx->err = "trx2_fold_batch: Cartesian-space runs are not implemented"; return 1; }
+  if (max_evals <= 0) max_evals = 1 << 30;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ensure_batch(ctx, B)) return 1;
+  const int L = ctx->L;
+  const size_t BL = (size_t)B * L;
+  auto t0 = std::chrono::steady_clock::now();
+  HIPCHK(hipMemcpyAsync(ctx->runs, runs, sizeof(trx2_run) * nruns, hipMemcpyHostToDevice, ctx->stream));
+  if (tors0) HIPCHK(hipMemcpyAsync(ctx->tors0, tors0, sizeof(float) * BL * 3, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->st_i, 0, sizeof(int) * B * SI_N, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->st_d, 0, sizeof(double) * B * SD_N, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->done_count, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(k_init_torsions, dim3((unsigned)((BL + 255) / 256)), dim3(256), 0, ctx->stream, L, B, seed, decoy0,
+                     tors0 ? ctx->tors0 : (const float*)nullptr, ctx->X, ctx->XT);
+  launch_chain(ctx, B, MODE_INIT, nruns, max_evals);
+  int launches = 0;
+  const int chunk = 64;
+  // hard cap on launches: every decoy stops by itself at max_evals; the extra margin covers skipped runs
+  const long cap = (long)max_evals + 64;
+  while (true) {
+    for (int i = 0; i < chunk; i++) {
+      launch_pair(ctx, B);
+      launch_chain(ctx, B, MODE_STEP, nruns, max_evals);
+    }
+    launches += chunk;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(ctx->h_done, ctx->done_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (*ctx->h_done >= B || launches >= cap) break;
+  }
+  // final report: energies of the accepted point X under the last run's weights
+  HIPCHK(hipMemcpyAsync(ctx->XT, ctx->X, sizeof(float4) * BL, hipMemcpyDeviceToDevice, ctx->stream));
+  {
+    std::vector<int> sti((size_t)B * SI_N);
+    HIPCHK(hipMemcpyAsync(sti.data(), ctx->st_i, sizeof(int) * B * SI_N, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < B; i++) {
+      if (status) status[i] = sti[(size_t)i * SI_N + SI_PHASE] == PH_DONE ? sti[(size_t)i * SI_N + SI_STATUS] : TRX2_MAXEVAL;
+      if (n_evals) n_evals[i] = sti[(size_t)i * SI_N + SI_NEVALS];
+      if (n_iters) n_iters[i] = sti[(size_t)i * SI_N + SI_NITERS];
+      sti[(size_t)i * SI_N + SI_RUN] = nruns - 1;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->st_i, sti.data(), sizeof(int) * B * SI_N, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  launch_chain(ctx, B, MODE_INIT, nruns, max_evals);
+  launch_pair(ctx, B);
+  launch_chain(ctx, B, MODE_FINISH, nruns, max_evals);
+  HIPCHK(hipGetLastError());
+  std::vector<float> tmpx, tmpt;
+  if (xyz_out) { tmpx.resize(BL * 16); HIPCHK(hipMemcpyAsync(tmpx.data(), ctx->xyz, sizeof(float) * BL * 16, hipMemcpyDeviceToHost, ctx->stream)); }
+  if (tors_out) { tmpt.resize(BL * 4); HIPCHK(hipMemcpyAsync(tmpt.data(), ctx->X, sizeof(float4) * BL, hipMemcpyDeviceToHost, ctx->stream)); }
+  if (e_terms) HIPCHK(hipMemcpyAsync(e_terms, ctx->e_last, sizeof(double) * B * TRX2_NTERMS, hipMemcpyDeviceToHost, ctx->stream));
+  if (f_final) HIPCHK(hipMemcpyAsync(f_final, ctx->f_last, sizeof(double) * B, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (xyz_out) for (size_t i = 0; i < BL; i++) memcpy(xyz_out + i * 15, tmpx.data() + i * 16, 15 * sizeof(float));
+  if (tors_out) for (size_t i = 0; i < BL; i++) memcpy(tors_out + i * 3, tmpt.data() + i * 4, 3 * sizeof(float));
+  ctx->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  ctx->last_launches = launches;
+  return 0;
+}
+
+extern "C" int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int sep_lo, int sep_hi, int n_rep,
+                                     double* ms_avg, double* term_evals) {
+  if (!ctx) return 1;
+  if (!ctx->L || !ctx->xyzT || B > ctx->Bcap || B < 1 || n_rep < 1) { ctx->err = "trx2_time_pair_kernel: run an eval/fold batch of this size first"; return 1; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const int L = ctx->L;
+  // weights / separation window for every decoy
+  std::vector<float> wc((size_t)ctx->Bpad * 8, 0.0f);
+  for (int i = 0; i < B; i++) {
+    float* p = wc.data() + (size_t)i * 8;
+    p[0] = w[0]; p[1] = w[1]; p[2] = w[2]; p[3] = w[3]; p[4] = (float)sep_lo; p[5] = (float)sep_hi; p[6] = 1.0f;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->wcur, wc.data(), wc.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  launch_pair(ctx, B);  // warm
+  HIPCHK(hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < n_rep; i++) launch_pair(ctx, B);
+  HIPCHK(hipEventRecord(e1, ctx->stream));
+  HIPCHK(hipEventSynchronize(e1));
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  HIPCHK(hipEventDestroy(e0));
+  HIPCHK(hipEventDestroy(e1));
+  if (ms_avg) *ms_avg = (double)ms / n_rep;
+  if (term_evals) {
+    std::vector<unsigned char> sel((size_t)L * L);
+    HIPCHK(hipMemcpy(sel.data(), ctx->sel, sel.size(), hipMemcpyDeviceToHost));
+    double n = 0;
+    for (int a = 0; a < L; a++)
+      for (int b = 0; b < L; b++) {
+        int sep = abs(a - b);
+        if (sep < sep_lo || sep >= sep_hi) continue;
+        unsigned m = sel[(size_t)a * L + b];
+        n += (m & 1) + ((m >> 1) & 1) + ((m >> 2) & 1) + ((m >> 3) & 1);
+      }
+    *term_evals = n * B;
+  }
+  return 0;
+}
+
+extern "C" int trx2_last_fold_stats(trx2_ctx* ctx, double* seconds, int* n_launches) {
+  if (!ctx) return 1;
+  if (seconds) *seconds = ctx->last_seconds;
+  if (n_launches) *n_launches = ctx->last_launches;
+  return 0;
+}
