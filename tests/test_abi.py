@@ -1,0 +1,55 @@
+"""CPU: the C-ABI library loads and exports every symbol include/trx2fold.h declares (no compute without a GPU)."""
+import ctypes
+import importlib
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared():
+    txt = open(os.path.join(ROOT, "include", "trx2fold.h")).read()
+    return sorted(set(re.findall(r"^(?:int|void|const char\*)\s+(trx2_[a-z_0-9]+)\(", txt, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    pkg = importlib.import_module("trrosettax2-dynamics_amd")
+    names = declared()
+    assert len(names) >= 10
+    lib = ctypes.CDLL(pkg._lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.trx2_abi_version() == 1
+
+
+def test_missing_gpu_fails_loudly_instead_of_falling_back():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    pkg = importlib.import_module("trrosettax2-dynamics_amd")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.Context(0)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkgdir = os.path.join(ROOT, "trrosettax2-dynamics_amd")
+    for dp, _, fs in os.walk(pkgdir):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "trx2_oracle" not in src and "libtrx2oracle" not in src, f
+
+
+def test_protocol_mode2_matches_reference_script():
+    """folding.py:119,164-171 + utils_ros.py:699-703: 5 guarded declash runs, 3 x sf, 1 x sf_cart, 5 guarded sf1."""
+    P = importlib.import_module("trrosettax2-dynamics_amd").protocol
+    runs = P.build_runs(90, 2)
+    assert len(runs) == 14
+    assert all(r["precheck"] == 1 and r["skip_to"] == 5 and r["max_iter"] == 500 and r["sep_hi"] == 0 for r in runs[:5])
+    assert [r["w"] for r in runs[5:8]] == [P.SF] * 3 and all(r["max_iter"] == 1000 for r in runs[5:9])
+    assert runs[8]["w"] == P.SF_CART
+    assert all(r["w"] == P.SF1 and r["precheck"] == 1 and r["skip_to"] == 14 for r in runs[9:])
+    assert [(r["sep_lo"], r["sep_hi"]) for r in P.build_runs(90, 0)[5:8]] == [(1, 12)] * 3

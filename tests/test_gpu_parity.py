@@ -1,0 +1,140 @@
+"""GPU: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerances (device arithmetic is float32, the oracle float64):
+  tables   : masks / summed probabilities / knots bit-identical; y identical after the float32 cast except where the
+             device's f64 log differs from libm's in the last ulp AND that flips the 3rd/5th printed decimal
+             (<= 1 unit, < 0.1 % of entries); y'' to 1e-5 relative.
+  NeRF     : 1e-3 A on coordinates of magnitude <= ~150 A (float32 eps 6e-8 x 90 composed frames).
+  energies : 1e-4 relative + 0.05 absolute per term; gradient: 5e-3 of the largest component.
+  fold     : outcome level -- statuses, energy depth and C-alpha RMSD to the reference's PyRosetta decoys.
+"""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+from oracle.kabsch import kabsch_rmsd
+
+T = importlib.import_module("trrosettax2-dynamics_amd")
+SF = np.array(T.protocol.SF, np.float64)
+
+
+@pytest.fixture(scope="module")
+def maps(golden_dir):
+    return {t: np.load(os.path.join(golden_dir, f"seq_{t}.npz")) for t in ("NMR", "Xray")}
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = T.Context(0)
+    yield c
+    c.close()
+
+
+def start_torsions(B, L, seed, noise=0.05):
+    rng = np.random.default_rng(seed)
+    return np.stack([O.random_torsions(L, seed, d) + rng.normal(size=(L, 3)) * noise for d in range(B)])
+
+
+@pytest.mark.parametrize("tag", ["NMR", "Xray"])
+def test_tables_match_oracle(ctx, maps, seq, tag):
+    m = maps[tag]
+    ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+    Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"])
+    gen, sel, kn = Tb.mask(False), Tb.mask(True), Tb.knots()
+    for ch, bit in (("dist", 1), ("omega", 2), ("theta", 4), ("phi", 8)):
+        d = ctx.get_tables(ch)
+        assert np.array_equal(d["gen"], gen) and np.array_equal(d["sel"], sel)
+        assert np.array_equal(d["prob"], Tb.prob(ch)), ch
+        assert np.array_equal(d["knots"], kn[ch].astype(np.float32)), ch
+        rows = (gen & bit) > 0
+        scale = 1e5 if ch == "omega" else 1e3
+        dy = np.abs(np.rint(d["y"][rows].astype(np.float64) * scale) - np.rint(Tb.y(ch)[rows] * scale))
+        assert dy.max() <= 1 and (dy > 0).mean() < 1e-3, (ch, dy.max(), (dy > 0).mean())
+        exact = dy.max(axis=-1) == 0  # compare y'' only on rows whose y agree exactly
+        assert np.allclose(d["y2"][rows][exact], Tb.y2(ch)[rows][exact], rtol=1e-5, atol=1e-5), ch
+
+
+@pytest.mark.parametrize("B", [1, 2, 5, 64, 70])
+def test_eval_matches_oracle(ctx, maps, seq, B):
+    m = maps["NMR"]
+    ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+    Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"])
+    tors = start_torsions(B, 90, 11 + B)
+    f, e, g, xyz = ctx.eval_batch(tors, SF)
+    for d in sorted(set([0, B // 2, B - 1])):
+        fo, eo, go, xo = O.evaluate(Tb, tors[d].astype(np.float32).astype(np.float64), SF)
+        assert np.abs(xyz[d] - xo).max() < 1e-3, ("xyz", d, np.abs(xyz[d] - xo).max())
+        assert np.all(np.abs(e[d, :7] - eo[:7]) <= 1e-4 * np.abs(eo[:7]) + 0.05), ("terms", d, e[d], eo)
+        assert abs(f[d] - fo) <= 1e-4 * abs(fo) + 0.5, ("total", d, f[d], fo)
+        assert np.abs(g[d] - go).max() <= 5e-3 * np.abs(go).max(), ("grad", d, np.abs(g[d] - go).max(), np.abs(go).max())
+
+
+def test_eval_no_orient_and_separation_window(ctx, maps, seq):
+    """--no-orient (dist only, arguments.py:16) and the add_rst separation window (utils_ros.py:719)."""
+    m = maps["Xray"]
+    ctx.set_map(m["dist"], seq=seq)
+    Tb = O.Tables(m["dist"])
+    tors = start_torsions(3, 90, 5)
+    for lo, hi in ((1, 90), (3, 24), (12, 90)):
+        f, e, g, _ = ctx.eval_batch(tors, SF, lo, hi)
+        fo, eo, go, _ = O.evaluate(Tb, tors[1].astype(np.float32).astype(np.float64), SF, lo, hi)
+        assert e[1, 1] == 0 and e[1, 2] == 0 and e[1, 3] == 0
+        assert abs(e[1, 0] - eo[0]) <= 1e-4 * abs(eo[0]) + 0.05, (lo, hi, e[1, 0], eo[0])
+        assert np.abs(g[1] - go).max() <= 5e-3 * np.abs(go).max()
+
+
+def test_eval_is_bitwise_reproducible(ctx, maps, seq):
+    """no atomics anywhere on the path: the same inputs give the same bits."""
+    m = maps["NMR"]
+    ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+    tors = start_torsions(64, 90, 3)
+    a, b = ctx.eval_batch(tors, SF), ctx.eval_batch(tors, SF)
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+
+
+def test_fold_reaches_reference_decoys(ctx, maps, seq, golden_dir):
+    """Outcome parity: fold the committed NMR map and compare with the reference's PyRosetta decoys
+    conf_2_1 / conf_2_2 (NMR/initial0,1).  Their own mutual RMSD is 0.86 A; criterion median <= 0.5 + 0.86 A."""
+    m = maps["NMR"]
+    ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+    dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    B = 16
+    r = ctx.fold_batch(B, T.protocol.build_runs(90, 2), seed=2024)
+    assert np.all(r["status"] == 0), r["status"]
+    assert np.all(np.isfinite(r["xyz"])) and np.all(np.isfinite(r["f"]))
+    x = r["xyz"]
+    ca = x[:, :, 1]
+    cc = np.linalg.norm(ca[:, 1:] - ca[:, :-1], axis=-1)
+    dw = np.degrees(np.abs((r["tors"][:, :-1, 2] % (2 * np.pi)) - np.pi))
+    best = np.array([min(kabsch_rmsd(ca[i], dec[k][:, 1]) for k in ("conf_2_1", "conf_2_2")) for i in range(B)])
+    print("\nfold: evals", r["n_evals"].min(), r["n_evals"].max(), "iters", r["n_iters"].min(), r["n_iters"].max(),
+          "seconds", round(r["seconds"], 3), "launches", r["launches"], "\n rmsd", np.round(np.sort(best), 2),
+          "\n CA-CA min", np.round(cc.min(1), 2), "\n |dw|max", np.round(dw.max(1), 0),
+          "\n dist", np.round(r["e_terms"][:, 0], 0), "\n theta", np.round(r["e_terms"][:, 2], 0))
+    # torsion-space moves keep the ideal bond lengths exactly (trx2_model.h), whatever omega does
+    for (i, j, shift, want) in ((0, 1, 0, 1.458), (1, 2, 0, 1.524), (2, 0, 1, 1.334), (2, 3, 0, 1.232)):
+        p, q = (x[:, :-1, i], x[:, 1:, j]) if shift else (x[:, :, i], x[:, :, j])
+        assert np.abs(np.linalg.norm(p - q, axis=-1) - want).max() < 2e-3, (i, j, want)
+    # the returned coordinates are exactly the backbone of the returned torsions (device NeRF vs oracle NeRF)
+    for i in (0, 1, B // 2, B - 1):
+        xo = O.nerf(r["tors"][i].astype(np.float64))
+        assert np.abs(x[i] - xo).max() < 1e-3, (i, np.abs(x[i] - xo).max())
+    # CA(i)-CA(i+1) is a function of omega alone; its range is [cis, trans], both COMPUTED from the model's ideal
+    # geometry (2.7789 / 3.8093 A) rather than typed in.  It is NOT "3.8 everywhere": the reference's own conf_1_1 has
+    # one at 3.19 A, and the shared energy model lets a few peptides twist (known deviations).
+    def ca_ca(omega_deg):
+        t = np.zeros((2, 3)); t[0, 2] = np.radians(omega_deg)
+        xx = O.nerf(t)
+        return np.linalg.norm(xx[1, 1] - xx[0, 1])
+    cis, trans = ca_ca(0.0), ca_ca(180.0)
+    assert cis - 2e-3 <= cc.min() and cc.max() <= trans + 2e-3, (cc.min(), cc.max(), cis, trans)
+    assert np.median(best) <= 0.5 + 0.86, np.sort(best)
+    # depth of optimisation: restraint energies of the reference decoys under the same tables are
+    # dist -19679/-19689, theta -28121/-28288
+    assert np.median(r["e_terms"][:, 0]) < -19000 and np.median(r["e_terms"][:, 2]) < -27000, r["e_terms"][:, :4].mean(0)

@@ -1,0 +1,123 @@
+"""CPU: pin the oracle (oracle/trx2_oracle.c) to vectors captured from the reference (tests/golden/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+BITS = {"dist": 1, "omega": 2, "theta": 4, "phi": 8}
+
+
+@pytest.mark.parametrize("tag", ["NMR", "Xray"])
+def test_tables_match_reference_gen_rst(golden_dir, tag):
+    """gen_rst (utils_ros.py:6-146): same restraint set, same probabilities, same knots; table values exact for
+    dist (float64 path) and within one unit of the last printed decimal for the float32 angle channels, where
+    numpy's float32 log differs from libm's in the last bit for a small fraction of entries."""
+    npz = np.load(os.path.join(golden_dir, f"seq_{tag}.npz"))
+    gold = np.load(os.path.join(golden_dir, f"gen_rst_{tag}.npz"))
+    T = O.Tables(npz["dist"], npz["omega"], npz["theta"], npz["phi"])
+    kn, gen = T.knots(), T.mask(False)
+    for ch, bit in BITS.items():
+        a, b, p, x, yi, sc = [gold[f"{ch}_{k}"] for k in ("a", "b", "p", "x", "yi", "scale")]
+        ga, gb = np.nonzero(gen & bit)
+        assert np.array_equal(ga, a) and np.array_equal(gb, b), f"{ch}: restraint set differs"
+        assert np.array_equal(kn[ch], x), f"{ch}: knots differ"
+        assert np.array_equal(T.prob(ch)[a, b].astype(np.float64), p), f"{ch}: summed probabilities differ"
+        diff = np.abs(np.rint(T.y(ch)[a, b] * sc).astype(np.int64) - yi)
+        if ch == "dist":
+            assert diff.max() == 0
+        else:
+            assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (ch, diff.max(), (diff > 0).mean())
+
+
+def test_selection_counts_match_survey(golden_dir):
+    """add_rst thresholds (utils_ros.py:719-723) on the NMR map: 3226 / 2562 / 5142 / 2541."""
+    npz = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
+    sel = O.Tables(npz["dist"], npz["omega"], npz["theta"], npz["phi"]).mask(True)
+    assert [int((sel & b > 0).sum()) for b in (1, 2, 4, 8)] == [3226, 2562, 5142, 2541]
+
+
+def test_no_orient_builds_dist_only(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "gen_rst_noorient.json")))
+    npz = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
+    T = O.Tables(npz["dist"])
+    assert not T.use_orient and g["NMR"]["channels"] == ["dist"]
+    assert int((T.mask(False) & 1 > 0).sum()) == g["NMR"]["n_dist"]
+
+
+def test_geometry_matches_reference_get_neighbors(golden_dir, seq):
+    """dihedral / angle conventions vs get_neighbors (utils_trX2dy/utils.py:125-182) on decoy conf_2_1."""
+    dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    fb = np.load(os.path.join(golden_dir, "feedback_NMR.npz"))
+    X = dec["conf_2_1"].astype(np.float64)
+    N, CA, C = X[:, 0], X[:, 1], X[:, 2]
+    b, c = CA - N, C - CA
+    vCB = -0.58273431 * np.cross(b, c) + 0.56802827 * b - 0.54067466 * c + CA
+    CB = np.where(np.array([s == "G" for s in seq])[:, None], vCB, X[:, 4])
+    worst = np.zeros(4)
+    for i in range(0, 90, 5):
+        for j in range(90):
+            if i == j or fb["dist6d"][i, j] == 0:
+                continue
+            got = (np.linalg.norm(CB[i] - CB[j]), O.dihedral(CA[i], CB[i], CB[j], CA[j]),
+                   O.dihedral(N[i], CA[i], CB[i], CB[j]), O.angle(CA[i], CB[i], CB[j]))
+            ref = (fb["dist6d"][i, j], fb["omega6d"][i, j], fb["theta6d"][i, j], fb["phi6d"][i, j])
+            worst = np.maximum(worst, np.abs(np.array(got) - np.array(ref)))
+    assert worst.max() < 2e-5, worst  # the reference computed these in float32
+
+
+def test_random_start_table(golden_dir):
+    """random_dihedral thresholds (utils_ros.py:674-696): replay the reference's draws through the same cut table."""
+    import random
+    rd = json.load(open(os.path.join(golden_dir, "random_dihedral.json")))
+    cum = [0.135, 0.29, 0.363, 0.485, 0.982, 2.0]
+    tab = [(-140, 153), (-72, 145), (-122, 117), (-82, -14), (-61, -41), (57, 39)]
+    for s, draws in rd.items():
+        random.seed(int(s))
+        for want in draws:
+            r = random.random()
+            k = next(i for i, c in enumerate(cum) if r <= c)
+            assert list(tab[k]) == want
+    t = O.random_torsions(90, 7, 3)
+    assert np.allclose(t[-1], np.radians([180, 180, 180])) and np.allclose(t[:, 2], np.pi)
+    assert {tuple(np.round(np.degrees(v[:2])).astype(int)) for v in t[:-1]} <= set(tab)
+
+
+def test_gradients_by_finite_differences(golden_dir):
+    rng = np.random.default_rng(0)
+    P = rng.normal(size=(4, 3)) * 2
+    for fn, n in ((O.dihedral, 4), (O.angle, 3)):
+        _, g = fn(*P[:n], grad=True)
+        fd = np.zeros((n, 3))
+        for k in range(n):
+            for c in range(3):
+                Pp, Pm = P[:n].copy(), P[:n].copy()
+                Pp[k, c] += 1e-6; Pm[k, c] -= 1e-6
+                fd[k, c] = (fn(*Pp) - fn(*Pm)) / 2e-6
+        assert np.abs(fd - g).max() < 1e-7
+    npz = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
+    T = O.Tables(npz["dist"], npz["omega"], npz["theta"], npz["phi"])
+    t0 = O.random_torsions(90, 1, 0) + rng.normal(size=(90, 3)) * 0.05
+    w = np.array([5, 4, 4, 1, 1, 0.5, 0, 0.0])
+    _, _, g, _ = O.evaluate(T, t0, w)
+    for i, k in [(5, 0), (5, 1), (5, 2), (40, 0), (40, 1), (40, 2), (88, 1), (0, 1), (89, 0)]:
+        tp, tm = t0.copy(), t0.copy()
+        tp[i, k] += 1e-6; tm[i, k] -= 1e-6
+        fd = (O.evaluate(T, tp, w, grad=False)[0] - O.evaluate(T, tm, w, grad=False)[0]) / 2e-6
+        assert abs(fd - g[i, k]) <= 1e-5 * (1 + abs(fd)), (i, k, fd, g[i, k])
+
+
+def test_nerf_reproduces_torsions_and_ideal_geometry():
+    rng = np.random.default_rng(3)
+    L = 40
+    t = rng.uniform(-np.pi, np.pi, size=(L, 3))
+    xyz = O.nerf(t)
+    w = lambda x: (x + np.pi) % (2 * np.pi) - np.pi
+    for i in range(L - 1):
+        assert abs(w(O.dihedral(xyz[i, 0], xyz[i, 1], xyz[i, 2], xyz[i + 1, 0]) - t[i, 1])) < 1e-9
+        assert abs(w(O.dihedral(xyz[i, 1], xyz[i, 2], xyz[i + 1, 0], xyz[i + 1, 1]) - t[i, 2])) < 1e-9
+        assert abs(w(O.dihedral(xyz[i, 2], xyz[i + 1, 0], xyz[i + 1, 1], xyz[i + 1, 2]) - t[i + 1, 0])) < 1e-9
+    assert np.allclose(np.linalg.norm(xyz[:, 1] - xyz[:, 0], axis=-1), 1.458)
+    assert np.allclose(np.linalg.norm(xyz[1:, 0] - xyz[:-1, 2], axis=-1), 1.334)

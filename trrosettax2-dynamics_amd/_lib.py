@@ -1,0 +1,161 @@
+"""ctypes binding of libtrx2fold.so (C ABI: include/trx2fold.h).
+
+There is NO CPU fallback: if the HIP library is missing or no GPU is usable, every call raises.  The oracle
+under oracle/ is test infrastructure and is never imported from here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrx2fold.so")
+NTERMS, NW = 8, 8
+K = (35, 28, 28, 16)
+TERM_NAMES = ("dist", "omega", "theta", "phi", "vdw", "rama", "omega_bb", "cart")
+
+
+class Params(C.Structure):
+    """trx2_params: folding/data/params.json + -pd (folding/utils_ros/arguments.py:11)"""
+    _fields_ = [("ebase", C.c_double), ("erep", C.c_double * 3), ("drep", C.c_double * 3), ("meff", C.c_double),
+                ("dcut", C.c_double), ("alpha", C.c_double), ("dstep", C.c_double), ("astep_deg", C.c_double),
+                ("pcut", C.c_double)]
+
+
+class Run(C.Structure):
+    """trx2_run (include/trx2_model.h)"""
+    _fields_ = [("w", C.c_float * NW), ("max_iter", C.c_int), ("sep_lo", C.c_int), ("sep_hi", C.c_int),
+                ("precheck", C.c_int), ("skip_to", C.c_int), ("cartesian", C.c_int), ("pad0", C.c_int), ("pad1", C.c_int)]
+
+
+DEFAULT_PARAMS = dict(ebase=-0.5, erep=(10.0, 3.0, 0.5), drep=(0.0, 2.0, 3.5), meff=1e-4, dcut=19.5, alpha=1.57,
+                      dstep=0.5, astep_deg=15.0, pcut=0.05)
+
+
+def make_params(**kw):
+    d = {**DEFAULT_PARAMS, **kw}
+    p = Params()
+    p.ebase, p.meff, p.dcut, p.alpha, p.dstep, p.astep_deg, p.pcut = (d[k] for k in ("ebase", "meff", "dcut", "alpha", "dstep", "astep_deg", "pcut"))
+    for i in range(3):
+        p.erep[i] = d["erep"][i]
+        p.drep[i] = d["drep"][i]
+    return p
+
+
+def make_runs(runs):
+    arr = (Run * len(runs))()
+    for i, r in enumerate(runs):
+        for k in range(NW):
+            arr[i].w[k] = float(r["w"][k])
+        arr[i].max_iter, arr[i].sep_lo, arr[i].sep_hi = int(r["max_iter"]), int(r["sep_lo"]), int(r["sep_hi"])
+        arr[i].precheck, arr[i].skip_to, arr[i].cartesian = int(r.get("precheck", 0)), int(r.get("skip_to", 0)), int(r.get("cartesian", 0))
+    return arr
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library or raise -- never degrade to a CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `make -C {_HERE}/csrc` (or __graft_entry__.build()); "
+                           "there is no CPU fallback for the fold path")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+    L.trx2_abi_version.restype = C.c_int
+    L.trx2_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.trx2_ctx_destroy.argtypes = [vp]
+    L.trx2_ctx_destroy.restype = None
+    L.trx2_last_error.argtypes = [vp]
+    L.trx2_last_error.restype = C.c_char_p
+    L.trx2_set_map.argtypes = [vp, C.c_int, C.c_char_p, vp, vp, vp, vp, C.POINTER(Params)]
+    L.trx2_set_map_device.argtypes = [vp, C.c_int, C.c_char_p, vp, vp, vp, vp, C.POINTER(Params)]
+    L.trx2_get_tables.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    L.trx2_eval_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.trx2_fold_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_uint64, C.c_uint32, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.trx2_time_pair_kernel.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, dp, dp]
+    L.trx2_last_fold_stats.argtypes = [vp, dp, ip]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One GPU stream + one distogram.  Mirrors what one folding.py process holds (folding/folding.py:48-63)."""
+
+    def __init__(self, device=0):
+        self._l = load()
+        h = C.c_void_p()
+        rc = self._l.trx2_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"trx2_ctx_create(device={device}) failed with code {rc}: no usable GPU (no CPU fallback)")
+        self._h = h
+        self.L = 0
+        self.use_orient = False
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.trx2_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self._l.trx2_last_error(self._h).decode()}")
+
+    def set_map(self, dist, omega=None, theta=None, phi=None, seq=None, **params):
+        arrs = [np.ascontiguousarray(a, np.float32) if a is not None else None for a in (dist, omega, theta, phi)]
+        L = int(arrs[0].shape[0])
+        for a, nb in zip(arrs, (37, 25, 25, 13)):
+            if a is not None and a.shape != (L, L, nb):
+                raise ValueError(f"expected shape {(L, L, nb)}, got {a.shape}")
+        s = (seq or "A" * L).encode()
+        self._chk(self._l.trx2_set_map(self._h, L, s, *[_p(a) for a in arrs], C.byref(make_params(**params))), "trx2_set_map")
+        self.L, self.use_orient = L, all(a is not None for a in arrs)
+
+    def get_tables(self, ch):
+        i = ("dist", "omega", "theta", "phi").index(ch)
+        L = self.L
+        yy = np.zeros((L, L, K[i], 2), np.float32); kn = np.zeros(K[i], np.float32); pr = np.zeros((L, L), np.float32)
+        gen = np.zeros((L, L), np.uint8); sel = np.zeros((L, L), np.uint8)
+        self._chk(self._l.trx2_get_tables(self._h, i, _p(yy), _p(kn), _p(pr), _p(gen), _p(sel)), "trx2_get_tables")
+        return dict(y=yy[..., 0], y2=yy[..., 1], knots=kn, prob=pr, gen=gen, sel=sel)
+
+    def eval_batch(self, tors, w, sep_lo=1, sep_hi=None):
+        tors = np.ascontiguousarray(tors, np.float32)
+        B, L = tors.shape[0], self.L
+        assert tors.shape == (B, L, 3)
+        w = np.ascontiguousarray(w, np.float32)
+        e = np.zeros((B, NTERMS)); f = np.zeros(B); g = np.zeros((B, L, 3), np.float32); xyz = np.zeros((B, L, 5, 3), np.float32)
+        self._chk(self._l.trx2_eval_batch(self._h, B, _p(tors), _p(w), int(sep_lo), int(L if sep_hi is None else sep_hi),
+                                          _p(e), _p(f), _p(g), _p(xyz)), "trx2_eval_batch")
+        return f, e, g, xyz
+
+    def fold_batch(self, B, runs, seed=0, decoy0=0, tors0=None, max_evals=0):
+        L = self.L
+        t0 = np.ascontiguousarray(tors0, np.float32) if tors0 is not None else None
+        if t0 is not None:
+            assert t0.shape == (B, L, 3)
+        arr = make_runs(runs)
+        tors = np.zeros((B, L, 3), np.float32); xyz = np.zeros((B, L, 5, 3), np.float32)
+        e = np.zeros((B, NTERMS)); f = np.zeros(B)
+        st = np.zeros(B, np.int32); ne = np.zeros(B, np.int32); ni = np.zeros(B, np.int32)
+        self._chk(self._l.trx2_fold_batch(self._h, B, arr, len(runs), int(seed), int(decoy0), _p(t0), int(max_evals), _p(tors),
+                                          _p(xyz), _p(e), _p(f), _p(st), _p(ne), _p(ni)), "trx2_fold_batch")
+        sec, nl = C.c_double(), C.c_int()
+        self._l.trx2_last_fold_stats(self._h, C.byref(sec), C.byref(nl))
+        return dict(tors=tors, xyz=xyz, e_terms=e, f=f, status=st, n_evals=ne, n_iters=ni, seconds=sec.value, launches=nl.value)
+
+    def time_pair_kernel(self, B, w, sep_lo=1, sep_hi=None, n_rep=50):
+        w = np.ascontiguousarray(w, np.float32)
+        ms, n = C.c_double(), C.c_double()
+        self._chk(self._l.trx2_time_pair_kernel(self._h, B, _p(w), int(sep_lo), int(self.L if sep_hi is None else sep_hi), int(n_rep),
+                                                C.byref(ms), C.byref(n)), "trx2_time_pair_kernel")
+        return ms.value, n.value
