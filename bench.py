@@ -1,0 +1,144 @@
+#!/usr/bin/env python
+"""bench.py -- decoys/sec of the MI355X-native fold, with the pair-kernel roofline and a CPU baseline.
+
+Contract:  python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank per GPU)
+prints ONE JSON line on rank 0.
+
+A "step" = one call of the hot path over one batch: fold B decoys of one distogram through the full staged protocol
+(folding/folding.py:118-171 mode 2), timed from tables-resident-in-HBM to the last coordinates on the host.
+Workload at N=1 = BASELINE.json configs[1]: L=150 single target, init_num=64, dist-only restraints (synthetic map,
+SURVEY.md 8d -- the reference ships data for L=90 only).  Other configs: --config 3 (all channels), --config 4 (L=400,
+B=32).  N>1: every rank folds its own B decoys of the same target (independent units, no data-path collective):
+weak scaling.
+
+Nothing here reads /root/reference.  The oracle is imported ONLY for the cpu_baseline leg (rank 0, N=1).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+CONFIGS = {
+    2: dict(L=150, B=64, orient=False, name="L=150 single target, init_num=64, dist-only, synthetic map seed 150"),
+    3: dict(L=150, B=64, orient=True, name="L=150 single target, init_num=64, dist+omega+theta+phi, synthetic map seed 150"),
+    4: dict(L=400, B=32, orient=True, name="L=400 single target, init_num=32, dist+omega+theta+phi, synthetic map seed 400"),
+}
+
+
+def algorithmic_bytes(B, n_terms_per_decoy, L):
+    """16 B per term-eval (one cubic segment) + 96*L B per decoy-eval (4 atoms x L x 12 B in and out)."""
+    return B * (16.0 * n_terms_per_decoy + 96.0 * L)
+
+
+def cpu_baseline(m, cfg, runs, budget_s=20.0):
+    """oracle (CPU restatement, single thread) on a bounded sample of the same workload"""
+    from oracle import oracle as O
+    Tb = O.Tables(m["dist"], *( [m["omega"], m["theta"], m["phi"]] if cfg["orient"] else [None, None, None]))
+    n, t0 = 0, time.time()
+    while True:
+        O.fold(Tb, O.random_torsions(cfg["L"], 12345, n), runs)
+        n += 1
+        el = time.time() - t0
+        if el + el / n > budget_s or n >= 16:
+            break
+    return dict(value=n / el, unit="decoys/sec", cores=1, kind="port",
+                sample=f"{n} decoys of the same map and protocol, oracle/trx2_oracle.c -O3 -march=native, 1 thread, {el:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    L, B = cfg["L"], cfg["B"]
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    T = importlib.import_module("trrosettax2-dynamics_amd")
+    synth = importlib.import_module("trrosettax2-dynamics_amd.synth")
+    m = synth.make_map(L)
+    runs = T.protocol.build_runs(L, 2)
+    ctx = T.Context(local_rank)
+    ctx.set_map(m["dist"], *( [m["omega"], m["theta"], m["phi"]] if cfg["orient"] else []), seq=m["seq"])
+
+    def step(i):
+        # distinct decoys for every step and rank (timed steps use indices 0.., warm-up steps 900..)
+        return ctx.fold_batch(B, runs, seed=150, decoy0=((rank * 1000 + i) * B))
+
+    def sync():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(900 + i)
+    sync()
+    t0 = time.perf_counter()
+    res = [step(i) for i in range(args.steps)]  # fold_batch returns with the coordinates on the host
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    ok = all(np.all(r["status"] == 0) and np.all(np.isfinite(r["xyz"])) for r in res)
+    evals = np.concatenate([r["n_evals"] for r in res])
+    launches = sum(r["launches"] for r in res)
+
+    # ---- roofline of the dominant kernel (pair terms), HIP events on the ctx stream, coordinates of the last batch
+    w = np.array(T.protocol.SF, np.float32)
+    ms, term_evals = ctx.time_pair_kernel(B, w, 1, L, n_rep=200)
+    n_terms = term_evals / B
+    abytes = algorithmic_bytes(B, n_terms, L)
+    achieved = abytes / (ms * 1e-3) / 1e9
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "decoys/sec", "value": world * args.steps * B / elapsed, "unit": "decoys/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["name"], "L": L, "decoys_per_step": B, "protocol": "mode 2, full staged minimisation",
+                       "parallelism": f"decoys sharded over {world} rank(s), no collective on the data path"},
+            "roofline": {"bound": "hbm", "kernel": f"k_pair<{min(64, 1 << (B - 1).bit_length())}>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": ms, "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": n_terms},
+            "all_decoys_converged": bool(ok), "evals_per_decoy": {"min": int(evals.min()), "median": float(np.median(evals)), "max": int(evals.max())},
+            "pair_launches_per_step": launches / args.steps,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(m, cfg, runs)
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
