@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrx2fold.so")
+# TRX2FOLD_LIB selects an alternative build of the SAME library (A/B timing of kernel variants); never a CPU path
+LIB_PATH = os.environ.get("TRX2FOLD_LIB") or os.path.join(_HERE, "libtrx2fold.so")
 NTERMS, NW = 8, 8
 K = (35, 28, 28, 16)
 TERM_NAMES = ("dist", "omega", "theta", "phi", "vdw", "rama", "omega_bb", "cart")

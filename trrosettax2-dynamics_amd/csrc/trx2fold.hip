@@ -187,8 +187,13 @@ __device__ __forceinline__ void spline_eval_dev(const float2* __restrict__ row, 
   de = inside ? dv : 0.0f;
 }
 
+// PAIR_MIN_WAVES (waves per SIMD the register allocator must admit) is a build-time knob so that occupancy-vs-spill
+// variants can be A/B-timed on hardware: 2 = no spills (220 VGPRs), 3 = 62 spilled, 4 = 104 spilled (profiles/README.md)
+#ifndef PAIR_MIN_WAVES
+#define PAIR_MIN_WAVES 2
+#endif
 template <int BW>
-__global__ __launch_bounds__(PAIR_THREADS) void k_pair(PairArgs A) {
+__global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs A) {
   constexpr int PW = 64 / BW;
   const int L = A.L;
   const int a = blockIdx.x, split = blockIdx.y, grp = blockIdx.z;
