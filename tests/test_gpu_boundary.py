@@ -1,0 +1,87 @@
+"""GPU: the drop-in boundary end to end -- launcher, CLI shim, iteration loop, final layout."""
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle.kabsch import kabsch_rmsd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FO = importlib.import_module("trrosettax2-dynamics_amd.fold")
+PL = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
+P = importlib.import_module("trrosettax2-dynamics_amd.pdbio")
+FB = importlib.import_module("trrosettax2-dynamics_amd.feedback")
+
+
+def test_folding_with_pred_npz_writes_the_reference_file_names(golden_dir, tmp_path, seq):
+    """utils.py:484-505: quoted paths, {out_name}{i}.pdb for repeat decoys, {out_name}.pdb for repeat=0"""
+    npz, fa, out = os.path.join(golden_dir, "seq_NMR.npz"), os.path.join(golden_dir, "seq.fasta"), str(tmp_path / "pdb")
+    FO.folding_with_pred_npz(f'"{npz}"', f'"{fa}"', out, "initial", "-m 2 --orient -r no-idp", repeat=3, seed=1)
+    FO.folding_with_pred_npz(f'"{npz}"', f'"{fa}"', out, "seq7", "-m 2 --no-orient -r no-idp", seed=2)
+    assert sorted(os.listdir(out)) == ["initial0.pdb", "initial1.pdb", "initial2.pdb", "seq7.pdb"]
+    scores = {}
+    for n in sorted(os.listdir(out)):
+        xyz, s = P.read_backbone(os.path.join(out, n))
+        assert s == seq and np.isfinite(xyz[:, :4]).all()
+        scores[n] = FB.calculate_reliability_score(os.path.join(out, n))
+        assert 0.0 < scores[n] <= 1.0
+    # No lower bound on the score here: the --no-orient decoy (seq7) is folded from distances alone, which cannot fix
+    # handedness -- in the shared energy model about half of such folds are mirror images with phi<=0 fractions of
+    # 0.6-0.9 (measured with the oracle; DESIGN.md, known deviations).  The score is what run_inference ranks by.
+    print("\nreliability scores:", {k: round(v, 3) for k, v in scores.items()})
+    with pytest.raises(ValueError):
+        FO.fold_arrays(np.load(npz), seq[:-1], 1)
+
+
+def test_cli_shim_accepts_the_reference_flags(golden_dir, tmp_path):
+    out = str(tmp_path / "o.pdb")
+    cmd = [sys.executable, os.path.join(ROOT, "folding", "folding.py"), "-NPZ", os.path.join(golden_dir, "seq_Xray.npz"), "-FASTA",
+           os.path.join(golden_dir, "seq.fasta"), "-OUT", out, "-m", "2", "--orient", "-r", "no-idp", "--fastrelax", "--seed", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "*** time:" in r.stdout and os.path.exists(out)
+    xyz, _ = P.read_backbone(out)
+    dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    rm = min(kabsch_rmsd(xyz[:, 1], dec[k][:, 1]) for k in ("conf_1_1", "conf_1_2"))
+    print("\nCLI decoy vs reference X-ray initials: %.2f A" % rm)
+    assert rm < 2.5
+
+
+def test_run_single_reproduces_the_example_layout(golden_dir, tmp_path):
+    """BASELINE config 1 plumbing (init_num=2, two models, angles on, Nmax=2): 8 files named like the committed example;
+    each compared with the reference decoy of the same provenance."""
+    save = str(tmp_path / "out")
+    n = PL.run_single("seq", os.path.join(golden_dir, "seq.fasta"), save, init_num=2, Nmax=2, angle=True, mult_two_models=True,
+                      npz_nmr=os.path.join(golden_dir, "seq_NMR.npz"), npz_xray=os.path.join(golden_dir, "seq_Xray.npz"), seed=11)
+    pdb_dir = os.path.join(save, "seq", "pred_pdb")
+    files = sorted(os.listdir(pdb_dir))
+    assert files == [f"conf_{m}_{k}.pdb" for m in (1, 2) for k in (1, 2, 3, 4)] and n == 8
+    assert not os.path.exists(os.path.join(save, "seq", "tmp_npz"))
+    assert sorted(os.listdir(os.path.join(save, "seq", "pred_npz"))) == ["seq_NMR.npz", "seq_Xray.npz"]
+    dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    rows = []
+    for f in files:
+        xyz, _ = P.read_backbone(os.path.join(pdb_dir, f))
+        k = f[:-4]
+        rows.append((k, kabsch_rmsd(xyz[:, 1], dec[k][:, 1]), kabsch_rmsd(xyz[:, 1], dec["apo"][:, 1]), kabsch_rmsd(xyz[:, 1], dec["holo"][:, 1])))
+    print("\nfile      vs same-provenance reference decoy / apo / holo (A)")
+    for r in rows:
+        print("  %-9s %5.2f %5.2f %5.2f" % r)
+    assert np.median([r[1] for r in rows]) < 2.0, rows
+    # summary.txt of the reference: best apo 3.018, best holo 3.931
+    print("  best apo %.2f (reference 3.02)  best holo %.2f (reference 3.93)" % (min(r[2] for r in rows), min(r[3] for r in rows)))
+
+
+def test_no_angle_iteration_converges_or_stops_at_nmax(golden_dir, tmp_path):
+    """--no-angle path (BASELINE configs[0]): dist-only restraints and dist/tmp-only npz files"""
+    tmpd, pdbd = str(tmp_path / "tmp"), str(tmp_path / "pdb")
+    last = PL.generate_npz_and_pdb("t", tmpd, pdbd, os.path.join(golden_dir, "seq_NMR.npz"), os.path.join(golden_dir, "seq.fasta"), N=2,
+                                   Nmax=2, angle=False, tta_opt="-m 2 --no-orient -r no-idp", seed=3)
+    assert last in (1, 2) and os.path.exists(os.path.join(pdbd, f"t{last}.pdb"))
+    z = np.load(os.path.join(tmpd, "t1.npz"))
+    assert sorted(z.files) == ["dist", "tmp"] and z["dist"].shape == (90, 90, 37)

@@ -134,7 +134,30 @@ def test_fold_reaches_reference_decoys(ctx, maps, seq, golden_dir):
         return np.linalg.norm(xx[1, 1] - xx[0, 1])
     cis, trans = ca_ca(0.0), ca_ca(180.0)
     assert cis - 2e-3 <= cc.min() and cc.max() <= trans + 2e-3, (cc.min(), cc.max(), cis, trans)
+    # The median hides gross failures, so count them: with all channels on, the oracle itself lands in the MIRROR-image
+    # topology (RMSD ~12 A, mirror ~3 A) for roughly 1 start in 6-20 -- report it, and bound it loosely.
+    n_gross = int((best > 3.0).sum())
+    print(" decoys with RMSD > 3 A (mirror-trapped / misfolded):", n_gross, "of", B)
+    assert n_gross <= B // 4, np.sort(best)
     assert np.median(best) <= 0.5 + 0.86, np.sort(best)
     # depth of optimisation: restraint energies of the reference decoys under the same tables are
     # dist -19679/-19689, theta -28121/-28288
     assert np.median(r["e_terms"][:, 0]) < -19000 and np.median(r["e_terms"][:, 2]) < -27000, r["e_terms"][:, :4].mean(0)
+
+
+@pytest.mark.parametrize("L,B", [(60, 3), (60, 32), (300, 4), (520, 2)])
+def test_eval_other_widths_and_long_chains(ctx, L, B):
+    """decoy-group widths 4 and 32 (B=3, 32) and the chain kernel's 2- and 4-residues-per-thread paths (L=300, 520),
+    on synthetic maps (the reference ships L=90 only)."""
+    S = importlib.import_module("trrosettax2-dynamics_amd.synth")
+    m = S.make_map(L, seed=L, n_moves=150)
+    ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=m["seq"])
+    Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"])
+    rng = np.random.default_rng(L + B)
+    tors = np.stack([m["tors"] + rng.normal(size=(L, 3)) * 0.08 for _ in range(B)])  # near the compact target
+    f, e, g, xyz = ctx.eval_batch(tors, SF)
+    for d in sorted({0, B - 1}):
+        fo, eo, go, xo = O.evaluate(Tb, tors[d].astype(np.float32).astype(np.float64), SF)
+        assert np.abs(xyz[d] - xo).max() < 3e-3, ("xyz", L, d, np.abs(xyz[d] - xo).max())
+        assert np.all(np.abs(e[d, :7] - eo[:7]) <= 2e-4 * np.abs(eo[:7]) + 0.1), ("terms", L, d, e[d], eo)
+        assert np.abs(g[d] - go).max() <= 1e-2 * np.abs(go).max(), ("grad", L, d, np.abs(g[d] - go).max(), np.abs(go).max())

@@ -1,0 +1,120 @@
+"""CPU: host logic around the fold -- feedback (pinned bit-for-bit to the reference), PDB I/O, option parsing, output layout."""
+import hashlib
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+F = importlib.import_module("trrosettax2-dynamics_amd.feedback")
+P = importlib.import_module("trrosettax2-dynamics_amd.pdbio")
+FO = importlib.import_module("trrosettax2-dynamics_amd.fold")
+PL = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
+sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def decoy_pdb(golden_dir, tmp_path, seq, name):
+    xyz = np.load(os.path.join(golden_dir, "ref_decoys.npz"))[name].copy()
+    xyz[np.isnan(xyz[:, 4, 0]), 4] = 0.0  # Gly: write_pdb omits CB anyway
+    path = str(tmp_path / f"{name}.pdb")
+    P.write_pdb(path, seq, xyz)
+    return path
+
+
+@pytest.mark.parametrize("tag,name", [("NMR", "conf_2_1"), ("Xray", "conf_1_1")])
+def test_feedback_is_bit_identical_to_reference(golden_dir, tmp_path, seq, tag, name):
+    """get_neighbors / pros / process_distribution_with_pred_distribution (utils.py:125-475), incl. quirks R1-R4, R11:
+    6-D geometry equal, bins equal, SHA-256 of every full output array equal to the reference's."""
+    g = np.load(os.path.join(golden_dir, f"feedback_{tag}.npz"))
+    pdb = decoy_pdb(golden_dir, tmp_path, seq, name)
+    xyz, s = P.read_backbone(pdb)
+    assert s == seq and np.isnan(xyz[[i for i, a in enumerate(seq) if a == "G"], 4]).all()
+    for a, k in zip(F.get_neighbors(xyz, seq), ("dist6d", "omega6d", "theta6d", "phi6d")):
+        assert np.array_equal(a, g[k]), k
+    jd, jt, jo, jp = F.get_distribution_from_pdb(pdb)
+    for k, v in (("bin_dist", jd), ("bin_omega", jo), ("bin_theta", jt), ("bin_phi", jp)):
+        assert np.array_equal(v, g[k]), k
+    npz = os.path.join(golden_dir, f"seq_{tag}.npz")
+    outs = dict(zip(("dist", "omega", "theta", "phi"), F.get_npz_from_pred_pdb(npz, pdb)))
+    outs["tmp"] = F.get_npz_from_pred_pdb(npz, pdb, tmp=True)
+    for ch, arr in outs.items():
+        assert str(arr.dtype) == str(g[f"{ch}_dtype"]) and sha(arr) == str(g[f"{ch}_sha256"]), ch
+    assert np.array_equal(F.get_npz_from_pred_pdb(npz, pdb, angle=False), outs["dist"])
+
+
+def test_phi_bins_come_from_theta(golden_dir, tmp_path, seq):
+    """quirk R1 (utils.py:226): the phi one-hot is theta binned on phi's edges, so negative theta gives bin 0"""
+    xyz, _ = P.read_backbone(decoy_pdb(golden_dir, tmp_path, seq, "conf_2_1"))
+    d6, o6, t6, p6 = F.get_neighbors(xyz, seq)
+    jd, jo, jt, jp = F.bin_geometry(d6, o6, t6, p6)
+    c = jd > 0
+    assert np.all(jp[c & (t6 <= 0)] == 0) and np.all(jp[c & (t6 > 0)] >= 1)
+    assert np.all(jo[~c] == 0) and np.all(jt[~c] == 0) and np.all(jp[~c] == 0)  # R2
+
+
+def test_reliability_score_matches_survey(golden_dir, tmp_path, seq):
+    """NMR initials 81/88 both, X-ray initials 83/88 both (ties -> initial0 wins)"""
+    for name, want in (("conf_2_1", 81), ("conf_2_2", 81), ("conf_1_1", 83), ("conf_1_2", 83)):
+        assert F.calculate_reliability_score(decoy_pdb(golden_dir, tmp_path, seq, name)) == pytest.approx(want / 88)
+
+
+def test_pdb_writer_format_and_safety(tmp_path):
+    seq = "AGW"
+    xyz = np.arange(45, dtype=np.float64).reshape(3, 5, 3) * 1.001
+    path = str(tmp_path / "o.pdb")
+    P.write_pdb(path, seq, xyz)
+    lines = [l for l in open(path).read().splitlines() if l.startswith("ATOM")]
+    assert len(lines) == 5 + 4 + 5 and not any(" CB  GLY" in l for l in lines)
+    assert lines[0][12:16] == " N  " and lines[0][17:20] == "ALA" and lines[0][21] == "A" and int(lines[0][22:26]) == 1
+    assert all(len(l) >= 54 and float(l[30:38]) == pytest.approx(round(float(l[30:38]), 3)) for l in lines)
+    back, s = P.read_backbone(path)
+    assert s == seq and np.allclose(np.nan_to_num(back), np.nan_to_num(np.where(np.isnan(back), np.nan, xyz)), atol=5e-4)
+    with pytest.raises(ValueError):
+        P.write_pdb(str(tmp_path / "bad.pdb"), seq, np.full((3, 5, 3), np.nan))
+    assert not os.path.exists(tmp_path / "bad.pdb") and not [f for f in os.listdir(tmp_path) if f.endswith(".tmp")]
+
+
+def test_option_string_parsing():
+    """the `options` string built at run_inference.py:295 and the flags of arguments.py:5-25"""
+    a = FO.parse_options("-m 2 --orient -r no-idp")
+    assert (a.mode, a.use_orient, a.rst, a.pcut, a.fastrelax) == (2, True, "no-idp", 0.05, True)
+    a = FO.parse_options("-m 0 --no-orient -pd 0.15 --no-fastrelax")
+    assert (a.mode, a.use_orient, a.pcut, a.fastrelax) == (0, False, 0.15, False)
+    assert FO._unquote('"/a b/c.npz"') == "/a b/c.npz" and FO._unquote("x.npz") == "x.npz"
+    with pytest.raises(NotImplementedError):
+        FO.parse_options("-r idp")
+
+
+def test_output_layout_matches_committed_example(tmp_path):
+    """provenance of example/output/seq/pred_pdb: conf_1_1/2 = Xray initials, conf_1_3/4 = NMR
+    iterations, conf_2_1/2 = NMR initials, conf_2_3/4 = Xray iterations; iteration files ordered by number."""
+    d = str(tmp_path)
+    files = {"NMR": ["initial0", "initial1", "seq1", "seq2"], "Xray": ["initial0", "initial1", "seq3", "seq4"]}
+    for sub, names in files.items():
+        os.makedirs(os.path.join(d, sub))
+        for n in names:
+            open(os.path.join(d, sub, n + ".pdb"), "w").write(f"{sub}/{n}")
+    PL.flatten_and_rename(d, 2)
+    got = {n: open(os.path.join(d, n)).read() for n in sorted(os.listdir(d))}
+    assert got == {"conf_1_1.pdb": "Xray/initial0", "conf_1_2.pdb": "Xray/initial1", "conf_1_3.pdb": "NMR/seq1",
+                   "conf_1_4.pdb": "NMR/seq2", "conf_2_1.pdb": "NMR/initial0", "conf_2_2.pdb": "NMR/initial1",
+                   "conf_2_3.pdb": "Xray/seq3", "conf_2_4.pdb": "Xray/seq4"}
+    d2 = str(tmp_path / "many")
+    os.makedirs(os.path.join(d2, "NMR"))
+    for k in range(1, 13):
+        open(os.path.join(d2, "NMR", f"t{k}.pdb"), "w").write(str(k))
+    PL.flatten_and_rename(d2, 12)
+    assert [open(os.path.join(d2, f"conf_1_{k}.pdb")).read() for k in range(1, 13)] == [str(k) for k in range(1, 13)]
+
+
+def test_synthetic_map_generator_is_deterministic_and_realisable():
+    S = importlib.import_module("trrosettax2-dynamics_amd.synth")
+    from oracle import oracle as O
+    a, b = S._make_map(40, 40, 100), S._make_map(40, 40, 100)
+    assert all(np.array_equal(a[k], b[k]) for k in ("dist", "omega", "theta", "phi", "tors"))
+    for k, nb in (("dist", 37), ("omega", 25), ("theta", 25), ("phi", 13)):
+        assert a[k].shape == (40, 40, nb) and a[k].dtype == np.float32 and np.allclose(a[k].sum(-1), 1, atol=1e-5)
+    assert np.allclose(a["dist"], a["dist"].transpose(1, 0, 2)) and np.allclose(a["omega"], a["omega"].transpose(1, 0, 2))
+    N, CA, C, CB = S.nerf_backbone(a["tors"])
+    xo = O.nerf(a["tors"])
+    assert max(np.abs(N - xo[:, 0]).max(), np.abs(CA - xo[:, 1]).max(), np.abs(CB - xo[:, 4]).max()) < 1e-9

@@ -1,0 +1,105 @@
+"""Drop-in for the reference's fold launcher.
+
+`folding_with_pred_npz` keeps the name, signature and file outputs of /root/reference/utils_trX2dy/utils.py:484-505,
+but instead of spawning one `python ./folding/folding.py` process per decoy (ThreadPoolExecutor over subprocess.run) it
+folds all `repeat` decoys of the distogram as ONE batch on the GPU.  `fold_npz` is the same thing for one output file
+and backs the `folding/folding.py` command-line shim.
+
+Differences from the reference, all deliberate:
+  D  failed folds raise RuntimeError instead of passing silently (utils.py:498 runs subprocess.run unchecked)
+  D  start torsions come from an explicit seed (the reference never seeds `random`, utils_ros.py:677)
+  D  --fastrelax is accepted and ignored: there is no full-atom stage (folding.py:200-268 is not replicated)
+"""
+import argparse
+import os
+import shlex
+
+import numpy as np
+
+from . import protocol
+from ._lib import Context
+from .pdbio import read_fasta, write_pdb
+
+_CTX = {}           # device -> Context, so that successive calls reuse the stream and buffers
+_SEED = [0x5EED]    # advances per call: distinct decoys across calls unless the caller fixes `seed`
+
+
+def parse_options(options):
+    """the flags of folding/utils_ros/arguments.py:5-25 that can appear in an `options` string or on the CLI"""
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("-pd", type=float, dest="pcut", default=0.05)
+    ap.add_argument("-m", type=int, dest="mode", default=2, choices=[0, 1, 2, 3])
+    ap.add_argument("-r", type=str, dest="rst", default="no-idp", choices=["no-idp", "idp", "gpcr", "af2"])
+    ap.add_argument("-w", type=str, dest="wdir", default="/dev/shm")
+    ap.add_argument("-n", type=int, dest="steps", default=1000)
+    ap.add_argument("--orient", dest="use_orient", action="store_true")
+    ap.add_argument("--no-orient", dest="use_orient", action="store_false")
+    ap.add_argument("--fastrelax", dest="fastrelax", action="store_true")
+    ap.add_argument("--no-fastrelax", dest="fastrelax", action="store_false")
+    ap.add_argument("--log", dest="log", default="")
+    ap.add_argument("--gpu", dest="gpu", default=-1, type=int)
+    ap.add_argument("-KNOWN", type=str, required=False)
+    ap.set_defaults(use_orient=True, fastrelax=True)
+    args, unknown = ap.parse_known_args(shlex.split(options) if isinstance(options, str) else list(options))
+    if args.rst != "no-idp":
+        raise NotImplementedError(f"-r {args.rst}: only the no-idp restraint builder (the one run_inference.py uses) is implemented")
+    if args.mode == 3:
+        raise NotImplementedError("-m 3 needs the npz 'idr' mask and is not reachable from run_inference.py")
+    return args
+
+
+def _unquote(p):
+    # run_inference.py:51-52 wraps the paths in literal double quotes for the shell
+    return p[1:-1] if len(p) >= 2 and p[0] == p[-1] and p[0] in "\"'" else p
+
+
+def get_context(device=0):
+    if device not in _CTX:
+        _CTX[device] = Context(device)
+    return _CTX[device]
+
+
+def fold_arrays(npz, seq, n_decoys, options="", device=0, seed=None, decoy0=0):
+    """fold n_decoys of one distogram -> dict(xyz[B,L,5,3], status, e_terms, ...); raises on any failed decoy"""
+    args = parse_options(options)
+    L = len(seq)
+    if npz["dist"].shape[0] != L:
+        raise ValueError(f"sequence length {L} does not match the distogram {npz['dist'].shape}")
+    ctx = get_context(device)
+    ang = [npz[k] for k in ("omega", "theta", "phi")] if args.use_orient else []
+    ctx.set_map(npz["dist"], *ang, seq=seq, pcut=args.pcut)
+    if seed is None:
+        seed = _SEED[0]
+        _SEED[0] += 1
+    r = ctx.fold_batch(n_decoys, protocol.build_runs(L, args.mode), seed=seed, decoy0=decoy0)
+    bad = np.nonzero((r["status"] != 0) | ~np.isfinite(r["xyz"]).all(axis=(1, 2, 3)))[0]
+    if len(bad):
+        raise RuntimeError(f"fold failed for decoys {bad.tolist()} (status {r['status'][bad].tolist()})")
+    return r
+
+
+def folding_with_pred_npz(base_npz, base_fasta, base_out, out_name, options="-m 2 -r no-idp --orient", repeat=0,
+                          start_id=0, device=0, seed=None):
+    """Writes {base_out}/{out_name}{i}.pdb for i in [start_id, start_id+repeat), or {out_name}.pdb when repeat == 0."""
+    npz = np.load(_unquote(base_npz))
+    seq = read_fasta(_unquote(base_fasta))
+    os.makedirs(base_out, exist_ok=True)
+    n = repeat if repeat else 1
+    r = fold_arrays(npz, seq, n, options, device=device, seed=seed, decoy0=start_id)
+    names = [f"{out_name}{i}.pdb" for i in range(start_id, start_id + repeat)] if repeat else [f"{out_name}.pdb"]
+    for k, name in enumerate(names):
+        write_pdb(os.path.join(base_out, name), seq, r["xyz"][k],
+                  remarks=[f"trx2fold decoy {k} seed {seed} evals {int(r['n_evals'][k])}"])
+        print(f"Folded: {os.path.join(base_out, name)}")
+    return r
+
+
+def fold_npz(npz_path, fasta_path, out_path, options="", device=0, seed=None):
+    """one decoy to one file: what `python folding/folding.py -NPZ .. -FASTA .. -OUT ..` does"""
+    npz = np.load(npz_path)
+    seq = read_fasta(fasta_path)
+    r = fold_arrays(npz, seq, 1, options, device=device, seed=seed)
+    d = os.path.dirname(os.path.abspath(out_path))
+    os.makedirs(d, exist_ok=True)
+    write_pdb(out_path, seq, r["xyz"][0])
+    return r

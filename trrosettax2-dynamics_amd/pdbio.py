@@ -1,0 +1,88 @@
+"""PDB text in and out for the fold path.
+
+write_pdb replaces pose.dump_pdb (/root/reference/folding/folding.py:273) for backbone decoys: ATOM records N, CA, C, O,
+CB (no CB for Gly -- folding.py:190-193 mutates Ala back to Gly before the dump), chain A, residues 1..L.  That is all
+the downstream readers need (utils_trX2dy/utils.py:252-291 reads N/CA/C/CB + residue names; PPBuilder needs C-N < 1.8 A;
+TMscore needs CA).  Files are written to a temporary name and renamed, so a partial PDB is never left behind.
+
+read_backbone replaces the Biopython parse of get_atom_positions_pdb (utils.py:252-291, retain_all_res=False): first
+model, amino-acid ATOM records, one row per residue in file order, NaN for absent atoms.  It reads both this package's
+output and the reference's full-atom PyRosetta PDBs.
+"""
+import os
+
+import numpy as np
+
+AA3 = {"A": "ALA", "R": "ARG", "N": "ASN", "D": "ASP", "C": "CYS", "Q": "GLN", "E": "GLU", "G": "GLY", "H": "HIS",
+       "I": "ILE", "L": "LEU", "K": "LYS", "M": "MET", "F": "PHE", "P": "PRO", "S": "SER", "T": "THR", "W": "TRP",
+       "Y": "TYR", "V": "VAL", "U": "SEC", "X": "UNK"}
+# utils.py:25-54 (res_name_dict), three-letter -> one-letter incl. the modified residues it lists
+AA1 = {v: k for k, v in AA3.items()}
+AA1.update({"PHD": "D", "MSE": "M", "ASX": "B", "GLX": "Z", "XLE": "J", "XAA": "X"})
+ATOMS = ("N", "CA", "C", "O", "CB")
+ELEMENT = {"N": "N", "CA": "C", "C": "C", "O": "O", "CB": "C"}
+
+
+def read_fasta(path):
+    """first chain of a FASTA file (folding.py:17-29)"""
+    seq = ""
+    with open(path) as f:
+        for line in f:
+            if line.startswith(">"):
+                if seq:
+                    break
+                continue
+            seq += line.rstrip()
+    return seq
+
+
+def write_pdb(path, seq, xyz, remarks=()):
+    xyz = np.asarray(xyz, dtype=np.float64)
+    L = len(seq)
+    if xyz.shape != (L, 5, 3):
+        raise ValueError(f"xyz must be ({L}, 5, 3), got {xyz.shape}")
+    if not np.all(np.isfinite(xyz)):
+        raise ValueError("refusing to write a PDB with non-finite coordinates")
+    lines = [f"REMARK   {r}" for r in remarks]
+    serial = 1
+    for i, aa in enumerate(seq):
+        res = AA3.get(aa.upper(), "UNK")
+        for k, name in enumerate(ATOMS):
+            if name == "CB" and res == "GLY":
+                continue
+            x, y, z = xyz[i, k]
+            aname = f" {name:<3s}"  # element right-justified in cols 13-14 for one-letter elements
+            lines.append(f"ATOM  {serial:5d} {aname} {res} A{i + 1:4d}    {x:8.3f}{y:8.3f}{z:8.3f}  1.00  0.00          {ELEMENT[name]:>2s}")
+            serial += 1
+    lines += [f"TER   {serial:5d}      {AA3.get(seq[-1].upper(), 'UNK')} A{L:4d}", "END"]
+    tmp = f"{path}.{os.getpid()}.tmp"
+    with open(tmp, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    os.replace(tmp, path)
+
+
+def read_backbone(path):
+    """-> (xyz[L,5,3] float32 with NaN for absent atoms, one-letter sequence)"""
+    rows, names, index = [], [], {}
+    with open(path) as f:
+        for line in f:
+            if line.startswith("ENDMDL"):
+                break
+            if not line.startswith("ATOM"):
+                continue
+            if line[16] not in (" ", "A"):  # first alternate location only
+                continue
+            res = line[17:20].strip()
+            if res not in AA1:
+                continue
+            key = (line[21], line[22:27])
+            if key not in index:
+                index[key] = len(rows)
+                rows.append(np.full((5, 3), np.nan, np.float32))
+                names.append(res)
+            an = line[12:16].strip()
+            if an in ATOMS:
+                rows[index[key]][ATOMS.index(an)] = (float(line[30:38]), float(line[38:46]), float(line[46:54]))
+    if not rows:
+        raise ValueError(f"{path}: no amino-acid ATOM records")
+    return np.stack(rows), "".join(AA1[n] for n in names)

@@ -1,0 +1,140 @@
+"""Iteration orchestrator and output layout of run_inference.py, on top of the batched GPU fold.
+
+Mirrors /root/reference/run_inference.py:16-143 (generate_npz_and_pdb), :145-278 (flatten + rename to conf_1_k /
+conf_2_k) and :280-337 (run_single).  Same file names at every stage: initial{i}.pdb, {name}{iter}.pdb,
+tmp_npz/{name}{iter}.npz with keys dist/theta/omega/phi/tmp, final conf_1_k.pdb / conf_2_k.pdb.
+
+The trX2 network front-end (pred_2d_geometry, utils_trX2dy/utils.py:768-797) is out of scope for this package: the
+distograms must already exist as pred_npz/{name}_NMR.npz (and _Xray.npz) or be passed in explicitly.
+
+Deliberate divergence: the reference's final numbering depends on os.walk / os.listdir order
+and sorts iteration files lexicographically (seq10 < seq2).  Here the order is fixed -- Xray/ is flattened before NMR/,
+which reproduces the provenance of the reference's committed example (conf_1_1 = Xray/initial0, conf_2_1 = NMR/initial0)
+-- and iteration files are ordered by their number.
+"""
+import os
+import re
+import shutil
+
+import numpy as np
+
+from .feedback import calculate_reliability_score, get_npz_from_pred_pdb
+from .fold import folding_with_pred_npz
+
+
+def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz, fasta, N=10, Nmax=500, begin_num=0,
+                         sigma=1.0, tta_opt="-m 2 -r no-idp --orient ", angle=True, device=0, seed=None):
+    """N initial decoys as one GPU batch -> best by reliability -> feedback -> one decoy per iteration until the
+    cumulative `tmp` array moves by < 0.01 or Nmax iterations (run_inference.py:97-139).  Returns the last index."""
+    os.makedirs(processed_npz_dir, exist_ok=True)
+    print("Start generating the initial structures")
+    folding_with_pred_npz(f'"{initial_npz}"', f'"{fasta}"', pred_pdb_dir, "initial", tta_opt, repeat=N, device=device, seed=seed)
+    print("Done generating initial structures")
+    best_score, best_pdb = -np.inf, None
+    for i in range(N):                                   # strict '>' : the first maximum wins (run_inference.py:67)
+        pdb = os.path.join(pred_pdb_dir, f"initial{i}.pdb")
+        score = calculate_reliability_score(pdb)
+        if score > best_score:
+            best_score, best_pdb = score, pdb
+
+    def feedback(npz_path, pdb_path):
+        if angle:
+            d, o, t, p = get_npz_from_pred_pdb(npz_path, pdb_path, simga=sigma, angle=True)
+            labels = {"dist": d, "theta": t, "omega": o, "phi": p}
+        else:
+            labels = {"dist": get_npz_from_pred_pdb(npz_path, pdb_path, simga=sigma, angle=False)}
+        labels["tmp"] = get_npz_from_pred_pdb(npz_path, pdb_path, simga=sigma, tmp=True, angle=angle)
+        return labels
+
+    old_tmp = np.load(initial_npz)["dist"]
+    pattern = os.path.join(processed_npz_dir, pdb_name + "{}.npz")
+    np.savez_compressed(pattern.format(begin_num + 1), **feedback(initial_npz, best_pdb))
+    iter_n = begin_num
+    while True:
+        iter_n += 1
+        current = pattern.format(iter_n)
+        if os.path.exists(current):
+            old_tmp = np.load(current)["tmp"]
+        print(f"Start generating structure {iter_n}")
+        folding_with_pred_npz(f'"{current}"', f'"{fasta}"', pred_pdb_dir, pdb_name + str(iter_n), tta_opt, device=device,
+                              seed=None if seed is None else seed + iter_n)
+        print("Done generating structure", iter_n)
+        if iter_n - begin_num >= Nmax:
+            break
+        labels = feedback(current, os.path.join(pred_pdb_dir, f"{pdb_name}{iter_n}.pdb"))
+        np.savez_compressed(pattern.format(iter_n + 1), **labels)
+        if np.max(np.abs(old_tmp - labels["tmp"])) < 0.01:
+            break
+    return iter_n
+
+
+def flatten_and_rename(save_pdb_dir, num_conf1_others):
+    """pred_pdb/{Xray,NMR}/ -> pred_pdb/conf_1_k.pdb, conf_2_k.pdb (run_inference.py:145-278, order made deterministic)."""
+    moved = []
+    for sub in ("Xray", "NMR"):
+        d = os.path.join(save_pdb_dir, sub)
+        if not os.path.isdir(d):
+            continue
+        for name in sorted(os.listdir(d)):
+            target = os.path.join(save_pdb_dir, name)
+            base, ext = os.path.splitext(name)
+            k = 1
+            while os.path.exists(target):                 # name clash -> _1, _2 ... (run_inference.py:154-159)
+                target = os.path.join(save_pdb_dir, f"{base}_{k}{ext}")
+                k += 1
+            shutil.move(os.path.join(d, name), target)
+            moved.append(os.path.basename(target))
+        os.rmdir(d)
+    init1, init2, others = [], [], []
+    for name in os.listdir(save_pdb_dir):
+        m1, m2 = re.fullmatch(r"initial(\d+)\.pdb", name), re.fullmatch(r"initial(\d+)_1\.pdb", name)
+        if m1:
+            init1.append((int(m1.group(1)), name))
+        elif m2:
+            init2.append((int(m2.group(1)), name))
+        elif re.fullmatch(r".*?(\d+)\.pdb", name) and not re.fullmatch(r"conf_[12]_\d+\.pdb", name):
+            others.append((int(re.fullmatch(r".*?(\d+)\.pdb", name).group(1)), name))
+    plan, c1, c2 = [], 0, 0
+    for x, name in sorted(init1):
+        plan.append((name, f"conf_1_{x + 1}.pdb")); c1 = max(c1, x + 1)
+    for x, name in sorted(init2):
+        plan.append((name, f"conf_2_{x + 1}.pdb")); c2 = max(c2, x + 1)
+    others.sort()
+    for _, name in others[:num_conf1_others]:
+        c1 += 1; plan.append((name, f"conf_1_{c1}.pdb"))
+    for _, name in others[num_conf1_others:]:
+        c2 += 1; plan.append((name, f"conf_2_{c2}.pdb"))
+    for old, new in plan:
+        os.rename(os.path.join(save_pdb_dir, old), os.path.join(save_pdb_dir, new))
+    return dict(plan)
+
+
+def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mult_two_models=True, npz_nmr=None,
+               npz_xray=None, device=0, seed=None):
+    """run_inference.py:280-337 without the network front-end: expects the distograms to exist."""
+    content = os.path.join(save_dir, name)
+    npz_dir, pdb_dir, tmp_dir = (os.path.join(content, d) for d in ("pred_npz", "pred_pdb", "tmp_npz"))
+    for d in (npz_dir, pdb_dir, tmp_dir):
+        os.makedirs(d, exist_ok=True)
+    tta_opt = "-m 2 --orient -r no-idp" if angle else "-m 2 --no-orient -r no-idp"      # run_inference.py:295
+    maps = [("NMR", npz_nmr)] + ([("Xray", npz_xray)] if mult_two_models else [])
+    num = total = 0
+    for tag, given in maps:
+        path = os.path.join(npz_dir, f"{name}_{tag}.npz")
+        if given and os.path.abspath(given) != os.path.abspath(path):
+            shutil.copyfile(given, path)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing: the trX2 network front-end (pred_2d_geometry) is not part of this "
+                                    f"package -- produce the distogram with the reference's model or pass --npz_{tag.lower()}")
+        total = generate_npz_and_pdb(name, os.path.join(tmp_dir, tag), os.path.join(pdb_dir, tag), path, fasta_file, N=init_num,
+                                     Nmax=Nmax, begin_num=total, angle=angle, tta_opt=tta_opt, device=device,
+                                     seed=None if seed is None else seed + 100000 * len(tag))
+        if tag == "NMR":
+            num = total
+    n_out = total + init_num * len(maps)
+    print("All structures generation finished.")
+    print(f"Total structures generated: {n_out}")
+    shutil.rmtree(tmp_dir)
+    flatten_and_rename(pdb_dir, num)
+    print(f"Inference for sample '{name}' completed. Results in {content}")
+    return n_out
