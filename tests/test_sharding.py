@@ -1,0 +1,74 @@
+"""CPU: the N>1 path -- partitioning and the stats gather, world_size 2 over gloo (no GPU, fold replaced by a stub)."""
+import importlib
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+S = importlib.import_module("trrosettax2-dynamics_amd.sched")
+
+
+def test_lpt_covers_every_decoy_once_and_balances():
+    # BASELINE config 5: 8 targets L in {100..400}, 32 decoys each, 8 ranks
+    items = S.make_items([(f"t{L}", L) for L in (100, 140, 180, 220, 260, 300, 350, 400)], chains=("NMR",), init_num=32)
+    plan = S.lpt_assign(items, 8)
+    seen = {}
+    for r, its in enumerate(plan):
+        for it in its:
+            for d in range(it.decoy0, it.decoy0 + it.n):
+                assert (it.target, it.chain, d) not in seen
+                seen[(it.target, it.chain, d)] = r
+    assert len(seen) == 8 * 32
+    loads = [sum(it.cost for it in its) for its in plan]
+    assert max(loads) <= 1.2 * sum(loads) / 8, loads   # one-target-per-GPU would be 2.5x the mean
+    assert S.lpt_assign(items, 8) == plan               # deterministic
+
+
+def test_fewer_items_than_ranks_are_split_into_decoy_blocks():
+    plan = S.lpt_assign(S.make_items([("a", 150)], chains=("NMR",), init_num=64), 4)
+    assert all(len(p) >= 1 for p in plan) and sorted(it.decoy0 for p in plan for it in p) == [0, 16, 32, 48]
+    assert [S.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 3), (6, 2), (8, 2)]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        items = S.make_items([("a", 100), ("b", 200), ("c", 300)], init_num=16)
+        folded = []
+
+        def fake_fold(it):  # stands in for Context.fold_batch: no GPU in this test
+            folded.append((it.target, it.chain, it.decoy0, it.n))
+            return dict(decoys=it.n, seconds=1e-6 * it.cost, failed=1 if (it.target == "b" and it.decoy0 == 0 and it.chain == "NMR") else 0)
+
+        res = S.run_sharded(items, fake_fold, rank, world, dist)
+        allf = [None] * world
+        dist.all_gather_object(allf, folded)
+        dist.barrier()
+        if rank == 0:
+            q.put((res, allf))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_sharded_run():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res, allf = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["decoys"] == 3 * 2 * 16 and res["failed"] == 1 and len(res["per_rank"]) == 2
+    assert res["seconds"] == pytest.approx(max(p["seconds"] for p in res["per_rank"]))     # job time = slowest rank
+    units = [(t, c, d) for f in allf for (t, c, d0, n) in f for d in range(d0, d0 + n)]
+    assert len(units) == len(set(units)) == 96                                              # disjoint and complete
+    assert all(len(f) > 0 for f in allf)
