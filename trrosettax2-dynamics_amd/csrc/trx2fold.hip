@@ -29,6 +29,7 @@
 #define CHAIN_THREADS 256
 #define PAIR_THREADS 256
 #define PAIR_WAVES (PAIR_THREADS / 64)
+#define RED_STRIDE 21
 
 __constant__ float c_vdw_r0sq[25];
 __constant__ float c_rama[TRX2_RAMA_NB * 3];  // phi_k, psi_k (rad), p_k
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   const bool live = dec < A.B;
 
   __shared__ float s_kn[TRX2_KTOT];
-  __shared__ float s_red[PAIR_WAVES * 64 * 20];
+  __shared__ float s_red[PAIR_WAVES * 64 * RED_STRIDE];  // [slot][decoy][20 (+1 pad: bank-conflict-free)]
   for (int i = threadIdx.x; i < TRX2_KTOT; i += PAIR_THREADS) s_kn[i] = A.knots[i];
   __syncthreads();
   const float* knd = s_kn;
@@ -340,25 +341,35 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
     }
   }
 
-  // ---- reduce over waves and over the PW residue sub-lanes; write decoy-major records
+  // ---- reduce over waves and over the PW residue sub-lanes; write decoy-major records.
+  // LDS image [slot][decoy][21]: a lane writes its own 20 values at stride 21 (no bank conflict); the readers are
+  // (decoy, quad) pairs, 4 lanes per decoy, so every store instruction writes whole 64-B (gradient) / 32-B (energy) runs.
   {
-    const int slot = wave * PW + h;  // PAIR_WAVES*PW slots, each [20][BW]
-    float* s = s_red + (size_t)slot * 20 * BW + d;
+    const int slot = wave * PW + h;
+    float* s = s_red + ((size_t)slot * BW + d) * RED_STRIDE;
     const float vals[20] = {gN.x, gN.y, gN.z, gCA.x, gCA.y, gCA.z, gC.x, gC.y, gC.z, gO.x,
                             gO.y, gO.z, gCB.x, gCB.y, gCB.z, e_d, e_o, e_t, e_p, e_v};
 #pragma unroll
-    for (int k = 0; k < 20; k++) s[k * BW] = vals[k];
+    for (int k = 0; k < 20; k++) s[k] = vals[k];
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < 20 * BW; t += PAIR_THREADS) {
-    const int dd = t / 20, k = t % 20;
+  for (int t = threadIdx.x; t < 6 * BW; t += PAIR_THREADS) {  // 6 quads per decoy: 4 gradient (16 floats) + 2 energy (8)
+    const int dd = t / 6, q = t % 6;
     const int dc = grp * BW + dd;
     if (dc >= A.B) continue;
-    float acc = 0;
-    for (int sl = 0; sl < PAIR_WAVES * PW; sl++) acc += s_red[(size_t)sl * 20 * BW + k * BW + dd];
+    float acc[4] = {0, 0, 0, 0};
+    const int k0 = q < 4 ? q * 4 : 15 + (q - 4) * 4;  // first value of this quad in the 20-value record
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int k = k0 + i;
+      const bool real = q < 4 ? (k < 15) : (k < 20);  // gradient pad (16th float) and energy pads are zero
+      if (real)
+        for (int sl = 0; sl < PAIR_WAVES * PW; sl++) acc[i] += s_red[((size_t)sl * BW + dd) * RED_STRIDE + k];
+    }
     const size_t rec = ((size_t)split * A.Bpad + dc) * L + a;
-    if (k < 15) A.fpart[rec * 16 + k] = acc;
-    else A.epart[rec * 8 + (k - 15)] = acc;
+    const float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (q < 4) reinterpret_cast<float4*>(A.fpart + rec * 16)[q] = v;
+    else reinterpret_cast<float4*>(A.epart + rec * 8)[q - 4] = v;
   }
 }
 
@@ -1122,8 +1133,15 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
   // b-range splits: enough workgroups (>= ~2 per CU) while every wave keeps a few residues b
   int nsplit = 1;
   {
+    // k_pair holds 2 workgroups per CU (220 VGPRs): 512 resident slots.  EMPIRICAL rule from profiles/README.md
+    // (L=150, B=64, splits 2/3/4/6 timed on MI355X): with distances only, the largest split whose grid fits one
+    // round is fastest (450 workgroups: 30.8 us vs 35.2 at 600); with the angle channels on, 600 smaller workgroups
+    // win despite the partial second round (52.5 us vs 58.0).  Every wave keeps at least two residues b.
     const int PW = 64 / BW;
-    while ((long)L * nsplit * ngrp < 512 && (L / (nsplit * 2)) >= PAIR_WAVES * PW * 2 && nsplit < 16) nsplit *= 2;
+    const long slots = ctx->use_orient ? 640 : 512;
+    for (int n = 1; n <= 16; n++)
+      if ((long)L * n * ngrp <= slots && L / n >= PAIR_WAVES * PW * 2) nsplit = n;
+    if (const char* e = getenv("TRX2_NSPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) nsplit = v; }  // A/B timing only
   }
   ctx->BW = BW; ctx->Bpad = Bpad; ctx->nsplit = nsplit;
   if (B <= ctx->Bcap && L <= ctx->Lcap && nsplit <= ctx->nsplit_cap) return 0;
