@@ -33,6 +33,7 @@
 
 __constant__ float c_vdw_r0sq[25];
 __constant__ float c_rama[TRX2_RAMA_NB * 3];  // phi_k, psi_k (rad), p_k
+__constant__ float c_rama_sc[TRX2_RAMA_NB * 4];  // sin phi_k, cos phi_k, sin psi_k, cos psi_k
 
 // =================================================================================================
 // K2: restraint tables
@@ -501,11 +502,15 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) {
         // torsion-space terms: rama (residues 2..L-1) and omega_bb (1..L-1)
         if (r >= 1 && r < L - 1) {
           float s = 0, dph = 0, dps = 0;
+          // sin/cos of (phi - phi_k), (psi - psi_k) by the angle-addition identities: 2 sincosf per residue, not 12
+          float sph, cph, sps, cps;
+          sincosf(xt[k].x, &sph, &cph);
+          sincosf(xt[k].y, &sps, &cps);
 #pragma unroll
           for (int j = 0; j < TRX2_RAMA_NB; j++) {
-            float sa, ca, sb, cb;
-            sincosf(xt[k].x - c_rama[j * 3], &sa, &ca);
-            sincosf(xt[k].y - c_rama[j * 3 + 1], &sb, &cb);
+            const float sk = c_rama_sc[j * 4], ck = c_rama_sc[j * 4 + 1], tk = c_rama_sc[j * 4 + 2], uk = c_rama_sc[j * 4 + 3];
+            const float sa = sph * ck - cph * sk, ca = cph * ck + sph * sk;
+            const float sb = sps * uk - cps * tk, cb = cps * uk + sps * tk;
             float t = c_rama[j * 3 + 2] * expf((float)TRX2_RAMA_KAPPA * (ca + cb - 2.0f));
             s += t; dph -= t * (float)TRX2_RAMA_KAPPA * sa; dps -= t * (float)TRX2_RAMA_KAPPA * sb;
           }
@@ -964,14 +969,17 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
   for (int p = 0; p < 5; p++)
     for (int q = 0; q < 5; q++) r0sq[p * 5 + q] = (float)(r0[p][q] * r0[p][q]);
   const double rama[TRX2_RAMA_NB][3] = TRX2_RAMA_INIT;
-  float rm[TRX2_RAMA_NB * 3];
+  float rm[TRX2_RAMA_NB * 3], rsc[TRX2_RAMA_NB * 4];
   for (int k = 0; k < TRX2_RAMA_NB; k++) {
-    rm[k * 3] = (float)(rama[k][0] * M_PI / 180.0);
-    rm[k * 3 + 1] = (float)(rama[k][1] * M_PI / 180.0);
+    const double ph = rama[k][0] * M_PI / 180.0, ps = rama[k][1] * M_PI / 180.0;
+    rm[k * 3] = (float)ph;
+    rm[k * 3 + 1] = (float)ps;
     rm[k * 3 + 2] = (float)rama[k][2];
+    rsc[k * 4] = (float)sin(ph); rsc[k * 4 + 1] = (float)cos(ph); rsc[k * 4 + 2] = (float)sin(ps); rsc[k * 4 + 3] = (float)cos(ps);
   }
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_vdw_r0sq), r0sq, sizeof r0sq) != hipSuccess ||
       hipMemcpyToSymbol(HIP_SYMBOL(c_rama), rm, sizeof rm) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(c_rama_sc), rsc, sizeof rsc) != hipSuccess ||
       hipHostMalloc((void**)&ctx->h_done, sizeof(int)) != hipSuccess) {
     delete ctx;
     return 4;
