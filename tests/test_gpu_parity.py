@@ -161,3 +161,28 @@ def test_eval_other_widths_and_long_chains(ctx, L, B):
         assert np.abs(xyz[d] - xo).max() < 3e-3, ("xyz", L, d, np.abs(xyz[d] - xo).max())
         assert np.all(np.abs(e[d, :7] - eo[:7]) <= 2e-4 * np.abs(eo[:7]) + 0.1), ("terms", L, d, e[d], eo)
         assert np.abs(g[d] - go).max() <= 1e-2 * np.abs(go).max(), ("grad", L, d, np.abs(g[d] - go).max(), np.abs(go).max())
+
+
+def test_minimiser_tracks_oracle_over_short_horizons(ctx, maps, seq):
+    """Same start, same protocol, same evaluation budget as the oracle.  Outcome tests cannot see a minimiser that
+    converges wastefully; this can.  Calibration (profiles/README.md): an experimental Gram-matrix L-BFGS whose dot
+    products were accumulated in float lost its directions to cancellation near the end of a run and needed ~20 halvings
+    per step -- summed accepted iterations 0.69x / 0.80x the oracle's at 80 / 160 evaluations, against 0.93x / 0.98x
+    for the shipped two-loop recursion."""
+    m = maps["NMR"]
+    ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+    Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"])
+    runs = T.protocol.build_runs(90, 2)
+    B = 4
+    t0 = np.stack([O.random_torsions(90, 99, d) for d in range(B)]).astype(np.float32)
+    ratio = {}
+    for n in (20, 80, 160):
+        r = ctx.fold_batch(B, runs, tors0=t0, max_evals=n)
+        orc = [O.fold(Tb, t0[d].astype(np.float64), runs, max_evals=n)[2] for d in range(B)]
+        if n == 20:  # before float32/float64 rounding flips the first line-search decision: lockstep
+            assert [int(x) for x in r["n_iters"]] == [o["n_iters"] for o in orc]
+            for d in range(B):
+                assert abs(r["f"][d] - orc[d]["f_final"]) <= 1e-3 * abs(orc[d]["f_final"]), (d, r["f"][d], orc[d]["f_final"])
+        ratio[n] = r["n_iters"].sum() / sum(o["n_iters"] for o in orc)
+    print("\naccepted iterations, device / oracle:", {k: round(float(v), 2) for k, v in ratio.items()})
+    assert ratio[80] >= 0.85 and ratio[160] >= 0.90, ratio
