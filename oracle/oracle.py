@@ -76,6 +76,10 @@ def lib():
         L.orc_eval.restype = C.c_double
         L.orc_eval.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]
         L.orc_energy_cart.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+        L.orc_eval_cart.restype = C.c_double
+        L.orc_eval_cart.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+        L.orc_extract_internal.argtypes = [C.c_int, vp, vp, vp]
+        L.orc_nerf_geom.argtypes = [C.c_int, vp, vp, vp]
         L.orc_uniform.restype = C.c_double
         L.orc_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.orc_random_torsions.argtypes = [C.c_int, C.c_uint64, C.c_uint32, vp]
@@ -189,6 +193,29 @@ def energy_cart(tab, xyz, w, sep_lo=1, sep_hi=None):
     e = np.zeros(NTERMS); gx = np.zeros_like(xyz)
     lib().orc_energy_cart(tab.h, _p(xyz), _p(w), int(sep_lo), int(sep_hi if sep_hi is not None else tab.L), _p(e), _p(gx))
     return e, gx
+
+
+def eval_cart(tab, xyz, w, sep_lo=1, sep_hi=None, grad=True):
+    """Cartesian-space evaluation (sf_cart incl. the bonded term): -> (total, terms[8], gx[L,5,3] or None)"""
+    xyz = np.ascontiguousarray(xyz, np.float64); w = np.ascontiguousarray(w, np.float64)
+    e = np.zeros(NTERMS); gx = np.zeros_like(xyz) if grad else None
+    f = lib().orc_eval_cart(tab.h, _p(xyz), _p(w), int(sep_lo), int(sep_hi if sep_hi is not None else tab.L), _p(e), _p(gx))
+    return f, e, gx
+
+
+def extract_internal(xyz):
+    """coordinates -> (torsions[L,3], internal geometry[L,12]) such that nerf_geom reproduces them up to a rigid motion"""
+    xyz = np.ascontiguousarray(xyz, np.float64); L = xyz.shape[0]
+    t = np.zeros((L, 3)); g = np.zeros((L, 12))
+    lib().orc_extract_internal(L, _p(xyz), _p(t), _p(g))
+    return t, g
+
+
+def nerf_geom(tors, geom):
+    tors = np.ascontiguousarray(tors, np.float64); geom = np.ascontiguousarray(geom, np.float64)
+    xyz = np.zeros((tors.shape[0], 5, 3))
+    lib().orc_nerf_geom(tors.shape[0], _p(tors), _p(geom), _p(xyz))
+    return xyz
 
 
 def random_torsions(L, seed, decoy):
