@@ -165,24 +165,26 @@ def test_eval_other_widths_and_long_chains(ctx, L, B):
 
 def test_minimiser_tracks_oracle_over_short_horizons(ctx, maps, seq):
     """Same start, same protocol, same evaluation budget as the oracle.  Outcome tests cannot see a minimiser that
-    converges wastefully; this can.  Calibration (profiles/README.md): an experimental Gram-matrix L-BFGS whose dot
-    products were accumulated in float lost its directions to cancellation near the end of a run and needed ~20 halvings
-    per step -- summed accepted iterations 0.69x / 0.80x the oracle's at 80 / 160 evaluations, against 0.93x / 0.98x
-    for the shipped two-loop recursion."""
+    converges wastefully; this can.  Statistic: accepted iterations summed over 12 decoys, device / oracle.
+    Calibration (profiles/README.md, tools/traj_stats.py): a healthy minimiser gives 0.99-1.00 at 20 evaluations (11-12 of
+    12 per-decoy counts identical), 0.89-0.92 at 80 and 0.87-0.98 at 160 over three seeds -- the float32 device is 5-10 %
+    less efficient per evaluation than the float64 oracle once the trajectories have separated.  An experimental
+    Gram-matrix L-BFGS with float-accumulated dot products lost its directions to cancellation and scored 0.69 at 80."""
     m = maps["NMR"]
     ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
     Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"])
     runs = T.protocol.build_runs(90, 2)
-    B = 4
+    B = 12
     t0 = np.stack([O.random_torsions(90, 99, d) for d in range(B)]).astype(np.float32)
-    ratio = {}
+    ratio, same = {}, {}
     for n in (20, 80, 160):
         r = ctx.fold_batch(B, runs, tors0=t0, max_evals=n)
         orc = [O.fold(Tb, t0[d].astype(np.float64), runs, max_evals=n)[2] for d in range(B)]
-        if n == 20:  # before float32/float64 rounding flips the first line-search decision: lockstep
-            assert [int(x) for x in r["n_iters"]] == [o["n_iters"] for o in orc]
-            for d in range(B):
-                assert abs(r["f"][d] - orc[d]["f_final"]) <= 1e-3 * abs(orc[d]["f_final"]), (d, r["f"][d], orc[d]["f_final"])
-        ratio[n] = r["n_iters"].sum() / sum(o["n_iters"] for o in orc)
-    print("\naccepted iterations, device / oracle:", {k: round(float(v), 2) for k, v in ratio.items()})
-    assert ratio[80] >= 0.85 and ratio[160] >= 0.90, ratio
+        oi = np.array([o["n_iters"] for o in orc])
+        ratio[n], same[n] = r["n_iters"].sum() / oi.sum(), int((oi == r["n_iters"]).sum())
+        if n == 20:  # before rounding differences flip the first line-search decisions: energies agree closely
+            close = sum(abs(r["f"][d] - orc[d]["f_final"]) <= 1e-3 * abs(orc[d]["f_final"]) for d in range(B))
+            assert close >= B - 2, close
+    print("\naccepted iterations, device / oracle:", {k: round(float(v), 2) for k, v in ratio.items()}, "identical counts:", same)
+    assert ratio[20] >= 0.97 and same[20] >= B - 2, (ratio, same)
+    assert ratio[80] >= 0.80, ratio

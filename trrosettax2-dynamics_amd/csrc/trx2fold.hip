@@ -393,6 +393,7 @@ struct ChainArgs {
   float4 *X, *G, *D, *XT;  // [B][L] (phi, psi, omega, -)
   float4 *S, *Y;           // [B][LBM][L]
   float* xyz;              // [B][L][16] trial coordinates, decoy-major
+  const float4* geom;      // [B][L][3] internal geometry per residue (ResGeom)
   float4* xyzT;            // decoy-minor copy for k_pair
   float* wcur;             // [Bpad][8]
   const float* fpart;      // [nsplit][Bpad][L][16]
@@ -419,17 +420,29 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double* s_buf /* [4*K]
 
 __device__ __forceinline__ float dot3(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 
-struct NerfConst {
-  float cNCAC, sNCAC, cCACN, sCACN, cCNCA, sCNCA, cCACO, sCACO;
+// Internal geometry of one residue, 3 float4 (what torsion-space moves keep fixed; ideal values: trx2_model.h; after a
+// Cartesian run the relaxed values extracted from the coordinates -- the oracle's ORC_NGEOM record):
+//   g0 = (|N-CA|, |CA-C|, |C-N'|, angle N-CA-C)   g1 = (angle CA-C-N', angle C-N'-CA', |C-O|, angle CA-C-O)
+//   g2 = (dihedral N-CA-C-O minus psi, CB coefficients on (b x c), b, c with b = CA-N, c = C-CA)
+struct ResGeom {
+  float4 g0, g1, g2;
 };
-
+__device__ __forceinline__ ResGeom ideal_geom() {
+  ResGeom g;
+  g.g0 = make_float4((float)TRX2_B_N_CA, (float)TRX2_B_CA_C, (float)TRX2_B_C_N, (float)TRX2_A_N_CA_C * TRX2_DEG_F);
+  g.g1 = make_float4((float)TRX2_A_CA_C_N * TRX2_DEG_F, (float)TRX2_A_C_N_CA * TRX2_DEG_F, (float)TRX2_B_C_O, (float)TRX2_A_CA_C_O * TRX2_DEG_F);
+  g.g2 = make_float4(TRX2_PI_F, (float)TRX2_CB_KA, (float)TRX2_CB_KB, (float)TRX2_CB_KC);
+  return g;
+}
 // local frame of a residue: CA at origin, C on +x, N in the xy plane (y>0 side)
-__device__ __forceinline__ void local_atoms(const NerfConst& nc, f3& N, f3& CA, f3& C, f3& CB) {
+__device__ __forceinline__ void local_atoms(const ResGeom& g, f3& N, f3& CA, f3& C, f3& CB) {
+  float sa, ca;
+  sincosf(g.g0.w, &sa, &ca);
   CA = mk3(0, 0, 0);
-  C = mk3((float)TRX2_B_CA_C, 0, 0);
-  N = mk3((float)TRX2_B_N_CA * nc.cNCAC, (float)TRX2_B_N_CA * nc.sNCAC, 0);
+  C = mk3(g.g0.y, 0, 0);
+  N = mk3(g.g0.x * ca, g.g0.x * sa, 0);
   f3 b = CA - N, c = C - CA, a = cross(b, c);
-  CB = CA + a * (float)TRX2_CB_KA + b * (float)TRX2_CB_KB + c * (float)TRX2_CB_KC;
+  CB = CA + a * g.g2.y + b * g.g2.z + c * g.g2.w;
 }
 
 template <int RPT>
@@ -453,12 +466,6 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) {
   if (A.mode == MODE_STEP && phase == PH_DONE) return;
 
   const size_t vb = (size_t)dec * L;  // base of this decoy's [L] vectors
-  NerfConst nc;
-  sincosf((float)TRX2_A_N_CA_C * TRX2_DEG_F, &nc.sNCAC, &nc.cNCAC);
-  sincosf((float)TRX2_A_CA_C_N * TRX2_DEG_F, &nc.sCACN, &nc.cCACN);
-  sincosf((float)TRX2_A_C_N_CA * TRX2_DEG_F, &nc.sCNCA, &nc.cCNCA);
-  sincosf((float)TRX2_A_CA_C_O * TRX2_DEG_F, &nc.sCACO, &nc.cCACO);
-
   float4 xt[RPT], gt[RPT];
   bool need_nerf = true;
 
@@ -805,32 +812,39 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) {
 
   // ------------------------------------------------------------------ K1: torsions XT -> backbone (NeRF scan)
   // M_r maps frame r+1 coordinates into frame r; F_r = F_0 o M_0 o ... o M_{r-1}
-  f3 lN, lCA, lC, lCB;
-  local_atoms(nc, lN, lCA, lC, lCB);
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < RPT; k++) s_phi[k * CHAIN_THREADS + tid] = xt[k].x;
   __syncthreads();
+  const float4* gq = A.geom + vb * 3;
   Xf carry;  // F_0: N at the origin, CA on +x, C in the xy plane (same start as the oracle)
   {
-    f3 N0 = mk3(0, 0, 0), CA0 = mk3((float)TRX2_B_N_CA, 0, 0);
-    f3 C0 = mk3((float)TRX2_B_N_CA - (float)TRX2_B_CA_C * nc.cNCAC, (float)TRX2_B_CA_C * nc.sNCAC, 0);
-    carry = xf_from_atoms(N0, CA0, C0);
+    const float4 q0 = gq[0];
+    float sa, ca;
+    sincosf(q0.w, &sa, &ca);
+    carry = xf_from_atoms(mk3(0, 0, 0), mk3(q0.x, 0, 0), mk3(q0.x - q0.y * ca, q0.y * sa, 0));
   }
 #pragma unroll
   for (int k = 0; k < RPT; k++) {
     const int r = k * CHAIN_THREADS + tid;
     Xf M = xf_identity();
-    float spsi = 0, cpsi = 1;
+    ResGeom gr = ideal_geom();
+    f3 lN = mk3(0, 0, 0), lCA = lN, lC = lN, lCB = lN;
     if (r < L) {
-      sincosf(xt[k].y, &spsi, &cpsi);
+      gr.g0 = gq[r * 3]; gr.g1 = gq[r * 3 + 1]; gr.g2 = gq[r * 3 + 2];
+      local_atoms(gr, lN, lCA, lC, lCB);
       if (r + 1 < L) {
-        float so, co, sp, cp;
+        const float4 n0 = gq[(r + 1) * 3];  // next residue: |N-CA|, |CA-C|, angle N-CA-C
+        float spsi, cpsi, so, co, sp, cp, s1, c1, s2, c2, s3, c3;
+        sincosf(xt[k].y, &spsi, &cpsi);
         sincosf(xt[k].z, &so, &co);
         sincosf(s_phi[r + 1], &sp, &cp);  // phi of residue r+1
-        f3 Nn = place_atom(lN, lCA, lC, (float)TRX2_B_C_N, nc.cCACN, nc.sCACN, cpsi, spsi);
-        f3 CAn = place_atom(lCA, lC, Nn, (float)TRX2_B_N_CA, nc.cCNCA, nc.sCNCA, co, so);
-        f3 Cn = place_atom(lC, Nn, CAn, (float)TRX2_B_CA_C, nc.cNCAC, nc.sNCAC, cp, sp);
+        sincosf(gr.g1.x, &s1, &c1);
+        sincosf(gr.g1.y, &s2, &c2);
+        sincosf(n0.w, &s3, &c3);
+        f3 Nn = place_atom(lN, lCA, lC, gr.g0.z, c1, s1, cpsi, spsi);
+        f3 CAn = place_atom(lCA, lC, Nn, n0.x, c2, s2, co, so);
+        f3 Cn = place_atom(lC, Nn, CAn, n0.y, c3, s3, cp, sp);
         M = xf_from_atoms(Nn, CAn, Cn);
       }
     }
@@ -865,7 +879,10 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) {
     Xf F = (lane == 0) ? pre : xf_compose(pre, prev);
     carry = tot;
     if (r < L) {
-      f3 lO = place_atom(lN, lCA, lC, (float)TRX2_B_C_O, nc.cCACO, nc.sCACO, -cpsi, -spsi);  // psi + pi
+      float so_, co_, s4, c4;
+      sincosf(xt[k].y + gr.g2.x, &so_, &co_);  // dihedral N-CA-C-O = psi + t_O (ideal: pi)
+      sincosf(gr.g1.w, &s4, &c4);
+      f3 lO = place_atom(lN, lCA, lC, gr.g1.z, c4, s4, co_, so_);
       f3 N = xf_apply(F, lN), CA = xf_apply(F, lCA), C = xf_apply(F, lC), O = xf_apply(F, lO), CB = xf_apply(F, lCB);
       float4 o0 = make_float4(N.x, N.y, N.z, CA.x), o1 = make_float4(CA.y, CA.z, C.x, C.y),
              o2 = make_float4(C.z, O.x, O.y, O.z), o3 = make_float4(CB.x, CB.y, CB.z, 0);
@@ -885,7 +902,7 @@ __device__ __forceinline__ uint64_t splitmix64_dev(uint64_t x) {
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
 }
-__global__ void k_init_torsions(int L, int B, uint64_t seed, uint32_t decoy0, const float* tors0, float4* X, float4* XT) {
+__global__ void k_init_torsions(int L, int B, uint64_t seed, uint32_t decoy0, const float* tors0, float4* X, float4* XT, float4* geom) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L * B) return;
   const int dec = i / L, r = i % L;
@@ -905,6 +922,8 @@ __global__ void k_init_torsions(int L, int B, uint64_t seed, uint32_t decoy0, co
   }
   X[i] = v;
   XT[i] = v;
+  const ResGeom gi = ideal_geom();  // pose_from_sequence: ideal bond geometry (folding.py:109)
+  geom[(size_t)i * 3] = gi.g0; geom[(size_t)i * 3 + 1] = gi.g1; geom[(size_t)i * 3 + 2] = gi.g2;
 }
 
 // =================================================================================================
@@ -927,7 +946,7 @@ struct trx2_ctx {
   int Bcap = 0, Lcap = 0, BW = 64, Bpad = 0, nsplit = 1, nsplit_cap = 0;
   int* st_i = nullptr; double* st_d = nullptr; float* rho = nullptr;
   float4 *X = nullptr, *G = nullptr, *D = nullptr, *XT = nullptr, *S = nullptr, *Y = nullptr;
-  float* xyz = nullptr; float4* xyzT = nullptr; float* wcur = nullptr;
+  float* xyz = nullptr; float4* xyzT = nullptr; float* wcur = nullptr; float4* geom = nullptr;
   float *fpart = nullptr, *epart = nullptr;
   double *e_last = nullptr, *f_last = nullptr;
   float* grad = nullptr; float* tors0 = nullptr;
@@ -999,13 +1018,13 @@ static void free_map(trx2_ctx* c) {
   c->L = 0;
 }
 static void free_batch(trx2_ctx* c) {
-  void* p[] = {c->st_i, c->st_d, c->rho, c->X, c->G, c->D, c->XT, c->S, c->Y, c->xyz, c->xyzT, c->wcur, c->fpart,
+  void* p[] = {c->st_i, c->st_d, c->rho, c->X, c->G, c->D, c->XT, c->S, c->Y, c->xyz, c->xyzT, c->geom, c->wcur, c->fpart,
                c->epart, c->e_last, c->f_last, c->grad, c->tors0, c->done_count, c->runs};
   for (void* q : p)
     if (q) (void)hipFree(q);
   c->st_i = nullptr; c->st_d = nullptr; c->rho = nullptr;
   c->X = c->G = c->D = c->XT = c->S = c->Y = nullptr;
-  c->xyz = nullptr; c->xyzT = nullptr; c->wcur = nullptr; c->fpart = c->epart = nullptr;
+  c->xyz = nullptr; c->xyzT = nullptr; c->geom = nullptr; c->wcur = nullptr; c->fpart = c->epart = nullptr;
   c->e_last = c->f_last = nullptr; c->grad = nullptr; c->tors0 = nullptr; c->done_count = nullptr; c->runs = nullptr;
   c->Bcap = c->Lcap = 0;
 }
@@ -1166,6 +1185,7 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
   HIPCHK(hipMalloc((void**)&ctx->S, sizeof(float4) * BL * LBM));
   HIPCHK(hipMalloc((void**)&ctx->Y, sizeof(float4) * BL * LBM));
   HIPCHK(hipMalloc((void**)&ctx->xyz, sizeof(float) * BL * 16));
+  HIPCHK(hipMalloc((void**)&ctx->geom, sizeof(float4) * BL * 3));
   HIPCHK(hipMalloc((void**)&ctx->xyzT, sizeof(float4) * (size_t)Bpad * L * 4));
   HIPCHK(hipMalloc((void**)&ctx->wcur, sizeof(float) * Bpad * 8));
   HIPCHK(hipMalloc((void**)&ctx->fpart, sizeof(float) * (size_t)nsplit * Bpad * L * 16));
@@ -1193,7 +1213,7 @@ static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_eva
   ChainArgs A;
   A.L = c->L; A.B = B; A.Bpad = c->Bpad; A.BW = c->BW; A.nsplit = c->nsplit; A.mode = mode; A.nruns = nruns;
   A.max_evals = max_evals; A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho;
-  A.X = c->X; A.G = c->G; A.D = c->D; A.XT = c->XT; A.S = c->S; A.Y = c->Y; A.xyz = c->xyz; A.xyzT = c->xyzT;
+  A.X = c->X; A.G = c->G; A.D = c->D; A.XT = c->XT; A.S = c->S; A.Y = c->Y; A.xyz = c->xyz; A.geom = c->geom; A.xyzT = c->xyzT;
   A.wcur = c->wcur; A.fpart = c->fpart; A.epart = c->epart; A.e_last = c->e_last; A.f_last = c->f_last;
   A.grad_out = c->grad; A.done_count = c->done_count;
   return A;
@@ -1243,7 +1263,7 @@ extern "C" int trx2_eval_batch(trx2_ctx* ctx, int B, const float* tors, const fl
   HIPCHK(hipMemsetAsync(ctx->st_i, 0, sizeof(int) * B * SI_N, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->st_d, 0, sizeof(double) * B * SD_N, ctx->stream));
   hipLaunchKernelGGL(k_init_torsions, dim3((unsigned)((BL + 255) / 256)), dim3(256), 0, ctx->stream, L, B, 0ull, 0u,
-                     ctx->tors0, ctx->X, ctx->XT);
+                     ctx->tors0, ctx->X, ctx->XT, ctx->geom);
   launch_chain(ctx, B, MODE_INIT, 1, 1 << 30);
   launch_pair(ctx, B);
   launch_chain(ctx, B, MODE_FINISH, 1, 1 << 30);
@@ -1282,7 +1302,7 @@ extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int n
   HIPCHK(hipMemsetAsync(ctx->st_d, 0, sizeof(double) * B * SD_N, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->done_count, 0, sizeof(int), ctx->stream));
   hipLaunchKernelGGL(k_init_torsions, dim3((unsigned)((BL + 255) / 256)), dim3(256), 0, ctx->stream, L, B, seed, decoy0,
-                     tors0 ? ctx->tors0 : (const float*)nullptr, ctx->X, ctx->XT);
+                     tors0 ? ctx->tors0 : (const float*)nullptr, ctx->X, ctx->XT, ctx->geom);
   launch_chain(ctx, B, MODE_INIT, nruns, max_evals);
   int launches = 0;
   const int chunk = 64;
