@@ -380,12 +380,13 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
 enum { PH_START = 0, PH_LS = 1, PH_DONE = 2 };
 enum { MODE_INIT = 0, MODE_STEP = 1, MODE_FINISH = 2 };
 // integer state slots
-enum { SI_RUN = 0, SI_PHASE, SI_ITER, SI_NLS, SI_HL, SI_HH, SI_NH, SI_STATUS, SI_NEVALS, SI_NITERS, SI_N = 16 };
+enum { SI_RUN = 0, SI_PHASE, SI_ITER, SI_NLS, SI_HL, SI_HH, SI_NH, SI_STATUS, SI_NEVALS, SI_NITERS, SI_SEQ, SI_N = 16 };
 // double state slots
 enum { SD_F = 0, SD_ALPHA, SD_GD, SD_FH0, SD_FH1, SD_FH2, SD_N = 8 };
 
 struct ChainArgs {
   int L, B, Bpad, BW, nsplit, mode, nruns, max_evals;
+  int seq;         // iteration number: a decoy is stepped once per evaluation, by k_chain OR k_cart (SI_SEQ)
   const trx2_run* runs;
   int* st_i;       // [B][SI_N]
   double* st_d;    // [B][SD_N]
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) {
   __syncthreads();
   int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
   if (A.mode == MODE_STEP && phase == PH_DONE) return;
+  if (A.mode == MODE_STEP && (s_i[SI_SEQ] == A.seq || A.runs[min(run, A.nruns - 1)].cartesian)) return;  // k_cart's turn
 
   const size_t vb = (size_t)dec * L;  // base of this decoy's [L] vectors
   float4 xt[RPT], gt[RPT];
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) {
     __syncthreads();
     if (tid == 0) {
       gi[SI_RUN] = run; gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
-      gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
+      gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters; gi[SI_SEQ] = A.seq;
       gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
       if (phase == PH_DONE) atomicAdd(A.done_count, 1);
     }
@@ -895,6 +897,393 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) {
   }
 }
 
+// =================================================================================================
+// Cartesian-space minimiser step (MinMover.cartesian(True) on sf_cart, folding.py:83-84,100-102).  One workgroup per
+// decoy, one residue per thread (L <= 256).  DOFs = the 15 coordinates of a residue, stored as 4 float4 (16th = 0):
+// the trial vector IS the xyz buffer.  The pair kernel's gradient slabs are already Cartesian; added here: rama and
+// omega from coordinates, and the harmonic bonded term (cart_bonded surrogate, trx2_model.h).  Terms that span two
+// residues are evaluated by both owners, each keeping the gradient on its own atoms (no atomics).  When the run ends
+// the relaxed internal geometry is extracted so that later torsion-space runs continue from it (oracle:
+// orc_extract_internal).  The L-BFGS state machine is the one of k_chain on 4 float4 per residue.
+// =================================================================================================
+struct CartArgs {
+  int L, B, Bpad, BW, nsplit, nruns, max_evals, seq;
+  const trx2_run* runs;
+  int* st_i; double* st_d; float* rho;
+  float4 *CX, *CG, *CD;      // [B][L][4] accepted point, its gradient, direction
+  float4 *CS, *CY;           // [B][LBM][L][4]
+  float* xyz;                // [B][L][16] trial coordinates = trial DOF vector (in/out)
+  float4* xyzT;
+  float4 *X, *XT, *geom;     // torsions and internal geometry, written when the run ends
+  float* wcur;
+  const float* fpart; const float* epart;
+  double *e_last, *f_last;
+  int* done_count;
+};
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+struct Res5 { f3 N, CA, C, O, CB; };
+__device__ __forceinline__ Res5 unpack5(const float* p) {
+  return Res5{mk3(p[0], p[1], p[2]), mk3(p[3], p[4], p[5]), mk3(p[6], p[7], p[8]), mk3(p[9], p[10], p[11]), mk3(p[12], p[13], p[14])};
+}
+__device__ __forceinline__ float wrap_pi_f(float x) { return x - 2.0f * TRX2_PI_F * rintf(x * (0.5f / TRX2_PI_F)); }
+// harmonic bond: energy, gradient on a (gradient on b is the negative)
+__device__ __forceinline__ float hbond(f3 a, f3 b, float d0, float k, f3& ga) {
+  f3 u = a - b; float d = sqrtf(dot(u, u)), dd = d - d0; ga = u * (2.0f * k * dd / d); return k * dd * dd;
+}
+__device__ __forceinline__ float hangle(f3 a, f3 b, f3 c, float a0, float k, f3& ga, f3& gb, f3& gc) {
+  float x = angle_grad(a, b, c, ga, gb, gc), dx = x - a0, sc = 2.0f * k * dx; ga = ga * sc; gb = gb * sc; gc = gc * sc; return k * dx * dx;
+}
+__device__ __forceinline__ float hdih(f3 a, f3 b, f3 c, f3 d, float t0, float k, f3& ga, f3& gb, f3& gc, f3& gd) {
+  float x = dihedral_grad(a, b, c, d, ga, gb, gc, gd), dx = wrap_pi_f(x - t0), sc = 2.0f * k * dx;
+  ga = ga * sc; gb = gb * sc; gc = gc * sc; gd = gd * sc; return k * dx * dx;
+}
+// link terms of the peptide bond P (residue i) -> Q (residue i+1): bond C-N', angles CA-C-N', C-N'-CA', O-C-N', improper CA-N'-C-O
+struct LinkGrad { f3 CA, C, O, Nn, CAn; float e; };
+__device__ __forceinline__ LinkGrad link_terms(const Res5& P, const Res5& Q) {
+  LinkGrad G; G.CA = G.C = G.O = G.Nn = G.CAn = mk3(0, 0, 0);
+  const float KL = (float)TRX2_CART_KLEN, KA = (float)TRX2_CART_KANG, KI = (float)TRX2_CART_KIMP;
+  f3 a, b, c, d;
+  float e = hbond(P.C, Q.N, (float)TRX2_B_C_N, KL, a); G.C += a; G.Nn += a * -1.0f;
+  e += hangle(P.CA, P.C, Q.N, (float)TRX2_A_CA_C_N * TRX2_DEG_F, KA, a, b, c); G.CA += a; G.C += b; G.Nn += c;
+  e += hangle(P.C, Q.N, Q.CA, (float)TRX2_A_C_N_CA * TRX2_DEG_F, KA, a, b, c); G.C += a; G.Nn += b; G.CAn += c;
+  e += hangle(P.O, P.C, Q.N, 2.0f * TRX2_PI_F - (float)(TRX2_A_CA_C_N + TRX2_A_CA_C_O) * TRX2_DEG_F, KA, a, b, c); G.O += a; G.C += b; G.Nn += c;
+  e += hdih(P.CA, Q.N, P.C, P.O, TRX2_PI_F, KI, a, b, c, d); G.CA += a; G.Nn += b; G.C += c; G.O += d;
+  G.e = e; return G;
+}
+
+__global__ __launch_bounds__(CHAIN_THREADS) void k_cart(CartArgs A) {
+  const int L = A.L, dec = blockIdx.x, tid = threadIdx.x, r = tid;
+  const bool act = r < L;
+  __shared__ double s_buf[4 * 8];
+  __shared__ float s_alpha[LBM];
+  __shared__ int s_i[SI_N];
+  __shared__ double s_d[SD_N];
+  __shared__ float s_rho[LBM];
+  __shared__ float s_xyz[CHAIN_THREADS * 16];
+  __shared__ float s_dt[CHAIN_THREADS * 3];
+  int* gi = A.st_i + (size_t)dec * SI_N;
+  double* gd_ = A.st_d + (size_t)dec * SD_N;
+  if (tid < SI_N) s_i[tid] = gi[tid];
+  if (tid < SD_N) s_d[tid] = gd_[tid];
+  if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
+  __syncthreads();
+  int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
+  if (phase == PH_DONE || s_i[SI_SEQ] == A.seq) return;
+  const trx2_run R = A.runs[min(run, A.nruns - 1)];
+  if (!R.cartesian) return;
+  const size_t vb = (size_t)dec * L;
+
+  // ---- trial coordinates; neighbours through LDS
+  float4 xt[4], gt[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { xt[q] = gt[q] = make_float4(0, 0, 0, 0); }
+  double esum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (act) {
+    const float4* xp = reinterpret_cast<const float4*>(A.xyz + (vb + r) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { xt[q] = xp[q]; reinterpret_cast<float4*>(s_xyz + r * 16)[q] = xt[q]; }
+    for (int s = 0; s < A.nsplit; s++) {
+      const size_t rec = ((size_t)s * A.Bpad + dec) * L + r;
+      const float4* fp = reinterpret_cast<const float4*>(A.fpart + rec * 16);
+#pragma unroll
+      for (int q = 0; q < 4; q++) { float4 v = fp[q]; gt[q].x += v.x; gt[q].y += v.y; gt[q].z += v.z; gt[q].w += v.w; }
+      const float4* ep = reinterpret_cast<const float4*>(A.epart + rec * 8);
+      float4 e0 = ep[0], e1 = ep[1];
+      esum[0] += e0.x; esum[1] += e0.y; esum[2] += e0.z; esum[3] += e0.w; esum[4] += e1.x;
+    }
+    gt[3].w = 0.0f;
+  }
+  __syncthreads();
+  f3 aN = mk3(0, 0, 0), aCA = aN, aC = aN, aO = aN, aCB = aN;  // gradient of the local terms on this residue's atoms
+  float dphi = 0, dpsi = 0, dom = 0;
+  Res5 Me = unpack5(s_xyz + (act ? r : 0) * 16), Pv = Me, Nx = Me;
+  if (act && r > 0) Pv = unpack5(s_xyz + (r - 1) * 16);
+  if (act && r + 1 < L) Nx = unpack5(s_xyz + (r + 1) * 16);
+  if (act) {
+    // rama (residues 2..L-1) and omega_bb (1..L-1): derivatives with respect to the torsion angles
+    f3 t1, t2, t3, t4;
+    if (r >= 1 && r < L - 1) {
+      const float ph = dihedral_grad(Pv.C, Me.N, Me.CA, Me.C, t1, t2, t3, t4), ps = dihedral_grad(Me.N, Me.CA, Me.C, Nx.N, t1, t2, t3, t4);
+      float sph, cph, sps, cps, sm = 0, a1 = 0, a2 = 0;
+      sincosf(ph, &sph, &cph); sincosf(ps, &sps, &cps);
+#pragma unroll
+      for (int j = 0; j < TRX2_RAMA_NB; j++) {
+        const float sk = c_rama_sc[j * 4], ck = c_rama_sc[j * 4 + 1], tk = c_rama_sc[j * 4 + 2], uk = c_rama_sc[j * 4 + 3];
+        const float sa = sph * ck - cph * sk, ca = cph * ck + sph * sk, sb = sps * uk - cps * tk, cb = cps * uk + sps * tk;
+        const float t = c_rama[j * 3 + 2] * expf((float)TRX2_RAMA_KAPPA * (ca + cb - 2.0f));
+        sm += t; a1 -= t * (float)TRX2_RAMA_KAPPA * sa; a2 -= t * (float)TRX2_RAMA_KAPPA * sb;
+      }
+      const float inv = 1.0f / (sm + (float)TRX2_RAMA_FLOOR);
+      esum[5] += -(double)logf((sm + (float)TRX2_RAMA_FLOOR) * (1.0f / (float)TRX2_RAMA_PREF));
+      dphi = -R.w[4] * a1 * inv; dpsi = -R.w[4] * a2 * inv;
+    }
+    if (r < L - 1) {
+      float dw = wrap_pi_f(dihedral_grad(Me.CA, Me.C, Nx.N, Nx.CA, t1, t2, t3, t4) - TRX2_PI_F) * (1.0f / TRX2_DEG_F);
+      esum[6] += (double)((float)TRX2_OMEGA_K * dw * dw);
+      dom = R.w[5] * 2.0f * (float)TRX2_OMEGA_K * dw * (1.0f / TRX2_DEG_F);
+    }
+    s_dt[r * 3] = dphi; s_dt[r * 3 + 1] = dpsi; s_dt[r * 3 + 2] = dom;
+  }
+  __syncthreads();
+  if (act) {
+    f3 d1, d2, d3, d4;
+    if (dphi != 0.0f) { dihedral_grad(Pv.C, Me.N, Me.CA, Me.C, d1, d2, d3, d4); aN = fma3(d2, dphi, aN); aCA = fma3(d3, dphi, aCA); aC = fma3(d4, dphi, aC); }
+    if (dpsi != 0.0f) { dihedral_grad(Me.N, Me.CA, Me.C, Nx.N, d1, d2, d3, d4); aN = fma3(d1, dpsi, aN); aCA = fma3(d2, dpsi, aCA); aC = fma3(d3, dpsi, aC); }
+    if (dom != 0.0f) { dihedral_grad(Me.CA, Me.C, Nx.N, Nx.CA, d1, d2, d3, d4); aCA = fma3(d1, dom, aCA); aC = fma3(d2, dom, aC); }
+    if (r + 1 < L) {  // phi of the next residue moves C of this one
+      const float c = s_dt[(r + 1) * 3];
+      if (c != 0.0f) { Res5 N2 = Nx; dihedral_grad(Me.C, N2.N, N2.CA, N2.C, d1, d2, d3, d4); aC = fma3(d1, c, aC); }
+    }
+    if (r > 0) {      // psi and omega of the previous residue move N (and CA) of this one
+      const float c1 = s_dt[(r - 1) * 3 + 1], c2 = s_dt[(r - 1) * 3 + 2];
+      if (c1 != 0.0f) { dihedral_grad(Pv.N, Pv.CA, Pv.C, Me.N, d1, d2, d3, d4); aN = fma3(d4, c1, aN); }
+      if (c2 != 0.0f) { dihedral_grad(Pv.CA, Pv.C, Me.N, Me.CA, d1, d2, d3, d4); aN = fma3(d3, c2, aN); aCA = fma3(d4, c2, aCA); }
+    }
+    // bonded term: ideal CB geometry from the ideal local frame
+    const float wcb = R.w[6];
+    if (wcb != 0.0f) {
+      f3 iN, iCA, iC, iCB;
+      local_atoms(ideal_geom(), iN, iCA, iC, iCB);
+      f3 u1, u2, u3, u4;
+      const float d_cacb = sqrtf(dot(iCB - iCA, iCB - iCA));
+      const float a_ncacb = angle_grad(iN, iCA, iCB, u1, u2, u3), a_ccacb = angle_grad(iC, iCA, iCB, u1, u2, u3);
+      const float t_cb = dihedral_grad(iN, iC, iCA, iCB, u1, u2, u3, u4);
+      const float KL = (float)TRX2_CART_KLEN, KA = (float)TRX2_CART_KANG, KI = (float)TRX2_CART_KIMP;
+      f3 bN = mk3(0, 0, 0), bCA = bN, bC = bN, bO = bN, bCB = bN, a, b, c, d;
+      float eb = hbond(Me.N, Me.CA, (float)TRX2_B_N_CA, KL, a); bN += a; bCA += a * -1.0f;
+      eb += hbond(Me.CA, Me.C, (float)TRX2_B_CA_C, KL, a); bCA += a; bC += a * -1.0f;
+      eb += hbond(Me.C, Me.O, (float)TRX2_B_C_O, KL, a); bC += a; bO += a * -1.0f;
+      eb += hbond(Me.CA, Me.CB, d_cacb, KL, a); bCA += a; bCB += a * -1.0f;
+      eb += hangle(Me.N, Me.CA, Me.C, (float)TRX2_A_N_CA_C * TRX2_DEG_F, KA, a, b, c); bN += a; bCA += b; bC += c;
+      eb += hangle(Me.CA, Me.C, Me.O, (float)TRX2_A_CA_C_O * TRX2_DEG_F, KA, a, b, c); bCA += a; bC += b; bO += c;
+      eb += hangle(Me.N, Me.CA, Me.CB, a_ncacb, KA, a, b, c); bN += a; bCA += b; bCB += c;
+      eb += hangle(Me.C, Me.CA, Me.CB, a_ccacb, KA, a, b, c); bC += a; bCA += b; bCB += c;
+      eb += hdih(Me.N, Me.C, Me.CA, Me.CB, t_cb, KI, a, b, c, d); bN += a; bC += b; bCA += c; bCB += d;
+      if (r + 1 < L) { LinkGrad G = link_terms(Me, Nx); eb += G.e; bCA += G.CA; bC += G.C; bO += G.O; }
+      if (r > 0) { LinkGrad G = link_terms(Pv, Me); bN += G.Nn; bCA += G.CAn; }
+      esum[7] += (double)eb;
+      aN = fma3(bN, wcb, aN); aCA = fma3(bCA, wcb, aCA); aC = fma3(bC, wcb, aC); aO = fma3(bO, wcb, aO); aCB = fma3(bCB, wcb, aCB);
+    }
+    gt[0].x += aN.x; gt[0].y += aN.y; gt[0].z += aN.z; gt[0].w += aCA.x;
+    gt[1].x += aCA.y; gt[1].y += aCA.z; gt[1].z += aC.x; gt[1].w += aC.y;
+    gt[2].x += aC.z; gt[2].y += aO.x; gt[2].z += aO.y; gt[2].w += aO.z;
+    gt[3].x += aCB.x; gt[3].y += aCB.y; gt[3].z += aCB.z;
+  }
+  block_sum<8>(esum, s_buf);
+  const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] + (double)R.w[3] * esum[4] +
+                     (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[6] * esum[7];
+  if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
+  if (tid == 0) A.f_last[dec] = f_t;
+
+  // ------------------------------------------------------------------ minimiser state machine (as k_chain, 4 float4 per residue)
+  int iter = s_i[SI_ITER], nls = s_i[SI_NLS], hl = s_i[SI_HL], hh = s_i[SI_HH], nh = s_i[SI_NH];
+  int n_evals = s_i[SI_NEVALS] + 1, n_iters = s_i[SI_NITERS], status = s_i[SI_STATUS];
+  double f = s_d[SD_F], alpha = s_d[SD_ALPHA], gdir = s_d[SD_GD];
+  double fh[3] = {s_d[SD_FH0], s_d[SD_FH1], s_d[SD_FH2]};
+  float4 x[4], g[4], dv[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    x[q] = g[q] = dv[q] = make_float4(0, 0, 0, 0);
+    if (act) { x[q] = A.CX[(vb + r) * 4 + q]; g[q] = A.CG[(vb + r) * 4 + q]; dv[q] = A.CD[(vb + r) * 4 + q]; }
+  }
+  bool next_run = false, new_dir = false, steepest = false, new_trial = false;
+  const bool finite_t = isfinite(f_t);
+  if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
+  else if (phase == PH_START) {
+    f = f_t;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { x[q] = xt[q]; g[q] = gt[q]; }
+    hl = 0; hh = 0; nh = 1; fh[0] = f; iter = 0;
+    steepest = true;
+  } else {
+    double fref = fh[0];
+    for (int k = 1; k < nh; k++) fref = fmax(fref, fh[k]);
+    const bool accept = finite_t && f_t <= fref + (double)TRX2_LS_C1 * alpha * gdir;
+    if (accept) {
+      double v3[3] = {0, 0, 0};
+      float4 sv[4], yv[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        sv[q] = make_float4(xt[q].x - x[q].x, xt[q].y - x[q].y, xt[q].z - x[q].z, xt[q].w - x[q].w);
+        yv[q] = make_float4(gt[q].x - g[q].x, gt[q].y - g[q].y, gt[q].z - g[q].z, gt[q].w - g[q].w);
+        v3[0] += (double)dot4(sv[q], yv[q]); v3[1] += (double)dot4(sv[q], sv[q]); v3[2] += (double)dot4(yv[q], yv[q]);
+      }
+      block_sum<3>(v3, s_buf);
+      if (v3[0] > 1e-12 * sqrt(v3[1] * v3[2])) {
+        if (act)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            A.CS[(((size_t)dec * LBM + hh) * L + r) * 4 + q] = sv[q];
+            A.CY[(((size_t)dec * LBM + hh) * L + r) * 4 + q] = yv[q];
+          }
+        __syncthreads();
+        if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
+        __syncthreads();
+        hh = (hh + 1) % LBM;
+        if (hl < LBM) hl++;
+      }
+      const double fprev = f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { x[q] = xt[q]; g[q] = gt[q]; }
+      f = f_t;
+      if (nh < TRX2_LS_PAST) fh[nh++] = f;
+      else { fh[0] = fh[1]; fh[1] = fh[2]; fh[2] = f; }
+      iter++; n_iters++;
+      const bool conv = 2.0 * fabs(fprev - f) <= (double)TRX2_MIN_TOL * (fabs(fprev) + fabs(f) + 1e-10);
+      if (conv || iter >= R.max_iter) next_run = true;
+      else new_dir = true;
+    } else {
+      nls++;
+      alpha *= (double)TRX2_LS_SHRINK;
+      if (nls > TRX2_LS_MAXTRIAL) {
+        if (hl > 0) { hl = 0; steepest = true; }
+        else next_run = true;
+      } else new_trial = true;
+    }
+  }
+  if (new_dir) {
+    float4 qv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) qv[q] = g[q];
+    for (int kk = 0; kk < hl; kk++) {
+      const int j = (hh - 1 - kk + LBM) % LBM;
+      double v1[1] = {0};
+      float4 sj[4], yj[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        sj[q] = yj[q] = make_float4(0, 0, 0, 0);
+        if (act) { sj[q] = A.CS[(((size_t)dec * LBM + j) * L + r) * 4 + q]; yj[q] = A.CY[(((size_t)dec * LBM + j) * L + r) * 4 + q]; }
+        v1[0] += (double)dot4(sj[q], qv[q]);
+      }
+      block_sum<1>(v1, s_buf);
+      const float al = s_rho[j] * (float)v1[0];
+      if (tid == 0) s_alpha[j] = al;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { qv[q].x -= al * yj[q].x; qv[q].y -= al * yj[q].y; qv[q].z -= al * yj[q].z; qv[q].w -= al * yj[q].w; }
+    }
+    if (hl > 0) {
+      const int j = (hh - 1 + LBM) % LBM;
+      double v1[1] = {0};
+      if (act)
+#pragma unroll
+        for (int q = 0; q < 4; q++) { float4 yj = A.CY[(((size_t)dec * LBM + j) * L + r) * 4 + q]; v1[0] += (double)dot4(yj, yj); }
+      block_sum<1>(v1, s_buf);
+      const float gam = (float)(1.0 / ((double)s_rho[j] * v1[0]));
+#pragma unroll
+      for (int q = 0; q < 4; q++) { qv[q].x *= gam; qv[q].y *= gam; qv[q].z *= gam; qv[q].w *= gam; }
+    }
+    __syncthreads();
+    for (int kk = hl - 1; kk >= 0; kk--) {
+      const int j = (hh - 1 - kk + LBM) % LBM;
+      double v1[1] = {0};
+      float4 sj[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        sj[q] = make_float4(0, 0, 0, 0);
+        if (act) {
+          float4 yj = A.CY[(((size_t)dec * LBM + j) * L + r) * 4 + q];
+          sj[q] = A.CS[(((size_t)dec * LBM + j) * L + r) * 4 + q];
+          v1[0] += (double)dot4(yj, qv[q]);
+        }
+      }
+      block_sum<1>(v1, s_buf);
+      const float c = s_alpha[j] - s_rho[j] * (float)v1[0];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { qv[q].x += c * sj[q].x; qv[q].y += c * sj[q].y; qv[q].z += c * sj[q].z; qv[q].w += c * sj[q].w; }
+    }
+    double v2[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      dv[q] = make_float4(-qv[q].x, -qv[q].y, -qv[q].z, -qv[q].w);
+      v2[0] += (double)dot4(g[q], dv[q]); v2[1] += (double)dot4(g[q], g[q]);
+    }
+    block_sum<2>(v2, s_buf);
+    if (!(v2[1] > 0)) next_run = true;
+    else if (hl == 0 || !(v2[0] < 0)) { hl = 0; steepest = true; }
+    else { gdir = v2[0]; alpha = 1.0; nls = 0; new_trial = true; }
+  }
+  if (steepest) {
+    double v1[1] = {0};
+#pragma unroll
+    for (int q = 0; q < 4; q++) { dv[q] = make_float4(-g[q].x, -g[q].y, -g[q].z, -g[q].w); v1[0] += (double)dot4(g[q], g[q]); }
+    block_sum<1>(v1, s_buf);
+    if (!(v1[0] > 0)) next_run = true;
+    else { gdir = -v1[0]; alpha = fmin(1.0, 1.0 / sqrt(v1[0])); nls = 0; new_trial = true; }
+  }
+  if (next_run) {
+    run++;
+    phase = (run >= A.nruns) ? PH_DONE : PH_START;
+#pragma unroll
+    for (int q = 0; q < 4; q++) xt[q] = x[q];  // coordinates of the accepted point go back into the xyz buffer
+  }
+  if (new_trial) {
+    phase = PH_LS;
+    const float al = (float)alpha;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      xt[q] = make_float4(fmaf(al, dv[q].x, x[q].x), fmaf(al, dv[q].y, x[q].y), fmaf(al, dv[q].z, x[q].z), fmaf(al, dv[q].w, x[q].w));
+  }
+  if (phase != PH_DONE && n_evals >= A.max_evals) { status = TRX2_MAXEVAL; phase = PH_DONE; }
+  // ---- store state and the coordinates for the next pair launch
+  if (act) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { A.CX[(vb + r) * 4 + q] = x[q]; A.CG[(vb + r) * 4 + q] = g[q]; A.CD[(vb + r) * 4 + q] = dv[q]; }
+    float4* xo = reinterpret_cast<float4*>(A.xyz + (vb + r) * 16);
+    const int grp = dec / A.BW, dd = dec % A.BW;
+    float4* xT = A.xyzT + ((size_t)(grp * L + r) * 4) * A.BW + dd;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { xo[q] = xt[q]; xT[q * A.BW] = xt[q]; }
+  }
+  // ---- leaving Cartesian space (run finished, or the decoy stops here on its evaluation budget / divergence): torsions +
+  //      relaxed internal geometry of the ACCEPTED point, for the torsion-space runs after it and for the final report
+  if (next_run || phase == PH_DONE) {
+    __syncthreads();
+    if (act)
+#pragma unroll
+      for (int q = 0; q < 4; q++) reinterpret_cast<float4*>(s_xyz + r * 16)[q] = x[q];
+    __syncthreads();
+    if (act) {
+      const Res5 M2 = unpack5(s_xyz + r * 16);
+      f3 d1, d2, d3, d4;
+      ResGeom G = ideal_geom();
+      G.g0.x = sqrtf(dot(M2.CA - M2.N, M2.CA - M2.N)); G.g0.y = sqrtf(dot(M2.C - M2.CA, M2.C - M2.CA));
+      G.g0.w = angle_grad(M2.N, M2.CA, M2.C, d1, d2, d3);
+      G.g1.z = sqrtf(dot(M2.O - M2.C, M2.O - M2.C)); G.g1.w = angle_grad(M2.CA, M2.C, M2.O, d1, d2, d3);
+      {  // CB on the (b x c, b, c) basis
+        f3 b = M2.CA - M2.N, c = M2.C - M2.CA, a = cross(b, c), d = M2.CB - M2.CA;
+        const float bb = dot(b, b), cc = dot(c, c), bc = dot(b, c), det = bb * cc - bc * bc, db = dot(d, b), dc = dot(d, c);
+        G.g2.y = dot(d, a) / dot(a, a); G.g2.z = (db * cc - dc * bc) / det; G.g2.w = (dc * bb - db * bc) / det;
+      }
+      const float dO = dihedral_grad(M2.N, M2.CA, M2.C, M2.O, d1, d2, d3, d4);
+      float phi = TRX2_PI_F, psi = TRX2_PI_F, omg = TRX2_PI_F;
+      if (r > 0) { const Res5 P2 = unpack5(s_xyz + (r - 1) * 16); phi = dihedral_grad(P2.C, M2.N, M2.CA, M2.C, d1, d2, d3, d4); }
+      if (r + 1 < L) {
+        const Res5 N2 = unpack5(s_xyz + (r + 1) * 16);
+        G.g0.z = sqrtf(dot(N2.N - M2.C, N2.N - M2.C));
+        G.g1.x = angle_grad(M2.CA, M2.C, N2.N, d1, d2, d3); G.g1.y = angle_grad(M2.C, N2.N, N2.CA, d1, d2, d3);
+        psi = dihedral_grad(M2.N, M2.CA, M2.C, N2.N, d1, d2, d3, d4);
+        omg = dihedral_grad(M2.CA, M2.C, N2.N, N2.CA, d1, d2, d3, d4);
+      } else psi = dO - TRX2_PI_F;
+      G.g2.x = wrap_pi_f(dO - psi);
+      const float4 tv = make_float4(phi, psi, omg, 0);
+      A.X[vb + r] = tv; A.XT[vb + r] = tv;
+      A.geom[(vb + r) * 3] = G.g0; A.geom[(vb + r) * 3 + 1] = G.g1; A.geom[(vb + r) * 3 + 2] = G.g2;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    gi[SI_RUN] = run; gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
+    gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters; gi[SI_SEQ] = A.seq;
+    gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
+    if (phase == PH_DONE) atomicAdd(A.done_count, 1);
+    const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
+    float* w = A.wcur + (size_t)dec * 8;
+    w[0] = Rn.w[0]; w[1] = Rn.w[1]; w[2] = Rn.w[2]; w[3] = Rn.w[3];
+    w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi; w[6] = (phase == PH_DONE) ? 0.0f : 1.0f; w[7] = 0;
+  }
+  if (tid < LBM) A.rho[(size_t)dec * LBM + tid] = s_rho[tid];
+}
+
 // random start torsions: set_random_dihedral (utils_ros.py:656-696) with explicit (seed, decoy, residue) hashing
 __device__ __forceinline__ uint64_t splitmix64_dev(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -950,6 +1339,8 @@ struct trx2_ctx {
   float *fpart = nullptr, *epart = nullptr;
   double *e_last = nullptr, *f_last = nullptr;
   float* grad = nullptr; float* tors0 = nullptr;
+  float4 *CX = nullptr, *CG = nullptr, *CD = nullptr, *CS = nullptr, *CY = nullptr;  // Cartesian runs (allocated on first use)
+  int cart_B = 0, cart_L = 0;
   int* done_count = nullptr;
   trx2_run* runs = nullptr;
   int* h_done = nullptr;  // pinned
@@ -1027,6 +1418,31 @@ static void free_batch(trx2_ctx* c) {
   c->xyz = nullptr; c->xyzT = nullptr; c->geom = nullptr; c->wcur = nullptr; c->fpart = c->epart = nullptr;
   c->e_last = c->f_last = nullptr; c->grad = nullptr; c->tors0 = nullptr; c->done_count = nullptr; c->runs = nullptr;
   c->Bcap = c->Lcap = 0;
+  void* q[] = {c->CX, c->CG, c->CD, c->CS, c->CY};
+  for (void* v : q)
+    if (v) (void)hipFree(v);
+  c->CX = c->CG = c->CD = c->CS = c->CY = nullptr;
+  c->cart_B = c->cart_L = 0;
+}
+static int ensure_cart(trx2_ctx* ctx, int B) {
+  const int L = ctx->L;
+  if (ctx->CX && B <= ctx->cart_B && L <= ctx->cart_L) return 0;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  void* q[] = {ctx->CX, ctx->CG, ctx->CD, ctx->CS, ctx->CY};
+  for (void* v : q)
+    if (v) (void)hipFree(v);
+  ctx->CX = ctx->CG = ctx->CD = ctx->CS = ctx->CY = nullptr;
+  const size_t n = (size_t)B * L * 4;
+  HIPCHK(hipMalloc((void**)&ctx->CX, sizeof(float4) * n));
+  HIPCHK(hipMalloc((void**)&ctx->CG, sizeof(float4) * n));
+  HIPCHK(hipMalloc((void**)&ctx->CD, sizeof(float4) * n));
+  HIPCHK(hipMalloc((void**)&ctx->CS, sizeof(float4) * n * LBM));
+  HIPCHK(hipMalloc((void**)&ctx->CY, sizeof(float4) * n * LBM));
+  HIPCHK(hipMemsetAsync(ctx->CX, 0, sizeof(float4) * n, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->CG, 0, sizeof(float4) * n, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->CD, 0, sizeof(float4) * n, ctx->stream));
+  ctx->cart_B = B; ctx->cart_L = L;
+  return 0;
 }
 
 extern "C" void trx2_ctx_destroy(trx2_ctx* ctx) {
@@ -1209,8 +1625,9 @@ static PairArgs pair_args(trx2_ctx* c, int B) {
   P.mask = c->sel; P.knots = c->knots_f; P.wcur = c->wcur; P.fpart = c->fpart; P.epart = c->epart;
   return P;
 }
-static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_evals) {
+static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_evals, int seq) {
   ChainArgs A;
+  A.seq = seq;
   A.L = c->L; A.B = B; A.Bpad = c->Bpad; A.BW = c->BW; A.nsplit = c->nsplit; A.mode = mode; A.nruns = nruns;
   A.max_evals = max_evals; A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho;
   A.X = c->X; A.G = c->G; A.D = c->D; A.XT = c->XT; A.S = c->S; A.Y = c->Y; A.xyz = c->xyz; A.geom = c->geom; A.xyzT = c->xyzT;
@@ -1232,8 +1649,17 @@ static void launch_pair(trx2_ctx* c, int B) {
     default: hipLaunchKernelGGL(k_pair<1>, grid, block, 0, c->stream, P); break;
   }
 }
-static void launch_chain(trx2_ctx* c, int B, int mode, int nruns, int max_evals) {
-  ChainArgs A = chain_args(c, B, mode, nruns, max_evals);
+static void launch_cart(trx2_ctx* c, int B, int nruns, int max_evals, int seq) {
+  CartArgs A;
+  A.L = c->L; A.B = B; A.Bpad = c->Bpad; A.BW = c->BW; A.nsplit = c->nsplit; A.nruns = nruns; A.max_evals = max_evals; A.seq = seq;
+  A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho;
+  A.CX = c->CX; A.CG = c->CG; A.CD = c->CD; A.CS = c->CS; A.CY = c->CY;
+  A.xyz = c->xyz; A.xyzT = c->xyzT; A.X = c->X; A.XT = c->XT; A.geom = c->geom; A.wcur = c->wcur;
+  A.fpart = c->fpart; A.epart = c->epart; A.e_last = c->e_last; A.f_last = c->f_last; A.done_count = c->done_count;
+  hipLaunchKernelGGL(k_cart, dim3(B), dim3(CHAIN_THREADS), 0, c->stream, A);
+}
+static void launch_chain(trx2_ctx* c, int B, int mode, int nruns, int max_evals, int seq = -1) {
+  ChainArgs A = chain_args(c, B, mode, nruns, max_evals, seq);
   dim3 grid(B), block(CHAIN_THREADS);
   if (c->L <= CHAIN_THREADS) hipLaunchKernelGGL(k_chain<1>, grid, block, 0, c->stream, A);
   else if (c->L <= 2 * CHAIN_THREADS) hipLaunchKernelGGL(k_chain<2>, grid, block, 0, c->stream, A);
@@ -1288,11 +1714,13 @@ extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int n
   if (!ctx) return 1;
   if (!ctx->L) { ctx->err = "trx2_fold_batch: no map set"; return 1; }
   if (B < 1 || !runs || nruns < 1 || nruns > TRX2_MAX_RUNS) { ctx->err = "trx2_fold_batch: bad arguments"; return 1; }
-  for (int i = 0; i < nruns; i++)
-    if (runs[i].cartesian) { ctx->err = "trx2_fold_batch: Cartesian-space runs are not implemented"; return 1; }
+  bool has_cart = false;
+  for (int i = 0; i < nruns; i++) has_cart |= runs[i].cartesian != 0;
+  if (has_cart && ctx->L > CHAIN_THREADS) { ctx->err = "trx2_fold_batch: Cartesian-space runs support chains of up to 256 residues"; return 1; }
   if (max_evals <= 0) max_evals = 1 << 30;
   HIPCHK(hipSetDevice(ctx->device));
   if (ensure_batch(ctx, B)) return 1;
+  if (has_cart && ensure_cart(ctx, B)) return 1;
   const int L = ctx->L;
   const size_t BL = (size_t)B * L;
   auto t0 = std::chrono::steady_clock::now();
@@ -1310,8 +1738,10 @@ extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int n
   const long cap = (long)max_evals + 64;
   while (true) {
     for (int i = 0; i < chunk; i++) {
+      const int seq = launches + i + 1;  // one evaluation = one sequence number; a decoy is stepped once per evaluation
       launch_pair(ctx, B);
-      launch_chain(ctx, B, MODE_STEP, nruns, max_evals);
+      launch_chain(ctx, B, MODE_STEP, nruns, max_evals, seq);
+      if (has_cart) launch_cart(ctx, B, nruns, max_evals, seq);
     }
     launches += chunk;
     HIPCHK(hipGetLastError());

@@ -35,9 +35,18 @@ def _declash(runs, w, max_iter, sep_lo, sep_hi):
         runs.append(_run(w, max_iter, sep_lo, sep_hi, precheck=1, skip_to=end))
 
 
-def build_runs(L, mode=2, cartesian_stage=False):
+CART_MAX_L = 256  # the Cartesian step kernel handles one residue per thread (csrc/trx2fold.hip, k_cart)
+
+
+def build_runs(L, mode=2, cartesian_stage=None):
     """Run list for `-m mode` (folding/utils_ros/arguments.py:12).  Mode 3 needs the npz 'idr' mask and is
-    not reachable from run_inference.py: not built."""
+    not reachable from run_inference.py: not built.
+
+    cartesian_stage: run min_mover_cart (folding.py:100-102,170) in Cartesian space, as the reference does.  None = yes for
+    chains the Cartesian kernel supports (L <= 256); longer chains run that stage in torsion space with sf_cart's
+    weights (no bonded term), which is what every chain did before the kernel existed."""
+    if cartesian_stage is None:
+        cartesian_stage = L <= CART_MAX_L
     runs = []
     # folding.py:119  remove_clash(sf_vdw, min_mover_vdw, pose) -- no restraints loaded yet
     _declash(runs, SF_VDW, MAX_ITER_VDW, 0, 0)
@@ -53,6 +62,7 @@ def build_runs(L, mode=2, cartesian_stage=False):
         for _ in range(N_REPEAT):                # repeat_mover.apply
             runs.append(_run(SF, MAX_ITER, lo, hi))
         # min_mover_cart.apply: Cartesian-space L-BFGS on sf_cart
-        runs.append(_run(SF_CART, MAX_ITER, lo, hi, cartesian=1 if cartesian_stage else 0))
+        w_cart = SF_CART if cartesian_stage else SF_CART[:6] + [0.0, 0.0]  # no bonded term in torsion space
+        runs.append(_run(w_cart, MAX_ITER, lo, hi, cartesian=1 if cartesian_stage else 0))
         _declash(runs, SF1, MAX_ITER, lo, hi)    # remove_clash(sf_vdw, min_mover1, pose)
     return runs
