@@ -380,7 +380,10 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
 enum { PH_START = 0, PH_LS = 1, PH_DONE = 2 };
 enum { MODE_INIT = 0, MODE_STEP = 1, MODE_FINISH = 2 };
 // integer state slots
-enum { SI_RUN = 0, SI_PHASE, SI_ITER, SI_NLS, SI_HL, SI_HH, SI_NH, SI_STATUS, SI_NEVALS, SI_NITERS, SI_SEQ, SI_N = 16 };
+// SI_RUN and SI_SEQ share one aligned 8-byte word: in the fused step launch the two workgroups of a decoy read its state
+// while one of them may be writing a run transition; a single 8-byte store / load cannot be seen half-updated, so a
+// reader gets (old run, old seq) or (new run, seq of THIS launch -> "already stepped"), never a mixture.
+enum { SI_RUN = 0, SI_SEQ, SI_PHASE, SI_ITER, SI_NLS, SI_HL, SI_HH, SI_NH, SI_STATUS, SI_NEVALS, SI_NITERS, SI_N = 16 };
 // double state slots
 enum { SD_F = 0, SD_ALPHA, SD_GD, SD_FH0, SD_FH1, SD_FH2, SD_N = 8 };
 
@@ -447,8 +450,8 @@ __device__ __forceinline__ void local_atoms(const ResGeom& g, f3& N, f3& CA, f3&
 }
 
 template <int RPT>
-__global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) {
-  const int L = A.L, dec = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
+  const int L = A.L, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ double s_buf[4 * 8];
   __shared__ float s_scan[4 * 12];
   __shared__ float s_alpha[LBM];
@@ -459,7 +462,11 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) {
 
   int* gi = A.st_i + (size_t)dec * SI_N;
   double* gd_ = A.st_d + (size_t)dec * SD_N;
-  if (tid < SI_N) s_i[tid] = gi[tid];
+  if (tid < SI_N && tid >= 2) s_i[tid] = gi[tid];
+  if (tid == 0) {  // (run, seq) in ONE 8-byte load
+    const unsigned long long rs = *reinterpret_cast<const volatile unsigned long long*>(gi);
+    s_i[SI_RUN] = (int)(unsigned)(rs & 0xffffffffull); s_i[SI_SEQ] = (int)(unsigned)(rs >> 32);
+  }
   if (tid < SD_N) s_d[tid] = gd_[tid];
   if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
   __syncthreads();
@@ -787,8 +794,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) {
     }
     __syncthreads();
     if (tid == 0) {
-      gi[SI_RUN] = run; gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
-      gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters; gi[SI_SEQ] = A.seq;
+      gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
+      gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
+      *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)A.seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
       gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
       if (phase == PH_DONE) atomicAdd(A.done_count, 1);
     }
@@ -951,8 +959,8 @@ __device__ __forceinline__ LinkGrad link_terms(const Res5& P, const Res5& Q) {
   G.e = e; return G;
 }
 
-__global__ __launch_bounds__(CHAIN_THREADS) void k_cart(CartArgs A) {
-  const int L = A.L, dec = blockIdx.x, tid = threadIdx.x, r = tid;
+__device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
+  const int L = A.L, tid = threadIdx.x, r = tid;
   const bool act = r < L;
   __shared__ double s_buf[4 * 8];
   __shared__ float s_alpha[LBM];
@@ -963,7 +971,11 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_cart(CartArgs A) {
   __shared__ float s_dt[CHAIN_THREADS * 3];
   int* gi = A.st_i + (size_t)dec * SI_N;
   double* gd_ = A.st_d + (size_t)dec * SD_N;
-  if (tid < SI_N) s_i[tid] = gi[tid];
+  if (tid < SI_N && tid >= 2) s_i[tid] = gi[tid];
+  if (tid == 0) {  // (run, seq) in ONE 8-byte load
+    const unsigned long long rs = *reinterpret_cast<const volatile unsigned long long*>(gi);
+    s_i[SI_RUN] = (int)(unsigned)(rs & 0xffffffffull); s_i[SI_SEQ] = (int)(unsigned)(rs >> 32);
+  }
   if (tid < SD_N) s_d[tid] = gd_[tid];
   if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
   __syncthreads();
@@ -1272,8 +1284,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_cart(CartArgs A) {
   }
   __syncthreads();
   if (tid == 0) {
-    gi[SI_RUN] = run; gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
-    gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters; gi[SI_SEQ] = A.seq;
+    gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
+    gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
+    *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)A.seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
     gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
     if (phase == PH_DONE) atomicAdd(A.done_count, 1);
     const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
@@ -1282,6 +1295,17 @@ __global__ __launch_bounds__(CHAIN_THREADS) void k_cart(CartArgs A) {
     w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi; w[6] = (phase == PH_DONE) ? 0.0f : 1.0f; w[7] = 0;
   }
   if (tid < LBM) A.rho[(size_t)dec * LBM + tid] = s_rho[tid];
+}
+
+// ---- launchable forms.  k_chain: INIT / FINISH passes and protocols without a Cartesian run.  k_step: one launch of 2B
+// workgroups per evaluation -- workgroup d < B steps decoy d in torsion space, workgroup B + d steps it in Cartesian
+// space; whichever does not match the decoy's current run exits at once.  The two roles touch disjoint decoys, so they
+// run concurrently instead of as two half-empty launches back to back (k_cart alone was 22-27 % of GPU time).
+template <int RPT>
+__global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) { chain_body<RPT>(A, blockIdx.x); }
+__global__ __launch_bounds__(CHAIN_THREADS) void k_step(ChainArgs A, CartArgs C) {
+  if ((int)blockIdx.x < A.B) chain_body<1>(A, blockIdx.x);
+  else cart_body(C, (int)blockIdx.x - A.B);
 }
 
 // random start torsions: set_random_dihedral (utils_ros.py:656-696) with explicit (seed, decoy, residue) hashing
@@ -1649,14 +1673,14 @@ static void launch_pair(trx2_ctx* c, int B) {
     default: hipLaunchKernelGGL(k_pair<1>, grid, block, 0, c->stream, P); break;
   }
 }
-static void launch_cart(trx2_ctx* c, int B, int nruns, int max_evals, int seq) {
+static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals, int seq) {
   CartArgs A;
   A.L = c->L; A.B = B; A.Bpad = c->Bpad; A.BW = c->BW; A.nsplit = c->nsplit; A.nruns = nruns; A.max_evals = max_evals; A.seq = seq;
   A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho;
   A.CX = c->CX; A.CG = c->CG; A.CD = c->CD; A.CS = c->CS; A.CY = c->CY;
   A.xyz = c->xyz; A.xyzT = c->xyzT; A.X = c->X; A.XT = c->XT; A.geom = c->geom; A.wcur = c->wcur;
   A.fpart = c->fpart; A.epart = c->epart; A.e_last = c->e_last; A.f_last = c->f_last; A.done_count = c->done_count;
-  hipLaunchKernelGGL(k_cart, dim3(B), dim3(CHAIN_THREADS), 0, c->stream, A);
+  return A;
 }
 static void launch_chain(trx2_ctx* c, int B, int mode, int nruns, int max_evals, int seq = -1) {
   ChainArgs A = chain_args(c, B, mode, nruns, max_evals, seq);
@@ -1740,8 +1764,11 @@ extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int n
     for (int i = 0; i < chunk; i++) {
       const int seq = launches + i + 1;  // one evaluation = one sequence number; a decoy is stepped once per evaluation
       launch_pair(ctx, B);
-      launch_chain(ctx, B, MODE_STEP, nruns, max_evals, seq);
-      if (has_cart) launch_cart(ctx, B, nruns, max_evals, seq);
+      if (has_cart)  // L <= 256 here, i.e. one residue per thread in both roles
+        hipLaunchKernelGGL(k_step, dim3(2 * B), dim3(CHAIN_THREADS), 0, ctx->stream, chain_args(ctx, B, MODE_STEP, nruns, max_evals, seq),
+                           cart_args(ctx, B, nruns, max_evals, seq));
+      else
+        launch_chain(ctx, B, MODE_STEP, nruns, max_evals, seq);
     }
     launches += chunk;
     HIPCHK(hipGetLastError());
