@@ -154,6 +154,16 @@ __global__ void k_build_tables(BuildArgs A) {
   A.sel[ab] = sel;
 }
 
+// mask2[a][b] = sel[a][b] | sel[b][a] << 4 : both directions of an ordered pair in ONE row-contiguous byte.  k_pair used
+// to fetch sel[a][b] and sel[b][a] (a column access: a fresh cache line per visit) before it could even issue its
+// coordinate loads -- ~950 of ~3250 cycles per visit (s_memtime stamps, profiles/README.md).
+__global__ void k_pack_masks(int L, const unsigned char* sel, unsigned char* mask2) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)L * L) return;
+  const int a = (int)(i / L), b = (int)(i % L);
+  mask2[i] = (unsigned char)((sel[i] & 15) | ((sel[(size_t)b * L + a] & 15) << 4));
+}
+
 // =================================================================================================
 // K3/K4: pair terms.  Workgroup = (row residue a, b-range split, decoy group); lane = decoy (BW decoys per
 // wave, 64/BW residues b per wave step).  Each ORDERED pair (a,b) is visited from a's row and only the
@@ -163,7 +173,7 @@ struct PairArgs {
   int L, B, nsplit, Bpad;
   const float4* xyzT;  // [ngrp][L][4][BW] float4 : residue record (N CA C O CB + pad), decoy-minor
   const float2 *Td, *To, *Tt, *Tp;
-  const unsigned char* mask;  // [L][L] selected bits, ordered pair
+  const unsigned char* mask;  // [L][L] packed: low nibble = selected bits of (a,b), high nibble = those of (b,a)
   const float* knots;         // [107] float
   const float* wcur;          // [Bpad][8] : w_ap w_dih w_ang w_vdw sep_lo sep_hi active -
   float* fpart;               // [nsplit][Bpad][L][16] gradient on N CA C O CB (+pad)
@@ -194,7 +204,29 @@ __device__ __forceinline__ void spline_eval_dev(const float2* __restrict__ row, 
 #ifndef PAIR_MIN_WAVES
 #define PAIR_MIN_WAVES 2
 #endif
-template <int BW>
+// Diagnostic build only (-DTRX2_STAMP, never the shipped library): wave 0 of the workgroup (a = L/2, split 0, group 0)
+// accumulates s_memtime cycles per phase; every stamp first drains the memory counters so that a load's latency is charged
+// to the phase that issued it.  The drains forbid overlaps the real kernel has: read SHARES, not the total.
+#ifdef TRX2_STAMP
+__device__ unsigned long long g_stamp[32];
+#define STAMP_DECL unsigned long long st_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long st_prev = 0; \
+  const bool st_on = (blockIdx.x == (unsigned)(A.L / 2) && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x >> 6) == 0); \
+  if (st_on) { __builtin_amdgcn_s_waitcnt(0); st_prev = __builtin_amdgcn_s_memtime(); }
+#define STAMP(k) if (st_on) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+  __builtin_amdgcn_s_waitcnt(0); st_acc[k] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); }
+#define STAMP_FLUSH if (st_on && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 16; k_++) g_stamp[k_] = st_acc[k_]; }
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH
+#endif
+// FAM selects the term families an instantiation evaluates: the monolithic kernel (all three) is register-bound at 220
+// VGPRs = 2 waves per SIMD (profiles/README.md); each family alone has a much smaller live state.
+#define FAM_SYM 1   /* dist + omega: needs CA, CB */
+#define FAM_ASYM 2  /* theta + phi (both directions): needs N, CA, CB */
+#define FAM_VDW 4   /* soft-sphere repulsion: needs all five atoms, no tables */
+#define FAM_ALL 7
+template <int BW, int FAM>
 __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs A) {
   constexpr int PW = 64 / BW;
   const int L = A.L;
@@ -204,9 +236,15 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   const int dec = grp * BW + d;
   const bool live = dec < A.B;
 
+  STAMP_DECL
   __shared__ float s_kn[TRX2_KTOT];
   __shared__ float s_red[PAIR_WAVES * 64 * RED_STRIDE];  // [slot][decoy][20 (+1 pad: bank-conflict-free)]
+  __shared__ unsigned char s_mask[1024];  // packed masks of this workgroup's residues b (chunk <= L <= 1024)
   for (int i = threadIdx.x; i < TRX2_KTOT; i += PAIR_THREADS) s_kn[i] = A.knots[i];
+  {
+    const int chunk0 = (L + A.nsplit - 1) / A.nsplit, lo0 = split * chunk0, hi0 = min(L, lo0 + chunk0);
+    for (int i = lo0 + threadIdx.x; i < hi0; i += PAIR_THREADS) s_mask[i - lo0] = A.mask[(size_t)a * L + i];
+  }
   __syncthreads();
   const float* knd = s_kn;
   const float* kno = s_kn + KD;
@@ -236,6 +274,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
 
   const int chunk = (L + A.nsplit - 1) / A.nsplit;
   const int b_lo = split * chunk, b_hi = min(L, b_lo + chunk);
+  STAMP(0)  // prologue: knots to LDS, barrier, weights, residue a
 
   for (int b0 = b_lo + wave * PW; b0 < b_hi; b0 += PAIR_WAVES * PW) {
     const int b = b0 + h;
@@ -244,22 +283,27 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
     const int sep = abs(a - bc);
     unsigned m_ab = 0, m_ba = 0;
     if (valid && sep >= sep_lo && sep < sep_hi) {
-      m_ab = A.mask[(size_t)a * L + bc];
-      m_ba = A.mask[(size_t)bc * L + a];
+      const unsigned mm = s_mask[bc - b_lo];
+      m_ab = mm & 15u;
+      m_ba = mm >> 4;
     }
+    if (!(FAM & FAM_SYM)) { m_ab &= ~(TRX2_M_DIST | TRX2_M_OMEGA); m_ba &= ~(TRX2_M_DIST | TRX2_M_OMEGA); }
+    if (!(FAM & FAM_ASYM)) { m_ab &= ~(TRX2_M_THETA | TRX2_M_PHI); m_ba &= ~(TRX2_M_THETA | TRX2_M_PHI); }
     const unsigned msym = (a < bc) ? m_ab : m_ba;  // DIST / OMEGA bits live on the (min,max) row
-    const bool dovdw = valid && sep >= TRX2_VDW_MINSEP && w_vdw != 0.0f;
+    const bool dovdw = (FAM & FAM_VDW) && valid && sep >= TRX2_VDW_MINSEP && w_vdw != 0.0f;
+    STAMP(1)  // masks (2 byte loads) + loop control
     if (!__any((int)(m_ab | m_ba | (unsigned)dovdw))) continue;
 
     const float4* xb = A.xyzT + ((size_t)(grp * L + bc) * 4) * BW + d;
     float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW];
     const f3 Nb = mk3(r0.x, r0.y, r0.z), CAb = mk3(r0.w, r1.x, r1.y), Cb = mk3(r1.z, r1.w, r2.x),
              Ob = mk3(r2.y, r2.z, r2.w), CBb = mk3(r3.x, r3.y, r3.z);
+    STAMP(2)  // coordinates of residue b (4 x 16 B per lane)
     const size_t iab = (size_t)a * L + bc, iba = (size_t)bc * L + a;
     const size_t isym = (a < bc) ? iab : iba;
     const bool first = a < bc;  // symmetric energies are counted from the lower row only
 
-    if (msym & TRX2_M_DIST) {
+    if ((FAM & FAM_SYM) && (msym & TRX2_M_DIST)) {
       f3 u = CBa - CBb;
       float d2 = dot(u, u), id = rsqrtf(d2), dd = d2 * id;
       int idx = dd < 2.0f ? 0 : (dd < 3.5f ? 1 : (dd < 4.25f ? 2 : 3 + (int)((dd - 4.25f) * 2.0f)));
@@ -268,7 +312,8 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       if (first) e_d += ev;
       gCB = fma3(u, w_ap * de * id, gCB);
     }
-    if (msym & TRX2_M_OMEGA) {
+    STAMP(3)  // dist
+    if ((FAM & FAM_SYM) && (msym & TRX2_M_OMEGA)) {
       f3 d1, d2, d3, d4;
       float x = dihedral_grad(CAa, CBa, CBb, CAb, d1, d2, d3, d4);
       float ev, de;
@@ -278,7 +323,8 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       gCA = fma3(d1, s, gCA);
       gCB = fma3(d2, s, gCB);
     }
-    if (m_ab & TRX2_M_THETA) {
+    STAMP(4)  // omega
+    if ((FAM & FAM_ASYM) && (m_ab & TRX2_M_THETA)) {
       f3 d1, d2, d3, d4;
       float x = dihedral_grad(Na, CAa, CBa, CBb, d1, d2, d3, d4);
       float ev, de;
@@ -289,14 +335,16 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       gCA = fma3(d2, s, gCA);
       gCB = fma3(d3, s, gCB);
     }
-    if (m_ba & TRX2_M_THETA) {  // theta(b,a): only its gradient on CB_a (4th point)
+    STAMP(5)  // theta(a,b)
+    if ((FAM & FAM_ASYM) && (m_ba & TRX2_M_THETA)) {  // theta(b,a): only its gradient on CB_a (4th point)
       f3 d1, d2, d3, d4;
       float x = dihedral_grad(Nb, CAb, CBb, CBa, d1, d2, d3, d4);
       float ev, de;
       spline_eval_dev(A.Tt + iba * KO, knt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
       gCB = fma3(d4, w_dih * de, gCB);
     }
-    if (m_ab & TRX2_M_PHI) {
+    STAMP(6)  // theta(b,a)
+    if ((FAM & FAM_ASYM) && (m_ab & TRX2_M_PHI)) {
       f3 d1, d2, d3;
       float x = angle_grad(CAa, CBa, CBb, d1, d2, d3);
       float ev, de;
@@ -306,14 +354,16 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       gCA = fma3(d1, s, gCA);
       gCB = fma3(d2, s, gCB);
     }
-    if (m_ba & TRX2_M_PHI) {  // phi(b,a): only its gradient on CB_a (3rd point)
+    STAMP(7)  // phi(a,b)
+    if ((FAM & FAM_ASYM) && (m_ba & TRX2_M_PHI)) {  // phi(b,a): only its gradient on CB_a (3rd point)
       f3 d1, d2, d3;
       float x = angle_grad(CAb, CBb, CBa, d1, d2, d3);
       float ev, de;
       spline_eval_dev(A.Tp + iba * KP, knp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
       gCB = fma3(d3, w_ang * de, gCB);
     }
-    if (dovdw) {
+    STAMP(8)  // phi(b,a)
+    if ((FAM & FAM_VDW) && dovdw) {
       f3 dca = CAa - CAb;
       if (dot(dca, dca) < (float)TRX2_VDW_CUT2) {
         const f3 pa[5] = {Na, CAa, Ca, Oa, CBa};
@@ -340,8 +390,10 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
         gCB = fma3(ga[4], s, gCB);
       }
     }
+    STAMP(9)  // vdw
   }
 
+  STAMP(10) // loop exit
   // ---- reduce over waves and over the PW residue sub-lanes; write decoy-major records.
   // LDS image [slot][decoy][21]: a lane writes its own 20 values at stride 21 (no bank conflict); the readers are
   // (decoy, quad) pairs, 4 lanes per decoy, so every store instruction writes whole 64-B (gradient) / 32-B (energy) runs.
@@ -372,6 +424,8 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
     if (q < 4) reinterpret_cast<float4*>(A.fpart + rec * 16)[q] = v;
     else reinterpret_cast<float4*>(A.epart + rec * 8)[q - 4] = v;
   }
+  STAMP(11)  // epilogue: LDS image, barrier, column sums, stores
+  STAMP_FLUSH
 }
 
 // =================================================================================================
@@ -1351,7 +1405,7 @@ struct trx2_ctx {
   std::string seq;
   float2 *Td = nullptr, *To = nullptr, *Tt = nullptr, *Tp = nullptr;
   float *pd = nullptr, *po = nullptr, *pt = nullptr, *pp = nullptr;
-  unsigned char *gen = nullptr, *sel = nullptr;
+  unsigned char *gen = nullptr, *sel = nullptr, *mask2 = nullptr;
   float* knots_f = nullptr;
   double* knots_d = nullptr;
   double knots_h[TRX2_KTOT];
@@ -1423,12 +1477,12 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
 }
 
 static void free_map(trx2_ctx* c) {
-  void* p[] = {c->Td, c->To, c->Tt, c->Tp, c->pd, c->po, c->pt, c->pp, c->gen, c->sel, c->knots_f, c->knots_d};
+  void* p[] = {c->Td, c->To, c->Tt, c->Tp, c->pd, c->po, c->pt, c->pp, c->gen, c->sel, c->mask2, c->knots_f, c->knots_d};
   for (void* q : p)
     if (q) (void)hipFree(q);
   c->Td = c->To = c->Tt = c->Tp = nullptr;
   c->pd = c->po = c->pt = c->pp = nullptr;
-  c->gen = c->sel = nullptr;
+  c->gen = c->sel = c->mask2 = nullptr;
   c->knots_f = nullptr; c->knots_d = nullptr;
   c->L = 0;
 }
@@ -1518,6 +1572,7 @@ static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist
   HIPCHK(hipMalloc((void**)&ctx->pd, LL * 4));
   HIPCHK(hipMalloc((void**)&ctx->gen, LL));
   HIPCHK(hipMalloc((void**)&ctx->sel, LL));
+  HIPCHK(hipMalloc((void**)&ctx->mask2, LL));
   HIPCHK(hipMemsetAsync(ctx->Td, 0, LL * KD * sizeof(float2), ctx->stream));
   if (orient) {
     HIPCHK(hipMalloc((void**)&ctx->To, LL * KO * sizeof(float2)));
@@ -1551,6 +1606,7 @@ static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist
   A.Td = ctx->Td; A.To = ctx->To; A.Tt = ctx->Tt; A.Tp = ctx->Tp;
   A.pd = ctx->pd; A.po = ctx->po; A.pt = ctx->pt; A.pp = ctx->pp; A.gen = ctx->gen; A.sel = ctx->sel;
   hipLaunchKernelGGL(k_build_tables, dim3((unsigned)((LL + 127) / 128)), dim3(128), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_pack_masks, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, ctx->stream, L, ctx->sel, ctx->mask2);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   if (!device_ptrs)
@@ -1646,7 +1702,7 @@ static PairArgs pair_args(trx2_ctx* c, int B) {
   PairArgs P;
   P.L = c->L; P.B = B; P.nsplit = c->nsplit; P.Bpad = c->Bpad;
   P.xyzT = c->xyzT; P.Td = c->Td; P.To = c->To; P.Tt = c->Tt; P.Tp = c->Tp;
-  P.mask = c->sel; P.knots = c->knots_f; P.wcur = c->wcur; P.fpart = c->fpart; P.epart = c->epart;
+  P.mask = c->mask2; P.knots = c->knots_f; P.wcur = c->wcur; P.fpart = c->fpart; P.epart = c->epart;
   return P;
 }
 static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_evals, int seq) {
@@ -1660,18 +1716,22 @@ static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_eva
   return A;
 }
 
+template <int FAM>
+static void launch_pair_fam(trx2_ctx* c, const PairArgs& P, dim3 grid, dim3 block, hipStream_t st) {
+  switch (c->BW) {
+    case 64: hipLaunchKernelGGL((k_pair<64, FAM>), grid, block, 0, st, P); break;
+    case 32: hipLaunchKernelGGL((k_pair<32, FAM>), grid, block, 0, st, P); break;
+    case 16: hipLaunchKernelGGL((k_pair<16, FAM>), grid, block, 0, st, P); break;
+    case 8: hipLaunchKernelGGL((k_pair<8, FAM>), grid, block, 0, st, P); break;
+    case 4: hipLaunchKernelGGL((k_pair<4, FAM>), grid, block, 0, st, P); break;
+    case 2: hipLaunchKernelGGL((k_pair<2, FAM>), grid, block, 0, st, P); break;
+    default: hipLaunchKernelGGL((k_pair<1, FAM>), grid, block, 0, st, P); break;
+  }
+}
 static void launch_pair(trx2_ctx* c, int B) {
   PairArgs P = pair_args(c, B);
   dim3 grid(c->L, c->nsplit, c->Bpad / c->BW), block(PAIR_THREADS);
-  switch (c->BW) {
-    case 64: hipLaunchKernelGGL(k_pair<64>, grid, block, 0, c->stream, P); break;
-    case 32: hipLaunchKernelGGL(k_pair<32>, grid, block, 0, c->stream, P); break;
-    case 16: hipLaunchKernelGGL(k_pair<16>, grid, block, 0, c->stream, P); break;
-    case 8: hipLaunchKernelGGL(k_pair<8>, grid, block, 0, c->stream, P); break;
-    case 4: hipLaunchKernelGGL(k_pair<4>, grid, block, 0, c->stream, P); break;
-    case 2: hipLaunchKernelGGL(k_pair<2>, grid, block, 0, c->stream, P); break;
-    default: hipLaunchKernelGGL(k_pair<1>, grid, block, 0, c->stream, P); break;
-  }
+  launch_pair_fam<FAM_ALL>(c, P, grid, block, c->stream);
 }
 static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals, int seq) {
   CartArgs A;
@@ -1856,3 +1916,9 @@ extern "C" int trx2_last_fold_stats(trx2_ctx* ctx, double* seconds, int* n_launc
   if (n_launches) *n_launches = ctx->last_launches;
   return 0;
 }
+
+#ifdef TRX2_STAMP
+extern "C" int trx2_debug_stamps(unsigned long long* out32) {
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
