@@ -19,6 +19,7 @@ import json
 import os
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -28,7 +29,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 CONFIGS = {
     2: dict(L=150, B=64, orient=False, name="L=150 single target, init_num=64, dist-only, synthetic map seed 150"),
-    3: dict(L=150, B=64, orient=True, name="L=150 single target, init_num=64, dist+omega+theta+phi, synthetic map seed 150"),
+    3: dict(L=150, B=64, orient=True, chains=2,
+            name="L=150 single target, init_num=64 per model, dist+omega+theta+phi, --mult_two_models: two independent chains "
+                 "(synthetic maps seed 150 and 151) folded concurrently on two streams"),
     4: dict(L=400, B=32, orient=True, name="L=400 single target, init_num=32, dist+omega+theta+phi, synthetic map seed 400"),
 }
 
@@ -76,14 +79,24 @@ def main():
 
     T = importlib.import_module("trrosettax2-dynamics_amd")
     synth = importlib.import_module("trrosettax2-dynamics_amd.synth")
-    m = synth.make_map(L)
+    n_chains = cfg.get("chains", 1)
+    ms_ = [synth.make_map(L, seed=L + c) for c in range(n_chains)]
+    m = ms_[0]
     runs = T.protocol.build_runs(L, 2)
-    ctx = T.Context(local_rank)
-    ctx.set_map(m["dist"], *( [m["omega"], m["theta"], m["phi"]] if cfg["orient"] else []), seq=m["seq"])
+    ctxs = [T.Context(local_rank) for _ in range(n_chains)]
+    for c_, m_ in zip(ctxs, ms_):
+        c_.set_map(m_["dist"], *([m_["omega"], m_["theta"], m_["phi"]] if cfg["orient"] else []), seq=m_["seq"])
+    ctx = ctxs[0]
 
     def step(i):
-        # distinct decoys for every step and rank (timed steps use indices 0.., warm-up steps 900..)
-        return ctx.fold_batch(B, runs, seed=150, decoy0=((rank * 1000 + i) * B))
+        # distinct decoys for every step, rank and chain (timed steps use indices 0.., warm-up steps 900..); the chains of a
+        # step are independent (run_inference.py:310-318) and run concurrently, one context = one stream each
+        def one(c):
+            return ctxs[c].fold_batch(B, runs, seed=150 + c, decoy0=((rank * 1000 + i) * B))
+        if n_chains == 1:
+            return [one(0)]
+        with ThreadPoolExecutor(max_workers=n_chains) as ex:
+            return list(ex.map(one, range(n_chains)))
 
     def sync():
         if dist is not None:
@@ -95,7 +108,7 @@ def main():
         step(900 + i)
     sync()
     t0 = time.perf_counter()
-    res = [step(i) for i in range(args.steps)]  # fold_batch returns with the coordinates on the host
+    res = [r for i in range(args.steps) for r in step(i)]  # fold_batch returns with the coordinates on the host
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -118,21 +131,22 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "decoys/sec", "value": world * args.steps * B / elapsed, "unit": "decoys/sec",
+            "metric": "decoys/sec", "value": world * args.steps * B * n_chains / elapsed, "unit": "decoys/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["name"], "L": L, "decoys_per_step": B, "protocol": "mode 2, full staged minimisation",
+            "config": {"workload": cfg["name"], "L": L, "decoys_per_step": B * n_chains, "protocol": "mode 2, full staged minimisation",
                        "parallelism": f"decoys sharded over {world} rank(s), no collective on the data path"},
             "roofline": {"bound": "hbm", "kernel": f"k_pair<{min(64, 1 << (B - 1).bit_length())}>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": ms, "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": n_terms},
             "all_decoys_converged": bool(ok), "evals_per_decoy": {"min": int(evals.min()), "median": float(np.median(evals)), "max": int(evals.max())},
-            "pair_launches_per_step": launches / args.steps,
+            "pair_launches_per_step": launches / args.steps / n_chains,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, cfg, runs)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
-    ctx.close()
+    for c_ in ctxs:
+        c_.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

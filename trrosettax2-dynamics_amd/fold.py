@@ -13,6 +13,7 @@ Differences from the reference, all deliberate:
 import argparse
 import os
 import shlex
+import threading
 
 import numpy as np
 
@@ -20,8 +21,10 @@ from . import protocol
 from ._lib import Context
 from .pdbio import read_fasta, write_pdb
 
-_CTX = {}           # device -> Context, so that successive calls reuse the stream and buffers
+_CTX = {}           # (device, host thread) -> Context: successive calls reuse the stream and buffers; a Context is not
+                    # thread-safe, distinct Contexts run concurrently (the NMR and X-ray chains are folded that way)
 _SEED = [0x5EED]    # advances per call: distinct decoys across calls unless the caller fixes `seed`
+_SEED_LOCK = threading.Lock()
 
 
 def parse_options(options):
@@ -54,9 +57,10 @@ def _unquote(p):
 
 
 def get_context(device=0):
-    if device not in _CTX:
-        _CTX[device] = Context(device)
-    return _CTX[device]
+    key = (device, threading.get_ident())
+    if key not in _CTX:
+        _CTX[key] = Context(device)
+    return _CTX[key]
 
 
 def fold_arrays(npz, seq, n_decoys, options="", device=0, seed=None, decoy0=0):
@@ -69,8 +73,9 @@ def fold_arrays(npz, seq, n_decoys, options="", device=0, seed=None, decoy0=0):
     ang = [npz[k] for k in ("omega", "theta", "phi")] if args.use_orient else []
     ctx.set_map(npz["dist"], *ang, seq=seq, pcut=args.pcut)
     if seed is None:
-        seed = _SEED[0]
-        _SEED[0] += 1
+        with _SEED_LOCK:  # chains are folded from concurrent host threads
+            seed = _SEED[0]
+            _SEED[0] += 1
     r = ctx.fold_batch(n_decoys, protocol.build_runs(L, args.mode), seed=seed, decoy0=decoy0)
     bad = np.nonzero((r["status"] != 0) | ~np.isfinite(r["xyz"]).all(axis=(1, 2, 3)))[0]
     if len(bad):
