@@ -128,6 +128,15 @@ def main():
     abytes = algorithmic_bytes(B, n_terms, L)
     achieved = abytes / (ms * 1e-3) / 1e9
 
+    # HBM-side bytes of that kernel per launch: PMC counters cannot be collected from inside this process, so the value is the
+    # one measured with rocprofv3 for this kernel build and config and committed under profiles/ (null if absent)
+    traffic, traffic_src = None, None
+    tf = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
+    if os.path.exists(tf):
+        rec = json.load(open(tf)).get(str(args.config))
+        if rec:
+            traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/r01_final_traffic.json: " + rec["method"]
+
     out = None
     if rank == 0:
         out = {
@@ -137,7 +146,7 @@ def main():
             "config": {"workload": cfg["name"], "L": L, "decoys_per_step": B * n_chains, "protocol": "mode 2, full staged minimisation",
                        "parallelism": f"decoys sharded over {world} rank(s), no collective on the data path"},
             "roofline": {"bound": "hbm", "kernel": f"k_pair<{min(64, 1 << (B - 1).bit_length())}>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": ms, "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": n_terms},
             "all_decoys_converged": bool(ok), "evals_per_decoy": {"min": int(evals.min()), "median": float(np.median(evals)), "max": int(evals.max())},
             "pair_launches_per_step": launches / args.steps / n_chains,
