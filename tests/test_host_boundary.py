@@ -118,3 +118,24 @@ def test_synthetic_map_generator_is_deterministic_and_realisable():
     N, CA, C, CB = S.nerf_backbone(a["tors"])
     xo = O.nerf(a["tors"])
     assert max(np.abs(N - xo[:, 0]).max(), np.abs(CA - xo[:, 1]).max(), np.abs(CB - xo[:, 4]).max()) < 1e-9
+
+
+@pytest.mark.parametrize("angle", [True, False])
+def test_single_parse_feedback_equals_the_two_reference_calls(golden_dir, tmp_path, seq, angle):
+    """feedback_labels (one PDB parse, arrays in memory) == get_npz_from_pred_pdb(...) + get_npz_from_pred_pdb(..., tmp=True),
+    the two calls run_inference.py:75-77,116-118 makes; also on a second iteration, where `tmp` comes from the first."""
+    npz = os.path.join(golden_dir, "seq_NMR.npz")
+    pdb1, pdb2 = decoy_pdb(golden_dir, tmp_path, seq, "conf_2_1"), decoy_pdb(golden_dir, tmp_path, seq, "conf_2_2")
+    z = np.load(npz)
+    lab = F.feedback_labels({k: z[k] for k in (("dist", "theta", "omega", "phi") if angle else ("dist",))}, pdb1, 1.0, angle)
+    ref = F.get_npz_from_pred_pdb(npz, pdb1, angle=angle)
+    want = dict(zip(("dist", "omega", "theta", "phi"), ref)) if angle else {"dist": ref}
+    want["tmp"] = F.get_npz_from_pred_pdb(npz, pdb1, tmp=True, angle=angle)
+    assert sorted(lab) == sorted(want) and all(np.array_equal(lab[k], want[k]) for k in want)
+    it2 = str(tmp_path / "it2.npz")
+    np.savez(it2, **lab)
+    lab2 = F.feedback_labels(lab, pdb2, 1.0, angle)
+    ref2 = F.get_npz_from_pred_pdb(it2, pdb2, angle=angle)
+    want2 = dict(zip(("dist", "omega", "theta", "phi"), ref2)) if angle else {"dist": ref2}
+    want2["tmp"] = F.get_npz_from_pred_pdb(it2, pdb2, tmp=True, angle=angle)
+    assert all(np.array_equal(lab2[k], want2[k]) for k in want2)

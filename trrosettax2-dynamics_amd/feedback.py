@@ -120,6 +120,20 @@ def get_npz_from_pred_pdb(unprocessed_npz_dir, pred_pdb_dir, tmp=False, simga=1.
             process_distribution_with_pred_distribution(npz["phi"], jp, True, True, simga))
 
 
+def feedback_labels(arrays, pred_pdb_dir, sigma=1.0, angle=True):
+    """What run_inference.py:75-88,116-131 computes per iteration with two get_npz_from_pred_pdb calls (processed channels,
+    then tmp=True), from arrays already in memory and ONE parse of the decoy.  -> dict dist[/theta/omega/phi]/tmp"""
+    jd, jt, jo, jp = get_distribution_from_pdb(pred_pdb_dir)
+    labels = {"dist": process_distribution_with_pred_distribution(arrays["dist"], jd, True, True, sigma)}
+    if angle:
+        labels["theta"] = process_distribution_with_pred_distribution(arrays["theta"], jt, True, True, sigma)
+        labels["omega"] = process_distribution_with_pred_distribution(arrays["omega"], jo, True, True, sigma)
+        labels["phi"] = process_distribution_with_pred_distribution(arrays["phi"], jp, True, True, sigma)
+    base = arrays["tmp"] if "tmp" in arrays else arrays["dist"]                  # R11
+    labels["tmp"] = process_distribution_with_pred_distribution(base, jd, norm=False)
+    return labels
+
+
 def backbone_phi_psi(xyz):
     """(phi, psi) pairs as Biopython's PPBuilder reports them (utils.py:337-349): chains are split where the C-N
     peptide distance exceeds 1.8 A; residues lacking either angle (segment ends) are dropped."""

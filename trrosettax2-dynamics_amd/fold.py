@@ -99,6 +99,15 @@ def folding_with_pred_npz(base_npz, base_fasta, base_out, out_name, options="-m 
     return r
 
 
+def fold_arrays_to_pdb(arrays, seq, base_out, names, options="", device=0, seed=None, decoy0=0):
+    """folding_with_pred_npz for distograms already in memory: writes base_out/name for every name"""
+    os.makedirs(base_out, exist_ok=True)
+    r = fold_arrays(arrays, seq, len(names), options, device=device, seed=seed, decoy0=decoy0)
+    for k, name in enumerate(names):
+        write_pdb(os.path.join(base_out, name), seq, r["xyz"][k], remarks=[f"trx2fold decoy {k} seed {seed} evals {int(r['n_evals'][k])}"])
+    return r
+
+
 def fold_npz(npz_path, fasta_path, out_path, options="", device=0, seed=None):
     """one decoy to one file: what `python folding/folding.py -NPZ .. -FASTA .. -OUT ..` does"""
     npz = np.load(npz_path)

@@ -19,17 +19,25 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-from .feedback import calculate_reliability_score, get_npz_from_pred_pdb
-from .fold import folding_with_pred_npz
+from .feedback import calculate_reliability_score, feedback_labels
+from .fold import fold_arrays_to_pdb
+from .pdbio import read_fasta
 
 
 def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz, fasta, N=10, Nmax=500, begin_num=0,
                          sigma=1.0, tta_opt="-m 2 -r no-idp --orient ", angle=True, device=0, seed=None):
     """N initial decoys as one GPU batch -> best by reliability -> feedback -> one decoy per iteration until the
-    cumulative `tmp` array moves by < 0.01 or Nmax iterations (run_inference.py:97-139).  Returns the last index."""
+    cumulative `tmp` array moves by < 0.01 or Nmax iterations (run_inference.py:97-139).  Returns the last index.
+
+    The reference hands every intermediate distogram to the next fold through tmp_npz/{name}{k}.npz because that fold is
+    another process.  Here the arrays stay in memory; the files are still written, with the same names and keys, but with
+    np.savez instead of np.savez_compressed: compressing 3 MB of float32 took 95 ms per iteration at L=90, more than the
+    fold (54 ms) or the feedback (25 ms), and run_single deletes tmp_npz/ at the end (run_inference.py:334)."""
     os.makedirs(processed_npz_dir, exist_ok=True)
+    seq = read_fasta(fasta)
+    init = dict(np.load(initial_npz))
     print("Start generating the initial structures")
-    folding_with_pred_npz(f'"{initial_npz}"', f'"{fasta}"', pred_pdb_dir, "initial", tta_opt, repeat=N, device=device, seed=seed)
+    fold_arrays_to_pdb(init, seq, pred_pdb_dir, [f"initial{i}.pdb" for i in range(N)], tta_opt, device=device, seed=seed)
     print("Done generating initial structures")
     best_score, best_pdb = -np.inf, None
     for i in range(N):                                   # strict '>' : the first maximum wins (run_inference.py:67)
@@ -38,33 +46,24 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
         if score > best_score:
             best_score, best_pdb = score, pdb
 
-    def feedback(npz_path, pdb_path):
-        if angle:
-            d, o, t, p = get_npz_from_pred_pdb(npz_path, pdb_path, simga=sigma, angle=True)
-            labels = {"dist": d, "theta": t, "omega": o, "phi": p}
-        else:
-            labels = {"dist": get_npz_from_pred_pdb(npz_path, pdb_path, simga=sigma, angle=False)}
-        labels["tmp"] = get_npz_from_pred_pdb(npz_path, pdb_path, simga=sigma, tmp=True, angle=angle)
-        return labels
-
-    old_tmp = np.load(initial_npz)["dist"]
     pattern = os.path.join(processed_npz_dir, pdb_name + "{}.npz")
-    np.savez_compressed(pattern.format(begin_num + 1), **feedback(initial_npz, best_pdb))
+    base = {k: init[k] for k in (("dist", "theta", "omega", "phi") if angle else ("dist",))}   # no "tmp": falls back to dist
+    old_tmp = init["dist"]
+    cur = feedback_labels(base, best_pdb, sigma, angle)
+    np.savez(pattern.format(begin_num + 1), **cur)
     iter_n = begin_num
     while True:
         iter_n += 1
-        current = pattern.format(iter_n)
-        if os.path.exists(current):
-            old_tmp = np.load(current)["tmp"]
+        old_tmp = cur["tmp"]                             # what np.load(current_npz)["tmp"] gives (run_inference.py:101-102)
         print(f"Start generating structure {iter_n}")
-        folding_with_pred_npz(f'"{current}"', f'"{fasta}"', pred_pdb_dir, pdb_name + str(iter_n), tta_opt, device=device,
-                              seed=None if seed is None else seed + iter_n)
+        fold_arrays_to_pdb(cur, seq, pred_pdb_dir, [f"{pdb_name}{iter_n}.pdb"], tta_opt, device=device,
+                           seed=None if seed is None else seed + iter_n)
         print("Done generating structure", iter_n)
         if iter_n - begin_num >= Nmax:
             break
-        labels = feedback(current, os.path.join(pred_pdb_dir, f"{pdb_name}{iter_n}.pdb"))
-        np.savez_compressed(pattern.format(iter_n + 1), **labels)
-        if np.max(np.abs(old_tmp - labels["tmp"])) < 0.01:
+        cur = feedback_labels(cur, os.path.join(pred_pdb_dir, f"{pdb_name}{iter_n}.pdb"), sigma, angle)
+        np.savez(pattern.format(iter_n + 1), **cur)
+        if np.max(np.abs(old_tmp - cur["tmp"])) < 0.01:
             break
     return iter_n
 
