@@ -71,11 +71,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # Rehearsal on a box with fewer GPUs than ranks: TRX2_BENCH_FORCE_DEVICE=0 puts every rank on that GPU and uses gloo
+    # (NCCL refuses two ranks on one device).  It exercises the multi-rank control flow, not multi-GPU performance.
+    forced = os.environ.get("TRX2_BENCH_FORCE_DEVICE")
+    if forced is not None:
+        local_rank = int(forced)
     if world > 1:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if forced is not None:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     T = importlib.import_module("trrosettax2-dynamics_amd")
     synth = importlib.import_module("trrosettax2-dynamics_amd.synth")
@@ -113,7 +121,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed], device="cuda")
+        tt = torch.tensor([elapsed], device="cpu" if forced is not None else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

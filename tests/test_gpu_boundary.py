@@ -85,3 +85,27 @@ def test_no_angle_iteration_converges_or_stops_at_nmax(golden_dir, tmp_path):
     assert last in (1, 2) and os.path.exists(os.path.join(pdbd, f"t{last}.pdb"))
     z = np.load(os.path.join(tmpd, "t1.npz"))
     assert sorted(z.files) == ["dist", "tmp"] and z["dist"].shape == (90, 90, 37)
+
+
+def test_device_resident_distograms_give_identical_tables(golden_dir, seq):
+    """trx2_set_map_device (hand-off from the network front-end without the npz round trip): tables, masks
+    and a fold from CUDA tensors equal those from the host arrays."""
+    import torch
+    T = importlib.import_module("trrosettax2-dynamics_amd")
+    z = np.load(os.path.join(golden_dir, "seq_Xray.npz"))
+    host, dev = T.Context(0), T.Context(0)
+    try:
+        host.set_map(z["dist"], z["omega"], z["theta"], z["phi"], seq=seq)
+        t = {k: torch.from_numpy(np.ascontiguousarray(z[k], np.float32)).cuda() for k in ("dist", "omega", "theta", "phi")}
+        torch.cuda.synchronize()
+        dev.set_map_device(90, t["dist"].data_ptr(), t["omega"].data_ptr(), t["theta"].data_ptr(), t["phi"].data_ptr(), seq=seq)
+        for ch in ("dist", "omega", "theta", "phi"):
+            a, b = host.get_tables(ch), dev.get_tables(ch)
+            assert all(np.array_equal(a[k], b[k]) for k in a), ch
+        runs = T.protocol.build_runs(90, 2)
+        ra, rb = host.fold_batch(4, runs, seed=3), dev.fold_batch(4, runs, seed=3)
+        assert np.array_equal(ra["xyz"], rb["xyz"])
+        with pytest.raises(ValueError):
+            dev.set_map_device(90, t["dist"].data_ptr(), t["omega"].data_ptr())
+    finally:
+        host.close(); dev.close()

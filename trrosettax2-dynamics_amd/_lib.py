@@ -121,6 +121,18 @@ class Context:
         self._chk(self._l.trx2_set_map(self._h, L, s, *[_p(a) for a in arrs], C.byref(make_params(**params))), "trx2_set_map")
         self.L, self.use_orient = L, all(a is not None for a in arrs)
 
+    def set_map_device(self, L, dist_ptr, omega_ptr=0, theta_ptr=0, phi_ptr=0, seq=None, **params):
+        """Same as set_map with DEVICE pointers (float32, row-major [L][L][37/25/25/13]) -- the in-memory hand-off from the
+        trX2 front-end, whose softmax outputs are already on the GPU (utils_trX2dy/utils.py:783-796 writes them to an npz
+        instead).  Pass e.g. tensor.data_ptr() of contiguous CUDA tensors; the caller keeps them alive during the call."""
+        ptrs = [int(dist_ptr), int(omega_ptr), int(theta_ptr), int(phi_ptr)]
+        if not ptrs[0] or (any(ptrs[1:]) and not all(ptrs[1:])):
+            raise ValueError("dist is required; omega/theta/phi must be given together or not at all")
+        s = (seq or "A" * L).encode()
+        self._chk(self._l.trx2_set_map_device(self._h, int(L), s, *[C.c_void_p(p) if p else None for p in ptrs],
+                                              C.byref(make_params(**params))), "trx2_set_map_device")
+        self.L, self.use_orient = int(L), all(ptrs)
+
     def get_tables(self, ch):
         i = ("dist", "omega", "theta", "phi").index(ch)
         L = self.L
