@@ -6,6 +6,8 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- BEFORE the package loads libtrx2fold.so: the PyTorch wheel bundles its own ROCm runtime, and when
+#                              the system runtime (pulled in by libtrx2fold.so) is loaded first, torch.cuda finds no GPU
 
 pytestmark = pytest.mark.gpu
 
@@ -109,3 +111,47 @@ def test_device_resident_distograms_give_identical_tables(golden_dir, seq):
             dev.set_map_device(90, t["dist"].data_ptr(), t["omega"].data_ptr())
     finally:
         host.close(); dev.close()
+
+
+def test_abi_error_paths_fail_loudly(golden_dir, seq):
+    """Misuse returns an error with a message (include/trx2fold.h: non-zero return + trx2_last_error); nothing crashes,
+    nothing silently proceeds."""
+    T = importlib.import_module("trrosettax2-dynamics_amd")
+    S = importlib.import_module("trrosettax2-dynamics_amd.synth")
+    z = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
+    c = T.Context(0)
+    try:
+        runs = T.protocol.build_runs(90, 2)
+        with pytest.raises(RuntimeError, match="no map set"):
+            c.fold_batch(2, runs)
+        with pytest.raises(RuntimeError, match="no map set"):
+            c.eval_batch(np.zeros((1, 90, 3), np.float32), np.ones(8, np.float32))
+        with pytest.raises(RuntimeError, match="4 <= L <= 1024"):
+            c.set_map(np.ones((3, 3, 37), np.float32) / 37)
+        with pytest.raises(ValueError, match="expected shape"):
+            c.set_map(z["dist"], z["omega"], z["theta"], z["phi"][:, :, :12])
+        c.set_map(z["dist"], z["omega"], z["theta"], z["phi"], seq=seq)
+        with pytest.raises(RuntimeError, match="bad arguments"):
+            c.fold_batch(2, [])
+        with pytest.raises(RuntimeError, match="bad arguments"):
+            c.fold_batch(0, runs)
+        with pytest.raises(RuntimeError, match="bad arguments"):
+            c.fold_batch(2, runs * 4)                      # more than TRX2_MAX_RUNS
+        c2 = T.Context(0)
+        try:
+            c2.set_map(z["dist"], seq=seq)
+            with pytest.raises(RuntimeError, match="bad channel"):
+                c2.get_tables("omega")                     # a dist-only map has no omega table
+        finally:
+            c2.close()
+        # the context is still usable after errors
+        r = c.fold_batch(2, runs, seed=1, max_evals=50)
+        assert np.all(r["status"] == 2) and np.all(np.isfinite(r["xyz"]))   # TRX2_MAXEVAL: budget exhausted, coordinates valid
+        # Cartesian runs beyond the kernel's chain length are refused, not mis-run
+        m = S.make_map(300, seed=300, n_moves=150)
+        c.set_map(m["dist"], m["omega"], m["theta"], m["phi"])
+        with pytest.raises(RuntimeError, match="up to 256 residues"):
+            c.fold_batch(1, T.protocol.build_runs(300, 2, cartesian_stage=True))
+        assert not any(q["cartesian"] for q in T.protocol.build_runs(300, 2))   # the default protocol does not ask for it
+    finally:
+        c.close()

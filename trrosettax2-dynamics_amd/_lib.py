@@ -142,9 +142,12 @@ class Context:
         return dict(y=yy[..., 0], y2=yy[..., 1], knots=kn, prob=pr, gen=gen, sel=sel)
 
     def eval_batch(self, tors, w, sep_lo=1, sep_hi=None):
+        if not self.L:
+            raise RuntimeError("trx2_eval_batch: no map set")
         tors = np.ascontiguousarray(tors, np.float32)
         B, L = tors.shape[0], self.L
-        assert tors.shape == (B, L, 3)
+        if tors.shape != (B, L, 3):
+            raise ValueError(f"torsions must have shape (B, {L}, 3), got {tors.shape}")
         w = np.ascontiguousarray(w, np.float32)
         e = np.zeros((B, NTERMS)); f = np.zeros(B); g = np.zeros((B, L, 3), np.float32); xyz = np.zeros((B, L, 5, 3), np.float32)
         self._chk(self._l.trx2_eval_batch(self._h, B, _p(tors), _p(w), int(sep_lo), int(L if sep_hi is None else sep_hi),
@@ -154,8 +157,8 @@ class Context:
     def fold_batch(self, B, runs, seed=0, decoy0=0, tors0=None, max_evals=0):
         L = self.L
         t0 = np.ascontiguousarray(tors0, np.float32) if tors0 is not None else None
-        if t0 is not None:
-            assert t0.shape == (B, L, 3)
+        if t0 is not None and t0.shape != (B, L, 3):
+            raise ValueError(f"start torsions must have shape ({B}, {L}, 3), got {t0.shape}")
         arr = make_runs(runs)
         tors = np.zeros((B, L, 3), np.float32); xyz = np.zeros((B, L, 5, 3), np.float32)
         e = np.zeros((B, NTERMS)); f = np.zeros(B)
