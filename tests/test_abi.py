@@ -51,7 +51,8 @@ def test_protocol_mode2_matches_reference_script():
     assert all(r["precheck"] == 1 and r["skip_to"] == 5 and r["max_iter"] == 500 and r["sep_hi"] == 0 for r in runs[:5])
     assert [r["w"] for r in runs[5:8]] == [P.SF] * 3 and all(r["max_iter"] == 1000 for r in runs[5:9])
     assert runs[8]["w"] == P.SF_CART and runs[8]["cartesian"] == 1          # min_mover_cart.cartesian(True), folding.py:102
-    long = P.build_runs(400, 2)                                              # beyond the Cartesian kernel: torsion-space stand-in
+    assert P.build_runs(400, 2)[8]["cartesian"] == 1                         # up to 512 residues
+    long = P.build_runs(600, 2)                                              # beyond the Cartesian kernel: torsion-space stand-in
     assert long[8]["cartesian"] == 0 and long[8]["w"][6] == 0.0 and long[8]["w"][:6] == P.SF_CART[:6]
     assert all(r["w"] == P.SF1 and r["precheck"] == 1 and r["skip_to"] == 14 for r in runs[9:])
     assert [(r["sep_lo"], r["sep_hi"]) for r in P.build_runs(90, 0)[5:8]] == [(1, 12)] * 3

@@ -148,10 +148,10 @@ def test_abi_error_paths_fail_loudly(golden_dir, seq):
         r = c.fold_batch(2, runs, seed=1, max_evals=50)
         assert np.all(r["status"] == 2) and np.all(np.isfinite(r["xyz"]))   # TRX2_MAXEVAL: budget exhausted, coordinates valid
         # Cartesian runs beyond the kernel's chain length are refused, not mis-run
-        m = S.make_map(300, seed=300, n_moves=150)
+        m = S.make_map(520, seed=520, n_moves=150)
         c.set_map(m["dist"], m["omega"], m["theta"], m["phi"])
-        with pytest.raises(RuntimeError, match="up to 256 residues"):
-            c.fold_batch(1, T.protocol.build_runs(300, 2, cartesian_stage=True))
-        assert not any(q["cartesian"] for q in T.protocol.build_runs(300, 2))   # the default protocol does not ask for it
+        with pytest.raises(RuntimeError, match="up to 512 residues"):
+            c.fold_batch(1, T.protocol.build_runs(520, 2, cartesian_stage=True))
+        assert not any(q["cartesian"] for q in T.protocol.build_runs(520, 2))   # the default protocol does not ask for it
     finally:
         c.close()

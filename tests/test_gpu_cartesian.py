@@ -89,3 +89,38 @@ def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med
     assert np.median(best) < med_max, np.sort(best)
     assert bond_sd < 0.02 and 1.5 < ang_sd < 4.5
     assert twisted <= 8 and (best > 3).sum() <= 6
+
+
+def test_cartesian_run_on_a_chain_longer_than_256(ctx):
+    """256 < L <= 512: the Cartesian role runs with 512 threads (one residue each) next to the 256-thread torsion role in the
+    same launch.  Same short-horizon agreement with the oracle as at L=90, then the full default protocol on the same map."""
+    S = importlib.import_module("trrosettax2-dynamics_amd.synth")
+    L, B = 300, 4
+    m = S.make_map(L, seed=L, n_moves=150)
+    ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=m["seq"])
+    Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"])
+    rng = np.random.default_rng(9)
+    t0 = np.stack([m["tors"] + rng.normal(size=(L, 3)) * 0.08 for _ in range(B)]).astype(np.float32)
+    rows = []
+    for n in (12, 40):
+        r = ctx.fold_batch(B, cart_only(L), tors0=t0, max_evals=n)
+        assert np.all(np.isfinite(r["xyz"]))
+        for d in range(B):
+            to, xo, st = O.fold(Tb, t0[d].astype(np.float64), cart_only(L), max_evals=n)
+            rows.append((n, d, r["f"][d], st["f_final"], int(r["n_iters"][d]), st["n_iters"], kabsch_rmsd(r["xyz"][d].reshape(-1, 3), xo.reshape(-1, 3))))
+    print("\nL=300  evals decoy      f_device      f_oracle   iters dev/orc   all-atom RMSD dev-vs-orc")
+    for q in rows:
+        print("       %5d %4d  %12.2f  %12.2f   %3d / %3d        %.4f" % q)
+    short = [q for q in rows if q[0] == 12]
+    rel = np.array([abs(q[2] - q[3]) / abs(q[3]) for q in short])
+    assert np.median(rel) <= 5e-3 and rel.max() <= 5e-2, rel
+    assert all(q[6] < 0.2 for q in short), short
+    runs = P.build_runs(L, 2)
+    assert any(q["cartesian"] for q in runs)
+    r = ctx.fold_batch(B, runs, tors0=t0)
+    assert np.all(r["status"] == 0) and np.all(np.isfinite(r["xyz"]))
+    ca = S.nerf_backbone(m["tors"])[1]
+    rm = [kabsch_rmsd(r["xyz"][i, :, 1], ca) for i in range(B)]
+    geo = [O.extract_internal(r["xyz"][i].astype(np.float64))[1] for i in range(B)]
+    print("L=300 full protocol from near-native starts: RMSD to target %s, CA-C sd %.3f, N-CA-C sd %.1f" % (np.round(rm, 2), np.mean([g[:, 1].std() for g in geo]), np.mean([np.degrees(g[:, 3]).std() for g in geo])))
+    assert np.mean([g[:, 1].std() for g in geo]) < 0.03 and np.median(rm) < 3.0

@@ -476,6 +476,25 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double* s_buf /* [4*K]
   for (int k = 0; k < K; k++) v[k] = (s_buf[k] + s_buf[K + k]) + (s_buf[2 * K + k] + s_buf[3 * K + k]);
 }
 
+template <int K, int NW>
+__device__ __forceinline__ void block_sum_n(double (&v)[K], double* s_buf /* [NW*K] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
+  __syncthreads();
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < K; k++) s_buf[wave * K + k] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    double a = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) a += s_buf[w * K + k];  // fixed order: deterministic
+    v[k] = a;
+  }
+}
+
 __device__ __forceinline__ float dot3(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
 
 // Internal geometry of one residue, 3 float4 (what torsion-space moves keep fixed; ideal values: trx2_model.h; after a
@@ -1013,16 +1032,18 @@ __device__ __forceinline__ LinkGrad link_terms(const Res5& P, const Res5& Q) {
   G.e = e; return G;
 }
 
+template <int NT>
 __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
+  constexpr int NW = NT / 64;  // one residue per thread: NT = 256 for chains up to 256 residues, 512 up to 512
   const int L = A.L, tid = threadIdx.x, r = tid;
   const bool act = r < L;
-  __shared__ double s_buf[4 * 8];
+  __shared__ double s_buf[NW * 8];
   __shared__ float s_alpha[LBM];
   __shared__ int s_i[SI_N];
   __shared__ double s_d[SD_N];
   __shared__ float s_rho[LBM];
-  __shared__ float s_xyz[CHAIN_THREADS * 16];
-  __shared__ float s_dt[CHAIN_THREADS * 3];
+  __shared__ float s_xyz[NT * 16];
+  __shared__ float s_dt[NT * 3];
   int* gi = A.st_i + (size_t)dec * SI_N;
   double* gd_ = A.st_d + (size_t)dec * SD_N;
   if (tid < SI_N && tid >= 2) s_i[tid] = gi[tid];
@@ -1135,7 +1156,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     gt[2].x += aC.z; gt[2].y += aO.x; gt[2].z += aO.y; gt[2].w += aO.z;
     gt[3].x += aCB.x; gt[3].y += aCB.y; gt[3].z += aCB.z;
   }
-  block_sum<8>(esum, s_buf);
+  block_sum_n<8, NW>(esum, s_buf);
   const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] + (double)R.w[3] * esum[4] +
                      (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[6] * esum[7];
   if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
@@ -1174,7 +1195,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
         yv[q] = make_float4(gt[q].x - g[q].x, gt[q].y - g[q].y, gt[q].z - g[q].z, gt[q].w - g[q].w);
         v3[0] += (double)dot4(sv[q], yv[q]); v3[1] += (double)dot4(sv[q], sv[q]); v3[2] += (double)dot4(yv[q], yv[q]);
       }
-      block_sum<3>(v3, s_buf);
+      block_sum_n<3, NW>(v3, s_buf);
       if (v3[0] > 1e-12 * sqrt(v3[1] * v3[2])) {
         if (act)
 #pragma unroll
@@ -1221,7 +1242,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
         if (act) { sj[q] = A.CS[(((size_t)dec * LBM + j) * L + r) * 4 + q]; yj[q] = A.CY[(((size_t)dec * LBM + j) * L + r) * 4 + q]; }
         v1[0] += (double)dot4(sj[q], qv[q]);
       }
-      block_sum<1>(v1, s_buf);
+      block_sum_n<1, NW>(v1, s_buf);
       const float al = s_rho[j] * (float)v1[0];
       if (tid == 0) s_alpha[j] = al;
 #pragma unroll
@@ -1233,7 +1254,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
       if (act)
 #pragma unroll
         for (int q = 0; q < 4; q++) { float4 yj = A.CY[(((size_t)dec * LBM + j) * L + r) * 4 + q]; v1[0] += (double)dot4(yj, yj); }
-      block_sum<1>(v1, s_buf);
+      block_sum_n<1, NW>(v1, s_buf);
       const float gam = (float)(1.0 / ((double)s_rho[j] * v1[0]));
 #pragma unroll
       for (int q = 0; q < 4; q++) { qv[q].x *= gam; qv[q].y *= gam; qv[q].z *= gam; qv[q].w *= gam; }
@@ -1252,7 +1273,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
           v1[0] += (double)dot4(yj, qv[q]);
         }
       }
-      block_sum<1>(v1, s_buf);
+      block_sum_n<1, NW>(v1, s_buf);
       const float c = s_alpha[j] - s_rho[j] * (float)v1[0];
 #pragma unroll
       for (int q = 0; q < 4; q++) { qv[q].x += c * sj[q].x; qv[q].y += c * sj[q].y; qv[q].z += c * sj[q].z; qv[q].w += c * sj[q].w; }
@@ -1263,7 +1284,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
       dv[q] = make_float4(-qv[q].x, -qv[q].y, -qv[q].z, -qv[q].w);
       v2[0] += (double)dot4(g[q], dv[q]); v2[1] += (double)dot4(g[q], g[q]);
     }
-    block_sum<2>(v2, s_buf);
+    block_sum_n<2, NW>(v2, s_buf);
     if (!(v2[1] > 0)) next_run = true;
     else if (hl == 0 || !(v2[0] < 0)) { hl = 0; steepest = true; }
     else { gdir = v2[0]; alpha = 1.0; nls = 0; new_trial = true; }
@@ -1272,7 +1293,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     double v1[1] = {0};
 #pragma unroll
     for (int q = 0; q < 4; q++) { dv[q] = make_float4(-g[q].x, -g[q].y, -g[q].z, -g[q].w); v1[0] += (double)dot4(g[q], g[q]); }
-    block_sum<1>(v1, s_buf);
+    block_sum_n<1, NW>(v1, s_buf);
     if (!(v1[0] > 0)) next_run = true;
     else { gdir = -v1[0]; alpha = fmin(1.0, 1.0 / sqrt(v1[0])); nls = 0; new_trial = true; }
   }
@@ -1357,9 +1378,11 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
 // run concurrently instead of as two half-empty launches back to back (k_cart alone was 22-27 % of GPU time).
 template <int RPT>
 __global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) { chain_body<RPT>(A, blockIdx.x); }
-__global__ __launch_bounds__(CHAIN_THREADS) void k_step(ChainArgs A, CartArgs C) {
-  if ((int)blockIdx.x < A.B) chain_body<1>(A, blockIdx.x);
-  else cart_body(C, (int)blockIdx.x - A.B);
+template <int RPT, int NT>
+__global__ __launch_bounds__(NT) void k_step(ChainArgs A, CartArgs C) {
+  if ((int)blockIdx.x < A.B) {
+    if (NT == CHAIN_THREADS || threadIdx.x < CHAIN_THREADS) chain_body<RPT>(A, blockIdx.x);  // its upper waves (NT = 512) exit at once
+  } else cart_body<NT>(C, (int)blockIdx.x - A.B);
 }
 
 // random start torsions: set_random_dihedral (utils_ros.py:656-696) with explicit (seed, decoy, residue) hashing
@@ -1800,7 +1823,7 @@ extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int n
   if (B < 1 || !runs || nruns < 1 || nruns > TRX2_MAX_RUNS) { ctx->err = "trx2_fold_batch: bad arguments"; return 1; }
   bool has_cart = false;
   for (int i = 0; i < nruns; i++) has_cart |= runs[i].cartesian != 0;
-  if (has_cart && ctx->L > CHAIN_THREADS) { ctx->err = "trx2_fold_batch: Cartesian-space runs support chains of up to 256 residues"; return 1; }
+  if (has_cart && ctx->L > 2 * CHAIN_THREADS) { ctx->err = "trx2_fold_batch: Cartesian-space runs support chains of up to 512 residues"; return 1; }
   if (max_evals <= 0) max_evals = 1 << 30;
   HIPCHK(hipSetDevice(ctx->device));
   if (ensure_batch(ctx, B)) return 1;
@@ -1824,9 +1847,12 @@ extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int n
     for (int i = 0; i < chunk; i++) {
       const int seq = launches + i + 1;  // one evaluation = one sequence number; a decoy is stepped once per evaluation
       launch_pair(ctx, B);
-      if (has_cart)  // L <= 256 here, i.e. one residue per thread in both roles
-        hipLaunchKernelGGL(k_step, dim3(2 * B), dim3(CHAIN_THREADS), 0, ctx->stream, chain_args(ctx, B, MODE_STEP, nruns, max_evals, seq),
-                           cart_args(ctx, B, nruns, max_evals, seq));
+      if (has_cart && L <= CHAIN_THREADS)
+        hipLaunchKernelGGL((k_step<1, CHAIN_THREADS>), dim3(2 * B), dim3(CHAIN_THREADS), 0, ctx->stream,
+                           chain_args(ctx, B, MODE_STEP, nruns, max_evals, seq), cart_args(ctx, B, nruns, max_evals, seq));
+      else if (has_cart)  // 256 < L <= 512: the Cartesian role needs 512 threads (one residue each), the torsion role uses 256 of them
+        hipLaunchKernelGGL((k_step<2, 2 * CHAIN_THREADS>), dim3(2 * B), dim3(2 * CHAIN_THREADS), 0, ctx->stream,
+                           chain_args(ctx, B, MODE_STEP, nruns, max_evals, seq), cart_args(ctx, B, nruns, max_evals, seq));
       else
         launch_chain(ctx, B, MODE_STEP, nruns, max_evals, seq);
     }

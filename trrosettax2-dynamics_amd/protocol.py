@@ -35,7 +35,7 @@ def _declash(runs, w, max_iter, sep_lo, sep_hi):
         runs.append(_run(w, max_iter, sep_lo, sep_hi, precheck=1, skip_to=end))
 
 
-CART_MAX_L = 256  # the Cartesian step kernel handles one residue per thread (csrc/trx2fold.hip, k_cart)
+CART_MAX_L = 512  # the Cartesian step kernel handles one residue per thread, up to 512 threads (csrc/trx2fold.hip, cart_body)
 
 
 def build_runs(L, mode=2, cartesian_stage=None):
@@ -43,7 +43,7 @@ def build_runs(L, mode=2, cartesian_stage=None):
     not reachable from run_inference.py: not built.
 
     cartesian_stage: run min_mover_cart (folding.py:100-102,170) in Cartesian space, as the reference does.  None = yes for
-    chains the Cartesian kernel supports (L <= 256); longer chains run that stage in torsion space with sf_cart's
+    chains the Cartesian kernel supports (L <= 512); longer chains run that stage in torsion space with sf_cart's
     weights (no bonded term), which is what every chain did before the kernel existed."""
     if cartesian_stage is None:
         cartesian_stage = L <= CART_MAX_L
