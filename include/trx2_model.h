@@ -76,7 +76,10 @@ enum {
 /* soft-sphere: E = VDW_SCALE * sum_{|i-j|>=VDW_MINSEP} max(0, r0^2 - d^2)^2 / r0^2 */
 #define TRX2_VDW_SCALE 0.8
 #define TRX2_VDW_MINSEP 3
-#define TRX2_VDW_CUT2 (10.0 * 10.0) /* skip residue pairs with |CA-CA|^2 above this (max r0 + 2*|CA-X| < 10) */
+/* skip residue pairs with |CA-CA|^2 above this.  An atom pair contributes only when d < r0, and d >= |CA-CA| - |CA-X_a| -
+ * |CA-X_b|; with the ideal extents (N 1.458, C 1.524, CB 1.53, O 2.40) the largest r0 + extents is O-O: 3.01 + 4.80 = 7.81,
+ * so 8.5 leaves 0.7 A for distorted Cartesian-stage geometry. */
+#define TRX2_VDW_CUT2 (8.5 * 8.5)
 /* r0 by atom-type pair, order N CA C O CB (0.1-percentile closest approach, |i-j|>=3, in the decoys) */
 #define TRX2_VDW_R0_INIT                                                                               \
   {                                                                                                    \

@@ -70,13 +70,17 @@ __device__ __forceinline__ f3 place_atom(f3 a, f3 b, f3 c, float len, float cang
   return c + bc * (-len * cang) + m * (len * sang * ctor) + n * (len * sang * stor);
 }
 
+// hardware reciprocal (v_rcp_f32, 1 ulp) for the geometric factors below: an IEEE division is ~10 vector instructions and
+// the pair kernel, which is vector-ALU-bound (profiles/README.md), evaluates up to eight of them per residue-pair visit
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // IUPAC dihedral p1-p2-p3-p4 and its gradient with respect to the four points
 __device__ __forceinline__ float dihedral_grad(f3 p1, f3 p2, f3 p3, f3 p4, f3& d1, f3& d2, f3& d3, f3& d4) {
   f3 F = p1 - p2, G = p2 - p3, H = p4 - p3;
   f3 A = cross(F, G), B = cross(H, G);
   float G2 = dot(G, G);
   float iGn = rsqrtf(G2), Gn = G2 * iGn;
-  float iA2 = 1.0f / fmaxf(dot(A, A), 1e-12f), iB2 = 1.0f / fmaxf(dot(B, B), 1e-12f);
+  float iA2 = frcp(fmaxf(dot(A, A), 1e-12f)), iB2 = frcp(fmaxf(dot(B, B), 1e-12f));
   float cosv = dot(A, B), sinv = dot(cross(B, A), G) * iGn;
   float ang = atan2f(sinv, cosv);
   float ca = dot(F, G) * iA2 * iGn, cb = dot(H, G) * iB2 * iGn;
@@ -95,7 +99,7 @@ __device__ __forceinline__ float angle_grad(f3 p1, f3 p2, f3 p3, f3& d1, f3& d2,
   f3 vh = v * ivn, wh = w * iwn;
   float c = fminf(1.0f, fmaxf(-1.0f, dot(vh, wh)));
   float ang = acosf(c);
-  float is = -1.0f / fmaxf(sqrtf(1.0f - c * c), 1e-8f);
+  float is = -frcp(fmaxf(sqrtf(1.0f - c * c), 1e-8f));
   d1 = (wh - vh * c) * (is * ivn);
   d3 = (vh - wh * c) * (is * iwn);
   d2 = (d1 + d3) * -1.0f;

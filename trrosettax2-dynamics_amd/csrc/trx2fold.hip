@@ -31,7 +31,20 @@
 #define PAIR_WAVES (PAIR_THREADS / 64)
 #define RED_STRIDE 21
 
-__constant__ float c_vdw_r0sq[25];
+// soft-sphere radii: compile-time literals, so the fully unrolled 5 x 5 atom-pair loop of k_pair folds r0^2 and 1/r0^2 into
+// its instructions (a runtime table cost 25 scalar loads and 25 IEEE divisions = ~250 vector instructions per kernel)
+struct VdwTab { float r0sq[25], ir0sq[25]; };
+static constexpr VdwTab make_vdw_tab() {
+  constexpr double r0[5][5] = TRX2_VDW_R0_INIT;
+  VdwTab t{};
+  for (int p = 0; p < 5; p++)
+    for (int q = 0; q < 5; q++) {
+      t.r0sq[p * 5 + q] = (float)(r0[p][q] * r0[p][q]);
+      t.ir0sq[p * 5 + q] = 1.0f / t.r0sq[p * 5 + q];  // correctly rounded, as the device's IEEE division was
+    }
+  return t;
+}
+static constexpr VdwTab k_vdw = make_vdw_tab();
 __constant__ float c_rama[TRX2_RAMA_NB * 3];  // phi_k, psi_k (rad), p_k
 __constant__ float c_rama_sc[TRX2_RAMA_NB * 4];  // sin phi_k, cos phi_k, sin psi_k, cos psi_k
 
@@ -178,17 +191,20 @@ struct PairArgs {
   const float* wcur;          // [Bpad][8] : w_ap w_dih w_ang w_vdw sep_lo sep_hi active -
   float* fpart;               // [nsplit][Bpad][L][16] gradient on N CA C O CB (+pad)
   float* epart;               // [nsplit][Bpad][L][8]  raw energies dist omega theta phi vdw
+  int* seq_ctr;               // evaluation counter in device memory: bumped here, read by the step kernel that follows
 };
 
-__device__ __forceinline__ void spline_eval_dev(const float2* __restrict__ row, const float* kn, int K, int idx, float x,
-                                                float& e, float& de) {
+// ikn[i] = 1 / (kn[i+1] - kn[i]), precomputed once per workgroup: the same correctly rounded quotient the evaluator used
+// to compute per term (an IEEE division = ~10 vector instructions, six times per visit)
+__device__ __forceinline__ void spline_eval_dev(const float2* __restrict__ row, const float* kn, const float* ikn, int K,
+                                                int idx, float x, float& e, float& de) {
   // idx is a guess; fix up against the (rounded, slightly non-uniform) knots
   idx = max(0, min(K - 2, idx));
   if (x < kn[idx]) idx = max(0, idx - 1);
   else if (x >= kn[idx + 1]) idx = min(K - 2, idx + 1);
   float lo = kn[idx], hi = kn[idx + 1];
   float2 k0 = row[idx], k1 = row[idx + 1];
-  float h = hi - lo, ih = 1.0f / h;
+  float h = hi - lo, ih = ikn[idx];
   float a = (hi - x) * ih, b = (x - lo) * ih;
   bool inside = (x > kn[0]) && (x < kn[K - 1]);
   float h26 = h * h * (1.0f / 6.0f);
@@ -237,10 +253,17 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   const bool live = dec < A.B;
 
   STAMP_DECL
-  __shared__ float s_kn[TRX2_KTOT];
+  __shared__ float s_kn[TRX2_KTOT], s_ikn[TRX2_KTOT];
   __shared__ float s_red[PAIR_WAVES * 64 * RED_STRIDE];  // [slot][decoy][20 (+1 pad: bank-conflict-free)]
   __shared__ unsigned char s_mask[1024];  // packed masks of this workgroup's residues b (chunk <= L <= 1024)
-  for (int i = threadIdx.x; i < TRX2_KTOT; i += PAIR_THREADS) s_kn[i] = A.knots[i];
+  // One evaluation = one sequence number.  Kept in device memory (not a kernel argument) so that a chunk of
+  // (pair, step) launches is a STATIC graph that can be replayed.  The step kernel of this evaluation starts after this
+  // kernel has finished (same stream), so every one of its workgroups reads the same, final value.
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && A.seq_ctr) *A.seq_ctr += 1;
+  for (int i = threadIdx.x; i < TRX2_KTOT; i += PAIR_THREADS) {
+    s_kn[i] = A.knots[i];
+    s_ikn[i] = i + 1 < TRX2_KTOT ? 1.0f / (A.knots[i + 1] - A.knots[i]) : 0.0f;  // entries straddling two tables are never read
+  }
   {
     const int chunk0 = (L + A.nsplit - 1) / A.nsplit, lo0 = split * chunk0, hi0 = min(L, lo0 + chunk0);
     for (int i = lo0 + threadIdx.x; i < hi0; i += PAIR_THREADS) s_mask[i - lo0] = A.mask[(size_t)a * L + i];
@@ -250,6 +273,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   const float* kno = s_kn + KD;
   const float* knt = s_kn + KD + KO;
   const float* knp = s_kn + KD + 2 * KO;
+  const float *iknd = s_ikn, *ikno = s_ikn + KD, *iknt = s_ikn + KD + KO, *iknp = s_ikn + KD + 2 * KO;
   const float inv_o = 1.0f / (kno[1] - kno[0]), inv_p = 1.0f / (knp[1] - knp[0]);
 
   float w_ap = 0, w_dih = 0, w_ang = 0, w_vdw = 0;
@@ -308,7 +332,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       float d2 = dot(u, u), id = rsqrtf(d2), dd = d2 * id;
       int idx = dd < 2.0f ? 0 : (dd < 3.5f ? 1 : (dd < 4.25f ? 2 : 3 + (int)((dd - 4.25f) * 2.0f)));
       float ev, de;
-      spline_eval_dev(A.Td + isym * KD, knd, KD, idx, dd, ev, de);
+      spline_eval_dev(A.Td + isym * KD, knd, iknd, KD, idx, dd, ev, de);
       if (first) e_d += ev;
       gCB = fma3(u, w_ap * de * id, gCB);
     }
@@ -317,7 +341,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       f3 d1, d2, d3, d4;
       float x = dihedral_grad(CAa, CBa, CBb, CAb, d1, d2, d3, d4);
       float ev, de;
-      spline_eval_dev(A.To + isym * KO, kno, KO, (int)((x - kno[0]) * inv_o), x, ev, de);
+      spline_eval_dev(A.To + isym * KO, kno, ikno, KO, (int)((x - kno[0]) * inv_o), x, ev, de);
       if (first) e_o += ev;
       float s = w_dih * de;
       gCA = fma3(d1, s, gCA);
@@ -328,7 +352,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       f3 d1, d2, d3, d4;
       float x = dihedral_grad(Na, CAa, CBa, CBb, d1, d2, d3, d4);
       float ev, de;
-      spline_eval_dev(A.Tt + iab * KO, knt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
+      spline_eval_dev(A.Tt + iab * KO, knt, iknt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
       e_t += ev;
       float s = w_dih * de;
       gN = fma3(d1, s, gN);
@@ -340,7 +364,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       f3 d1, d2, d3, d4;
       float x = dihedral_grad(Nb, CAb, CBb, CBa, d1, d2, d3, d4);
       float ev, de;
-      spline_eval_dev(A.Tt + iba * KO, knt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
+      spline_eval_dev(A.Tt + iba * KO, knt, iknt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
       gCB = fma3(d4, w_dih * de, gCB);
     }
     STAMP(6)  // theta(b,a)
@@ -348,7 +372,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       f3 d1, d2, d3;
       float x = angle_grad(CAa, CBa, CBb, d1, d2, d3);
       float ev, de;
-      spline_eval_dev(A.Tp + iab * KP, knp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
+      spline_eval_dev(A.Tp + iab * KP, knp, iknp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
       e_p += ev;
       float s = w_ang * de;
       gCA = fma3(d1, s, gCA);
@@ -359,7 +383,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       f3 d1, d2, d3;
       float x = angle_grad(CAb, CBb, CBa, d1, d2, d3);
       float ev, de;
-      spline_eval_dev(A.Tp + iba * KP, knp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
+      spline_eval_dev(A.Tp + iba * KP, knp, iknp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
       gCB = fma3(d3, w_ang * de, gCB);
     }
     STAMP(8)  // phi(b,a)
@@ -375,9 +399,9 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
 #pragma unroll
           for (int q = 0; q < 5; q++) {
             f3 u = pa[p] - pb[q];
-            float r02 = c_vdw_r0sq[p * 5 + q];
+            constexpr VdwTab T = make_vdw_tab();
+            const float r02 = T.r0sq[p * 5 + q], ir = T.ir0sq[p * 5 + q];
             float c = fmaxf(r02 - dot(u, u), 0.0f);
-            float ir = 1.0f / r02;
             ev = fmaf(c * c, ir, ev);
             ga[p] = fma3(u, -4.0f * c * ir, ga[p]);
           }
@@ -443,7 +467,8 @@ enum { SD_F = 0, SD_ALPHA, SD_GD, SD_FH0, SD_FH1, SD_FH2, SD_N = 8 };
 
 struct ChainArgs {
   int L, B, Bpad, BW, nsplit, mode, nruns, max_evals;
-  int seq;         // iteration number: a decoy is stepped once per evaluation, by k_chain OR k_cart (SI_SEQ)
+  const int* seq_ctr;  // evaluation number (device counter bumped by k_pair): a decoy is stepped once per evaluation, by the
+                       // torsion OR the Cartesian role (SI_SEQ)
   const trx2_run* runs;
   int* st_i;       // [B][SI_N]
   double* st_d;    // [B][SD_N]
@@ -545,7 +570,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   __syncthreads();
   int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
   if (A.mode == MODE_STEP && phase == PH_DONE) return;
-  if (A.mode == MODE_STEP && (s_i[SI_SEQ] == A.seq || A.runs[min(run, A.nruns - 1)].cartesian)) return;  // k_cart's turn
+  const int seq = (A.mode == MODE_STEP) ? *A.seq_ctr : -1;
+  if (A.mode == MODE_STEP && (s_i[SI_SEQ] == seq || A.runs[min(run, A.nruns - 1)].cartesian)) return;  // the Cartesian role's turn
 
   const size_t vb = (size_t)dec * L;  // base of this decoy's [L] vectors
   float4 xt[RPT], gt[RPT];
@@ -869,7 +895,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
     if (tid == 0) {
       gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
       gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
-      *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)A.seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
+      *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
       gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
       if (phase == PH_DONE) atomicAdd(A.done_count, 1);
     }
@@ -988,7 +1014,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
 // orc_extract_internal).  The L-BFGS state machine is the one of k_chain on 4 float4 per residue.
 // =================================================================================================
 struct CartArgs {
-  int L, B, Bpad, BW, nsplit, nruns, max_evals, seq;
+  int L, B, Bpad, BW, nsplit, nruns, max_evals;
+  const int* seq_ctr;
   const trx2_run* runs;
   int* st_i; double* st_d; float* rho;
   float4 *CX, *CG, *CD;      // [B][L][4] accepted point, its gradient, direction
@@ -1055,7 +1082,8 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
   __syncthreads();
   int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
-  if (phase == PH_DONE || s_i[SI_SEQ] == A.seq) return;
+  const int seq = *A.seq_ctr;
+  if (phase == PH_DONE || s_i[SI_SEQ] == seq) return;
   const trx2_run R = A.runs[min(run, A.nruns - 1)];
   if (!R.cartesian) return;
   const size_t vb = (size_t)dec * L;
@@ -1361,7 +1389,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   if (tid == 0) {
     gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
     gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
-    *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)A.seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
+    *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
     gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
     if (phase == PH_DONE) atomicAdd(A.done_count, 1);
     const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
@@ -1443,6 +1471,11 @@ struct trx2_ctx {
   float4 *CX = nullptr, *CG = nullptr, *CD = nullptr, *CS = nullptr, *CY = nullptr;  // Cartesian runs (allocated on first use)
   int cart_B = 0, cart_L = 0;
   int* done_count = nullptr;
+  int* seq_ctr = nullptr;
+  // replayable graph of one chunk of (pair, step) launches; rebuilt when anything baked into the kernel arguments changes
+  hipGraphExec_t gexec = nullptr;
+  long g_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long alloc_epoch = 0;
   trx2_run* runs = nullptr;
   int* h_done = nullptr;  // pinned
   double last_seconds = 0; int last_launches = 0;
@@ -1475,10 +1508,6 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
     delete ctx;
     return 3;
   }
-  const double r0[5][5] = TRX2_VDW_R0_INIT;
-  float r0sq[25];
-  for (int p = 0; p < 5; p++)
-    for (int q = 0; q < 5; q++) r0sq[p * 5 + q] = (float)(r0[p][q] * r0[p][q]);
   const double rama[TRX2_RAMA_NB][3] = TRX2_RAMA_INIT;
   float rm[TRX2_RAMA_NB * 3], rsc[TRX2_RAMA_NB * 4];
   for (int k = 0; k < TRX2_RAMA_NB; k++) {
@@ -1488,8 +1517,7 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
     rm[k * 3 + 2] = (float)rama[k][2];
     rsc[k * 4] = (float)sin(ph); rsc[k * 4 + 1] = (float)cos(ph); rsc[k * 4 + 2] = (float)sin(ps); rsc[k * 4 + 3] = (float)cos(ps);
   }
-  if (hipMemcpyToSymbol(HIP_SYMBOL(c_vdw_r0sq), r0sq, sizeof r0sq) != hipSuccess ||
-      hipMemcpyToSymbol(HIP_SYMBOL(c_rama), rm, sizeof rm) != hipSuccess ||
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_rama), rm, sizeof rm) != hipSuccess ||
       hipMemcpyToSymbol(HIP_SYMBOL(c_rama_sc), rsc, sizeof rsc) != hipSuccess ||
       hipHostMalloc((void**)&ctx->h_done, sizeof(int)) != hipSuccess) {
     delete ctx;
@@ -1511,14 +1539,15 @@ static void free_map(trx2_ctx* c) {
 }
 static void free_batch(trx2_ctx* c) {
   void* p[] = {c->st_i, c->st_d, c->rho, c->X, c->G, c->D, c->XT, c->S, c->Y, c->xyz, c->xyzT, c->geom, c->wcur, c->fpart,
-               c->epart, c->e_last, c->f_last, c->grad, c->tors0, c->done_count, c->runs};
+               c->epart, c->e_last, c->f_last, c->grad, c->tors0, c->done_count, c->seq_ctr, c->runs};
   for (void* q : p)
     if (q) (void)hipFree(q);
   c->st_i = nullptr; c->st_d = nullptr; c->rho = nullptr;
   c->X = c->G = c->D = c->XT = c->S = c->Y = nullptr;
   c->xyz = nullptr; c->xyzT = nullptr; c->geom = nullptr; c->wcur = nullptr; c->fpart = c->epart = nullptr;
-  c->e_last = c->f_last = nullptr; c->grad = nullptr; c->tors0 = nullptr; c->done_count = nullptr; c->runs = nullptr;
+  c->e_last = c->f_last = nullptr; c->grad = nullptr; c->tors0 = nullptr; c->done_count = nullptr; c->seq_ctr = nullptr; c->runs = nullptr;
   c->Bcap = c->Lcap = 0;
+  c->alloc_epoch++;
   void* q[] = {c->CX, c->CG, c->CD, c->CS, c->CY};
   for (void* v : q)
     if (v) (void)hipFree(v);
@@ -1543,6 +1572,7 @@ static int ensure_cart(trx2_ctx* ctx, int B) {
   HIPCHK(hipMemsetAsync(ctx->CG, 0, sizeof(float4) * n, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->CD, 0, sizeof(float4) * n, ctx->stream));
   ctx->cart_B = B; ctx->cart_L = L;
+  ctx->alloc_epoch++;
   return 0;
 }
 
@@ -1550,6 +1580,7 @@ extern "C" void trx2_ctx_destroy(trx2_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
   free_map(ctx);
   free_batch(ctx);
   if (ctx->h_done) (void)hipHostFree(ctx->h_done);
@@ -1568,6 +1599,7 @@ static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   free_map(ctx);
+  ctx->alloc_epoch++;
   const size_t LL = (size_t)L * L;
   ctx->L = L; ctx->use_orient = orient; ctx->seq = seq ? std::string(seq, strnlen(seq, L)) : std::string();
   // knot positions after the reference's "%.3f" / "%.5f" text round trip (utils_ros.py:70,92,111,135)
@@ -1714,10 +1746,13 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
   HIPCHK(hipMalloc((void**)&ctx->grad, sizeof(float) * BL * 3));
   HIPCHK(hipMalloc((void**)&ctx->tors0, sizeof(float) * BL * 3));
   HIPCHK(hipMalloc((void**)&ctx->done_count, sizeof(int)));
+  HIPCHK(hipMalloc((void**)&ctx->seq_ctr, sizeof(int)));
+  HIPCHK(hipMemsetAsync(ctx->seq_ctr, 0, sizeof(int), ctx->stream));
   HIPCHK(hipMalloc((void**)&ctx->runs, sizeof(trx2_run) * TRX2_MAX_RUNS));
   HIPCHK(hipMemsetAsync(ctx->xyzT, 0, sizeof(float4) * (size_t)Bpad * L * 4, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->wcur, 0, sizeof(float) * Bpad * 8, ctx->stream));
   ctx->Bcap = B; ctx->Lcap = L; ctx->nsplit_cap = nsplit;
+  ctx->alloc_epoch++;
   return 0;
 }
 
@@ -1725,12 +1760,13 @@ static PairArgs pair_args(trx2_ctx* c, int B) {
   PairArgs P;
   P.L = c->L; P.B = B; P.nsplit = c->nsplit; P.Bpad = c->Bpad;
   P.xyzT = c->xyzT; P.Td = c->Td; P.To = c->To; P.Tt = c->Tt; P.Tp = c->Tp;
+  P.seq_ctr = c->seq_ctr;
   P.mask = c->mask2; P.knots = c->knots_f; P.wcur = c->wcur; P.fpart = c->fpart; P.epart = c->epart;
   return P;
 }
-static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_evals, int seq) {
+static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_evals) {
   ChainArgs A;
-  A.seq = seq;
+  A.seq_ctr = c->seq_ctr;
   A.L = c->L; A.B = B; A.Bpad = c->Bpad; A.BW = c->BW; A.nsplit = c->nsplit; A.mode = mode; A.nruns = nruns;
   A.max_evals = max_evals; A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho;
   A.X = c->X; A.G = c->G; A.D = c->D; A.XT = c->XT; A.S = c->S; A.Y = c->Y; A.xyz = c->xyz; A.geom = c->geom; A.xyzT = c->xyzT;
@@ -1756,17 +1792,17 @@ static void launch_pair(trx2_ctx* c, int B) {
   dim3 grid(c->L, c->nsplit, c->Bpad / c->BW), block(PAIR_THREADS);
   launch_pair_fam<FAM_ALL>(c, P, grid, block, c->stream);
 }
-static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals, int seq) {
+static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals) {
   CartArgs A;
-  A.L = c->L; A.B = B; A.Bpad = c->Bpad; A.BW = c->BW; A.nsplit = c->nsplit; A.nruns = nruns; A.max_evals = max_evals; A.seq = seq;
+  A.L = c->L; A.B = B; A.Bpad = c->Bpad; A.BW = c->BW; A.nsplit = c->nsplit; A.nruns = nruns; A.max_evals = max_evals; A.seq_ctr = c->seq_ctr;
   A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho;
   A.CX = c->CX; A.CG = c->CG; A.CD = c->CD; A.CS = c->CS; A.CY = c->CY;
   A.xyz = c->xyz; A.xyzT = c->xyzT; A.X = c->X; A.XT = c->XT; A.geom = c->geom; A.wcur = c->wcur;
   A.fpart = c->fpart; A.epart = c->epart; A.e_last = c->e_last; A.f_last = c->f_last; A.done_count = c->done_count;
   return A;
 }
-static void launch_chain(trx2_ctx* c, int B, int mode, int nruns, int max_evals, int seq = -1) {
-  ChainArgs A = chain_args(c, B, mode, nruns, max_evals, seq);
+static void launch_chain(trx2_ctx* c, int B, int mode, int nruns, int max_evals) {
+  ChainArgs A = chain_args(c, B, mode, nruns, max_evals);
   dim3 grid(B), block(CHAIN_THREADS);
   if (c->L <= CHAIN_THREADS) hipLaunchKernelGGL(k_chain<1>, grid, block, 0, c->stream, A);
   else if (c->L <= 2 * CHAIN_THREADS) hipLaunchKernelGGL(k_chain<2>, grid, block, 0, c->stream, A);
@@ -1843,19 +1879,41 @@ extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int n
   const int chunk = 64;
   // hard cap on launches: every decoy stops by itself at max_evals; the extra margin covers skipped runs
   const long cap = (long)max_evals + 64;
-  while (true) {
+  HIPCHK(hipMemsetAsync(ctx->seq_ctr, 0, sizeof(int), ctx->stream));
+  auto enqueue_chunk = [&]() {
     for (int i = 0; i < chunk; i++) {
-      const int seq = launches + i + 1;  // one evaluation = one sequence number; a decoy is stepped once per evaluation
-      launch_pair(ctx, B);
+      launch_pair(ctx, B);  // bumps the device-side evaluation counter
       if (has_cart && L <= CHAIN_THREADS)
         hipLaunchKernelGGL((k_step<1, CHAIN_THREADS>), dim3(2 * B), dim3(CHAIN_THREADS), 0, ctx->stream,
-                           chain_args(ctx, B, MODE_STEP, nruns, max_evals, seq), cart_args(ctx, B, nruns, max_evals, seq));
+                           chain_args(ctx, B, MODE_STEP, nruns, max_evals), cart_args(ctx, B, nruns, max_evals));
       else if (has_cart)  // 256 < L <= 512: the Cartesian role needs 512 threads (one residue each), the torsion role uses 256 of them
         hipLaunchKernelGGL((k_step<2, 2 * CHAIN_THREADS>), dim3(2 * B), dim3(2 * CHAIN_THREADS), 0, ctx->stream,
-                           chain_args(ctx, B, MODE_STEP, nruns, max_evals, seq), cart_args(ctx, B, nruns, max_evals, seq));
+                           chain_args(ctx, B, MODE_STEP, nruns, max_evals), cart_args(ctx, B, nruns, max_evals));
       else
-        launch_chain(ctx, B, MODE_STEP, nruns, max_evals, seq);
+        launch_chain(ctx, B, MODE_STEP, nruns, max_evals);
     }
+  };
+  // The chunk is a static graph (its only per-evaluation input, the sequence number, lives in device memory): capture it
+  // once per (batch shape, protocol length, buffers) and replay it -- 128 launches become one hipGraphLaunch, which matters
+  // into one hipGraphLaunch.  Measured on MI355X it changes nothing (the loop is not launch-bound: profiles/README.md),
+  // so direct launches stay the default and TRX2_GRAPH=1 opts in.
+  static const bool no_graph = getenv("TRX2_GRAPH") == nullptr;
+  if (!no_graph) {
+    const long key[8] = {B, nruns, max_evals, has_cart ? 1 : 0, L, ctx->nsplit, ctx->BW, ctx->alloc_epoch};
+    if (!ctx->gexec || memcmp(key, ctx->g_key, sizeof key) != 0) {
+      if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
+      hipGraph_t graph = nullptr;
+      HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+      enqueue_chunk();
+      HIPCHK(hipStreamEndCapture(ctx->stream, &graph));
+      HIPCHK(hipGraphInstantiate(&ctx->gexec, graph, nullptr, nullptr, 0));
+      HIPCHK(hipGraphDestroy(graph));
+      memcpy(ctx->g_key, key, sizeof key);
+    }
+  }
+  while (true) {
+    if (no_graph) enqueue_chunk();
+    else HIPCHK(hipGraphLaunch(ctx->gexec, ctx->stream));
     launches += chunk;
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ctx->h_done, ctx->done_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
