@@ -74,7 +74,7 @@ def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med
     m = np.load(os.path.join(golden_dir, f"seq_{tag}.npz"))
     ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
     dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
-    B = 24
+    B = 64  # mirror trapping is decided by the random start (1-8 % of starts): a rate needs a full batch
     runs = P.build_runs(90, 2)
     assert any(q["cartesian"] for q in runs)
     r = ctx.fold_batch(B, runs, seed=4242)
@@ -88,7 +88,7 @@ def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med
           % (B, np.median(best), np.median(best[best < 3]), int((best > 3).sum()), twisted, bond_sd, ang_sd, np.median(r["n_evals"]), r["seconds"]))
     assert np.median(best) < med_max, np.sort(best)
     assert bond_sd < 0.02 and 1.5 < ang_sd < 4.5
-    assert twisted <= 8 and (best > 3).sum() <= 6
+    assert twisted <= 0.25 * B and (best > 3).sum() <= 0.2 * B
 
 
 def test_cartesian_run_on_a_chain_longer_than_256(ctx):

@@ -1,6 +1,6 @@
 """Large-sample outcome parity on the reference's example maps: C-alpha RMSD of folded decoys to the reference's PyRosetta
 decoys (closest of the two initial decoys of the same map), for the full protocol and the torsion-only one.
-usage: parity_sample.py <repo> [n_batches of 64]"""
+usage: parity_sample.py <repo> [n_batches of 64] [first seed]"""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, sys.argv[1])
@@ -9,13 +9,14 @@ from oracle.kabsch import kabsch_rmsd
 T = importlib.import_module("trrosettax2-dynamics_amd")
 g = os.path.join(sys.argv[1], "tests", "golden"); dec = np.load(os.path.join(g, "ref_decoys.npz"))
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
 ctx = T.Context(0)
 for tag, refs in (("NMR", ("conf_2_1", "conf_2_2")), ("Xray", ("conf_1_1", "conf_1_2"))):
     m = np.load(os.path.join(g, f"seq_{tag}.npz")); ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"])
     for label, cart in (("full protocol (Cartesian stage)", True), ("torsion-only", False)):
         rm, mir, tw, bsd, asd, ev, sec = [], [], [], [], [], [], 0.0
         for b in range(nb):
-            r = ctx.fold_batch(64, T.protocol.build_runs(90, 2, cartesian_stage=cart), seed=1000 + b)
+            r = ctx.fold_batch(64, T.protocol.build_runs(90, 2, cartesian_stage=cart), seed=seed0 + b)
             assert np.all(r["status"] == 0)
             sec += r["seconds"]; ev += list(r["n_evals"])
             for i in range(64):

@@ -300,7 +300,19 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   const int b_lo = split * chunk, b_hi = min(L, b_lo + chunk);
   STAMP(0)  // prologue: knots to LDS, barrier, weights, residue a
 
-  for (int b0 = b_lo + wave * PW; b0 < b_hi; b0 += PAIR_WAVES * PW) {
+  // The loop runs in blocks of up to 32 visits.  Restraint terms are evaluated in the visit (the pair, hence the table, is
+  // the same for all decoys of the wave).  Repulsion is different: WHICH residues touch depends on the decoy, so in lockstep
+  // the 25 atom pairs ran whenever ANY of the 64 decoys was within the cutoff -- on ~85 % of the visits of a distance-only
+  // fold although ~10 % of (pair, decoy) combinations are in contact (profiles/README.md).  A visit therefore only records
+  // a contact bit per lane; after the block every lane walks ITS OWN bits, gathering its own residue b.  The walk takes
+  // max-over-lanes(contacts) steps instead of count-of-visits-with-any-contact.  Order per lane stays fixed: deterministic.
+  constexpr int VSTRIDE = PAIR_WAVES * PW;
+  for (int bb = b_lo + wave * PW; bb < b_hi; bb += 32 * VSTRIDE) {
+  unsigned vmask = 0;
+#pragma unroll 1
+  for (int v = 0; v < 32; v++) {
+    const int b0 = bb + v * VSTRIDE;
+    if (b0 >= b_hi) break;
     const int b = b0 + h;
     const bool valid = live && active && b < b_hi && b != a;
     const int bc = min(b, L - 1);
@@ -389,32 +401,40 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
     STAMP(8)  // phi(b,a)
     if ((FAM & FAM_VDW) && dovdw) {
       f3 dca = CAa - CAb;
-      if (dot(dca, dca) < (float)TRX2_VDW_CUT2) {
-        const f3 pa[5] = {Na, CAa, Ca, Oa, CBa};
-        const f3 pb[5] = {Nb, CAb, Cb, Ob, CBb};
-        f3 ga[5] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
-        float ev = 0;
-#pragma unroll
-        for (int p = 0; p < 5; p++)
-#pragma unroll
-          for (int q = 0; q < 5; q++) {
-            f3 u = pa[p] - pb[q];
-            constexpr VdwTab T = make_vdw_tab();
-            const float r02 = T.r0sq[p * 5 + q], ir = T.ir0sq[p * 5 + q];
-            float c = fmaxf(r02 - dot(u, u), 0.0f);
-            ev = fmaf(c * c, ir, ev);
-            ga[p] = fma3(u, -4.0f * c * ir, ga[p]);
-          }
-        const float s = w_vdw * (float)TRX2_VDW_SCALE;
-        if (first) e_v += (float)TRX2_VDW_SCALE * ev;
-        gN = fma3(ga[0], s, gN);
-        gCA = fma3(ga[1], s, gCA);
-        gC = fma3(ga[2], s, gC);
-        gO = fma3(ga[3], s, gO);
-        gCB = fma3(ga[4], s, gCB);
-      }
+      if (dot(dca, dca) < (float)TRX2_VDW_CUT2) vmask |= 1u << v;
     }
-    STAMP(9)  // vdw
+  }
+  while (vmask) {  // per-lane trip count; lanes without further contacts idle
+    const int v = __ffs((int)vmask) - 1;
+    vmask &= vmask - 1;
+    const int b = bb + v * VSTRIDE + h;
+    const float4* xb = A.xyzT + ((size_t)(grp * L + b) * 4) * BW + d;
+    float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW];
+    const f3 pa[5] = {Na, CAa, Ca, Oa, CBa};
+    const f3 pb[5] = {mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), mk3(r2.y, r2.z, r2.w),
+                      mk3(r3.x, r3.y, r3.z)};
+    f3 ga[5] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
+    float ev = 0;
+#pragma unroll
+    for (int p = 0; p < 5; p++)
+#pragma unroll
+      for (int q = 0; q < 5; q++) {
+        f3 u = pa[p] - pb[q];
+        constexpr VdwTab T = make_vdw_tab();
+        const float r02 = T.r0sq[p * 5 + q], ir = T.ir0sq[p * 5 + q];
+        float c = fmaxf(r02 - dot(u, u), 0.0f);
+        ev = fmaf(c * c, ir, ev);
+        ga[p] = fma3(u, -4.0f * c * ir, ga[p]);
+      }
+    const float s = w_vdw * (float)TRX2_VDW_SCALE;
+    if (a < b) e_v += (float)TRX2_VDW_SCALE * ev;  // symmetric energy: counted from the lower row only
+    gN = fma3(ga[0], s, gN);
+    gCA = fma3(ga[1], s, gCA);
+    gC = fma3(ga[2], s, gC);
+    gO = fma3(ga[3], s, gO);
+    gCB = fma3(ga[4], s, gCB);
+  }
+  STAMP(9)  // vdw
   }
 
   STAMP(10) // loop exit
@@ -501,11 +521,19 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double* s_buf /* [4*K]
   for (int k = 0; k < K; k++) v[k] = (s_buf[k] + s_buf[K + k]) + (s_buf[2 * K + k] + s_buf[3 * K + k]);
 }
 
+// workgroup barrier of an NW-wave role.  One wave: its LDS operations execute in program order, so only the compiler has
+// to be kept from reordering them.
+template <int NW>
+__device__ __forceinline__ void bsync() {
+  if (NW > 1) __syncthreads();
+  else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+}
 template <int K, int NW>
 __device__ __forceinline__ void block_sum_n(double (&v)[K], double* s_buf /* [NW*K] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
+  if (NW == 1) return;  // the butterfly leaves the total in every lane
   __syncthreads();
   if (lane == 0)
 #pragma unroll
@@ -547,16 +575,21 @@ __device__ __forceinline__ void local_atoms(const ResGeom& g, f3& N, f3& CA, f3&
   CB = CA + a * g.g2.y + b * g.g2.z + c * g.g2.w;
 }
 
-template <int RPT>
+// NT threads step one decoy, RPT residues per thread (RPT * NT >= L).  NT = 256 is what runs.  One wave (NT = 64, RPT = 3 at
+// L = 150) makes every reduction and scan barrier-free but was SLOWER on MI355X (73.7 vs 61.2 us per evaluation,
+// profiles/README.md): the step is bound by the per-thread chain of dependent arithmetic and loads, which RPT multiplies,
+// not by its ~25 barriers.
+template <int RPT, int NT>
 __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
+  constexpr int NW = NT / 64;
   const int L = A.L, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __shared__ double s_buf[4 * 8];
-  __shared__ float s_scan[4 * 12];
+  __shared__ double s_buf[NW * 8];
+  __shared__ float s_scan[NW * 12];
   __shared__ float s_alpha[LBM];
   __shared__ int s_i[SI_N];
   __shared__ double s_d[SD_N];
   __shared__ float s_rho[LBM];
-  __shared__ float s_phi[4 * CHAIN_THREADS + 1];
+  __shared__ float s_phi[RPT * NT + 1];
 
   int* gi = A.st_i + (size_t)dec * SI_N;
   double* gd_ = A.st_d + (size_t)dec * SD_N;
@@ -567,7 +600,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   }
   if (tid < SD_N) s_d[tid] = gd_[tid];
   if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
-  __syncthreads();
+  bsync<NW>();
   int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
   if (A.mode == MODE_STEP && phase == PH_DONE) return;
   const int seq = (A.mode == MODE_STEP) ? *A.seq_ctr : -1;
@@ -585,7 +618,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
     f3 gO_[RPT], gC_[RPT], gCB_[RPT], pN[RPT], pCA[RPT], pC[RPT], pO[RPT], pCB[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-      const int r = k * CHAIN_THREADS + tid;
+      const int r = k * NT + tid;
       xt[k] = make_float4(0, 0, 0, 0);
       gt[k] = make_float4(0, 0, 0, 0);
       g2[k] = g1[k] = gO_[k] = gC_[k] = gCB_[k] = pN[k] = pCA[k] = pC[k] = pO[k] = pCB[k] = mk3(0, 0, 0);
@@ -656,13 +689,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
           if (lane + o < 64) v[i] += t;
         }
       }
-      __syncthreads();
+      bsync<NW>();
       if (lane == 0)
 #pragma unroll
         for (int i = 0; i < 6; i++) s_scan[wave * 6 + i] = v[i];
-      __syncthreads();
+      bsync<NW>();
       float tot[6] = {0, 0, 0, 0, 0, 0}, after[6] = {0, 0, 0, 0, 0, 0};
-      for (int w = 0; w < 4; w++)
+      for (int w = 0; w < NW; w++)
 #pragma unroll
         for (int i = 0; i < 6; i++) {
           float t = s_scan[w * 6 + i];
@@ -673,7 +706,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       f3 inc2 = mk3(v[0] + after[0] + car2.x, v[1] + after[1] + car2.y, v[2] + after[2] + car2.z);
       f3 inc1 = mk3(v[3] + after[3] + car1.x, v[4] + after[4] + car1.y, v[5] + after[5] + car1.z);
       f3 ex2 = inc2 - g2[k], ex1 = inc1 - g1[k];  // residues > r
-      const int r = k * CHAIN_THREADS + tid;
+      const int r = k * NT + tid;
       if (r < L) {
         // omega_r: axis C_r -> N_{r+1}
         if (r + 1 < L) {
@@ -697,7 +730,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       car2 = car2 + mk3(tot[0], tot[1], tot[2]);
       car1 = car1 + mk3(tot[3], tot[4], tot[5]);
     }
-    block_sum<8>(esum, s_buf);
+    block_sum_n<8, NW>(esum, s_buf);
     const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] +
                        (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6];
     if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
@@ -707,7 +740,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       if (A.grad_out)
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
-          const int r = k * CHAIN_THREADS + tid;
+          const int r = k * NT + tid;
           if (r < L) {
             float* go = A.grad_out + (vb + r) * 3;
             go[0] = gt[k].x; go[1] = gt[k].y; go[2] = gt[k].z;
@@ -724,7 +757,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
     float4 x[RPT], g[RPT], dv[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-      const int r = k * CHAIN_THREADS + tid;
+      const int r = k * NT + tid;
       x[k] = g[k] = dv[k] = make_float4(0, 0, 0, 0);
       if (r < L) { x[k] = A.X[vb + r]; g[k] = A.G[vb + r]; dv[k] = A.D[vb + r]; }
     }
@@ -756,19 +789,19 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
           y[k] = make_float4(gt[k].x - g[k].x, gt[k].y - g[k].y, gt[k].z - g[k].z, 0);
           v3[0] += (double)dot3(s[k], y[k]); v3[1] += (double)dot3(s[k], s[k]); v3[2] += (double)dot3(y[k], y[k]);
         }
-        block_sum<3>(v3, s_buf);
+        block_sum_n<3, NW>(v3, s_buf);
         if (v3[0] > 1e-12 * sqrt(v3[1] * v3[2])) {
 #pragma unroll
           for (int k = 0; k < RPT; k++) {
-            const int r = k * CHAIN_THREADS + tid;
+            const int r = k * NT + tid;
             if (r < L) {
               A.S[((size_t)dec * LBM + hh) * L + r] = s[k];
               A.Y[((size_t)dec * LBM + hh) * L + r] = y[k];
             }
           }
-          __syncthreads();
+          bsync<NW>();
           if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
-          __syncthreads();
+          bsync<NW>();
           hh = (hh + 1) % LBM;
           if (hl < LBM) hl++;
         }
@@ -802,12 +835,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         float4 sj[RPT], yj[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
-          const int r = k * CHAIN_THREADS + tid;
+          const int r = k * NT + tid;
           sj[k] = yj[k] = make_float4(0, 0, 0, 0);
           if (r < L) { sj[k] = A.S[((size_t)dec * LBM + j) * L + r]; yj[k] = A.Y[((size_t)dec * LBM + j) * L + r]; }
           v1[0] += (double)dot3(sj[k], q[k]);
         }
-        block_sum<1>(v1, s_buf);
+        block_sum_n<1, NW>(v1, s_buf);
         const float al = s_rho[j] * (float)v1[0];
         if (tid == 0) s_alpha[j] = al;
 #pragma unroll
@@ -818,22 +851,22 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         double v1[1] = {0};
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
-          const int r = k * CHAIN_THREADS + tid;
+          const int r = k * NT + tid;
           if (r < L) { float4 yj = A.Y[((size_t)dec * LBM + j) * L + r]; v1[0] += (double)dot3(yj, yj); }
         }
-        block_sum<1>(v1, s_buf);
+        block_sum_n<1, NW>(v1, s_buf);
         const float gam = (float)(1.0 / ((double)s_rho[j] * v1[0]));
 #pragma unroll
         for (int k = 0; k < RPT; k++) { q[k].x *= gam; q[k].y *= gam; q[k].z *= gam; }
       }
-      __syncthreads();
+      bsync<NW>();
       for (int kk = hl - 1; kk >= 0; kk--) {
         const int j = (hh - 1 - kk + LBM) % LBM;
         double v1[1] = {0};
         float4 sj[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; k++) {
-          const int r = k * CHAIN_THREADS + tid;
+          const int r = k * NT + tid;
           sj[k] = make_float4(0, 0, 0, 0);
           if (r < L) {
             float4 yj = A.Y[((size_t)dec * LBM + j) * L + r];
@@ -841,7 +874,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
             v1[0] += (double)dot3(yj, q[k]);
           }
         }
-        block_sum<1>(v1, s_buf);
+        block_sum_n<1, NW>(v1, s_buf);
         const float c = s_alpha[j] - s_rho[j] * (float)v1[0];
 #pragma unroll
         for (int k = 0; k < RPT; k++) { q[k].x += c * sj[k].x; q[k].y += c * sj[k].y; q[k].z += c * sj[k].z; }
@@ -852,7 +885,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         dv[k] = make_float4(-q[k].x, -q[k].y, -q[k].z, 0);
         v2[0] += (double)dot3(g[k], dv[k]); v2[1] += (double)dot3(g[k], g[k]);
       }
-      block_sum<2>(v2, s_buf);
+      block_sum_n<2, NW>(v2, s_buf);
       if (!(v2[1] > 0)) next_run = true;
       else if (hl == 0 || !(v2[0] < 0)) { hl = 0; steepest = true; }
       else { gdir = v2[0]; alpha = 1.0; nls = 0; new_trial = true; }
@@ -861,7 +894,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       double v1[1] = {0};
 #pragma unroll
       for (int k = 0; k < RPT; k++) { dv[k] = make_float4(-g[k].x, -g[k].y, -g[k].z, 0); v1[0] += (double)dot3(g[k], g[k]); }
-      block_sum<1>(v1, s_buf);
+      block_sum_n<1, NW>(v1, s_buf);
       if (!(v1[0] > 0)) next_run = true;
       else {
         gdir = -v1[0];
@@ -888,10 +921,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
     // ---- store state
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-      const int r = k * CHAIN_THREADS + tid;
+      const int r = k * NT + tid;
       if (r < L) { A.X[vb + r] = x[k]; A.G[vb + r] = g[k]; A.D[vb + r] = dv[k]; A.XT[vb + r] = xt[k]; }
     }
-    __syncthreads();
+    bsync<NW>();
     if (tid == 0) {
       gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
       gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
@@ -903,7 +936,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   } else {
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
-      const int r = k * CHAIN_THREADS + tid;
+      const int r = k * NT + tid;
       xt[k] = (r < L) ? A.XT[vb + r] : make_float4(0, 0, 0, 0);
     }
   }
@@ -921,10 +954,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
 
   // ------------------------------------------------------------------ K1: torsions XT -> backbone (NeRF scan)
   // M_r maps frame r+1 coordinates into frame r; F_r = F_0 o M_0 o ... o M_{r-1}
-  __syncthreads();
+  bsync<NW>();
 #pragma unroll
-  for (int k = 0; k < RPT; k++) s_phi[k * CHAIN_THREADS + tid] = xt[k].x;
-  __syncthreads();
+  for (int k = 0; k < RPT; k++) s_phi[k * NT + tid] = xt[k].x;
+  bsync<NW>();
   const float4* gq = A.geom + vb * 3;
   Xf carry;  // F_0: N at the origin, CA on +x, C in the xy plane (same start as the oracle)
   {
@@ -935,7 +968,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   }
 #pragma unroll
   for (int k = 0; k < RPT; k++) {
-    const int r = k * CHAIN_THREADS + tid;
+    const int r = k * NT + tid;
     Xf M = xf_identity();
     ResGeom gr = ideal_geom();
     f3 lN = mk3(0, 0, 0), lCA = lN, lC = lN, lCB = lN;
@@ -964,17 +997,17 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       Xf t = xf_shfl_up(P, o);
       if (lane >= o) P = xf_compose(t, P);
     }
-    __syncthreads();
+    bsync<NW>();
     if (lane == 63) {
 #pragma unroll
       for (int i = 0; i < 9; i++) s_scan[wave * 12 + i] = P.r[i];
 #pragma unroll
       for (int i = 0; i < 3; i++) s_scan[wave * 12 + 9 + i] = P.t[i];
     }
-    __syncthreads();
+    bsync<NW>();
     Xf pre = carry;  // transform of everything before this wave
     Xf tot = carry;
-    for (int w = 0; w < 4; w++) {
+    for (int w = 0; w < NW; w++) {
       Xf T;
 #pragma unroll
       for (int i = 0; i < 9; i++) T.r[i] = s_scan[w * 12 + i];
@@ -1404,12 +1437,13 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
 // workgroups per evaluation -- workgroup d < B steps decoy d in torsion space, workgroup B + d steps it in Cartesian
 // space; whichever does not match the decoy's current run exits at once.  The two roles touch disjoint decoys, so they
 // run concurrently instead of as two half-empty launches back to back (k_cart alone was 22-27 % of GPU time).
-template <int RPT>
-__global__ __launch_bounds__(CHAIN_THREADS) void k_chain(ChainArgs A) { chain_body<RPT>(A, blockIdx.x); }
-template <int RPT, int NT>
+// The torsion role runs on TN threads, RPT residues each.
+template <int RPT, int TN>
+__global__ __launch_bounds__(TN) void k_chain(ChainArgs A) { chain_body<RPT, TN>(A, blockIdx.x); }
+template <int RPT, int TN, int NT>
 __global__ __launch_bounds__(NT) void k_step(ChainArgs A, CartArgs C) {
   if ((int)blockIdx.x < A.B) {
-    if (NT == CHAIN_THREADS || threadIdx.x < CHAIN_THREADS) chain_body<RPT>(A, blockIdx.x);  // its upper waves (NT = 512) exit at once
+    if (NT == TN || threadIdx.x < TN) chain_body<RPT, TN>(A, blockIdx.x);  // the other waves of the workgroup exit at once
   } else cart_body<NT>(C, (int)blockIdx.x - A.B);
 }
 
@@ -1803,10 +1837,11 @@ static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals) {
 }
 static void launch_chain(trx2_ctx* c, int B, int mode, int nruns, int max_evals) {
   ChainArgs A = chain_args(c, B, mode, nruns, max_evals);
-  dim3 grid(B), block(CHAIN_THREADS);
-  if (c->L <= CHAIN_THREADS) hipLaunchKernelGGL(k_chain<1>, grid, block, 0, c->stream, A);
-  else if (c->L <= 2 * CHAIN_THREADS) hipLaunchKernelGGL(k_chain<2>, grid, block, 0, c->stream, A);
-  else hipLaunchKernelGGL(k_chain<4>, grid, block, 0, c->stream, A);
+  const dim3 grid(B);
+  const int L = c->L;
+  if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_chain<1, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), 0, c->stream, A);
+  else if (L <= 2 * CHAIN_THREADS) hipLaunchKernelGGL((k_chain<2, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), 0, c->stream, A);
+  else hipLaunchKernelGGL((k_chain<4, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), 0, c->stream, A);
 }
 
 static int upload_single_run(trx2_ctx* ctx, const float* w, int sep_lo, int sep_hi) {
@@ -1883,20 +1918,21 @@ extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int n
   auto enqueue_chunk = [&]() {
     for (int i = 0; i < chunk; i++) {
       launch_pair(ctx, B);  // bumps the device-side evaluation counter
-      if (has_cart && L <= CHAIN_THREADS)
-        hipLaunchKernelGGL((k_step<1, CHAIN_THREADS>), dim3(2 * B), dim3(CHAIN_THREADS), 0, ctx->stream,
-                           chain_args(ctx, B, MODE_STEP, nruns, max_evals), cart_args(ctx, B, nruns, max_evals));
-      else if (has_cart)  // 256 < L <= 512: the Cartesian role needs 512 threads (one residue each), the torsion role uses 256 of them
-        hipLaunchKernelGGL((k_step<2, 2 * CHAIN_THREADS>), dim3(2 * B), dim3(2 * CHAIN_THREADS), 0, ctx->stream,
-                           chain_args(ctx, B, MODE_STEP, nruns, max_evals), cart_args(ctx, B, nruns, max_evals));
-      else
+      if (has_cart) {
+        // fused launch: workgroups of 256 (512 for 256 < L <= 512) threads, one residue per thread in the Cartesian role
+        const ChainArgs ca = chain_args(ctx, B, MODE_STEP, nruns, max_evals);
+        const CartArgs cc = cart_args(ctx, B, nruns, max_evals);
+        const dim3 g2(2 * B), b1(CHAIN_THREADS), b2(2 * CHAIN_THREADS);
+        if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS>), g2, b1, 0, ctx->stream, ca, cc);
+        else hipLaunchKernelGGL((k_step<2, CHAIN_THREADS, 2 * CHAIN_THREADS>), g2, b2, 0, ctx->stream, ca, cc);
+      } else
         launch_chain(ctx, B, MODE_STEP, nruns, max_evals);
     }
   };
   // The chunk is a static graph (its only per-evaluation input, the sequence number, lives in device memory): capture it
-  // once per (batch shape, protocol length, buffers) and replay it -- 128 launches become one hipGraphLaunch, which matters
-  // into one hipGraphLaunch.  Measured on MI355X it changes nothing (the loop is not launch-bound: profiles/README.md),
-  // so direct launches stay the default and TRX2_GRAPH=1 opts in.
+  // once per (batch shape, protocol length, buffers) and replay it -- 128 launches become one hipGraphLaunch.  Measured on
+  // MI355X it changes nothing (the loop is not launch-bound: profiles/README.md), so direct launches stay the default and
+  // TRX2_GRAPH=1 opts in.
   static const bool no_graph = getenv("TRX2_GRAPH") == nullptr;
   if (!no_graph) {
     const long key[8] = {B, nruns, max_evals, has_cart ? 1 : 0, L, ctx->nsplit, ctx->BW, ctx->alloc_epoch};
