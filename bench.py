@@ -8,8 +8,8 @@ A "step" = one call of the hot path over one batch: fold B decoys of one distogr
 (folding/folding.py:118-171 mode 2), timed from tables-resident-in-HBM to the last coordinates on the host.
 Workload at N=1 = BASELINE.json configs[1]: L=150 single target, init_num=64, dist-only restraints (synthetic map,
 SURVEY.md 8d -- the reference ships data for L=90 only).  Other configs: --config 3 (all channels), --config 4 (L=400,
-B=32).  N>1: every rank folds its own B decoys of the same target (independent units, no data-path collective):
-weak scaling.
+B=32), --config 5 (eight targets L=100..400, 32 decoys each, assigned to ranks longest-first: strong scaling).
+N>1: every rank folds its own B decoys of the same target (independent units, no data-path collective): weak scaling.
 
 Nothing here reads /root/reference.  The oracle is imported ONLY for the cpu_baseline leg (rank 0, N=1).
 """
@@ -33,6 +33,9 @@ CONFIGS = {
             name="L=150 single target, init_num=64 per model, dist+omega+theta+phi, --mult_two_models: two independent chains "
                  "(synthetic maps seed 150 and 151) folded concurrently on two streams"),
     4: dict(L=400, B=32, orient=True, name="L=400 single target, init_num=32, dist+omega+theta+phi, synthetic map seed 400"),
+    5: dict(L=400, B=32, orient=True, targets=(100, 140, 180, 220, 260, 300, 350, 400),
+            name="eight targets L in {100,140,180,220,260,300,350,400}, init_num=32 each, dist+omega+theta+phi, synthetic maps "
+                 "seed L; (target, decoy-block) items assigned to ranks longest-processing-time-first"),
 }
 
 
@@ -54,6 +57,84 @@ def cpu_baseline(m, cfg, runs, budget_s=20.0):
             break
     return dict(value=n / el, unit="decoys/sec", cores=1, kind="port",
                 sample=f"{n} decoys of the same map and protocol, oracle/trx2_oracle.c -O3 -march=native, 1 thread, {el:.1f} s")
+
+
+def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced):
+    """a list of targets of different length.  Work item = (target, decoy block); every rank
+    derives the same longest-first plan (sched.lpt_assign splits decoy blocks while ranks would idle or the load is uneven)
+    and folds its items, up to three at a time on separate contexts (streams).  Total work is fixed: strong scaling."""
+    sched = importlib.import_module("trrosettax2-dynamics_amd.sched")
+    B = cfg["B"]
+    items = sched.make_items([(f"L{L}", L) for L in cfg["targets"]], chains=("NMR",), init_num=B)
+    mine = sched.lpt_assign(items, world)[rank]
+    maps = {it.L: synth.make_map(it.L, seed=it.L) for it in mine}
+    ctxs = []
+    for it in mine:  # tables of every item resident before the timed region
+        c = T.Context(local_rank)
+        m = maps[it.L]
+        c.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=m["seq"])
+        ctxs.append(c)
+
+    def fold(k, i):
+        it = mine[k]
+        return ctxs[k].fold_batch(it.n, T.protocol.build_runs(it.L, 2), seed=it.L, decoy0=i * B + it.decoy0)
+
+    def step(i):
+        with ThreadPoolExecutor(max_workers=3) as ex:
+            return list(ex.map(lambda k: fold(k, i), range(len(mine))))
+
+    def sync():
+        if dist is not None:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(900 + i)
+    sync()
+    t0 = time.perf_counter()
+    res = [r for i in range(args.steps) for r in step(i)]
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], device="cpu" if forced is not None else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ok = all(np.all(r["status"] == 0) and np.all(np.isfinite(r["xyz"])) for r in res)
+    stats = sched.gather_stats(dict(decoys=sum(it.n for it in mine) * args.steps, seconds=elapsed, failed=0 if ok else 1), dist)
+    out = None
+    if rank == 0:
+        it = mine[0]  # rank 0's heaviest item: its pair kernel on the coordinates of the last batch
+        ms, term_evals = ctxs[0].time_pair_kernel(it.n, np.array(T.protocol.SF, np.float32), 1, it.L, n_rep=100)
+        abytes = algorithmic_bytes(it.n, term_evals / it.n, it.L)
+        total = len(cfg["targets"]) * B
+        out = {
+            "metric": "decoys/sec", "value": args.steps * total / elapsed, "unit": "decoys/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["name"], "decoys_per_step": total, "protocol": "mode 2, full staged minimisation",
+                       "parallelism": f"{len(items)} targets -> {sum(len(p) for p in sched.lpt_assign(items, world))} items over {world} rank(s), "
+                                      "no collective on the data path",
+                       "items_rank0": [(i.target, i.decoy0, i.n) for i in mine]},
+            "roofline": {"bound": "hbm", "kernel": f"k_pair<{min(64, 1 << (it.n - 1).bit_length())}> of target {it.target}",
+                         "achieved": abytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+                         "algorithmic_bytes_per_launch": abytes},
+            "all_decoys_converged": bool(all(p["failed"] == 0 for p in stats)),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            L0 = min(cfg["targets"])
+            out["cpu_baseline"] = cpu_baseline(synth.make_map(L0, seed=L0), dict(L=L0, orient=True), T.protocol.build_runs(L0, 2))
+            out["cpu_baseline"]["sample"] += f" (the L={L0} target only)"
+            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+    for c in ctxs:
+        c.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
 
 
 def main():
@@ -88,6 +169,8 @@ def main():
     T = importlib.import_module("trrosettax2-dynamics_amd")
     synth = importlib.import_module("trrosettax2-dynamics_amd.synth")
     n_chains = cfg.get("chains", 1)
+    if "targets" in cfg:
+        return multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced)
     ms_ = [synth.make_map(L, seed=L + c) for c in range(n_chains)]
     m = ms_[0]
     runs = T.protocol.build_runs(L, 2)

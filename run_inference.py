@@ -35,8 +35,31 @@ def main(argv=None):
     pipe = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
     kw = dict(init_num=a.init_num, Nmax=a.Nmax, angle=a.angle, mult_two_models=a.mult_two_models, device=dev, seed=a.seed)
     if a.name_lst:
-        for name in [l.strip() for l in open(a.name_lst) if l.strip()]:     # run_inference.py:343-348
-            pipe.run_single(name, os.path.join(a.fasta_dir, name + ".fasta"), a.save_dir, **kw)
+        # run_inference.py:343-348, sharded over ranks when launched by torch.distributed.run (one process per GPU):
+        # targets are independent, the only communication is the final gather of the per-rank summaries
+        names = [l.strip() for l in open(a.name_lst) if l.strip()]
+        rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
+        dist = None
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group("gloo")
+            kw["device"] = local
+        dev_ = kw.pop("device")
+        res = pipe.run_batch(names, a.fasta_dir, a.save_dir, rank=rank, world=world, dist=dist, device=dev_, **kw)
+        if rank == 0:
+            print(f"Batch finished: {res['decoys']} structures from {len(names)} targets on {world} rank(s) in {res['seconds']:.1f} s, "
+                  f"{res['failed']} failed")
+            for e in res["errors"]:
+                print("  FAILED", e, file=sys.stderr)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 1 if res["failed"] else 0
     else:
         pipe.run_single(a.name, a.fasta, a.save_dir, npz_nmr=a.npz_nmr, npz_xray=a.npz_xray, **kw)
     return 0

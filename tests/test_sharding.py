@@ -72,3 +72,58 @@ def test_world_size_2_gloo_sharded_run():
     units = [(t, c, d) for f in allf for (t, c, d0, n) in f for d in range(d0, d0 + n)]
     assert len(units) == len(set(units)) == 96                                              # disjoint and complete
     assert all(len(f) > 0 for f in allf)
+
+
+def _batch_worker(rank, world, port, q, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
+        names = ["t%d" % L for L in (40, 90, 60, 120, 75)]
+
+        def fake_run_single(name, fasta_file, save_dir, device=0, **kw):  # no GPU here: stands in for pipeline.run_single
+            assert os.path.exists(fasta_file) and device == rank and kw["init_num"] == 4
+            if name == "t60":
+                raise RuntimeError("fold failed for decoys [1]")
+            open(os.path.join(save_dir, f"{name}.rank{rank}"), "w").close()
+            return 2 * kw["init_num"] + 3
+
+        res = P.run_batch(names, tmp, tmp, rank=rank, world=world, dist=dist, device=rank, run=fake_run_single, init_num=4,
+                          mult_two_models=True)
+        dist.barrier()
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_batch_mode_shards_targets(tmp_path):
+    """run_inference.py batch mode over two ranks: every target runs exactly once, on the rank the LPT plan gives it; a
+    failing target is reported by every rank's summary and does not stop the others."""
+    for L in (40, 90, 60, 120, 75):
+        (tmp_path / f"t{L}.fasta").write_text(f">t{L}\n" + "A" * L + "\n")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1]                                   # every rank holds the same summary
+    res = got[0]
+    assert res["failed"] == 1 and res["errors"] == ["t60: RuntimeError: fold failed for decoys [1]"]
+    assert res["decoys"] == 4 * 11 and len(res["per_rank"]) == 2
+    done = sorted(f for f in os.listdir(tmp_path) if ".rank" in f)
+    assert sorted(d.split(".")[0] for d in done) == ["t120", "t40", "t75", "t90"]      # each surviving target exactly once
+    by_rank = {r: sorted(p["targets"]) for r, p in enumerate(res["per_rank"])}
+    assert by_rank[0] and by_rank[1] and "t120" in by_rank[0]  # LPT: the heaviest target goes to rank 0 first
+    plan = S.lpt_assign([S.Item(f"t{L}", "all", L, 0, 8) for L in (40, 90, 60, 120, 75)], 2, min_block=1 << 30)
+    assert all(it.n == 8 for its in plan for it in its)       # targets are never split
+    for r in (0, 1):                                          # what ran where is what the plan says (minus the failure)
+        assert by_rank[r] == sorted(it.target for it in plan[r] if it.target != "t60")
+    loads = [sum(it.cost for it in its) for its in plan]
+    assert max(loads) <= 1.25 * sum(loads) / 2, loads

@@ -19,6 +19,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
+from . import sched
 from .feedback import calculate_reliability_score, feedback_labels
 from .fold import fold_arrays_to_pdb
 from .pdbio import read_fasta
@@ -155,3 +156,34 @@ def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mu
     flatten_and_rename(pdb_dir, num)
     print(f"Inference for sample '{name}' completed. Results in {content}")
     return n_out
+
+
+def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, run=None, **kw):
+    """Batch mode (run_inference.py:339-348: `for name in names: run_single(...)`) sharded over ranks, one process per GPU.
+
+    Targets are independent, so there is no data-path collective: every rank derives the same longest-processing-time-first
+    plan (cost = decoys x L^2, sched.lpt_assign) from the name list and runs ITS targets on ITS device.  A target is not split:
+    its iteration loop is sequential and the choice of the best initial decoy needs all of them (run_inference.py:60-73).
+    A failing target is recorded and the rest of the list still runs (the reference's loop dies at the first exception);
+    the summary -- gathered with all_gather_object, the only communication -- carries the failures and the caller turns
+    them into a non-zero exit code.  `run` stands in for run_single in the CPU tests."""
+    import time
+    run = run or run_single
+    n_chain = 2 if kw.get("mult_two_models", True) else 1
+    init_num = kw.get("init_num", 10)
+    fasta = {n: os.path.join(fasta_dir, n + ".fasta") for n in names}
+    items = [sched.Item(n, "all", len(read_fasta(fasta[n])), 0, init_num * n_chain) for n in names]
+    mine = sched.lpt_assign(items, world, min_block=1 << 30)[rank]   # min_block: never split a target
+    local = dict(decoys=0, seconds=0.0, failed=0, targets=[], errors=[])
+    for it in mine:
+        t0 = time.perf_counter()
+        try:
+            local["decoys"] += run(it.target, fasta[it.target], save_dir, device=device, **kw)
+            local["targets"].append(it.target)
+        except Exception as e:  # noqa: BLE001 -- recorded, reported, and reflected in the exit code
+            local["failed"] += 1
+            local["errors"].append(f"{it.target}: {type(e).__name__}: {e}")
+        local["seconds"] += time.perf_counter() - t0
+    per = sched.gather_stats(local, dist)
+    return dict(decoys=sum(p["decoys"] for p in per), seconds=max(p["seconds"] for p in per), failed=sum(p["failed"] for p in per),
+                errors=[e for p in per for e in p["errors"]], per_rank=per)
