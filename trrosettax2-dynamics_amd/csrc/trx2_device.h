@@ -106,13 +106,31 @@ __device__ __forceinline__ float angle_grad(f3 p1, f3 p2, f3 p3, f3& d1, f3& d2,
   return ang;
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+// ---- wave-wide sum, total in every lane; all 64 lanes must be active.
+// __shfl_xor is a ds_bpermute through the LDS crossbar (~120 cycles, two per double): six dependent rounds made one
+// reduction ~1000+ cycles, and a minimiser step has ~27 of them (s_memtime stamps, profiles/README.md).  DPP row operations
+// do the butterfly inside each row of 16 lanes in a few cycles per round; v_readlane then combines the four rows.
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float lane_value(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+template <typename T>
+__device__ __forceinline__ T wave_sum_dpp(T v) {
+  v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_move<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_move<0x141>(v);  // row_half_mirror: lane i <- 7 - i of its group of 8 (the other quad)
+  v += dpp_move<0x140>(v);  // row_mirror: lane i <- 15 - i of its row (the other half)
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
+}
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }

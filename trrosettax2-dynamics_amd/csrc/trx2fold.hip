@@ -483,7 +483,8 @@ enum { MODE_INIT = 0, MODE_STEP = 1, MODE_FINISH = 2 };
 // reader gets (old run, old seq) or (new run, seq of THIS launch -> "already stepped"), never a mixture.
 enum { SI_RUN = 0, SI_SEQ, SI_PHASE, SI_ITER, SI_NLS, SI_HL, SI_HH, SI_NH, SI_STATUS, SI_NEVALS, SI_NITERS, SI_N = 16 };
 // double state slots
-enum { SD_F = 0, SD_ALPHA, SD_GD, SD_FH0, SD_FH1, SD_FH2, SD_N = 8 };
+// SD_GAMMA: s.y / y.y of the newest stored pair = the initial Hessian scaling of the two-loop recursion (torsion role)
+enum { SD_F = 0, SD_ALPHA, SD_GD, SD_FH0, SD_FH1, SD_FH2, SD_GAMMA, SD_N = 8 };
 
 struct ChainArgs {
   int L, B, Bpad, BW, nsplit, mode, nruns, max_evals;
@@ -575,6 +576,21 @@ __device__ __forceinline__ void local_atoms(const ResGeom& g, f3& N, f3& CA, f3&
   CB = CA + a * g.g2.y + b * g.g2.z + c * g.g2.w;
 }
 
+// Diagnostic build only (-DTRX2_STAMP): thread 0 of decoy 0's torsion-role workgroup accumulates s_memtime cycles per phase
+// of every STEP launch into g_cstamp (slot 30 = launches, 31 = launches that computed a new direction).  Every stamp drains
+// the memory counters first, so a phase is charged the latency of the loads it issued.
+#ifdef TRX2_STAMP
+__device__ unsigned long long g_cstamp[32];
+#define CSTAMP_DECL unsigned long long cst_prev = 0; const bool cst_on = (dec == 0 && A.mode == MODE_STEP && threadIdx.x == 0); \
+  if (cst_on) { __builtin_amdgcn_s_waitcnt(0); cst_prev = __builtin_amdgcn_s_memtime(); }
+#define CSTAMP(k) if (cst_on) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+  __builtin_amdgcn_s_waitcnt(0); atomicAdd(&g_cstamp[k], t_ - cst_prev); __builtin_amdgcn_s_waitcnt(0); cst_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define CCOUNT(k) if (cst_on) atomicAdd(&g_cstamp[k], 1ull);
+#else
+#define CSTAMP_DECL
+#define CSTAMP(k)
+#define CCOUNT(k)
+#endif
 // NT threads step one decoy, RPT residues per thread (RPT * NT >= L).  NT = 256 is what runs.  One wave (NT = 64, RPT = 3 at
 // L = 150) makes every reduction and scan barrier-free but was SLOWER on MI355X (73.7 vs 61.2 us per evaluation,
 // profiles/README.md): the step is bound by the per-thread chain of dependent arithmetic and loads, which RPT multiplies,
@@ -593,6 +609,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
 
   int* gi = A.st_i + (size_t)dec * SI_N;
   double* gd_ = A.st_d + (size_t)dec * SD_N;
+  CSTAMP_DECL
   if (tid < SI_N && tid >= 2) s_i[tid] = gi[tid];
   if (tid == 0) {  // (run, seq) in ONE 8-byte load
     const unsigned long long rs = *reinterpret_cast<const volatile unsigned long long*>(gi);
@@ -609,10 +626,21 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   const size_t vb = (size_t)dec * L;  // base of this decoy's [L] vectors
   float4 xt[RPT], gt[RPT];
   bool need_nerf = true;
+  CSTAMP(0)  // state load, barrier, role test
+  CCOUNT(30)
 
   if (A.mode != MODE_INIT) {
     // ------------------------------------------------------------------ consume the evaluation at XT
     const trx2_run R = A.runs[min(run, A.nruns - 1)];
+    // accepted point, its gradient and the direction: needed only by the state machine below, loaded here so that their
+    // latency overlaps the slab loads and the gradient assembly
+    float4 x[RPT], g[RPT], dv[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int r = k * NT + tid;
+      x[k] = g[k] = dv[k] = make_float4(0, 0, 0, 0);
+      if (r < L && A.mode == MODE_STEP) { x[k] = A.X[vb + r]; g[k] = A.G[vb + r]; dv[k] = A.D[vb + r]; }
+    }
     double esum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     f3 g2[RPT], g1[RPT];       // per-residue sums of gradient / x cross gradient
     f3 gO_[RPT], gC_[RPT], gCB_[RPT], pN[RPT], pCA[RPT], pC[RPT], pO[RPT], pCB[RPT];
@@ -676,6 +704,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         }
       }
     }
+    CSTAMP(1)  // slab sums, coordinates, rama / omega per residue
     // ---- suffix sums over residues of (g2, g1): chunks from the end, wave shuffles + LDS wave totals
     f3 car2 = mk3(0, 0, 0), car1 = mk3(0, 0, 0);  // sum over all residues in later chunks
 #pragma unroll
@@ -730,6 +759,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       car2 = car2 + mk3(tot[0], tot[1], tot[2]);
       car1 = car1 + mk3(tot[3], tot[4], tot[5]);
     }
+    CSTAMP(2)  // suffix scan + torsion gradient
     block_sum_n<8, NW>(esum, s_buf);
     const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] +
                        (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6];
@@ -754,15 +784,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
     int n_evals = s_i[SI_NEVALS] + 1, n_iters = s_i[SI_NITERS], status = s_i[SI_STATUS];
     double f = s_d[SD_F], alpha = s_d[SD_ALPHA], gdir = s_d[SD_GD];
     double fh[3] = {s_d[SD_FH0], s_d[SD_FH1], s_d[SD_FH2]};
-    float4 x[RPT], g[RPT], dv[RPT];
-#pragma unroll
-    for (int k = 0; k < RPT; k++) {
-      const int r = k * NT + tid;
-      x[k] = g[k] = dv[k] = make_float4(0, 0, 0, 0);
-      if (r < L) { x[k] = A.X[vb + r]; g[k] = A.G[vb + r]; dv[k] = A.D[vb + r]; }
-    }
+    double gamma_h = s_d[SD_GAMMA];
     bool next_run = false, new_dir = false, steepest = false, new_trial = false;
     const bool finite_t = isfinite(f_t);
+    CSTAMP(3)  // energy reduction + loads of X, G, D
     if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
     else if (phase == PH_START) {
       if (R.precheck && esum[5] + esum[4] < (double)TRX2_CLASH_BREAK) {
@@ -801,6 +826,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
           }
           bsync<NW>();
           if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
+          gamma_h = v3[0] / v3[2];
           bsync<NW>();
           hh = (hh + 1) % LBM;
           if (hl < LBM) hl++;
@@ -824,68 +850,75 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         } else new_trial = true;
       }
     }
+    CSTAMP(4)  // Armijo test; on acceptance the (s, y) pair: one reduction + stores
     if (new_dir) {
-      // two-loop recursion over the stored pairs (A.S / A.Y are L2-resident; coalesced float4 per residue)
-      float4 q[RPT];
+      CCOUNT(31)
+      // Two-loop recursion over the stored pairs (A.S / A.Y are L2-resident; coalesced float4 per residue): 2 x hl dependent
+      // rounds of { dot with the pair, reduce, axpy }, ~1000 cycles each = 40 % of a step (s_memtime stamps,
+      // profiles/README.md).  The next pair is requested before the current reduction.  Measured and NOT kept: the whole
+      // recursion on one wave (in-wave sums only, no barriers) and two-deep prefetch through three rotating register
+      // buffers -- all within 2 % of this form: a round is bound by its own serial arithmetic (f64 DPP sum, readlanes, the
+      // LDS read of rho, the axpy), not by the loads or the barriers.
+      double v2[2] = {0, 0};
+      auto pair_at = [&](int kk) { return (hh - 1 - kk + LBM) % LBM; };
+      {
+        float4 q[RPT];
 #pragma unroll
-      for (int k = 0; k < RPT; k++) q[k] = g[k];
-      for (int kk = 0; kk < hl; kk++) {
-        const int j = (hh - 1 - kk + LBM) % LBM;
-        double v1[1] = {0};
-        float4 sj[RPT], yj[RPT];
+        for (int k = 0; k < RPT; k++) q[k] = g[k];
+        auto load_pair = [&](int j, float4 (&s_)[RPT], float4 (&y_)[RPT]) {
 #pragma unroll
-        for (int k = 0; k < RPT; k++) {
-          const int r = k * NT + tid;
-          sj[k] = yj[k] = make_float4(0, 0, 0, 0);
-          if (r < L) { sj[k] = A.S[((size_t)dec * LBM + j) * L + r]; yj[k] = A.Y[((size_t)dec * LBM + j) * L + r]; }
-          v1[0] += (double)dot3(sj[k], q[k]);
-        }
-        block_sum_n<1, NW>(v1, s_buf);
-        const float al = s_rho[j] * (float)v1[0];
-        if (tid == 0) s_alpha[j] = al;
+          for (int k = 0; k < RPT; k++) {
+            const int r = k * NT + tid;
+            s_[k] = y_[k] = make_float4(0, 0, 0, 0);
+            if (r < L) { s_[k] = A.S[((size_t)dec * LBM + j) * L + r]; y_[k] = A.Y[((size_t)dec * LBM + j) * L + r]; }
+          }
+        };
+        float4 sj[RPT], yj[RPT], sn[RPT], yn[RPT];
+        if (hl > 0) load_pair(pair_at(0), sj, yj);
+        for (int kk = 0; kk < hl; kk++) {
+          const int j = pair_at(kk);
+          load_pair(pair_at(kk + 1 < hl ? kk + 1 : hl - 1), sn, yn);
+          double v1[1] = {0};
 #pragma unroll
-        for (int k = 0; k < RPT; k++) { q[k].x -= al * yj[k].x; q[k].y -= al * yj[k].y; q[k].z -= al * yj[k].z; }
-      }
-      if (hl > 0) {
-        const int j = (hh - 1 + LBM) % LBM;
-        double v1[1] = {0};
+          for (int k = 0; k < RPT; k++) v1[0] += (double)dot3(sj[k], q[k]);
+          block_sum_n<1, NW>(v1, s_buf);
+          const float al = s_rho[j] * (float)v1[0];
+          if (tid == 0) s_alpha[j] = al;
 #pragma unroll
-        for (int k = 0; k < RPT; k++) {
-          const int r = k * NT + tid;
-          if (r < L) { float4 yj = A.Y[((size_t)dec * LBM + j) * L + r]; v1[0] += (double)dot3(yj, yj); }
-        }
-        block_sum_n<1, NW>(v1, s_buf);
-        const float gam = (float)(1.0 / ((double)s_rho[j] * v1[0]));
-#pragma unroll
-        for (int k = 0; k < RPT; k++) { q[k].x *= gam; q[k].y *= gam; q[k].z *= gam; }
-      }
-      bsync<NW>();
-      for (int kk = hl - 1; kk >= 0; kk--) {
-        const int j = (hh - 1 - kk + LBM) % LBM;
-        double v1[1] = {0};
-        float4 sj[RPT];
-#pragma unroll
-        for (int k = 0; k < RPT; k++) {
-          const int r = k * NT + tid;
-          sj[k] = make_float4(0, 0, 0, 0);
-          if (r < L) {
-            float4 yj = A.Y[((size_t)dec * LBM + j) * L + r];
-            sj[k] = A.S[((size_t)dec * LBM + j) * L + r];
-            v1[0] += (double)dot3(yj, q[k]);
+          for (int k = 0; k < RPT; k++) {
+            q[k].x -= al * yj[k].x; q[k].y -= al * yj[k].y; q[k].z -= al * yj[k].z;
+            sj[k] = sn[k]; yj[k] = yn[k];
           }
         }
-        block_sum_n<1, NW>(v1, s_buf);
-        const float c = s_alpha[j] - s_rho[j] * (float)v1[0];
+        CSTAMP(5)  // two-loop, first loop
+        if (hl > 0) {
+          const float gam = (float)gamma_h;
 #pragma unroll
-        for (int k = 0; k < RPT; k++) { q[k].x += c * sj[k].x; q[k].y += c * sj[k].y; q[k].z += c * sj[k].z; }
-      }
-      double v2[2] = {0, 0};
+          for (int k = 0; k < RPT; k++) { q[k].x *= gam; q[k].y *= gam; q[k].z *= gam; }
+        }
+        bsync<NW>();
+        for (int kk = hl - 1; kk >= 0; kk--) {
+          const int j = pair_at(kk);
+          if (kk > 0) load_pair(pair_at(kk - 1), sn, yn);
+          double v1[1] = {0};
 #pragma unroll
-      for (int k = 0; k < RPT; k++) {
-        dv[k] = make_float4(-q[k].x, -q[k].y, -q[k].z, 0);
-        v2[0] += (double)dot3(g[k], dv[k]); v2[1] += (double)dot3(g[k], g[k]);
+          for (int k = 0; k < RPT; k++) v1[0] += (double)dot3(yj[k], q[k]);
+          block_sum_n<1, NW>(v1, s_buf);
+          const float c = s_alpha[j] - s_rho[j] * (float)v1[0];
+#pragma unroll
+          for (int k = 0; k < RPT; k++) {
+            q[k].x += c * sj[k].x; q[k].y += c * sj[k].y; q[k].z += c * sj[k].z;
+            sj[k] = sn[k]; yj[k] = yn[k];
+          }
+        }
+        CSTAMP(7)  // two-loop, second loop
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          dv[k] = make_float4(-q[k].x, -q[k].y, -q[k].z, 0);
+          v2[0] += (double)dot3(g[k], dv[k]); v2[1] += (double)dot3(g[k], g[k]);
+        }
+        block_sum_n<2, NW>(v2, s_buf);
       }
-      block_sum_n<2, NW>(v2, s_buf);
       if (!(v2[1] > 0)) next_run = true;
       else if (hl == 0 || !(v2[0] < 0)) { hl = 0; steepest = true; }
       else { gdir = v2[0]; alpha = 1.0; nls = 0; new_trial = true; }
@@ -903,6 +936,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         new_trial = true;
       }
     }
+    CSTAMP(8)  // descent test / steepest-descent restart
     if (next_run) {
       run++;
       phase = (run >= A.nruns) ? PH_DONE : PH_START;
@@ -930,6 +964,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
       *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
       gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
+      gd_[SD_GAMMA] = gamma_h;
       if (phase == PH_DONE) atomicAdd(A.done_count, 1);
     }
     if (tid < LBM) A.rho[(size_t)dec * LBM + tid] = s_rho[tid];
@@ -941,6 +976,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
     }
   }
 
+  CSTAMP(9)  // trial point, state stores
   // ------------------------------------------------------------------ weights for the next pair launch
   if (tid == 0) {
     const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
@@ -990,6 +1026,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         M = xf_from_atoms(Nn, CAn, Cn);
       }
     }
+    CSTAMP(10)  // NeRF: geometry loads, sincos, local frames
     // inclusive scan of M within the wave
     Xf P = M;
 #pragma unroll
@@ -1016,6 +1053,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       if (w < wave) pre = xf_compose(pre, T);
       tot = xf_compose(tot, T);
     }
+    CSTAMP(11)  // NeRF: scan of rigid transforms (in-wave + across waves)
     // frame of residue r = pre o (inclusive scan of the previous lane)
     Xf prev = xf_shfl_up(P, 1);
     Xf F = (lane == 0) ? pre : xf_compose(pre, prev);
@@ -1034,6 +1072,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       float4* xT = A.xyzT + ((size_t)(grp * L + r) * 4) * A.BW + dd;
       xT[0] = o0; xT[A.BW] = o1; xT[2 * A.BW] = o2; xT[3 * A.BW] = o3;
     }
+    CSTAMP(12)  // NeRF: atoms from frames, coordinate stores
   }
 }
 
@@ -2038,6 +2077,14 @@ extern "C" int trx2_last_fold_stats(trx2_ctx* ctx, double* seconds, int* n_launc
 }
 
 #ifdef TRX2_STAMP
+extern "C" int trx2_debug_chain_stamps(unsigned long long* out32, int reset) {
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_cstamp), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[32] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_cstamp), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
 extern "C" int trx2_debug_stamps(unsigned long long* out32) {
   return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
 }
