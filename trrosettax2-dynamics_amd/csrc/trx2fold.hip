@@ -508,20 +508,6 @@ struct ChainArgs {
   int* done_count;
 };
 
-template <int K>
-__device__ __forceinline__ void block_sum(double (&v)[K], double* s_buf /* [4*K] */) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
-  __syncthreads();
-  if (lane == 0)
-#pragma unroll
-    for (int k = 0; k < K; k++) s_buf[wave * K + k] = v[k];
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < K; k++) v[k] = (s_buf[k] + s_buf[K + k]) + (s_buf[2 * K + k] + s_buf[3 * K + k]);
-}
-
 // workgroup barrier of an NW-wave role.  One wave: its LDS operations execute in program order, so only the compiler has
 // to be kept from reordering them.
 template <int NW>
@@ -529,22 +515,27 @@ __device__ __forceinline__ void bsync() {
   if (NW > 1) __syncthreads();
   else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 }
+// Sum over the workgroup, total in every thread.  Consecutive calls alternate between two LDS buffers (`flip`), so one
+// barrier per call is enough: a wave can be at most one call ahead of the slowest, and then it writes the OTHER buffer.
+// (With one buffer every call needed a second barrier just to protect the previous call's reads; the two-loop recursion
+// makes 2 x 12 dependent calls per step.)  Every wave must make the same sequence of calls.
 template <int K, int NW>
-__device__ __forceinline__ void block_sum_n(double (&v)[K], double* s_buf /* [NW*K] */) {
+__device__ __forceinline__ void block_sum_n(double (&v)[K], double* s_buf /* [2][NW*8] */, int& flip) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
-  if (NW == 1) return;  // the butterfly leaves the total in every lane
-  __syncthreads();
+  if (NW == 1) return;  // the in-wave sum leaves the total in every lane
+  double* buf = s_buf + flip * (NW * 8);
+  flip ^= 1;
   if (lane == 0)
 #pragma unroll
-    for (int k = 0; k < K; k++) s_buf[wave * K + k] = v[k];
-  __syncthreads();
+    for (int k = 0; k < K; k++) buf[wave * K + k] = v[k];
+  bsync<NW>();
 #pragma unroll
   for (int k = 0; k < K; k++) {
     double a = 0;
 #pragma unroll
-    for (int w = 0; w < NW; w++) a += s_buf[w * K + k];  // fixed order: deterministic
+    for (int w = 0; w < NW; w++) a += buf[w * K + k];  // fixed order: deterministic
     v[k] = a;
   }
 }
@@ -599,7 +590,8 @@ template <int RPT, int NT>
 __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   constexpr int NW = NT / 64;
   const int L = A.L, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __shared__ double s_buf[NW * 8];
+  __shared__ double s_buf[2 * NW * 8];
+  int flip = 0;
   __shared__ float s_scan[NW * 12];
   __shared__ float s_alpha[LBM];
   __shared__ int s_i[SI_N];
@@ -760,7 +752,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       car1 = car1 + mk3(tot[3], tot[4], tot[5]);
     }
     CSTAMP(2)  // suffix scan + torsion gradient
-    block_sum_n<8, NW>(esum, s_buf);
+    block_sum_n<8, NW>(esum, s_buf, flip);
     const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] +
                        (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6];
     if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
@@ -814,7 +806,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
           y[k] = make_float4(gt[k].x - g[k].x, gt[k].y - g[k].y, gt[k].z - g[k].z, 0);
           v3[0] += (double)dot3(s[k], y[k]); v3[1] += (double)dot3(s[k], s[k]); v3[2] += (double)dot3(y[k], y[k]);
         }
-        block_sum_n<3, NW>(v3, s_buf);
+        block_sum_n<3, NW>(v3, s_buf, flip);
         if (v3[0] > 1e-12 * sqrt(v3[1] * v3[2])) {
 #pragma unroll
           for (int k = 0; k < RPT; k++) {
@@ -881,7 +873,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
           double v1[1] = {0};
 #pragma unroll
           for (int k = 0; k < RPT; k++) v1[0] += (double)dot3(sj[k], q[k]);
-          block_sum_n<1, NW>(v1, s_buf);
+          block_sum_n<1, NW>(v1, s_buf, flip);
           const float al = s_rho[j] * (float)v1[0];
           if (tid == 0) s_alpha[j] = al;
 #pragma unroll
@@ -903,7 +895,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
           double v1[1] = {0};
 #pragma unroll
           for (int k = 0; k < RPT; k++) v1[0] += (double)dot3(yj[k], q[k]);
-          block_sum_n<1, NW>(v1, s_buf);
+          block_sum_n<1, NW>(v1, s_buf, flip);
           const float c = s_alpha[j] - s_rho[j] * (float)v1[0];
 #pragma unroll
           for (int k = 0; k < RPT; k++) {
@@ -917,7 +909,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
           dv[k] = make_float4(-q[k].x, -q[k].y, -q[k].z, 0);
           v2[0] += (double)dot3(g[k], dv[k]); v2[1] += (double)dot3(g[k], g[k]);
         }
-        block_sum_n<2, NW>(v2, s_buf);
+        block_sum_n<2, NW>(v2, s_buf, flip);
       }
       if (!(v2[1] > 0)) next_run = true;
       else if (hl == 0 || !(v2[0] < 0)) { hl = 0; steepest = true; }
@@ -927,7 +919,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       double v1[1] = {0};
 #pragma unroll
       for (int k = 0; k < RPT; k++) { dv[k] = make_float4(-g[k].x, -g[k].y, -g[k].z, 0); v1[0] += (double)dot3(g[k], g[k]); }
-      block_sum_n<1, NW>(v1, s_buf);
+      block_sum_n<1, NW>(v1, s_buf, flip);
       if (!(v1[0] > 0)) next_run = true;
       else {
         gdir = -v1[0];
@@ -1136,7 +1128,8 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   constexpr int NW = NT / 64;  // one residue per thread: NT = 256 for chains up to 256 residues, 512 up to 512
   const int L = A.L, tid = threadIdx.x, r = tid;
   const bool act = r < L;
-  __shared__ double s_buf[NW * 8];
+  __shared__ double s_buf[2 * NW * 8];
+  int flip = 0;
   __shared__ float s_alpha[LBM];
   __shared__ int s_i[SI_N];
   __shared__ double s_d[SD_N];
@@ -1256,7 +1249,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     gt[2].x += aC.z; gt[2].y += aO.x; gt[2].z += aO.y; gt[2].w += aO.z;
     gt[3].x += aCB.x; gt[3].y += aCB.y; gt[3].z += aCB.z;
   }
-  block_sum_n<8, NW>(esum, s_buf);
+  block_sum_n<8, NW>(esum, s_buf, flip);
   const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] + (double)R.w[3] * esum[4] +
                      (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[6] * esum[7];
   if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
@@ -1295,7 +1288,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
         yv[q] = make_float4(gt[q].x - g[q].x, gt[q].y - g[q].y, gt[q].z - g[q].z, gt[q].w - g[q].w);
         v3[0] += (double)dot4(sv[q], yv[q]); v3[1] += (double)dot4(sv[q], sv[q]); v3[2] += (double)dot4(yv[q], yv[q]);
       }
-      block_sum_n<3, NW>(v3, s_buf);
+      block_sum_n<3, NW>(v3, s_buf, flip);
       if (v3[0] > 1e-12 * sqrt(v3[1] * v3[2])) {
         if (act)
 #pragma unroll
@@ -1342,7 +1335,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
         if (act) { sj[q] = A.CS[(((size_t)dec * LBM + j) * L + r) * 4 + q]; yj[q] = A.CY[(((size_t)dec * LBM + j) * L + r) * 4 + q]; }
         v1[0] += (double)dot4(sj[q], qv[q]);
       }
-      block_sum_n<1, NW>(v1, s_buf);
+      block_sum_n<1, NW>(v1, s_buf, flip);
       const float al = s_rho[j] * (float)v1[0];
       if (tid == 0) s_alpha[j] = al;
 #pragma unroll
@@ -1354,7 +1347,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
       if (act)
 #pragma unroll
         for (int q = 0; q < 4; q++) { float4 yj = A.CY[(((size_t)dec * LBM + j) * L + r) * 4 + q]; v1[0] += (double)dot4(yj, yj); }
-      block_sum_n<1, NW>(v1, s_buf);
+      block_sum_n<1, NW>(v1, s_buf, flip);
       const float gam = (float)(1.0 / ((double)s_rho[j] * v1[0]));
 #pragma unroll
       for (int q = 0; q < 4; q++) { qv[q].x *= gam; qv[q].y *= gam; qv[q].z *= gam; qv[q].w *= gam; }
@@ -1373,7 +1366,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
           v1[0] += (double)dot4(yj, qv[q]);
         }
       }
-      block_sum_n<1, NW>(v1, s_buf);
+      block_sum_n<1, NW>(v1, s_buf, flip);
       const float c = s_alpha[j] - s_rho[j] * (float)v1[0];
 #pragma unroll
       for (int q = 0; q < 4; q++) { qv[q].x += c * sj[q].x; qv[q].y += c * sj[q].y; qv[q].z += c * sj[q].z; qv[q].w += c * sj[q].w; }
@@ -1384,7 +1377,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
       dv[q] = make_float4(-qv[q].x, -qv[q].y, -qv[q].z, -qv[q].w);
       v2[0] += (double)dot4(g[q], dv[q]); v2[1] += (double)dot4(g[q], g[q]);
     }
-    block_sum_n<2, NW>(v2, s_buf);
+    block_sum_n<2, NW>(v2, s_buf, flip);
     if (!(v2[1] > 0)) next_run = true;
     else if (hl == 0 || !(v2[0] < 0)) { hl = 0; steepest = true; }
     else { gdir = v2[0]; alpha = 1.0; nls = 0; new_trial = true; }
@@ -1393,7 +1386,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     double v1[1] = {0};
 #pragma unroll
     for (int q = 0; q < 4; q++) { dv[q] = make_float4(-g[q].x, -g[q].y, -g[q].z, -g[q].w); v1[0] += (double)dot4(g[q], g[q]); }
-    block_sum_n<1, NW>(v1, s_buf);
+    block_sum_n<1, NW>(v1, s_buf, flip);
     if (!(v1[0] > 0)) next_run = true;
     else { gdir = -v1[0]; alpha = fmin(1.0, 1.0 / sqrt(v1[0])); nls = 0; new_trial = true; }
   }
