@@ -22,4 +22,12 @@ print(f"   cycles per step (100 MHz s_memtime ticks x shader clock ratio unknown
 for k, (nm, x) in enumerate(zip(names, v)):
     per = x / (nd if k in (5, 6, 7) else n)
     print(f"   {nm:34s} {100*x/v.sum():5.1f} %   {per:8.0f} ticks per {'new-direction step' if k in (5,6,7) else 'step'}")
+v = np.array(out[16:27], float); n, nd = out[28], out[29]
+names = ["state load + role test", "coordinates -> LDS, slab sums", "rama/omega: angles, dE/dangle", "rama/omega: gradients on atoms", "bonded term",
+         "energy reduction + X,G,D loads", "Armijo / (s,y) pair", "two-loop: first loop", "two-loop: gamma", "two-loop: second loop", "direction, trial, stores"]
+if n:
+    print(f"Cartesian role: decoy 0, {n} steps, {nd} with a new direction; ticks per step: total {v.sum()/n:.0f}")
+    for k, (nm, xx) in enumerate(zip(names, v)):
+        per = xx / (nd if k in (7, 8, 9) else n)
+        print(f"   {nm:34s} {100*xx/v.sum():5.1f} %   {per:8.0f} ticks per {'new-direction step' if k in (7,8,9) else 'step'}")
 ctx.close()

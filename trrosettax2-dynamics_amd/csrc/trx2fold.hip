@@ -577,11 +577,25 @@ __device__ unsigned long long g_cstamp[32];
 #define CSTAMP(k) if (cst_on) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
   __builtin_amdgcn_s_waitcnt(0); atomicAdd(&g_cstamp[k], t_ - cst_prev); __builtin_amdgcn_s_waitcnt(0); cst_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
 #define CCOUNT(k) if (cst_on) atomicAdd(&g_cstamp[k], 1ull);
+#define KSTAMP_DECL unsigned long long cst_prev = 0; const bool cst_on = (dec == 0 && threadIdx.x == 0); \
+  if (cst_on) { __builtin_amdgcn_s_waitcnt(0); cst_prev = __builtin_amdgcn_s_memtime(); }
 #else
+#define KSTAMP_DECL
 #define CSTAMP_DECL
 #define CSTAMP(k)
 #define CCOUNT(k)
 #endif
+// L-BFGS history of the decoy staged in LDS for the duration of one step: [LBM][s | y][NT] float4, dynamic shared memory
+// (HIST_LDS_BYTES, only the one-residue-per-thread instantiations; gfx950 has 160 KB of LDS per CU).  The two-loop
+// recursion is 2 x 12 DEPENDENT rounds; read from global memory every round exposed an L2 round trip (~500-700 of its
+// ~1000 cycles; the compiler turns a register prefetch into a wait on the load just issued).  Instead the whole history is
+// requested at the top of the step with LDS-DMA loads (global_load_lds_dwordx4: no registers, nothing waits on them until
+// the recursion starts a phase later) and every round reads the thread's own slot from LDS.
+extern __shared__ float4 s_hist[];
+#define HIST_LDS_BYTES(NT) (LBM * 2 * (NT) * 16)
+__device__ __forceinline__ void lds_dma16(const float4* src /* per lane */, float4* dst_wave /* wave-uniform: lane i lands at dst + i */) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst_wave, 16, 0, 0);
+}
 // NT threads step one decoy, RPT residues per thread (RPT * NT >= L).  NT = 256 is what runs.  One wave (NT = 64, RPT = 3 at
 // L = 150) makes every reduction and scan barrier-free but was SLOWER on MI355X (73.7 vs 61.2 us per evaluation,
 // profiles/README.md): the step is bound by the per-thread chain of dependent arithmetic and loads, which RPT multiplies,
@@ -618,6 +632,16 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   const size_t vb = (size_t)dec * L;  // base of this decoy's [L] vectors
   float4 xt[RPT], gt[RPT];
   bool need_nerf = true;
+  constexpr bool HIST_LDS = (RPT == 1);
+  if (HIST_LDS && A.mode == MODE_STEP) {
+    // the hl stored pairs, newest first; lanes beyond L copy the last residue (no branch around the load), never used
+    const int hl0 = s_i[SI_HL], hh0 = s_i[SI_HH], rc = min(tid, L - 1);
+    for (int kk = 0; kk < hl0; kk++) {
+      const int j = (hh0 - 1 - kk + LBM) % LBM;
+      lds_dma16(A.S + ((size_t)dec * LBM + j) * L + rc, s_hist + (j * 2 + 0) * NT + wave * 64);
+      lds_dma16(A.Y + ((size_t)dec * LBM + j) * L + rc, s_hist + (j * 2 + 1) * NT + wave * 64);
+    }
+  }
   CSTAMP(0)  // state load, barrier, role test
   CCOUNT(30)
 
@@ -696,6 +720,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         }
       }
     }
+    if (HIST_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the wave: by now it has landed anyway
     CSTAMP(1)  // slab sums, coordinates, rama / omega per residue
     // ---- suffix sums over residues of (g2, g1): chunks from the end, wave shuffles + LDS wave totals
     f3 car2 = mk3(0, 0, 0), car1 = mk3(0, 0, 0);  // sum over all residues in later chunks
@@ -816,6 +841,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
               A.Y[((size_t)dec * LBM + hh) * L + r] = y[k];
             }
           }
+          if (HIST_LDS) {  // slot hh of the staged copy: its DMA (the oldest pair) must have landed before it is replaced
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_hist[(hh * 2 + 0) * NT + tid] = s[0];
+            s_hist[(hh * 2 + 1) * NT + tid] = y[0];
+          }
           bsync<NW>();
           if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
           gamma_h = v3[0] / v3[2];
@@ -857,7 +887,14 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         float4 q[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; k++) q[k] = g[k];
+        if (HIST_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged history has landed (long ago)
         auto load_pair = [&](int j, float4 (&s_)[RPT], float4 (&y_)[RPT]) {
+          if (HIST_LDS) {
+            const float4 z = make_float4(0, 0, 0, 0), sv = s_hist[(j * 2 + 0) * NT + tid], yv = s_hist[(j * 2 + 1) * NT + tid];
+            s_[0] = tid < L ? sv : z;
+            y_[0] = tid < L ? yv : z;
+            return;
+          }
 #pragma unroll
           for (int k = 0; k < RPT; k++) {
             const int r = k * NT + tid;
@@ -1138,6 +1175,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   __shared__ float s_dt[NT * 3];
   int* gi = A.st_i + (size_t)dec * SI_N;
   double* gd_ = A.st_d + (size_t)dec * SD_N;
+  KSTAMP_DECL
   if (tid < SI_N && tid >= 2) s_i[tid] = gi[tid];
   if (tid == 0) {  // (run, seq) in ONE 8-byte load
     const unsigned long long rs = *reinterpret_cast<const volatile unsigned long long*>(gi);
@@ -1152,6 +1190,8 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   const trx2_run R = A.runs[min(run, A.nruns - 1)];
   if (!R.cartesian) return;
   const size_t vb = (size_t)dec * L;
+  CSTAMP(16)  // state load, role test
+  CCOUNT(28)
 
   // ---- trial coordinates; neighbours through LDS
   float4 xt[4], gt[4];
@@ -1174,6 +1214,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     gt[3].w = 0.0f;
   }
   __syncthreads();
+  CSTAMP(17)  // coordinates -> LDS, slab sums
   f3 aN = mk3(0, 0, 0), aCA = aN, aC = aN, aO = aN, aCB = aN;  // gradient of the local terms on this residue's atoms
   float dphi = 0, dpsi = 0, dom = 0;
   Res5 Me = unpack5(s_xyz + (act ? r : 0) * 16), Pv = Me, Nx = Me;
@@ -1205,6 +1246,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     s_dt[r * 3] = dphi; s_dt[r * 3 + 1] = dpsi; s_dt[r * 3 + 2] = dom;
   }
   __syncthreads();
+  CSTAMP(18)  // rama / omega: angles and dE/dangle
   if (act) {
     f3 d1, d2, d3, d4;
     if (dphi != 0.0f) { dihedral_grad(Pv.C, Me.N, Me.CA, Me.C, d1, d2, d3, d4); aN = fma3(d2, dphi, aN); aCA = fma3(d3, dphi, aCA); aC = fma3(d4, dphi, aC); }
@@ -1220,6 +1262,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
       if (c2 != 0.0f) { dihedral_grad(Pv.CA, Pv.C, Me.N, Me.CA, d1, d2, d3, d4); aN = fma3(d3, c2, aN); aCA = fma3(d4, c2, aCA); }
     }
     // bonded term: ideal CB geometry from the ideal local frame
+    CSTAMP(19)  // rama / omega gradients on atoms (up to 6 dihedral gradients)
     const float wcb = R.w[6];
     if (wcb != 0.0f) {
       f3 iN, iCA, iC, iCB;
@@ -1249,6 +1292,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     gt[2].x += aC.z; gt[2].y += aO.x; gt[2].z += aO.y; gt[2].w += aO.z;
     gt[3].x += aCB.x; gt[3].y += aCB.y; gt[3].z += aCB.z;
   }
+  CSTAMP(20)  // bonded term
   block_sum_n<8, NW>(esum, s_buf, flip);
   const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] + (double)R.w[3] * esum[4] +
                      (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[6] * esum[7];
@@ -1260,6 +1304,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   int n_evals = s_i[SI_NEVALS] + 1, n_iters = s_i[SI_NITERS], status = s_i[SI_STATUS];
   double f = s_d[SD_F], alpha = s_d[SD_ALPHA], gdir = s_d[SD_GD];
   double fh[3] = {s_d[SD_FH0], s_d[SD_FH1], s_d[SD_FH2]};
+  double gamma_h = s_d[SD_GAMMA];
   float4 x[4], g[4], dv[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -1268,6 +1313,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   }
   bool next_run = false, new_dir = false, steepest = false, new_trial = false;
   const bool finite_t = isfinite(f_t);
+  CSTAMP(21)  // energy reduction, loads of X, G, D
   if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
   else if (phase == PH_START) {
     f = f_t;
@@ -1298,6 +1344,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
           }
         __syncthreads();
         if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
+        gamma_h = v3[0] / v3[2];
         __syncthreads();
         hh = (hh + 1) % LBM;
         if (hl < LBM) hl++;
@@ -1321,56 +1368,82 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
       } else new_trial = true;
     }
   }
+  CSTAMP(22)  // Armijo / (s, y) pair
   if (new_dir) {
+    CCOUNT(29)
+    // Two-loop recursion, 8 float4 per thread and stored pair.  Loads are branch-free (index clamped to the last residue; idle
+    // threads are masked out of the dot and the update instead) so that a pair's eight loads issue together -- guarded
+    // per element, each load had its own branch and wait (~2000 cycles per round, 57 % of a Cartesian step: s_memtime
+    // stamps, profiles/README.md).  Two named buffers and a loop unrolled by two keep the next pair in flight without a
+    // register copy (a copy makes the compiler wait for the load it has just issued).
     float4 qv[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) qv[q] = g[q];
-    for (int kk = 0; kk < hl; kk++) {
-      const int j = (hh - 1 - kk + LBM) % LBM;
-      double v1[1] = {0};
-      float4 sj[4], yj[4];
+    const int rc = min(r, L - 1);
+    auto pair_at = [&](int kk) { return (hh - 1 - kk + LBM) % LBM; };
+    auto load_pair = [&](int kk, float4 (&s_)[4], float4 (&y_)[4]) {
+      const size_t o = (((size_t)dec * LBM + pair_at(kk)) * L + rc) * 4;
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        sj[q] = yj[q] = make_float4(0, 0, 0, 0);
-        if (act) { sj[q] = A.CS[(((size_t)dec * LBM + j) * L + r) * 4 + q]; yj[q] = A.CY[(((size_t)dec * LBM + j) * L + r) * 4 + q]; }
-        v1[0] += (double)dot4(sj[q], qv[q]);
-      }
+      for (int q = 0; q < 4; q++) { s_[q] = A.CS[o + q]; y_[q] = A.CY[o + q]; }
+    };
+    auto round1 = [&](int kk, const float4 (&s_)[4], const float4 (&y_)[4]) {
+      const int j = pair_at(kk);
+      double v1[1] = {0};
+#pragma unroll
+      for (int q = 0; q < 4; q++) v1[0] += (double)dot4(s_[q], qv[q]);  // qv is zero in idle threads
       block_sum_n<1, NW>(v1, s_buf, flip);
       const float al = s_rho[j] * (float)v1[0];
       if (tid == 0) s_alpha[j] = al;
+      const float am = act ? al : 0.0f;
 #pragma unroll
-      for (int q = 0; q < 4; q++) { qv[q].x -= al * yj[q].x; qv[q].y -= al * yj[q].y; qv[q].z -= al * yj[q].z; qv[q].w -= al * yj[q].w; }
-    }
-    if (hl > 0) {
-      const int j = (hh - 1 + LBM) % LBM;
+      for (int q = 0; q < 4; q++) { qv[q].x -= am * y_[q].x; qv[q].y -= am * y_[q].y; qv[q].z -= am * y_[q].z; qv[q].w -= am * y_[q].w; }
+    };
+    auto round2 = [&](int kk, const float4 (&s_)[4], const float4 (&y_)[4]) {
+      const int j = pair_at(kk);
       double v1[1] = {0};
-      if (act)
 #pragma unroll
-        for (int q = 0; q < 4; q++) { float4 yj = A.CY[(((size_t)dec * LBM + j) * L + r) * 4 + q]; v1[0] += (double)dot4(yj, yj); }
+      for (int q = 0; q < 4; q++) v1[0] += (double)dot4(y_[q], qv[q]);
       block_sum_n<1, NW>(v1, s_buf, flip);
-      const float gam = (float)(1.0 / ((double)s_rho[j] * v1[0]));
+      const float c = act ? s_alpha[j] - s_rho[j] * (float)v1[0] : 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { qv[q].x += c * s_[q].x; qv[q].y += c * s_[q].y; qv[q].z += c * s_[q].z; qv[q].w += c * s_[q].w; }
+    };
+    float4 sa[4], ya[4], sb[4], yb[4];
+    if (hl > 0) load_pair(0, sa, ya);
+    for (int kk = 0; kk < hl; kk += 2) {  // pair kk in buffer a, pair kk+1 in buffer b
+      if (kk + 1 < hl) load_pair(kk + 1, sb, yb);
+      round1(kk, sa, ya);
+      if (kk + 1 < hl) {
+        if (kk + 2 < hl) load_pair(kk + 2, sa, ya);
+        round1(kk + 1, sb, yb);
+      }
+    }
+    CSTAMP(23)  // two-loop: first loop
+    if (hl > 0) {
+      const float gam = (float)gamma_h;
 #pragma unroll
       for (int q = 0; q < 4; q++) { qv[q].x *= gam; qv[q].y *= gam; qv[q].z *= gam; qv[q].w *= gam; }
     }
     __syncthreads();
-    for (int kk = hl - 1; kk >= 0; kk--) {
-      const int j = (hh - 1 - kk + LBM) % LBM;
-      double v1[1] = {0};
-      float4 sj[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        sj[q] = make_float4(0, 0, 0, 0);
-        if (act) {
-          float4 yj = A.CY[(((size_t)dec * LBM + j) * L + r) * 4 + q];
-          sj[q] = A.CS[(((size_t)dec * LBM + j) * L + r) * 4 + q];
-          v1[0] += (double)dot4(yj, qv[q]);
+    CSTAMP(24)  // two-loop: gamma
+    // backwards: the oldest pair (hl-1) is still in its buffer -- a if hl is odd, b if even
+    if (hl > 0) {
+      int kk = hl - 1;
+      if (kk & 1) {  // pair kk sits in b
+        if (kk > 0) load_pair(kk - 1, sa, ya);
+        round2(kk, sb, yb);
+        kk--;
+      }
+      for (; kk >= 0; kk -= 2) {  // pair kk in a, pair kk-1 goes to b
+        if (kk > 0) load_pair(kk - 1, sb, yb);
+        round2(kk, sa, ya);
+        if (kk > 0) {
+          if (kk > 1) load_pair(kk - 2, sa, ya);
+          round2(kk - 1, sb, yb);
         }
       }
-      block_sum_n<1, NW>(v1, s_buf, flip);
-      const float c = s_alpha[j] - s_rho[j] * (float)v1[0];
-#pragma unroll
-      for (int q = 0; q < 4; q++) { qv[q].x += c * sj[q].x; qv[q].y += c * sj[q].y; qv[q].z += c * sj[q].z; qv[q].w += c * sj[q].w; }
     }
+    CSTAMP(25)  // two-loop: second loop
     double v2[2] = {0, 0};
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -1414,6 +1487,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
 #pragma unroll
     for (int q = 0; q < 4; q++) { xo[q] = xt[q]; xT[q * A.BW] = xt[q]; }
   }
+  CSTAMP(26)  // direction test, trial point, state + coordinate stores
   // ---- leaving Cartesian space (run finished, or the decoy stops here on its evaluation budget / divergence): torsions +
   //      relaxed internal geometry of the ACCEPTED point, for the torsion-space runs after it and for the final report
   if (next_run || phase == PH_DONE) {
@@ -1456,6 +1530,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
     *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
     gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
+    gd_[SD_GAMMA] = gamma_h;
     if (phase == PH_DONE) atomicAdd(A.done_count, 1);
     const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
     float* w = A.wcur + (size_t)dec * 8;
@@ -1582,6 +1657,12 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
     rm[k * 3 + 1] = (float)ps;
     rm[k * 3 + 2] = (float)rama[k][2];
     rsc[k * 4] = (float)sin(ph); rsc[k * 4 + 1] = (float)cos(ph); rsc[k * 4 + 2] = (float)sin(ps); rsc[k * 4 + 3] = (float)cos(ps);
+  }
+  // the step kernels of short chains stage the L-BFGS history in 96 KB of dynamic LDS (above the 64 KB default limit)
+  if (hipFuncSetAttribute((const void*)k_chain<1, CHAIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(CHAIN_THREADS)) != hipSuccess ||
+      hipFuncSetAttribute((const void*)k_step<1, CHAIN_THREADS, CHAIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(CHAIN_THREADS)) != hipSuccess) {
+    delete ctx;
+    return 4;
   }
   if (hipMemcpyToSymbol(HIP_SYMBOL(c_rama), rm, sizeof rm) != hipSuccess ||
       hipMemcpyToSymbol(HIP_SYMBOL(c_rama_sc), rsc, sizeof rsc) != hipSuccess ||
@@ -1871,7 +1952,7 @@ static void launch_chain(trx2_ctx* c, int B, int mode, int nruns, int max_evals)
   ChainArgs A = chain_args(c, B, mode, nruns, max_evals);
   const dim3 grid(B);
   const int L = c->L;
-  if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_chain<1, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), 0, c->stream, A);
+  if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_chain<1, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), HIST_LDS_BYTES(CHAIN_THREADS), c->stream, A);
   else if (L <= 2 * CHAIN_THREADS) hipLaunchKernelGGL((k_chain<2, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), 0, c->stream, A);
   else hipLaunchKernelGGL((k_chain<4, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), 0, c->stream, A);
 }
@@ -1955,7 +2036,7 @@ extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int n
         const ChainArgs ca = chain_args(ctx, B, MODE_STEP, nruns, max_evals);
         const CartArgs cc = cart_args(ctx, B, nruns, max_evals);
         const dim3 g2(2 * B), b1(CHAIN_THREADS), b2(2 * CHAIN_THREADS);
-        if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS>), g2, b1, 0, ctx->stream, ca, cc);
+        if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS>), g2, b1, HIST_LDS_BYTES(CHAIN_THREADS), ctx->stream, ca, cc);
         else hipLaunchKernelGGL((k_step<2, CHAIN_THREADS, 2 * CHAIN_THREADS>), g2, b2, 0, ctx->stream, ca, cc);
       } else
         launch_chain(ctx, B, MODE_STEP, nruns, max_evals);
