@@ -47,6 +47,9 @@ static constexpr VdwTab make_vdw_tab() {
 static constexpr VdwTab k_vdw = make_vdw_tab();
 __constant__ float c_rama[TRX2_RAMA_NB * 3];  // phi_k, psi_k (rad), p_k
 __constant__ float c_rama_sc[TRX2_RAMA_NB * 4];  // sin phi_k, cos phi_k, sin psi_k, cos psi_k
+// ideal C-beta placement seen from the ideal local frame: |CA-CB|, angle N-CA-CB, angle C-CA-CB, improper N-C-CA-CB
+// (the bonded term's targets; every thread used to rebuild them from the ideal frame at every Cartesian step)
+__constant__ float c_cb_ideal[4];
 
 // =================================================================================================
 // K2: restraint tables
@@ -1265,12 +1268,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     CSTAMP(19)  // rama / omega gradients on atoms (up to 6 dihedral gradients)
     const float wcb = R.w[6];
     if (wcb != 0.0f) {
-      f3 iN, iCA, iC, iCB;
-      local_atoms(ideal_geom(), iN, iCA, iC, iCB);
-      f3 u1, u2, u3, u4;
-      const float d_cacb = sqrtf(dot(iCB - iCA, iCB - iCA));
-      const float a_ncacb = angle_grad(iN, iCA, iCB, u1, u2, u3), a_ccacb = angle_grad(iC, iCA, iCB, u1, u2, u3);
-      const float t_cb = dihedral_grad(iN, iC, iCA, iCB, u1, u2, u3, u4);
+      const float d_cacb = c_cb_ideal[0], a_ncacb = c_cb_ideal[1], a_ccacb = c_cb_ideal[2], t_cb = c_cb_ideal[3];
       const float KL = (float)TRX2_CART_KLEN, KA = (float)TRX2_CART_KANG, KI = (float)TRX2_CART_KIMP;
       f3 bN = mk3(0, 0, 0), bCA = bN, bC = bN, bO = bN, bCB = bN, a, b, c, d;
       float eb = hbond(Me.N, Me.CA, (float)TRX2_B_N_CA, KL, a); bN += a; bCA += a * -1.0f;
@@ -1664,7 +1662,26 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
     delete ctx;
     return 4;
   }
-  if (hipMemcpyToSymbol(HIP_SYMBOL(c_rama), rm, sizeof rm) != hipSuccess ||
+  float cb[4];
+  {  // local frame of local_atoms(): CA at the origin, C on +x, N in the xy plane; CB = CA + ka (b x c) + kb b + kc c
+    const double ang = TRX2_A_N_CA_C * M_PI / 180.0, N[3] = {TRX2_B_N_CA * cos(ang), TRX2_B_N_CA * sin(ang), 0}, C[3] = {TRX2_B_CA_C, 0, 0};
+    const double b[3] = {-N[0], -N[1], -N[2]}, c[3] = {C[0], C[1], C[2]};
+    const double a[3] = {b[1] * c[2] - b[2] * c[1], b[2] * c[0] - b[0] * c[2], b[0] * c[1] - b[1] * c[0]};
+    double CB[3];
+    for (int i = 0; i < 3; i++) CB[i] = TRX2_CB_KA * a[i] + TRX2_CB_KB * b[i] + TRX2_CB_KC * c[i];
+    auto dot3d = [](const double* u, const double* v) { return u[0] * v[0] + u[1] * v[1] + u[2] * v[2]; };
+    auto angle = [&](const double* p, const double* q) { return acos(dot3d(p, q) / sqrt(dot3d(p, p) * dot3d(q, q))); };
+    const double d = sqrt(dot3d(CB, CB));
+    // improper N-C-CA-CB (IUPAC sign, as dihedral_grad): F = N - C, G = C - CA (CA is the origin), H = CB - CA
+    const double F[3] = {N[0] - C[0], N[1] - C[1], N[2] - C[2]}, G[3] = {C[0], C[1], C[2]}, H[3] = {CB[0], CB[1], CB[2]};
+    auto cross3 = [](const double* u, const double* v, double* o) { o[0] = u[1] * v[2] - u[2] * v[1]; o[1] = u[2] * v[0] - u[0] * v[2]; o[2] = u[0] * v[1] - u[1] * v[0]; };
+    double A_[3], B_[3], BA[3];
+    cross3(F, G, A_); cross3(H, G, B_); cross3(B_, A_, BA);
+    const double tor = atan2(dot3d(BA, G) / sqrt(dot3d(G, G)), dot3d(A_, B_));
+    cb[0] = (float)d; cb[1] = (float)angle(N, CB); cb[2] = (float)angle(C, CB); cb[3] = (float)tor;
+  }
+  if (hipMemcpyToSymbol(HIP_SYMBOL(c_cb_ideal), cb, sizeof cb) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(c_rama), rm, sizeof rm) != hipSuccess ||
       hipMemcpyToSymbol(HIP_SYMBOL(c_rama_sc), rsc, sizeof rsc) != hipSuccess ||
       hipHostMalloc((void**)&ctx->h_done, sizeof(int)) != hipSuccess) {
     delete ctx;
