@@ -27,6 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+SIMDS = 256 * 4        # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9       # max shader clock (same table); the in-kernel clock under load is lower, so busy_frac reads low
 CONFIGS = {
     2: dict(L=150, B=64, orient=False, name="L=150 single target, init_num=64, dist-only, synthetic map seed 150"),
     3: dict(L=150, B=64, orient=True, chains=2,
@@ -221,12 +223,19 @@ def main():
 
     # HBM-side bytes of that kernel per launch: PMC counters cannot be collected from inside this process, so the value is the
     # one measured with rocprofv3 for this kernel build and config and committed under profiles/ (null if absent)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, valu = None, None, None
     tf = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
     if os.path.exists(tf):
         rec = json.load(open(tf)).get(str(args.config))
         if rec:
             traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/r01_final_traffic.json: " + rec["method"]
+            # The kernel computes in f32 on the vector ALUs (no contraction to put on MFMA): next to the contract's HBM figure,
+            # how busy the SIMDs' VALUs are.  Counter SQ_ACTIVE_INST_VALU (units of 4 cycles, summed over waves; one wave64
+            # f32 instruction occupies its SIMD for 4 cycles) from the same PMC run, over 1024 SIMDs and the LIVE duration.
+            cyc = rec["valu_active_quad_cycles"] * 4.0 / SIMDS
+            valu = {"insts_per_launch": rec["valu_insts_per_launch"], "busy_cycles_per_simd": cyc,
+                    "busy_frac": cyc / (ms * 1e-3 * CLOCK_HZ), "clock_hz_assumed": CLOCK_HZ,
+                    "wave_time_waiting_frac": rec["wait_any_quad_cycles"] / rec["wave_quad_cycles"]}
 
     out = None
     if rank == 0:
@@ -238,7 +247,7 @@ def main():
                        "parallelism": f"decoys sharded over {world} rank(s), no collective on the data path"},
             "roofline": {"bound": "hbm", "kernel": f"k_pair<{min(64, 1 << (B - 1).bit_length())}>", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": ms, "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": n_terms},
+                         "avg_launch_ms": ms, "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": n_terms, "valu": valu},
             "all_decoys_converged": bool(ok), "evals_per_decoy": {"min": int(evals.min()), "median": float(np.median(evals)), "max": int(evals.max())},
             "pair_launches_per_step": launches / args.steps / n_chains,
         }
