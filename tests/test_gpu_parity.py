@@ -164,6 +164,34 @@ def test_eval_other_widths_and_long_chains(ctx, L, B):
         assert np.abs(g[d] - go).max() <= 1e-2 * np.abs(go).max(), ("grad", L, d, np.abs(g[d] - go).max(), np.abs(go).max())
 
 
+def test_minimiser_on_a_chain_longer_than_512(ctx):
+    """L = 520: four residues per thread in the step kernel, history read from global memory (the LDS-staged history is for
+    L <= 256), more than 64 visits per wave in the pair kernel (three blocks of its contact-bit walk).  Torsion-space
+    protocol (the Cartesian kernel stops at 512 residues); same start and evaluation budget as the oracle.
+    tools/horizon_check.py on this start: agreement to 1e-7 .. 1e-6 for the first evaluations, identical iteration counts up
+    to 8, then the float32 and float64 trajectories separate (1e-5 at 3 evaluations for one decoy, 3e-4 at 4, percent level
+    from 8 on) -- so the comparison is pinned at 4 evaluations and the longer run is a sanity check."""
+    S = importlib.import_module("trrosettax2-dynamics_amd.synth")
+    L, B = 520, 3
+    m = S.make_map(L, seed=L, n_moves=150)
+    ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=m["seq"])
+    Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"])
+    runs = T.protocol.build_runs(L, 2)
+    assert not any(q["cartesian"] for q in runs)
+    rng = np.random.default_rng(7)
+    t0 = np.stack([m["tors"] + rng.normal(size=(L, 3)) * 0.15 for _ in range(B)]).astype(np.float32)
+    r = ctx.fold_batch(B, runs, tors0=t0, max_evals=4)
+    rel, same = [], 0
+    for d in range(B):
+        to, xo, st = O.fold(Tb, t0[d].astype(np.float64), runs, max_evals=4)
+        rel.append(abs(r["f"][d] - st["f_final"]) / abs(st["f_final"]))
+        same += int(r["n_iters"][d] == st["n_iters"])
+    print("\nL=520, 4 evaluations: relative energy difference device vs oracle %s, identical iteration counts %d of %d" % (np.round(rel, 7), same, B))
+    assert max(rel) <= 2e-3 and np.median(rel) <= 2e-5 and same == B, (rel, same)
+    r = ctx.fold_batch(B, runs, tors0=t0, max_evals=30)
+    assert np.all(np.isfinite(r["xyz"])) and np.all(r["n_evals"] == 30) and np.all(r["n_iters"] >= 15)
+
+
 def test_minimiser_tracks_oracle_over_short_horizons(ctx, maps, seq):
     """Same start, same protocol, same evaluation budget as the oracle.  Outcome tests cannot see a minimiser that
     converges wastefully; this can.  Statistic: accepted iterations summed over 12 decoys, device / oracle.
