@@ -251,6 +251,20 @@ def main():
             "all_decoys_converged": bool(ok), "evals_per_decoy": {"min": int(evals.min()), "median": float(np.median(evals)), "max": int(evals.max())},
             "pair_launches_per_step": launches / args.steps / n_chains,
         }
+        if world == 1 and n_chains == 1:
+            # The same job with the library's two lanes (trx2_ctx_set_lanes: two half-batches on two streams, one half's step
+            # kernel overlapping the other's pair kernel).  Reported beside `value`, which stays the single-stream figure so
+            # that the per-kernel roofline above and the committed kernel trace describe the launches that were timed.
+            c2 = T.Context(local_rank, lanes=2)
+            c2.set_map(m["dist"], *([m["omega"], m["theta"], m["phi"]] if cfg["orient"] else []), seq=m["seq"])
+            c2.fold_batch(B, runs, seed=150, decoy0=900 * B)
+            t1 = time.perf_counter()
+            r2 = [c2.fold_batch(B, runs, seed=150, decoy0=i * B) for i in range(args.steps)]
+            e2 = time.perf_counter() - t1
+            c2.close()
+            out["two_lanes"] = {"value": args.steps * B / e2, "unit": "decoys/sec", "ms_per_step": 1e3 * e2 / args.steps,
+                                "all_decoys_converged": bool(all(np.all(r["status"] == 0) for r in r2)),
+                                "note": f"same job, Context(lanes=2): halves of {(B + 1) // 2} and {B // 2} decoys on two streams"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(m, cfg, runs)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()

@@ -47,6 +47,13 @@ int trx2_abi_version(void);
 /* replaces pyrosetta.init + process start-up (folding/folding.py:48): binds a GPU and creates a stream */
 int trx2_ctx_create(int device, trx2_ctx** out);
 void trx2_ctx_destroy(trx2_ctx* ctx);
+/* lanes = 2: trx2_fold_batch folds batches of 32 or more decoys as two halves on two streams (second half from an internal
+ * host thread), so that one half's step kernel overlaps the other half's pair kernel: +24 % (distances only) / +32 % (all
+ * channels) decoys/s at L=150, B=64 on MI355X.  The reference has no counterpart: its decoys are separate OS processes
+ * (utils_trX2dy/utils.py:501-503).  Every decoy keeps its identity (seed, decoy0 + index); results equal those of folding the
+ * two halves as separate batches.  lanes = 1 (default) restores one stream.  More than three streams folding at once in a
+ * process need GPU_MAX_HW_QUEUES=8 (HIP runtime). */
+int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes);
 const char* trx2_last_error(const trx2_ctx* ctx);
 
 /* replaces np.load(NPZ) + gen_rst + add_rst selection (folding/folding.py:56-63; utils_ros.py:6-146,706-723).

@@ -18,6 +18,7 @@ FO = importlib.import_module("trrosettax2-dynamics_amd.fold")
 PL = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
 P = importlib.import_module("trrosettax2-dynamics_amd.pdbio")
 FB = importlib.import_module("trrosettax2-dynamics_amd.feedback")
+T = importlib.import_module("trrosettax2-dynamics_amd")
 
 
 def test_folding_with_pred_npz_writes_the_reference_file_names(golden_dir, tmp_path, seq):
@@ -155,3 +156,40 @@ def test_abi_error_paths_fail_loudly(golden_dir, seq):
         assert not any(q["cartesian"] for q in T.protocol.build_runs(520, 2))   # the default protocol does not ask for it
     finally:
         c.close()
+
+
+def test_two_lanes_fold_the_two_halves_of_a_batch(golden_dir, seq):
+    """trx2_ctx_set_lanes(2): a batch of 32 or more decoys is folded as two halves on two streams, the second from an
+    internal thread.  The contract (include/trx2fold.h): every decoy keeps its identity (seed, decoy0 + index) and the result
+    is bitwise that of folding the halves as separate batches; smaller batches take the single-stream path unchanged.
+    Also: lanes set before or after the map, dropped again, and an odd split."""
+    m = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
+    runs = T.protocol.build_runs(90, 2)
+    keys = ("xyz", "tors", "f", "status", "n_evals", "n_iters", "e_terms")
+    one = T.Context(0)
+    one.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+    two = T.Context(0, lanes=2)                       # lanes before the map
+    two.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+    for B in (64, 33):
+        r = two.fold_batch(B, runs, seed=11, decoy0=5)
+        B0 = (B + 1) // 2
+        a = one.fold_batch(B0, runs, seed=11, decoy0=5)
+        b = one.fold_batch(B - B0, runs, seed=11, decoy0=5 + B0)
+        for k in keys:
+            assert np.array_equal(r[k], np.concatenate([a[k], b[k]])), (B, k)
+        assert np.all(r["status"] == 0)
+    small = two.fold_batch(12, runs, seed=3)
+    ref = one.fold_batch(12, runs, seed=3)
+    assert all(np.array_equal(small[k], ref[k]) for k in keys)
+    one.set_lanes(2)                                  # lanes after the map: the second lane borrows the existing tables
+    r2 = one.fold_batch(64, runs, seed=11, decoy0=5)
+    r1 = two.fold_batch(64, runs, seed=11, decoy0=5)
+    assert all(np.array_equal(r1[k], r2[k]) for k in keys)
+    one.set_map(m["dist"], seq=seq)                   # a new map while a lane exists: both lanes see it
+    d1 = one.fold_batch(40, runs, seed=2)
+    one.set_lanes(1)
+    d0a, d0b = one.fold_batch(20, runs, seed=2), one.fold_batch(20, runs, seed=2, decoy0=20)
+    assert np.array_equal(d1["xyz"], np.concatenate([d0a["xyz"], d0b["xyz"]]))
+    with pytest.raises(RuntimeError):
+        one.set_lanes(3)
+    one.close(); two.close()

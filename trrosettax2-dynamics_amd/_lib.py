@@ -70,6 +70,7 @@ def load():
     L.trx2_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.trx2_ctx_destroy.argtypes = [vp]
     L.trx2_ctx_destroy.restype = None
+    L.trx2_ctx_set_lanes.argtypes = [vp, C.c_int]
     L.trx2_last_error.argtypes = [vp]
     L.trx2_last_error.restype = C.c_char_p
     L.trx2_set_map.argtypes = [vp, C.c_int, C.c_char_p, vp, vp, vp, vp, C.POINTER(Params)]
@@ -88,9 +89,10 @@ def _p(a):
 
 
 class Context:
-    """One GPU stream + one distogram.  Mirrors what one folding.py process holds (folding/folding.py:48-63)."""
+    """One GPU stream + one distogram.  Mirrors what one folding.py process holds (folding/folding.py:48-63).
+    lanes=2: batches of 32 or more decoys are folded as two halves on two streams (trx2_ctx_set_lanes, include/trx2fold.h)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, lanes=1):
         self._l = load()
         h = C.c_void_p()
         rc = self._l.trx2_ctx_create(int(device), C.byref(h))
@@ -99,6 +101,13 @@ class Context:
         self._h = h
         self.L = 0
         self.use_orient = False
+        self.lanes = 1
+        if lanes != 1:
+            self.set_lanes(lanes)
+
+    def set_lanes(self, lanes):
+        self._chk(self._l.trx2_ctx_set_lanes(self._h, int(lanes)), "trx2_ctx_set_lanes")
+        self.lanes = int(lanes)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/trx2fold.h"
@@ -1618,6 +1619,10 @@ struct trx2_ctx {
   trx2_run* runs = nullptr;
   int* h_done = nullptr;  // pinned
   double last_seconds = 0; int last_launches = 0;
+  // second lane (trx2_ctx_set_lanes): a context of its own stream and batch buffers that BORROWS this one's tables, so that
+  // one job can run as two half-batches whose pair and step kernels overlap
+  trx2_ctx* child = nullptr;
+  bool borrows_map = false;
 };
 
 #define HIPCHK(expr)                                                                                        \
@@ -1691,10 +1696,17 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
   return 0;
 }
 
+static void lend_map(trx2_ctx* c);
 static void free_map(trx2_ctx* c) {
+  if (c->child) {  // the borrower must be idle and forget the tables before they go
+    if (c->child->stream) (void)hipStreamSynchronize(c->child->stream);
+    trx2_ctx* k = c->child;
+    k->Td = k->To = k->Tt = k->Tp = nullptr; k->pd = k->po = k->pt = k->pp = nullptr;
+    k->gen = k->sel = k->mask2 = nullptr; k->knots_f = nullptr; k->knots_d = nullptr; k->L = 0; k->alloc_epoch++;
+  }
   void* p[] = {c->Td, c->To, c->Tt, c->Tp, c->pd, c->po, c->pt, c->pp, c->gen, c->sel, c->mask2, c->knots_f, c->knots_d};
   for (void* q : p)
-    if (q) (void)hipFree(q);
+    if (q && !c->borrows_map) (void)hipFree(q);
   c->Td = c->To = c->Tt = c->Tp = nullptr;
   c->pd = c->po = c->pt = c->pp = nullptr;
   c->gen = c->sel = c->mask2 = nullptr;
@@ -1740,9 +1752,38 @@ static int ensure_cart(trx2_ctx* ctx, int B) {
   return 0;
 }
 
+// the child sees the parent's tables (read-only on both streams)
+static void lend_map(trx2_ctx* c) {
+  trx2_ctx* k = c->child;
+  if (!k) return;
+  k->L = c->L; k->use_orient = c->use_orient; k->seq = c->seq;
+  k->Td = c->Td; k->To = c->To; k->Tt = c->Tt; k->Tp = c->Tp; k->pd = c->pd; k->po = c->po; k->pt = c->pt; k->pp = c->pp;
+  k->gen = c->gen; k->sel = c->sel; k->mask2 = c->mask2; k->knots_f = c->knots_f; k->knots_d = c->knots_d;
+  memcpy(k->knots_h, c->knots_h, sizeof c->knots_h);
+  k->alloc_epoch++;
+}
+
+extern "C" int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes) {
+  if (!ctx) return 1;
+  if (lanes != 1 && lanes != 2) { ctx->err = "trx2_ctx_set_lanes: 1 or 2"; return 1; }
+  if (lanes == 2 && !ctx->child) {
+    trx2_ctx* k = nullptr;
+    if (trx2_ctx_create(ctx->device, &k) != 0) { ctx->err = "trx2_ctx_set_lanes: cannot create the second lane"; return 1; }
+    k->borrows_map = true;
+    ctx->child = k;
+    if (ctx->L) { HIPCHK(hipStreamSynchronize(ctx->stream)); lend_map(ctx); }
+  } else if (lanes == 1 && ctx->child) {
+    trx2_ctx* k = ctx->child;
+    ctx->child = nullptr;
+    trx2_ctx_destroy(k);  // borrows_map: frees its batch buffers only
+  }
+  return 0;
+}
+
 extern "C" void trx2_ctx_destroy(trx2_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->child) { trx2_ctx* k = ctx->child; ctx->child = nullptr; trx2_ctx_destroy(k); }
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
   free_map(ctx);
@@ -1831,6 +1872,7 @@ static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist
   if (!device_ptrs)
     for (int c = 0; c < 4; c++)
       if (dev[c]) HIPCHK(hipFree(dev[c]));
+  if (ctx->child) { HIPCHK(hipStreamSynchronize(ctx->stream)); lend_map(ctx); }  // tables complete before the other stream reads them
   return 0;
 }
 
@@ -2016,9 +2058,9 @@ extern "C" int trx2_eval_batch(trx2_ctx* ctx, int B, const float* tors, const fl
   return 0;
 }
 
-extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint64_t seed, uint32_t decoy0,
-                               const float* tors0, int max_evals, float* tors_out, float* xyz_out, double* e_terms,
-                               double* f_final, int* status, int* n_evals, int* n_iters) {
+static int fold_impl(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint64_t seed, uint32_t decoy0,
+                     const float* tors0, int max_evals, float* tors_out, float* xyz_out, double* e_terms,
+                     double* f_final, int* status, int* n_evals, int* n_iters) {
   if (!ctx) return 1;
   if (!ctx->L) { ctx->err = "trx2_fold_batch: no map set"; return 1; }
   if (B < 1 || !runs || nruns < 1 || nruns > TRX2_MAX_RUNS) { ctx->err = "trx2_fold_batch: bad arguments"; return 1; }
@@ -2116,6 +2158,35 @@ extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int n
   ctx->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   ctx->last_launches = launches;
   return 0;
+}
+
+// Two lanes: decoys [0, B0) on this context, [B0, B) on the child, the child driven from its own host thread.  A decoy is
+// still identified by (seed, decoy0 + index), so which lane folds it does not change its start; but the half-batches have
+// their own decoy-group width and slab split, so results are those of folding the halves separately, not of one batch of B.
+#define TRX2_LANE_MIN_B 32
+extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint64_t seed, uint32_t decoy0,
+                               const float* tors0, int max_evals, float* tors_out, float* xyz_out, double* e_terms,
+                               double* f_final, int* status, int* n_evals, int* n_iters) {
+  if (!ctx) return 1;
+  trx2_ctx* k = ctx->child;
+  if (!k || B < TRX2_LANE_MIN_B || !ctx->L)
+    return fold_impl(ctx, B, runs, nruns, seed, decoy0, tors0, max_evals, tors_out, xyz_out, e_terms, f_final, status, n_evals, n_iters);
+  const int B0 = (B + 1) / 2, B1 = B - B0;
+  const size_t L = (size_t)ctx->L;
+  auto t0 = std::chrono::steady_clock::now();
+  int rc1 = 0;
+  std::thread other([&]() {
+    rc1 = fold_impl(k, B1, runs, nruns, seed, decoy0 + (uint32_t)B0, tors0 ? tors0 + (size_t)B0 * L * 3 : nullptr, max_evals,
+                    tors_out ? tors_out + (size_t)B0 * L * 3 : nullptr, xyz_out ? xyz_out + (size_t)B0 * L * 15 : nullptr,
+                    e_terms ? e_terms + (size_t)B0 * TRX2_NTERMS : nullptr, f_final ? f_final + B0 : nullptr,
+                    status ? status + B0 : nullptr, n_evals ? n_evals + B0 : nullptr, n_iters ? n_iters + B0 : nullptr);
+  });
+  const int rc0 = fold_impl(ctx, B0, runs, nruns, seed, decoy0, tors0, max_evals, tors_out, xyz_out, e_terms, f_final, status, n_evals, n_iters);
+  other.join();
+  if (rc1 != 0 && rc0 == 0) ctx->err = "second lane: " + k->err;
+  ctx->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  ctx->last_launches = ctx->last_launches > k->last_launches ? ctx->last_launches : k->last_launches;
+  return rc0 != 0 ? rc0 : rc1;
 }
 
 extern "C" int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int sep_lo, int sep_hi, int n_rep,

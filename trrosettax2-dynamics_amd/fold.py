@@ -56,20 +56,24 @@ def _unquote(p):
     return p[1:-1] if len(p) >= 2 and p[0] == p[-1] and p[0] in "\"'" else p
 
 
-def get_context(device=0):
+def get_context(device=0, lanes=1):
     key = (device, threading.get_ident())
     if key not in _CTX:
         _CTX[key] = Context(device)
+    if _CTX[key].lanes != lanes:
+        _CTX[key].set_lanes(lanes)
     return _CTX[key]
 
 
-def fold_arrays(npz, seq, n_decoys, options="", device=0, seed=None, decoy0=0):
-    """fold n_decoys of one distogram -> dict(xyz[B,L,5,3], status, e_terms, ...); raises on any failed decoy"""
+def fold_arrays(npz, seq, n_decoys, options="", device=0, seed=None, decoy0=0, lanes=2):
+    """fold n_decoys of one distogram -> dict(xyz[B,L,5,3], status, e_terms, ...); raises on any failed decoy.
+    lanes=2 (default): 32 or more decoys are folded as two halves on two streams (+24..32 % decoys/s, include/trx2fold.h);
+    callers that already fold several chains concurrently (pipeline.run_single with two models) pass lanes=1."""
     args = parse_options(options)
     L = len(seq)
     if npz["dist"].shape[0] != L:
         raise ValueError(f"sequence length {L} does not match the distogram {npz['dist'].shape}")
-    ctx = get_context(device)
+    ctx = get_context(device, lanes)
     ang = [npz[k] for k in ("omega", "theta", "phi")] if args.use_orient else []
     ctx.set_map(npz["dist"], *ang, seq=seq, pcut=args.pcut)
     if seed is None:
@@ -99,10 +103,10 @@ def folding_with_pred_npz(base_npz, base_fasta, base_out, out_name, options="-m 
     return r
 
 
-def fold_arrays_to_pdb(arrays, seq, base_out, names, options="", device=0, seed=None, decoy0=0):
+def fold_arrays_to_pdb(arrays, seq, base_out, names, options="", device=0, seed=None, decoy0=0, lanes=2):
     """folding_with_pred_npz for distograms already in memory: writes base_out/name for every name"""
     os.makedirs(base_out, exist_ok=True)
-    r = fold_arrays(arrays, seq, len(names), options, device=device, seed=seed, decoy0=decoy0)
+    r = fold_arrays(arrays, seq, len(names), options, device=device, seed=seed, decoy0=decoy0, lanes=lanes)
     for k, name in enumerate(names):
         write_pdb(os.path.join(base_out, name), seq, r["xyz"][k], remarks=[f"trx2fold decoy {k} seed {seed} evals {int(r['n_evals'][k])}"])
     return r

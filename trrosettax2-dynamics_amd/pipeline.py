@@ -26,7 +26,7 @@ from .pdbio import read_fasta
 
 
 def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz, fasta, N=10, Nmax=500, begin_num=0,
-                         sigma=1.0, tta_opt="-m 2 -r no-idp --orient ", angle=True, device=0, seed=None):
+                         sigma=1.0, tta_opt="-m 2 -r no-idp --orient ", angle=True, device=0, seed=None, lanes=2):
     """N initial decoys as one GPU batch -> best by reliability -> feedback -> one decoy per iteration until the
     cumulative `tmp` array moves by < 0.01 or Nmax iterations (run_inference.py:97-139).  Returns the last index.
 
@@ -38,7 +38,7 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     seq = read_fasta(fasta)
     init = dict(np.load(initial_npz))
     print("Start generating the initial structures")
-    fold_arrays_to_pdb(init, seq, pred_pdb_dir, [f"initial{i}.pdb" for i in range(N)], tta_opt, device=device, seed=seed)
+    fold_arrays_to_pdb(init, seq, pred_pdb_dir, [f"initial{i}.pdb" for i in range(N)], tta_opt, device=device, seed=seed, lanes=lanes)
     print("Done generating initial structures")
     best_score, best_pdb = -np.inf, None
     for i in range(N):                                   # strict '>' : the first maximum wins (run_inference.py:67)
@@ -136,7 +136,8 @@ def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mu
         # files are renumbered afterwards to what the sequential order would have produced.
         return generate_npz_and_pdb(name + name_offset, os.path.join(tmp_dir, tag), os.path.join(pdb_dir, tag), paths[tag], fasta_file,
                                     N=init_num, Nmax=Nmax, begin_num=0, angle=angle, tta_opt=tta_opt, device=device,
-                                    seed=None if seed is None else seed + 100000 * len(tag))
+                                    seed=None if seed is None else seed + 100000 * len(tag),
+                                    lanes=1 if len(maps) == 2 else 2)   # two chains already occupy two streams
 
     if len(maps) == 2:
         with ThreadPoolExecutor(max_workers=2) as ex:
