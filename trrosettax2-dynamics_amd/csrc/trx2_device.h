@@ -74,6 +74,43 @@ __device__ __forceinline__ f3 place_atom(f3 a, f3 b, f3 c, float len, float cang
 // the pair kernel, which is vector-ALU-bound (profiles/README.md), evaluates up to eight of them per residue-pair visit
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 
+// atan2 for the restraint angles: the library's is 43 vector instructions, this is ~23.  atan(a) = a P(a^2) on [0,1] (degree-7
+// fit, max error 1.4e-7 rad evaluated in float32 = 1-2 ulp at pi/4), octant fix-ups by selects.  atan2(0,0) = 0 as in libm.
+__device__ __forceinline__ float fast_atan2f(float y, float x) {
+  const float ax = fabsf(x), ay = fabsf(y), mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+  const float a = mn * frcp(fmaxf(mx, 1e-30f)), s = a * a;
+  float p = -4.054523205e-03f;
+  p = fmaf(p, s, 2.186279171e-02f);
+  p = fmaf(p, s, -5.591207582e-02f);
+  p = fmaf(p, s, 9.642178046e-02f);
+  p = fmaf(p, s, -1.390862164e-01f);
+  p = fmaf(p, s, 1.994656400e-01f);
+  p = fmaf(p, s, -3.332986064e-01f);
+  p = fmaf(p, s, 9.999993355e-01f);
+  float r = p * a;
+  r = ay > ax ? 0.5f * TRX2_PI_F - r : r;
+  r = x < 0.0f ? TRX2_PI_F - r : r;
+  return y < 0.0f ? -r : r;
+}
+// sin and cos for torsion / bond angles: the library's sincosf is 122 vector instructions (it carries the Payne-Hanek path for
+// huge arguments); the step kernel needs ten per residue and step.  Cody-Waite reduction to [-pi/4, pi/4] with pi/2 split in
+// two floats (the fused multiply-adds keep the products exact), cephes polynomials; max error 9e-8 for |x| < 1000, checked
+// in float32 arithmetic against double.  Torsions are bounded by the line search to a few turns.
+__device__ __forceinline__ void fast_sincosf(float x, float* sn, float* cs) {
+  const float k = rintf(x * 0.63661977236758134f);
+  float r = fmaf(k, -1.5707963705062866f, x);
+  r = fmaf(k, 4.3711390063e-08f, r);
+  const float s2 = r * r;
+  const float sp = fmaf(fmaf(-1.9515295891e-4f, s2, 8.3321608736e-3f), s2, -1.6666654611e-1f);
+  const float s_ = fmaf(r * s2, sp, r);
+  const float cp = fmaf(fmaf(2.443315711809948e-5f, s2, -1.388731625493765e-3f), s2, 4.166664568298827e-2f);
+  const float c_ = fmaf(s2 * s2, cp, fmaf(-0.5f, s2, 1.0f));
+  const int q = (int)k;
+  const float s1 = (q & 1) ? c_ : s_, c1 = (q & 1) ? s_ : c_;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
 // IUPAC dihedral p1-p2-p3-p4 and its gradient with respect to the four points
 __device__ __forceinline__ float dihedral_grad(f3 p1, f3 p2, f3 p3, f3 p4, f3& d1, f3& d2, f3& d3, f3& d4) {
   f3 F = p1 - p2, G = p2 - p3, H = p4 - p3;
@@ -82,7 +119,7 @@ __device__ __forceinline__ float dihedral_grad(f3 p1, f3 p2, f3 p3, f3 p4, f3& d
   float iGn = rsqrtf(G2), Gn = G2 * iGn;
   float iA2 = frcp(fmaxf(dot(A, A), 1e-12f)), iB2 = frcp(fmaxf(dot(B, B), 1e-12f));
   float cosv = dot(A, B), sinv = dot(cross(B, A), G) * iGn;
-  float ang = atan2f(sinv, cosv);
+  float ang = fast_atan2f(sinv, cosv);
   float ca = dot(F, G) * iA2 * iGn, cb = dot(H, G) * iB2 * iGn;
   float ga = Gn * iA2, gb = Gn * iB2;
   d1 = A * (-ga);

@@ -563,7 +563,7 @@ __device__ __forceinline__ ResGeom ideal_geom() {
 // local frame of a residue: CA at origin, C on +x, N in the xy plane (y>0 side)
 __device__ __forceinline__ void local_atoms(const ResGeom& g, f3& N, f3& CA, f3& C, f3& CB) {
   float sa, ca;
-  sincosf(g.g0.w, &sa, &ca);
+  fast_sincosf(g.g0.w, &sa, &ca);
   CA = mk3(0, 0, 0);
   C = mk3(g.g0.y, 0, 0);
   N = mk3(g.g0.x * ca, g.g0.x * sa, 0);
@@ -700,8 +700,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
           float s = 0, dph = 0, dps = 0;
           // sin/cos of (phi - phi_k), (psi - psi_k) by the angle-addition identities: 2 sincosf per residue, not 12
           float sph, cph, sps, cps;
-          sincosf(xt[k].x, &sph, &cph);
-          sincosf(xt[k].y, &sps, &cps);
+          fast_sincosf(xt[k].x, &sph, &cph);
+          fast_sincosf(xt[k].y, &sps, &cps);
 #pragma unroll
           for (int j = 0; j < TRX2_RAMA_NB; j++) {
             const float sk = c_rama_sc[j * 4], ck = c_rama_sc[j * 4 + 1], tk = c_rama_sc[j * 4 + 2], uk = c_rama_sc[j * 4 + 3];
@@ -1032,7 +1032,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   {
     const float4 q0 = gq[0];
     float sa, ca;
-    sincosf(q0.w, &sa, &ca);
+    fast_sincosf(q0.w, &sa, &ca);
     carry = xf_from_atoms(mk3(0, 0, 0), mk3(q0.x, 0, 0), mk3(q0.x - q0.y * ca, q0.y * sa, 0));
   }
 #pragma unroll
@@ -1047,12 +1047,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       if (r + 1 < L) {
         const float4 n0 = gq[(r + 1) * 3];  // next residue: |N-CA|, |CA-C|, angle N-CA-C
         float spsi, cpsi, so, co, sp, cp, s1, c1, s2, c2, s3, c3;
-        sincosf(xt[k].y, &spsi, &cpsi);
-        sincosf(xt[k].z, &so, &co);
-        sincosf(s_phi[r + 1], &sp, &cp);  // phi of residue r+1
-        sincosf(gr.g1.x, &s1, &c1);
-        sincosf(gr.g1.y, &s2, &c2);
-        sincosf(n0.w, &s3, &c3);
+        fast_sincosf(xt[k].y, &spsi, &cpsi);
+        fast_sincosf(xt[k].z, &so, &co);
+        fast_sincosf(s_phi[r + 1], &sp, &cp);  // phi of residue r+1
+        fast_sincosf(gr.g1.x, &s1, &c1);
+        fast_sincosf(gr.g1.y, &s2, &c2);
+        fast_sincosf(n0.w, &s3, &c3);
         f3 Nn = place_atom(lN, lCA, lC, gr.g0.z, c1, s1, cpsi, spsi);
         f3 CAn = place_atom(lCA, lC, Nn, n0.x, c2, s2, co, so);
         f3 Cn = place_atom(lC, Nn, CAn, n0.y, c3, s3, cp, sp);
@@ -1093,8 +1093,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
     carry = tot;
     if (r < L) {
       float so_, co_, s4, c4;
-      sincosf(xt[k].y + gr.g2.x, &so_, &co_);  // dihedral N-CA-C-O = psi + t_O (ideal: pi)
-      sincosf(gr.g1.w, &s4, &c4);
+      fast_sincosf(xt[k].y + gr.g2.x, &so_, &co_);  // dihedral N-CA-C-O = psi + t_O (ideal: pi)
+      fast_sincosf(gr.g1.w, &s4, &c4);
       f3 lO = place_atom(lN, lCA, lC, gr.g1.z, c4, s4, co_, so_);
       f3 N = xf_apply(F, lN), CA = xf_apply(F, lCA), C = xf_apply(F, lC), O = xf_apply(F, lO), CB = xf_apply(F, lCB);
       float4 o0 = make_float4(N.x, N.y, N.z, CA.x), o1 = make_float4(CA.y, CA.z, C.x, C.y),
@@ -1230,7 +1230,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     if (r >= 1 && r < L - 1) {
       const float ph = dihedral_grad(Pv.C, Me.N, Me.CA, Me.C, t1, t2, t3, t4), ps = dihedral_grad(Me.N, Me.CA, Me.C, Nx.N, t1, t2, t3, t4);
       float sph, cph, sps, cps, sm = 0, a1 = 0, a2 = 0;
-      sincosf(ph, &sph, &cph); sincosf(ps, &sps, &cps);
+      fast_sincosf(ph, &sph, &cph); fast_sincosf(ps, &sps, &cps);
 #pragma unroll
       for (int j = 0; j < TRX2_RAMA_NB; j++) {
         const float sk = c_rama_sc[j * 4], ck = c_rama_sc[j * 4 + 1], tk = c_rama_sc[j * 4 + 2], uk = c_rama_sc[j * 4 + 3];
