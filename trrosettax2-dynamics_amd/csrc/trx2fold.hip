@@ -208,14 +208,17 @@ __device__ __forceinline__ void spline_eval_dev(const float2* __restrict__ row, 
   else if (x >= kn[idx + 1]) idx = min(K - 2, idx + 1);
   float lo = kn[idx], hi = kn[idx + 1];
   float2 k0 = row[idx], k1 = row[idx + 1];
-  float h = hi - lo, ih = ikn[idx];
-  float a = (hi - x) * ih, b = (x - lo) * ih;
+  // the segment's cubic in t = x - lo, formed from (y, y'') of its two knots and evaluated by Horner (17 operations; the
+  // symmetric a/b form of the textbook needs ~30):  c1 = (y1-y0)/h - h (2 y0'' + y1'')/6,  c2 = y0''/2,  c3 = (y1''-y0'')/(6h)
+  float h = hi - lo, ih = ikn[idx], t = x - lo;
   bool inside = (x > kn[0]) && (x < kn[K - 1]);
-  float h26 = h * h * (1.0f / 6.0f);
-  float ev = a * k0.x + b * k1.x + ((a * a * a - a) * k0.y + (b * b * b - b) * k1.y) * h26;
-  float dv = (k1.x - k0.x) * ih + ((3.0f * b * b - 1.0f) * k1.y - (3.0f * a * a - 1.0f) * k0.y) * (h * (1.0f / 6.0f));
-  // outside the knot range: constant end value, zero slope (SplineFunc)
-  e = inside ? ev : (x <= kn[0] ? row[0].x : row[K - 1].x);
+  float c1 = fmaf(-h * (1.0f / 6.0f), fmaf(2.0f, k0.y, k1.y), (k1.x - k0.x) * ih);
+  float c3 = (k1.y - k0.y) * (ih * (1.0f / 6.0f));
+  float ev = fmaf(fmaf(fmaf(c3, t, 0.5f * k0.y), t, c1), t, k0.x);
+  float dv = fmaf(fmaf(3.0f * c3, t, k0.y), t, c1);
+  // outside the knot range: constant end value, zero slope (SplineFunc).  The end knots are the ones already fetched:
+  // x <= kn[0] => idx == 0 => k0 is row[0];  x >= kn[K-1] => idx == K-2 => k1 is row[K-1]
+  e = inside ? ev : (x <= kn[0] ? k0.x : k1.x);
   de = inside ? dv : 0.0f;
 }
 
