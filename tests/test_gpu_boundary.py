@@ -83,11 +83,17 @@ def test_run_single_reproduces_the_example_layout(golden_dir, tmp_path):
 def test_no_angle_iteration_converges_or_stops_at_nmax(golden_dir, tmp_path):
     """--no-angle path (BASELINE configs[0]): dist-only restraints and dist/tmp-only npz files"""
     tmpd, pdbd = str(tmp_path / "tmp"), str(tmp_path / "pdb")
-    last = PL.generate_npz_and_pdb("t", tmpd, pdbd, os.path.join(golden_dir, "seq_NMR.npz"), os.path.join(golden_dir, "seq.fasta"), N=2,
-                                   Nmax=2, angle=False, tta_opt="-m 2 --no-orient -r no-idp", seed=3)
+    args = ("t", tmpd, pdbd, os.path.join(golden_dir, "seq_NMR.npz"), os.path.join(golden_dir, "seq.fasta"))
+    kw = dict(N=2, Nmax=2, angle=False, tta_opt="-m 2 --no-orient -r no-idp", seed=3)
+    last = PL.generate_npz_and_pdb(*args, write_tmp_npz=True, **kw)      # the reference's intermediate files, on request
     assert last in (1, 2) and os.path.exists(os.path.join(pdbd, f"t{last}.pdb"))
     z = np.load(os.path.join(tmpd, "t1.npz"))
     assert sorted(z.files) == ["dist", "tmp"] and z["dist"].shape == (90, 90, 37)
+    for f in os.listdir(tmpd):
+        os.remove(os.path.join(tmpd, f))
+    first = open(os.path.join(pdbd, f"t{last}.pdb")).read()
+    assert PL.generate_npz_and_pdb(*args, **kw) == last and os.listdir(tmpd) == []   # default: arrays stay in memory
+    assert open(os.path.join(pdbd, f"t{last}.pdb")).read() == first                   # and the decoys are the same
 
 
 def test_device_resident_distograms_give_identical_tables(golden_dir, seq):

@@ -136,17 +136,19 @@ def feedback_labels(arrays, pred_pdb_dir, sigma=1.0, angle=True):
 
 def backbone_phi_psi(xyz):
     """(phi, psi) pairs as Biopython's PPBuilder reports them (utils.py:337-349): chains are split where the C-N
-    peptide distance exceeds 1.8 A; residues lacking either angle (segment ends) are dropped."""
+    peptide distance exceeds 1.8 A; residues lacking either angle (segment ends) are dropped.  All residues at once: the
+    per-element arithmetic of get_dihedrals does not depend on how many rows it is given."""
     N, CA, C = (xyz[:, k].astype(np.float64) for k in range(3))
     L = len(CA)
+    if L < 3:
+        return []
     link = np.linalg.norm(C[:-1] - N[1:], axis=-1) < 1.8
-    res = []
-    for i in range(1, L - 1):
-        if link[i - 1] and link[i]:
-            phi = get_dihedrals(C[i - 1][None], N[i][None], CA[i][None], C[i][None])[0]
-            psi = get_dihedrals(N[i][None], CA[i][None], C[i][None], N[i + 1][None])[0]
-            res.append((phi, psi))
-    return res
+    i = np.nonzero(link[:-1] & link[1:])[0] + 1          # residues 1..L-2 bonded on both sides
+    if len(i) == 0:
+        return []
+    phi = get_dihedrals(C[i - 1], N[i], CA[i], C[i])
+    psi = get_dihedrals(N[i], CA[i], C[i], N[i + 1])
+    return list(zip(phi.tolist(), psi.tolist()))
 
 
 def calculate_reliability_score(pdb_file):

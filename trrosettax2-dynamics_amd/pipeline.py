@@ -26,14 +26,17 @@ from .pdbio import read_fasta
 
 
 def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz, fasta, N=10, Nmax=500, begin_num=0,
-                         sigma=1.0, tta_opt="-m 2 -r no-idp --orient ", angle=True, device=0, seed=None, lanes=2):
+                         sigma=1.0, tta_opt="-m 2 -r no-idp --orient ", angle=True, device=0, seed=None, lanes=2,
+                         write_tmp_npz=False):
     """N initial decoys as one GPU batch -> best by reliability -> feedback -> one decoy per iteration until the
     cumulative `tmp` array moves by < 0.01 or Nmax iterations (run_inference.py:97-139).  Returns the last index.
 
     The reference hands every intermediate distogram to the next fold through tmp_npz/{name}{k}.npz because that fold is
     another process.  Here the arrays stay in memory; the files are still written, with the same names and keys, but with
     np.savez instead of np.savez_compressed: compressing 3 MB of float32 took 95 ms per iteration at L=90, more than the
-    fold (54 ms) or the feedback (25 ms), and run_single deletes tmp_npz/ at the end (run_inference.py:334)."""
+    fold (54 ms) or the feedback (25 ms), and run_single deletes tmp_npz/ at the end (run_inference.py:334).  Nothing reads
+    those files any more, and even uncompressed they cost 9 ms of a 50 ms iteration: they are written only with
+    write_tmp_npz=True (`run_inference.py --keep_tmp_npz`)."""
     os.makedirs(processed_npz_dir, exist_ok=True)
     seq = read_fasta(fasta)
     init = dict(np.load(initial_npz))
@@ -51,7 +54,8 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     base = {k: init[k] for k in (("dist", "theta", "omega", "phi") if angle else ("dist",))}   # no "tmp": falls back to dist
     old_tmp = init["dist"]
     cur = feedback_labels(base, best_pdb, sigma, angle)
-    np.savez(pattern.format(begin_num + 1), **cur)
+    if write_tmp_npz:
+        np.savez(pattern.format(begin_num + 1), **cur)
     iter_n = begin_num
     while True:
         iter_n += 1
@@ -63,7 +67,8 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
         if iter_n - begin_num >= Nmax:
             break
         cur = feedback_labels(cur, os.path.join(pred_pdb_dir, f"{pdb_name}{iter_n}.pdb"), sigma, angle)
-        np.savez(pattern.format(iter_n + 1), **cur)
+        if write_tmp_npz:
+            np.savez(pattern.format(iter_n + 1), **cur)
         if np.max(np.abs(old_tmp - cur["tmp"])) < 0.01:
             break
     return iter_n
@@ -111,7 +116,7 @@ def flatten_and_rename(save_pdb_dir, num_conf1_others):
 
 
 def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mult_two_models=True, npz_nmr=None,
-               npz_xray=None, device=0, seed=None):
+               npz_xray=None, device=0, seed=None, keep_tmp_npz=False):
     """run_inference.py:280-337 without the network front-end: expects the distograms to exist."""
     content = os.path.join(save_dir, name)
     npz_dir, pdb_dir, tmp_dir = (os.path.join(content, d) for d in ("pred_npz", "pred_pdb", "tmp_npz"))
@@ -137,7 +142,8 @@ def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mu
         return generate_npz_and_pdb(name + name_offset, os.path.join(tmp_dir, tag), os.path.join(pdb_dir, tag), paths[tag], fasta_file,
                                     N=init_num, Nmax=Nmax, begin_num=0, angle=angle, tta_opt=tta_opt, device=device,
                                     seed=None if seed is None else seed + 100000 * len(tag),
-                                    lanes=1 if len(maps) == 2 else 2)   # two chains already occupy two streams
+                                    lanes=1 if len(maps) == 2 else 2,   # two chains already occupy two streams
+                                    write_tmp_npz=keep_tmp_npz)
 
     if len(maps) == 2:
         with ThreadPoolExecutor(max_workers=2) as ex:
