@@ -1,0 +1,300 @@
+// kernel_pair.h -- K3/K4: pair-term kernel (restraint splines + soft-sphere repulsion) -- included by trx2fold.hip.
+// Not a stand-alone header: it relies on the macros, constant tables and helpers defined above its #include.
+#pragma once
+// =================================================================================================
+// K3/K4: pair terms.  Workgroup = (row residue a, b-range split, decoy group); lane = decoy (BW decoys per
+// wave, 64/BW residues b per wave step).  Each ORDERED pair (a,b) is visited from a's row and only the
+// gradient on a's atoms is kept -> no atomics, no cross-workgroup reduction, deterministic.
+// =================================================================================================
+struct PairArgs {
+  int L, B, nsplit, Bpad;
+  const float4* xyzT;  // [ngrp][L][4][BW] float4 : residue record (N CA C O CB + pad), decoy-minor
+  const float2 *Td, *To, *Tt, *Tp;
+  const unsigned char* mask;  // [L][L] packed: low nibble = selected bits of (a,b), high nibble = those of (b,a)
+  const float* knots;         // [107] float
+  const float* wcur;          // [Bpad][8] : w_ap w_dih w_ang w_vdw sep_lo sep_hi active -
+  float* fpart;               // [nsplit][Bpad][L][16] gradient on N CA C O CB (+pad)
+  float* epart;               // [nsplit][Bpad][L][8]  raw energies dist omega theta phi vdw
+  int* seq_ctr;               // evaluation counter in device memory: bumped here, read by the step kernel that follows
+};
+
+// ikn[i] = 1 / (kn[i+1] - kn[i]), precomputed once per workgroup: the same correctly rounded quotient the evaluator used
+// to compute per term (an IEEE division = ~10 vector instructions, six times per visit)
+__device__ __forceinline__ void spline_eval_dev(const float2* __restrict__ row, const float* kn, const float* ikn, int K,
+                                                int idx, float x, float& e, float& de) {
+  // idx is a guess; fix up against the (rounded, slightly non-uniform) knots
+  idx = max(0, min(K - 2, idx));
+  if (x < kn[idx]) idx = max(0, idx - 1);
+  else if (x >= kn[idx + 1]) idx = min(K - 2, idx + 1);
+  float lo = kn[idx], hi = kn[idx + 1];
+  float2 k0 = row[idx], k1 = row[idx + 1];
+  // the segment's cubic in t = x - lo, formed from (y, y'') of its two knots and evaluated by Horner (17 operations; the
+  // symmetric a/b form of the textbook needs ~30):  c1 = (y1-y0)/h - h (2 y0'' + y1'')/6,  c2 = y0''/2,  c3 = (y1''-y0'')/(6h)
+  float h = hi - lo, ih = ikn[idx], t = x - lo;
+  bool inside = (x > kn[0]) && (x < kn[K - 1]);
+  float c1 = fmaf(-h * (1.0f / 6.0f), fmaf(2.0f, k0.y, k1.y), (k1.x - k0.x) * ih);
+  float c3 = (k1.y - k0.y) * (ih * (1.0f / 6.0f));
+  float ev = fmaf(fmaf(fmaf(c3, t, 0.5f * k0.y), t, c1), t, k0.x);
+  float dv = fmaf(fmaf(3.0f * c3, t, k0.y), t, c1);
+  // outside the knot range: constant end value, zero slope (SplineFunc).  The end knots are the ones already fetched:
+  // x <= kn[0] => idx == 0 => k0 is row[0];  x >= kn[K-1] => idx == K-2 => k1 is row[K-1]
+  e = inside ? ev : (x <= kn[0] ? k0.x : k1.x);
+  de = inside ? dv : 0.0f;
+}
+
+// PAIR_MIN_WAVES (waves per SIMD the register allocator must admit) is a build-time knob so that occupancy-vs-spill
+// variants can be A/B-timed on hardware: 2 = no spills (220 VGPRs), 3 = 62 spilled, 4 = 104 spilled (profiles/README.md)
+#ifndef PAIR_MIN_WAVES
+#define PAIR_MIN_WAVES 2
+#endif
+// Diagnostic build only (-DTRX2_STAMP, never the shipped library): wave 0 of the workgroup (a = L/2, split 0, group 0)
+// accumulates s_memtime cycles per phase; every stamp first drains the memory counters so that a load's latency is charged
+// to the phase that issued it.  The drains forbid overlaps the real kernel has: read SHARES, not the total.
+#ifdef TRX2_STAMP
+__device__ unsigned long long g_stamp[32];
+#define STAMP_DECL unsigned long long st_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long st_prev = 0; \
+  const bool st_on = (blockIdx.x == (unsigned)(A.L / 2) && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x >> 6) == 0); \
+  if (st_on) { __builtin_amdgcn_s_waitcnt(0); st_prev = __builtin_amdgcn_s_memtime(); }
+#define STAMP(k) if (st_on) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+  __builtin_amdgcn_s_waitcnt(0); st_acc[k] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); }
+#define STAMP_FLUSH if (st_on && (threadIdx.x & 63) == 0) { for (int k_ = 0; k_ < 16; k_++) g_stamp[k_] = st_acc[k_]; }
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH
+#endif
+// FAM selects the term families an instantiation evaluates: the monolithic kernel (all three) is register-bound at 220
+// VGPRs = 2 waves per SIMD (profiles/README.md); each family alone has a much smaller live state.
+#define FAM_SYM 1   /* dist + omega: needs CA, CB */
+#define FAM_ASYM 2  /* theta + phi (both directions): needs N, CA, CB */
+#define FAM_VDW 4   /* soft-sphere repulsion: needs all five atoms, no tables */
+#define FAM_ALL 7
+template <int BW, int FAM>
+__global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs A) {
+  constexpr int PW = 64 / BW;
+  const int L = A.L;
+  const int a = blockIdx.x, split = blockIdx.y, grp = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int d = lane % BW, h = lane / BW;
+  const int dec = grp * BW + d;
+  const bool live = dec < A.B;
+
+  STAMP_DECL
+  __shared__ float s_kn[TRX2_KTOT], s_ikn[TRX2_KTOT];
+  __shared__ float s_red[PAIR_WAVES * 64 * RED_STRIDE];  // [slot][decoy][20 (+1 pad: bank-conflict-free)]
+  __shared__ unsigned char s_mask[1024];  // packed masks of this workgroup's residues b (chunk <= L <= 1024)
+  // One evaluation = one sequence number.  Kept in device memory (not a kernel argument) so that a chunk of
+  // (pair, step) launches is a STATIC graph that can be replayed.  The step kernel of this evaluation starts after this
+  // kernel has finished (same stream), so every one of its workgroups reads the same, final value.
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && A.seq_ctr) *A.seq_ctr += 1;
+  for (int i = threadIdx.x; i < TRX2_KTOT; i += PAIR_THREADS) {
+    s_kn[i] = A.knots[i];
+    s_ikn[i] = i + 1 < TRX2_KTOT ? 1.0f / (A.knots[i + 1] - A.knots[i]) : 0.0f;  // entries straddling two tables are never read
+  }
+  {
+    const int chunk0 = (L + A.nsplit - 1) / A.nsplit, lo0 = split * chunk0, hi0 = min(L, lo0 + chunk0);
+    for (int i = lo0 + threadIdx.x; i < hi0; i += PAIR_THREADS) s_mask[i - lo0] = A.mask[(size_t)a * L + i];
+  }
+  __syncthreads();
+  const float* knd = s_kn;
+  const float* kno = s_kn + KD;
+  const float* knt = s_kn + KD + KO;
+  const float* knp = s_kn + KD + 2 * KO;
+  const float *iknd = s_ikn, *ikno = s_ikn + KD, *iknt = s_ikn + KD + KO, *iknp = s_ikn + KD + 2 * KO;
+  const float inv_o = 1.0f / (kno[1] - kno[0]), inv_p = 1.0f / (knp[1] - knp[0]);
+
+  float w_ap = 0, w_dih = 0, w_ang = 0, w_vdw = 0;
+  int sep_lo = 0, sep_hi = 0;
+  bool active = false;
+  if (live) {
+    const float4* wp = reinterpret_cast<const float4*>(A.wcur + (size_t)dec * 8);
+    float4 w0 = wp[0], w1 = wp[1];
+    w_ap = w0.x; w_dih = w0.y; w_ang = w0.z; w_vdw = w0.w;
+    sep_lo = (int)w1.x; sep_hi = (int)w1.y;
+    active = w1.z != 0.0f;
+  }
+
+  // residue a
+  const float4* xa = A.xyzT + ((size_t)(grp * L + a) * 4) * BW + d;
+  float4 q0 = xa[0], q1 = xa[BW], q2 = xa[2 * BW], q3 = xa[3 * BW];
+  const f3 Na = mk3(q0.x, q0.y, q0.z), CAa = mk3(q0.w, q1.x, q1.y), Ca = mk3(q1.z, q1.w, q2.x),
+           Oa = mk3(q2.y, q2.z, q2.w), CBa = mk3(q3.x, q3.y, q3.z);
+
+  f3 gN = mk3(0, 0, 0), gCA = gN, gC = gN, gO = gN, gCB = gN;
+  float e_d = 0, e_o = 0, e_t = 0, e_p = 0, e_v = 0;
+
+  const int chunk = (L + A.nsplit - 1) / A.nsplit;
+  const int b_lo = split * chunk, b_hi = min(L, b_lo + chunk);
+  STAMP(0)  // prologue: knots to LDS, barrier, weights, residue a
+
+  // The loop runs in blocks of up to 32 visits.  Restraint terms are evaluated in the visit (the pair, hence the table, is
+  // the same for all decoys of the wave).  Repulsion is different: WHICH residues touch depends on the decoy, so in lockstep
+  // the 25 atom pairs ran whenever ANY of the 64 decoys was within the cutoff -- on ~85 % of the visits of a distance-only
+  // fold although ~10 % of (pair, decoy) combinations are in contact (profiles/README.md).  A visit therefore only records
+  // a contact bit per lane; after the block every lane walks ITS OWN bits, gathering its own residue b.  The walk takes
+  // max-over-lanes(contacts) steps instead of count-of-visits-with-any-contact.  Order per lane stays fixed: deterministic.
+  constexpr int VSTRIDE = PAIR_WAVES * PW;
+  for (int bb = b_lo + wave * PW; bb < b_hi; bb += 32 * VSTRIDE) {
+  unsigned vmask = 0;
+#pragma unroll 1
+  for (int v = 0; v < 32; v++) {
+    const int b0 = bb + v * VSTRIDE;
+    if (b0 >= b_hi) break;
+    const int b = b0 + h;
+    const bool valid = live && active && b < b_hi && b != a;
+    const int bc = min(b, L - 1);
+    const int sep = abs(a - bc);
+    unsigned m_ab = 0, m_ba = 0;
+    if (valid && sep >= sep_lo && sep < sep_hi) {
+      const unsigned mm = s_mask[bc - b_lo];
+      m_ab = mm & 15u;
+      m_ba = mm >> 4;
+    }
+    if (!(FAM & FAM_SYM)) { m_ab &= ~(TRX2_M_DIST | TRX2_M_OMEGA); m_ba &= ~(TRX2_M_DIST | TRX2_M_OMEGA); }
+    if (!(FAM & FAM_ASYM)) { m_ab &= ~(TRX2_M_THETA | TRX2_M_PHI); m_ba &= ~(TRX2_M_THETA | TRX2_M_PHI); }
+    const unsigned msym = (a < bc) ? m_ab : m_ba;  // DIST / OMEGA bits live on the (min,max) row
+    const bool dovdw = (FAM & FAM_VDW) && valid && sep >= TRX2_VDW_MINSEP && w_vdw != 0.0f;
+    STAMP(1)  // masks (2 byte loads) + loop control
+    if (!__any((int)(m_ab | m_ba | (unsigned)dovdw))) continue;
+
+    const float4* xb = A.xyzT + ((size_t)(grp * L + bc) * 4) * BW + d;
+    float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW];
+    const f3 Nb = mk3(r0.x, r0.y, r0.z), CAb = mk3(r0.w, r1.x, r1.y), Cb = mk3(r1.z, r1.w, r2.x),
+             Ob = mk3(r2.y, r2.z, r2.w), CBb = mk3(r3.x, r3.y, r3.z);
+    STAMP(2)  // coordinates of residue b (4 x 16 B per lane)
+    const size_t iab = (size_t)a * L + bc, iba = (size_t)bc * L + a;
+    const size_t isym = (a < bc) ? iab : iba;
+    const bool first = a < bc;  // symmetric energies are counted from the lower row only
+
+    if ((FAM & FAM_SYM) && (msym & TRX2_M_DIST)) {
+      f3 u = CBa - CBb;
+      float d2 = dot(u, u), id = rsqrtf(d2), dd = d2 * id;
+      int idx = dd < 2.0f ? 0 : (dd < 3.5f ? 1 : (dd < 4.25f ? 2 : 3 + (int)((dd - 4.25f) * 2.0f)));
+      float ev, de;
+      spline_eval_dev(A.Td + isym * KD, knd, iknd, KD, idx, dd, ev, de);
+      if (first) e_d += ev;
+      gCB = fma3(u, w_ap * de * id, gCB);
+    }
+    STAMP(3)  // dist
+    if ((FAM & FAM_SYM) && (msym & TRX2_M_OMEGA)) {
+      f3 d1, d2, d3, d4;
+      float x = dihedral_grad(CAa, CBa, CBb, CAb, d1, d2, d3, d4);
+      float ev, de;
+      spline_eval_dev(A.To + isym * KO, kno, ikno, KO, (int)((x - kno[0]) * inv_o), x, ev, de);
+      if (first) e_o += ev;
+      float s = w_dih * de;
+      gCA = fma3(d1, s, gCA);
+      gCB = fma3(d2, s, gCB);
+    }
+    STAMP(4)  // omega
+    if ((FAM & FAM_ASYM) && (m_ab & TRX2_M_THETA)) {
+      f3 d1, d2, d3, d4;
+      float x = dihedral_grad(Na, CAa, CBa, CBb, d1, d2, d3, d4);
+      float ev, de;
+      spline_eval_dev(A.Tt + iab * KO, knt, iknt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
+      e_t += ev;
+      float s = w_dih * de;
+      gN = fma3(d1, s, gN);
+      gCA = fma3(d2, s, gCA);
+      gCB = fma3(d3, s, gCB);
+    }
+    STAMP(5)  // theta(a,b)
+    if ((FAM & FAM_ASYM) && (m_ba & TRX2_M_THETA)) {  // theta(b,a): only its gradient on CB_a (4th point)
+      f3 d1, d2, d3, d4;
+      float x = dihedral_grad(Nb, CAb, CBb, CBa, d1, d2, d3, d4);
+      float ev, de;
+      spline_eval_dev(A.Tt + iba * KO, knt, iknt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
+      gCB = fma3(d4, w_dih * de, gCB);
+    }
+    STAMP(6)  // theta(b,a)
+    if ((FAM & FAM_ASYM) && (m_ab & TRX2_M_PHI)) {
+      f3 d1, d2, d3;
+      float x = angle_grad(CAa, CBa, CBb, d1, d2, d3);
+      float ev, de;
+      spline_eval_dev(A.Tp + iab * KP, knp, iknp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
+      e_p += ev;
+      float s = w_ang * de;
+      gCA = fma3(d1, s, gCA);
+      gCB = fma3(d2, s, gCB);
+    }
+    STAMP(7)  // phi(a,b)
+    if ((FAM & FAM_ASYM) && (m_ba & TRX2_M_PHI)) {  // phi(b,a): only its gradient on CB_a (3rd point)
+      f3 d1, d2, d3;
+      float x = angle_grad(CAb, CBb, CBa, d1, d2, d3);
+      float ev, de;
+      spline_eval_dev(A.Tp + iba * KP, knp, iknp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
+      gCB = fma3(d3, w_ang * de, gCB);
+    }
+    STAMP(8)  // phi(b,a)
+    if ((FAM & FAM_VDW) && dovdw) {
+      f3 dca = CAa - CAb;
+      if (dot(dca, dca) < (float)TRX2_VDW_CUT2) vmask |= 1u << v;
+    }
+  }
+  while (vmask) {  // per-lane trip count; lanes without further contacts idle
+    const int v = __ffs((int)vmask) - 1;
+    vmask &= vmask - 1;
+    const int b = bb + v * VSTRIDE + h;
+    const float4* xb = A.xyzT + ((size_t)(grp * L + b) * 4) * BW + d;
+    float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW];
+    const f3 pa[5] = {Na, CAa, Ca, Oa, CBa};
+    const f3 pb[5] = {mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), mk3(r2.y, r2.z, r2.w),
+                      mk3(r3.x, r3.y, r3.z)};
+    f3 ga[5] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
+    float ev = 0;
+#pragma unroll
+    for (int p = 0; p < 5; p++)
+#pragma unroll
+      for (int q = 0; q < 5; q++) {
+        f3 u = pa[p] - pb[q];
+        constexpr VdwTab T = make_vdw_tab();
+        const float r02 = T.r0sq[p * 5 + q], ir = T.ir0sq[p * 5 + q];
+        float c = fmaxf(r02 - dot(u, u), 0.0f);
+        ev = fmaf(c * c, ir, ev);
+        ga[p] = fma3(u, -4.0f * c * ir, ga[p]);
+      }
+    const float s = w_vdw * (float)TRX2_VDW_SCALE;
+    if (a < b) e_v += (float)TRX2_VDW_SCALE * ev;  // symmetric energy: counted from the lower row only
+    gN = fma3(ga[0], s, gN);
+    gCA = fma3(ga[1], s, gCA);
+    gC = fma3(ga[2], s, gC);
+    gO = fma3(ga[3], s, gO);
+    gCB = fma3(ga[4], s, gCB);
+  }
+  STAMP(9)  // vdw
+  }
+
+  STAMP(10) // loop exit
+  // ---- reduce over waves and over the PW residue sub-lanes; write decoy-major records.
+  // LDS image [slot][decoy][21]: a lane writes its own 20 values at stride 21 (no bank conflict); the readers are
+  // (decoy, quad) pairs, 4 lanes per decoy, so every store instruction writes whole 64-B (gradient) / 32-B (energy) runs.
+  {
+    const int slot = wave * PW + h;
+    float* s = s_red + ((size_t)slot * BW + d) * RED_STRIDE;
+    const float vals[20] = {gN.x, gN.y, gN.z, gCA.x, gCA.y, gCA.z, gC.x, gC.y, gC.z, gO.x,
+                            gO.y, gO.z, gCB.x, gCB.y, gCB.z, e_d, e_o, e_t, e_p, e_v};
+#pragma unroll
+    for (int k = 0; k < 20; k++) s[k] = vals[k];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 6 * BW; t += PAIR_THREADS) {  // 6 quads per decoy: 4 gradient (16 floats) + 2 energy (8)
+    const int dd = t / 6, q = t % 6;
+    const int dc = grp * BW + dd;
+    if (dc >= A.B) continue;
+    float acc[4] = {0, 0, 0, 0};
+    const int k0 = q < 4 ? q * 4 : 15 + (q - 4) * 4;  // first value of this quad in the 20-value record
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int k = k0 + i;
+      const bool real = q < 4 ? (k < 15) : (k < 20);  // gradient pad (16th float) and energy pads are zero
+      if (real)
+        for (int sl = 0; sl < PAIR_WAVES * PW; sl++) acc[i] += s_red[((size_t)sl * BW + dd) * RED_STRIDE + k];
+    }
+    const size_t rec = ((size_t)split * A.Bpad + dc) * L + a;
+    const float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    if (q < 4) reinterpret_cast<float4*>(A.fpart + rec * 16)[q] = v;
+    else reinterpret_cast<float4*>(A.epart + rec * 8)[q - 4] = v;
+  }
+  STAMP(11)  // epilogue: LDS image, barrier, column sums, stores
+  STAMP_FLUSH
+}

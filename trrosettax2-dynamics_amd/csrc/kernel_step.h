@@ -1,0 +1,1110 @@
+// kernel_step.h -- K1/K5/K6: per-decoy step kernels, torsion-space and Cartesian-space roles, and their launchable forms -- included by trx2fold.hip.
+// Not a stand-alone header: it relies on the macros, constant tables and helpers defined above its #include.
+#pragma once
+// =================================================================================================
+// K1/K5/K6: per-decoy chain kernel
+// =================================================================================================
+enum { PH_START = 0, PH_LS = 1, PH_DONE = 2 };
+enum { MODE_INIT = 0, MODE_STEP = 1, MODE_FINISH = 2 };
+// integer state slots
+// SI_RUN and SI_SEQ share one aligned 8-byte word: in the fused step launch the two workgroups of a decoy read its state
+// while one of them may be writing a run transition; a single 8-byte store / load cannot be seen half-updated, so a
+// reader gets (old run, old seq) or (new run, seq of THIS launch -> "already stepped"), never a mixture.
+enum { SI_RUN = 0, SI_SEQ, SI_PHASE, SI_ITER, SI_NLS, SI_HL, SI_HH, SI_NH, SI_STATUS, SI_NEVALS, SI_NITERS, SI_N = 16 };
+// double state slots
+// SD_GAMMA: s.y / y.y of the newest stored pair = the initial Hessian scaling of the two-loop recursion (torsion role)
+enum { SD_F = 0, SD_ALPHA, SD_GD, SD_FH0, SD_FH1, SD_FH2, SD_GAMMA, SD_N = 8 };
+
+struct ChainArgs {
+  int L, B, Bpad, BW, nsplit, mode, nruns, max_evals;
+  const int* seq_ctr;  // evaluation number (device counter bumped by k_pair): a decoy is stepped once per evaluation, by the
+                       // torsion OR the Cartesian role (SI_SEQ)
+  const trx2_run* runs;
+  int* st_i;       // [B][SI_N]
+  double* st_d;    // [B][SD_N]
+  float* rho;      // [B][LBM]
+  float4 *X, *G, *D, *XT;  // [B][L] (phi, psi, omega, -)
+  float4 *S, *Y;           // [B][LBM][L]
+  float* xyz;              // [B][L][16] trial coordinates, decoy-major
+  const float4* geom;      // [B][L][3] internal geometry per residue (ResGeom)
+  float4* xyzT;            // decoy-minor copy for k_pair
+  float* wcur;             // [Bpad][8]
+  const float* fpart;      // [nsplit][Bpad][L][16]
+  const float* epart;      // [nsplit][Bpad][L][8]
+  double* e_last;          // [B][NTERMS] raw terms of the last evaluation
+  double* f_last;          // [B]
+  float* grad_out;         // [B][L][3] (MODE_FINISH)
+  int* done_count;
+};
+
+// workgroup barrier of an NW-wave role.  One wave: its LDS operations execute in program order, so only the compiler has
+// to be kept from reordering them.
+template <int NW>
+__device__ __forceinline__ void bsync() {
+  if (NW > 1) __syncthreads();
+  else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+}
+// Sum over the workgroup, total in every thread.  Consecutive calls alternate between two LDS buffers (`flip`), so one
+// barrier per call is enough: a wave can be at most one call ahead of the slowest, and then it writes the OTHER buffer.
+// (With one buffer every call needed a second barrier just to protect the previous call's reads; the two-loop recursion
+// makes 2 x 12 dependent calls per step.)  Every wave must make the same sequence of calls.
+template <int K, int NW>
+__device__ __forceinline__ void block_sum_n(double (&v)[K], double* s_buf /* [2][NW*8] */, int& flip) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
+  if (NW == 1) return;  // the in-wave sum leaves the total in every lane
+  double* buf = s_buf + flip * (NW * 8);
+  flip ^= 1;
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < K; k++) buf[wave * K + k] = v[k];
+  bsync<NW>();
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    double a = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) a += buf[w * K + k];  // fixed order: deterministic
+    v[k] = a;
+  }
+}
+
+__device__ __forceinline__ float dot3(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+
+// Internal geometry of one residue, 3 float4 (what torsion-space moves keep fixed; ideal values: trx2_model.h; after a
+// Cartesian run the relaxed values extracted from the coordinates -- the oracle's ORC_NGEOM record):
+//   g0 = (|N-CA|, |CA-C|, |C-N'|, angle N-CA-C)   g1 = (angle CA-C-N', angle C-N'-CA', |C-O|, angle CA-C-O)
+//   g2 = (dihedral N-CA-C-O minus psi, CB coefficients on (b x c), b, c with b = CA-N, c = C-CA)
+struct ResGeom {
+  float4 g0, g1, g2;
+};
+__device__ __forceinline__ ResGeom ideal_geom() {
+  ResGeom g;
+  g.g0 = make_float4((float)TRX2_B_N_CA, (float)TRX2_B_CA_C, (float)TRX2_B_C_N, (float)TRX2_A_N_CA_C * TRX2_DEG_F);
+  g.g1 = make_float4((float)TRX2_A_CA_C_N * TRX2_DEG_F, (float)TRX2_A_C_N_CA * TRX2_DEG_F, (float)TRX2_B_C_O, (float)TRX2_A_CA_C_O * TRX2_DEG_F);
+  g.g2 = make_float4(TRX2_PI_F, (float)TRX2_CB_KA, (float)TRX2_CB_KB, (float)TRX2_CB_KC);
+  return g;
+}
+// local frame of a residue: CA at origin, C on +x, N in the xy plane (y>0 side)
+__device__ __forceinline__ void local_atoms(const ResGeom& g, f3& N, f3& CA, f3& C, f3& CB) {
+  float sa, ca;
+  fast_sincosf(g.g0.w, &sa, &ca);
+  CA = mk3(0, 0, 0);
+  C = mk3(g.g0.y, 0, 0);
+  N = mk3(g.g0.x * ca, g.g0.x * sa, 0);
+  f3 b = CA - N, c = C - CA, a = cross(b, c);
+  CB = CA + a * g.g2.y + b * g.g2.z + c * g.g2.w;
+}
+
+// Diagnostic build only (-DTRX2_STAMP): thread 0 of decoy 0's torsion-role workgroup accumulates s_memtime cycles per phase
+// of every STEP launch into g_cstamp (slot 30 = launches, 31 = launches that computed a new direction).  Every stamp drains
+// the memory counters first, so a phase is charged the latency of the loads it issued.
+#ifdef TRX2_STAMP
+__device__ unsigned long long g_cstamp[32];
+#define CSTAMP_DECL unsigned long long cst_prev = 0; const bool cst_on = (dec == 0 && A.mode == MODE_STEP && threadIdx.x == 0); \
+  if (cst_on) { __builtin_amdgcn_s_waitcnt(0); cst_prev = __builtin_amdgcn_s_memtime(); }
+#define CSTAMP(k) if (cst_on) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+  __builtin_amdgcn_s_waitcnt(0); atomicAdd(&g_cstamp[k], t_ - cst_prev); __builtin_amdgcn_s_waitcnt(0); cst_prev = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define CCOUNT(k) if (cst_on) atomicAdd(&g_cstamp[k], 1ull);
+#define KSTAMP_DECL unsigned long long cst_prev = 0; const bool cst_on = (dec == 0 && threadIdx.x == 0); \
+  if (cst_on) { __builtin_amdgcn_s_waitcnt(0); cst_prev = __builtin_amdgcn_s_memtime(); }
+#else
+#define KSTAMP_DECL
+#define CSTAMP_DECL
+#define CSTAMP(k)
+#define CCOUNT(k)
+#endif
+// L-BFGS history of the decoy staged in LDS for the duration of one step: [LBM][s | y][NT] float4, dynamic shared memory
+// (HIST_LDS_BYTES, only the one-residue-per-thread instantiations; gfx950 has 160 KB of LDS per CU).  The two-loop
+// recursion is 2 x 12 DEPENDENT rounds; read from global memory every round exposed an L2 round trip (~500-700 of its
+// ~1000 cycles; the compiler turns a register prefetch into a wait on the load just issued).  Instead the whole history is
+// requested at the top of the step with LDS-DMA loads (global_load_lds_dwordx4: no registers, nothing waits on them until
+// the recursion starts a phase later) and every round reads the thread's own slot from LDS.
+extern __shared__ float4 s_hist[];
+#define HIST_LDS_BYTES(NT) (LBM * 2 * (NT) * 16)
+__device__ __forceinline__ void lds_dma16(const float4* src /* per lane */, float4* dst_wave /* wave-uniform: lane i lands at dst + i */) {
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst_wave, 16, 0, 0);
+}
+// NT threads step one decoy, RPT residues per thread (RPT * NT >= L).  NT = 256 is what runs.  One wave (NT = 64, RPT = 3 at
+// L = 150) makes every reduction and scan barrier-free but was SLOWER on MI355X (73.7 vs 61.2 us per evaluation,
+// profiles/README.md): the step is bound by the per-thread chain of dependent arithmetic and loads, which RPT multiplies,
+// not by its ~25 barriers.
+template <int RPT, int NT>
+__device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
+  constexpr int NW = NT / 64;
+  const int L = A.L, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ double s_buf[2 * NW * 8];
+  int flip = 0;
+  __shared__ float s_scan[NW * 12];
+  __shared__ float s_alpha[LBM];
+  __shared__ int s_i[SI_N];
+  __shared__ double s_d[SD_N];
+  __shared__ float s_rho[LBM];
+  __shared__ float s_phi[RPT * NT + 1];
+
+  int* gi = A.st_i + (size_t)dec * SI_N;
+  double* gd_ = A.st_d + (size_t)dec * SD_N;
+  CSTAMP_DECL
+  if (tid < SI_N && tid >= 2) s_i[tid] = gi[tid];
+  if (tid == 0) {  // (run, seq) in ONE 8-byte load
+    const unsigned long long rs = *reinterpret_cast<const volatile unsigned long long*>(gi);
+    s_i[SI_RUN] = (int)(unsigned)(rs & 0xffffffffull); s_i[SI_SEQ] = (int)(unsigned)(rs >> 32);
+  }
+  if (tid < SD_N) s_d[tid] = gd_[tid];
+  if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
+  bsync<NW>();
+  int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
+  if (A.mode == MODE_STEP && phase == PH_DONE) return;
+  const int seq = (A.mode == MODE_STEP) ? *A.seq_ctr : -1;
+  if (A.mode == MODE_STEP && (s_i[SI_SEQ] == seq || A.runs[min(run, A.nruns - 1)].cartesian)) return;  // the Cartesian role's turn
+
+  const size_t vb = (size_t)dec * L;  // base of this decoy's [L] vectors
+  float4 xt[RPT], gt[RPT];
+  bool need_nerf = true;
+  constexpr bool HIST_LDS = (RPT == 1);
+  if (HIST_LDS && A.mode == MODE_STEP) {
+    // the hl stored pairs, newest first; lanes beyond L copy the last residue (no branch around the load), never used
+    const int hl0 = s_i[SI_HL], hh0 = s_i[SI_HH], rc = min(tid, L - 1);
+    for (int kk = 0; kk < hl0; kk++) {
+      const int j = (hh0 - 1 - kk + LBM) % LBM;
+      lds_dma16(A.S + ((size_t)dec * LBM + j) * L + rc, s_hist + (j * 2 + 0) * NT + wave * 64);
+      lds_dma16(A.Y + ((size_t)dec * LBM + j) * L + rc, s_hist + (j * 2 + 1) * NT + wave * 64);
+    }
+  }
+  CSTAMP(0)  // state load, barrier, role test
+  CCOUNT(30)
+
+  if (A.mode != MODE_INIT) {
+    // ------------------------------------------------------------------ consume the evaluation at XT
+    const trx2_run R = A.runs[min(run, A.nruns - 1)];
+    // accepted point, its gradient and the direction: needed only by the state machine below, loaded here so that their
+    // latency overlaps the slab loads and the gradient assembly
+    float4 x[RPT], g[RPT], dv[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int r = k * NT + tid;
+      x[k] = g[k] = dv[k] = make_float4(0, 0, 0, 0);
+      if (r < L && A.mode == MODE_STEP) { x[k] = A.X[vb + r]; g[k] = A.G[vb + r]; dv[k] = A.D[vb + r]; }
+    }
+    double esum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    f3 g2[RPT], g1[RPT];       // per-residue sums of gradient / x cross gradient
+    f3 gO_[RPT], gC_[RPT], gCB_[RPT], pN[RPT], pCA[RPT], pC[RPT], pO[RPT], pCB[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int r = k * NT + tid;
+      xt[k] = make_float4(0, 0, 0, 0);
+      gt[k] = make_float4(0, 0, 0, 0);
+      g2[k] = g1[k] = gO_[k] = gC_[k] = gCB_[k] = pN[k] = pCA[k] = pC[k] = pO[k] = pCB[k] = mk3(0, 0, 0);
+      if (r < L) {
+        xt[k] = A.XT[vb + r];
+        float g[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) g[i] = 0;
+        for (int s = 0; s < A.nsplit; s++) {
+          const size_t rec = ((size_t)s * A.Bpad + dec) * L + r;
+          const float4* fp = reinterpret_cast<const float4*>(A.fpart + rec * 16);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            float4 v = fp[q];
+            g[q * 4] += v.x; g[q * 4 + 1] += v.y; g[q * 4 + 2] += v.z; g[q * 4 + 3] += v.w;
+          }
+          const float4* ep = reinterpret_cast<const float4*>(A.epart + rec * 8);
+          float4 e0 = ep[0], e1 = ep[1];
+          esum[0] += e0.x; esum[1] += e0.y; esum[2] += e0.z; esum[3] += e0.w; esum[4] += e1.x;
+        }
+        const float4* xp = reinterpret_cast<const float4*>(A.xyz + (vb + r) * 16);
+        float4 c0 = xp[0], c1 = xp[1], c2 = xp[2], c3 = xp[3];
+        pN[k] = mk3(c0.x, c0.y, c0.z); pCA[k] = mk3(c0.w, c1.x, c1.y); pC[k] = mk3(c1.z, c1.w, c2.x);
+        pO[k] = mk3(c2.y, c2.z, c2.w); pCB[k] = mk3(c3.x, c3.y, c3.z);
+        f3 gN = mk3(g[0], g[1], g[2]), gCA = mk3(g[3], g[4], g[5]);
+        gC_[k] = mk3(g[6], g[7], g[8]); gO_[k] = mk3(g[9], g[10], g[11]); gCB_[k] = mk3(g[12], g[13], g[14]);
+        g2[k] = gN + gCA + gC_[k] + gO_[k] + gCB_[k];
+        g1[k] = cross(pN[k], gN) + cross(pCA[k], gCA) + cross(pC[k], gC_[k]) + cross(pO[k], gO_[k]) + cross(pCB[k], gCB_[k]);
+        // torsion-space terms: rama (residues 2..L-1) and omega_bb (1..L-1)
+        if (r >= 1 && r < L - 1) {
+          float s = 0, dph = 0, dps = 0;
+          // sin/cos of (phi - phi_k), (psi - psi_k) by the angle-addition identities: 2 sincosf per residue, not 12
+          float sph, cph, sps, cps;
+          fast_sincosf(xt[k].x, &sph, &cph);
+          fast_sincosf(xt[k].y, &sps, &cps);
+#pragma unroll
+          for (int j = 0; j < TRX2_RAMA_NB; j++) {
+            const float sk = c_rama_sc[j * 4], ck = c_rama_sc[j * 4 + 1], tk = c_rama_sc[j * 4 + 2], uk = c_rama_sc[j * 4 + 3];
+            const float sa = sph * ck - cph * sk, ca = cph * ck + sph * sk;
+            const float sb = sps * uk - cps * tk, cb = cps * uk + sps * tk;
+            float t = c_rama[j * 3 + 2] * expf((float)TRX2_RAMA_KAPPA * (ca + cb - 2.0f));
+            s += t; dph -= t * (float)TRX2_RAMA_KAPPA * sa; dps -= t * (float)TRX2_RAMA_KAPPA * sb;
+          }
+          float inv = 1.0f / (s + (float)TRX2_RAMA_FLOOR);
+          esum[5] += -(double)logf((s + (float)TRX2_RAMA_FLOOR) * (1.0f / (float)TRX2_RAMA_PREF));
+          gt[k].x += -R.w[4] * dph * inv;
+          gt[k].y += -R.w[4] * dps * inv;
+        }
+        if (r < L - 1) {
+          float dw = xt[k].z - TRX2_PI_F;
+          dw -= 2.0f * TRX2_PI_F * rintf(dw * (0.5f / TRX2_PI_F));
+          dw *= (1.0f / TRX2_DEG_F);
+          esum[6] += (double)((float)TRX2_OMEGA_K * dw * dw);
+          gt[k].z += R.w[5] * 2.0f * (float)TRX2_OMEGA_K * dw * (1.0f / TRX2_DEG_F);
+        }
+      }
+    }
+    if (HIST_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA may outlive the wave: by now it has landed anyway
+    CSTAMP(1)  // slab sums, coordinates, rama / omega per residue
+    // ---- suffix sums over residues of (g2, g1): chunks from the end, wave shuffles + LDS wave totals
+    f3 car2 = mk3(0, 0, 0), car1 = mk3(0, 0, 0);  // sum over all residues in later chunks
+#pragma unroll
+    for (int k = RPT - 1; k >= 0; k--) {
+      float v[6] = {g2[k].x, g2[k].y, g2[k].z, g1[k].x, g1[k].y, g1[k].z};
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          float t = __shfl_down(v[i], o, 64);
+          if (lane + o < 64) v[i] += t;
+        }
+      }
+      bsync<NW>();
+      if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < 6; i++) s_scan[wave * 6 + i] = v[i];
+      bsync<NW>();
+      float tot[6] = {0, 0, 0, 0, 0, 0}, after[6] = {0, 0, 0, 0, 0, 0};
+      for (int w = 0; w < NW; w++)
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          float t = s_scan[w * 6 + i];
+          tot[i] += t;
+          if (w > wave) after[i] += t;
+        }
+      // inclusive suffix sum for this residue = v + later waves + later chunks; exclusive = minus own
+      f3 inc2 = mk3(v[0] + after[0] + car2.x, v[1] + after[1] + car2.y, v[2] + after[2] + car2.z);
+      f3 inc1 = mk3(v[3] + after[3] + car1.x, v[4] + after[4] + car1.y, v[5] + after[5] + car1.z);
+      f3 ex2 = inc2 - g2[k], ex1 = inc1 - g1[k];  // residues > r
+      const int r = k * NT + tid;
+      if (r < L) {
+        // omega_r: axis C_r -> N_{r+1}
+        if (r + 1 < L) {
+          const float* nx = A.xyz + (vb + r + 1) * 16;
+          f3 Nn = mk3(nx[0], nx[1], nx[2]);
+          f3 n = unit(Nn - pC[k]);
+          gt[k].z += dot(n, ex1) - dot(cross(n, pC[k]), ex2);
+        }
+        {  // psi_r: axis CA -> C, moves O_r and residues > r
+          f3 h1 = ex1 + cross(pO[k], gO_[k]), h2 = ex2 + gO_[k];
+          f3 n = unit(pC[k] - pCA[k]);
+          gt[k].y += dot(n, h1) - dot(cross(n, pCA[k]), h2);
+        }
+        {  // phi_r: axis N -> CA, moves CB_r, C_r, O_r and residues > r
+          f3 h1 = ex1 + cross(pO[k], gO_[k]) + cross(pC[k], gC_[k]) + cross(pCB[k], gCB_[k]);
+          f3 h2 = ex2 + gO_[k] + gC_[k] + gCB_[k];
+          f3 n = unit(pCA[k] - pN[k]);
+          gt[k].x += dot(n, h1) - dot(cross(n, pN[k]), h2);
+        }
+      }
+      car2 = car2 + mk3(tot[0], tot[1], tot[2]);
+      car1 = car1 + mk3(tot[3], tot[4], tot[5]);
+    }
+    CSTAMP(2)  // suffix scan + torsion gradient
+    block_sum_n<8, NW>(esum, s_buf, flip);
+    const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] +
+                       (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6];
+    if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
+    if (tid == 0) A.f_last[dec] = f_t;
+
+    if (A.mode == MODE_FINISH) {
+      if (A.grad_out)
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          const int r = k * NT + tid;
+          if (r < L) {
+            float* go = A.grad_out + (vb + r) * 3;
+            go[0] = gt[k].x; go[1] = gt[k].y; go[2] = gt[k].z;
+          }
+        }
+      return;
+    }
+
+    // ------------------------------------------------------------------ minimiser state machine (uniform)
+    int iter = s_i[SI_ITER], nls = s_i[SI_NLS], hl = s_i[SI_HL], hh = s_i[SI_HH], nh = s_i[SI_NH];
+    int n_evals = s_i[SI_NEVALS] + 1, n_iters = s_i[SI_NITERS], status = s_i[SI_STATUS];
+    double f = s_d[SD_F], alpha = s_d[SD_ALPHA], gdir = s_d[SD_GD];
+    double fh[3] = {s_d[SD_FH0], s_d[SD_FH1], s_d[SD_FH2]};
+    double gamma_h = s_d[SD_GAMMA];
+    bool next_run = false, new_dir = false, steepest = false, new_trial = false;
+    const bool finite_t = isfinite(f_t);
+    CSTAMP(3)  // energy reduction + loads of X, G, D
+    if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
+    else if (phase == PH_START) {
+      if (R.precheck && esum[5] + esum[4] < (double)TRX2_CLASH_BREAK) {
+        run = R.skip_to;
+        if (run >= A.nruns) phase = PH_DONE;
+        need_nerf = false;
+      } else {
+        f = f_t;
+#pragma unroll
+        for (int k = 0; k < RPT; k++) g[k] = gt[k];
+        hl = 0; hh = 0; nh = 1; fh[0] = f; iter = 0;
+        steepest = true;
+      }
+    } else {  // PH_LS
+      double fref = fh[0];
+      for (int k = 1; k < nh; k++) fref = fmax(fref, fh[k]);
+      const bool accept = finite_t && f_t <= fref + (double)TRX2_LS_C1 * alpha * gdir;
+      if (accept) {
+        double v3[3] = {0, 0, 0};
+        float4 s[RPT], y[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          s[k] = make_float4(xt[k].x - x[k].x, xt[k].y - x[k].y, xt[k].z - x[k].z, 0);
+          y[k] = make_float4(gt[k].x - g[k].x, gt[k].y - g[k].y, gt[k].z - g[k].z, 0);
+          v3[0] += (double)dot3(s[k], y[k]); v3[1] += (double)dot3(s[k], s[k]); v3[2] += (double)dot3(y[k], y[k]);
+        }
+        block_sum_n<3, NW>(v3, s_buf, flip);
+        if (v3[0] > 1e-12 * sqrt(v3[1] * v3[2])) {
+#pragma unroll
+          for (int k = 0; k < RPT; k++) {
+            const int r = k * NT + tid;
+            if (r < L) {
+              A.S[((size_t)dec * LBM + hh) * L + r] = s[k];
+              A.Y[((size_t)dec * LBM + hh) * L + r] = y[k];
+            }
+          }
+          if (HIST_LDS) {  // slot hh of the staged copy: its DMA (the oldest pair) must have landed before it is replaced
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_hist[(hh * 2 + 0) * NT + tid] = s[0];
+            s_hist[(hh * 2 + 1) * NT + tid] = y[0];
+          }
+          bsync<NW>();
+          if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
+          gamma_h = v3[0] / v3[2];
+          bsync<NW>();
+          hh = (hh + 1) % LBM;
+          if (hl < LBM) hl++;
+        }
+        const double fprev = f;
+#pragma unroll
+        for (int k = 0; k < RPT; k++) { x[k] = xt[k]; g[k] = gt[k]; }
+        f = f_t;
+        if (nh < TRX2_LS_PAST) fh[nh++] = f;
+        else { fh[0] = fh[1]; fh[1] = fh[2]; fh[2] = f; }
+        iter++; n_iters++;
+        const bool conv = 2.0 * fabs(fprev - f) <= (double)TRX2_MIN_TOL * (fabs(fprev) + fabs(f) + 1e-10);
+        if (conv || iter >= R.max_iter) next_run = true;
+        else new_dir = true;
+      } else {
+        nls++;
+        alpha *= (double)TRX2_LS_SHRINK;
+        if (nls > TRX2_LS_MAXTRIAL) {
+          if (hl > 0) { hl = 0; steepest = true; }
+          else next_run = true;
+        } else new_trial = true;
+      }
+    }
+    CSTAMP(4)  // Armijo test; on acceptance the (s, y) pair: one reduction + stores
+    if (new_dir) {
+      CCOUNT(31)
+      // Two-loop recursion over the stored pairs (A.S / A.Y are L2-resident; coalesced float4 per residue): 2 x hl dependent
+      // rounds of { dot with the pair, reduce, axpy }, ~1000 cycles each = 40 % of a step (s_memtime stamps,
+      // profiles/README.md).  The next pair is requested before the current reduction.  Measured and NOT kept: the whole
+      // recursion on one wave (in-wave sums only, no barriers) and two-deep prefetch through three rotating register
+      // buffers -- all within 2 % of this form: a round is bound by its own serial arithmetic (f64 DPP sum, readlanes, the
+      // LDS read of rho, the axpy), not by the loads or the barriers.
+      double v2[2] = {0, 0};
+      auto pair_at = [&](int kk) { return (hh - 1 - kk + LBM) % LBM; };
+      {
+        float4 q[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; k++) q[k] = g[k];
+        if (HIST_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged history has landed (long ago)
+        auto load_pair = [&](int j, float4 (&s_)[RPT], float4 (&y_)[RPT]) {
+          if (HIST_LDS) {
+            const float4 z = make_float4(0, 0, 0, 0), sv = s_hist[(j * 2 + 0) * NT + tid], yv = s_hist[(j * 2 + 1) * NT + tid];
+            s_[0] = tid < L ? sv : z;
+            y_[0] = tid < L ? yv : z;
+            return;
+          }
+#pragma unroll
+          for (int k = 0; k < RPT; k++) {
+            const int r = k * NT + tid;
+            s_[k] = y_[k] = make_float4(0, 0, 0, 0);
+            if (r < L) { s_[k] = A.S[((size_t)dec * LBM + j) * L + r]; y_[k] = A.Y[((size_t)dec * LBM + j) * L + r]; }
+          }
+        };
+        float4 sj[RPT], yj[RPT], sn[RPT], yn[RPT];
+        if (hl > 0) load_pair(pair_at(0), sj, yj);
+        for (int kk = 0; kk < hl; kk++) {
+          const int j = pair_at(kk);
+          load_pair(pair_at(kk + 1 < hl ? kk + 1 : hl - 1), sn, yn);
+          double v1[1] = {0};
+#pragma unroll
+          for (int k = 0; k < RPT; k++) v1[0] += (double)dot3(sj[k], q[k]);
+          block_sum_n<1, NW>(v1, s_buf, flip);
+          const float al = s_rho[j] * (float)v1[0];
+          if (tid == 0) s_alpha[j] = al;
+#pragma unroll
+          for (int k = 0; k < RPT; k++) {
+            q[k].x -= al * yj[k].x; q[k].y -= al * yj[k].y; q[k].z -= al * yj[k].z;
+            sj[k] = sn[k]; yj[k] = yn[k];
+          }
+        }
+        CSTAMP(5)  // two-loop, first loop
+        if (hl > 0) {
+          const float gam = (float)gamma_h;
+#pragma unroll
+          for (int k = 0; k < RPT; k++) { q[k].x *= gam; q[k].y *= gam; q[k].z *= gam; }
+        }
+        bsync<NW>();
+        for (int kk = hl - 1; kk >= 0; kk--) {
+          const int j = pair_at(kk);
+          if (kk > 0) load_pair(pair_at(kk - 1), sn, yn);
+          double v1[1] = {0};
+#pragma unroll
+          for (int k = 0; k < RPT; k++) v1[0] += (double)dot3(yj[k], q[k]);
+          block_sum_n<1, NW>(v1, s_buf, flip);
+          const float c = s_alpha[j] - s_rho[j] * (float)v1[0];
+#pragma unroll
+          for (int k = 0; k < RPT; k++) {
+            q[k].x += c * sj[k].x; q[k].y += c * sj[k].y; q[k].z += c * sj[k].z;
+            sj[k] = sn[k]; yj[k] = yn[k];
+          }
+        }
+        CSTAMP(7)  // two-loop, second loop
+#pragma unroll
+        for (int k = 0; k < RPT; k++) {
+          dv[k] = make_float4(-q[k].x, -q[k].y, -q[k].z, 0);
+          v2[0] += (double)dot3(g[k], dv[k]); v2[1] += (double)dot3(g[k], g[k]);
+        }
+        block_sum_n<2, NW>(v2, s_buf, flip);
+      }
+      if (!(v2[1] > 0)) next_run = true;
+      else if (hl == 0 || !(v2[0] < 0)) { hl = 0; steepest = true; }
+      else { gdir = v2[0]; alpha = 1.0; nls = 0; new_trial = true; }
+    }
+    if (steepest) {
+      double v1[1] = {0};
+#pragma unroll
+      for (int k = 0; k < RPT; k++) { dv[k] = make_float4(-g[k].x, -g[k].y, -g[k].z, 0); v1[0] += (double)dot3(g[k], g[k]); }
+      block_sum_n<1, NW>(v1, s_buf, flip);
+      if (!(v1[0] > 0)) next_run = true;
+      else {
+        gdir = -v1[0];
+        alpha = fmin(1.0, 1.0 / sqrt(v1[0]));
+        nls = 0;
+        new_trial = true;
+      }
+    }
+    CSTAMP(8)  // descent test / steepest-descent restart
+    if (next_run) {
+      run++;
+      phase = (run >= A.nruns) ? PH_DONE : PH_START;
+#pragma unroll
+      for (int k = 0; k < RPT; k++) xt[k] = x[k];
+      need_nerf = true;  // XT := X (the accepted point) so that coordinates match for the next evaluation
+    }
+    if (new_trial) {
+      phase = PH_LS;
+      const float al = (float)alpha;
+#pragma unroll
+      for (int k = 0; k < RPT; k++)
+        xt[k] = make_float4(fmaf(al, dv[k].x, x[k].x), fmaf(al, dv[k].y, x[k].y), fmaf(al, dv[k].z, x[k].z), 0);
+    }
+    if (phase != PH_DONE && n_evals >= A.max_evals) { status = TRX2_MAXEVAL; phase = PH_DONE; }
+    // ---- store state
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int r = k * NT + tid;
+      if (r < L) { A.X[vb + r] = x[k]; A.G[vb + r] = g[k]; A.D[vb + r] = dv[k]; A.XT[vb + r] = xt[k]; }
+    }
+    bsync<NW>();
+    if (tid == 0) {
+      gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
+      gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
+      *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
+      gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
+      gd_[SD_GAMMA] = gamma_h;
+      if (phase == PH_DONE) atomicAdd(A.done_count, 1);
+    }
+    if (tid < LBM) A.rho[(size_t)dec * LBM + tid] = s_rho[tid];
+  } else {
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+      const int r = k * NT + tid;
+      xt[k] = (r < L) ? A.XT[vb + r] : make_float4(0, 0, 0, 0);
+    }
+  }
+
+  CSTAMP(9)  // trial point, state stores
+  // ------------------------------------------------------------------ weights for the next pair launch
+  if (tid == 0) {
+    const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
+    float* w = A.wcur + (size_t)dec * 8;
+    w[0] = Rn.w[0]; w[1] = Rn.w[1]; w[2] = Rn.w[2]; w[3] = Rn.w[3];
+    w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi;
+    w[6] = (phase == PH_DONE && A.mode == MODE_STEP) ? 0.0f : 1.0f;
+    w[7] = 0;
+  }
+  if (!need_nerf) return;
+
+  // ------------------------------------------------------------------ K1: torsions XT -> backbone (NeRF scan)
+  // M_r maps frame r+1 coordinates into frame r; F_r = F_0 o M_0 o ... o M_{r-1}
+  bsync<NW>();
+#pragma unroll
+  for (int k = 0; k < RPT; k++) s_phi[k * NT + tid] = xt[k].x;
+  bsync<NW>();
+  const float4* gq = A.geom + vb * 3;
+  Xf carry;  // F_0: N at the origin, CA on +x, C in the xy plane (same start as the oracle)
+  {
+    const float4 q0 = gq[0];
+    float sa, ca;
+    fast_sincosf(q0.w, &sa, &ca);
+    carry = xf_from_atoms(mk3(0, 0, 0), mk3(q0.x, 0, 0), mk3(q0.x - q0.y * ca, q0.y * sa, 0));
+  }
+#pragma unroll
+  for (int k = 0; k < RPT; k++) {
+    const int r = k * NT + tid;
+    Xf M = xf_identity();
+    ResGeom gr = ideal_geom();
+    f3 lN = mk3(0, 0, 0), lCA = lN, lC = lN, lCB = lN;
+    if (r < L) {
+      gr.g0 = gq[r * 3]; gr.g1 = gq[r * 3 + 1]; gr.g2 = gq[r * 3 + 2];
+      local_atoms(gr, lN, lCA, lC, lCB);
+      if (r + 1 < L) {
+        const float4 n0 = gq[(r + 1) * 3];  // next residue: |N-CA|, |CA-C|, angle N-CA-C
+        float spsi, cpsi, so, co, sp, cp, s1, c1, s2, c2, s3, c3;
+        fast_sincosf(xt[k].y, &spsi, &cpsi);
+        fast_sincosf(xt[k].z, &so, &co);
+        fast_sincosf(s_phi[r + 1], &sp, &cp);  // phi of residue r+1
+        fast_sincosf(gr.g1.x, &s1, &c1);
+        fast_sincosf(gr.g1.y, &s2, &c2);
+        fast_sincosf(n0.w, &s3, &c3);
+        f3 Nn = place_atom(lN, lCA, lC, gr.g0.z, c1, s1, cpsi, spsi);
+        f3 CAn = place_atom(lCA, lC, Nn, n0.x, c2, s2, co, so);
+        f3 Cn = place_atom(lC, Nn, CAn, n0.y, c3, s3, cp, sp);
+        M = xf_from_atoms(Nn, CAn, Cn);
+      }
+    }
+    CSTAMP(10)  // NeRF: geometry loads, sincos, local frames
+    // inclusive scan of M within the wave
+    Xf P = M;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      Xf t = xf_shfl_up(P, o);
+      if (lane >= o) P = xf_compose(t, P);
+    }
+    bsync<NW>();
+    if (lane == 63) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) s_scan[wave * 12 + i] = P.r[i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) s_scan[wave * 12 + 9 + i] = P.t[i];
+    }
+    bsync<NW>();
+    Xf pre = carry;  // transform of everything before this wave
+    Xf tot = carry;
+    for (int w = 0; w < NW; w++) {
+      Xf T;
+#pragma unroll
+      for (int i = 0; i < 9; i++) T.r[i] = s_scan[w * 12 + i];
+#pragma unroll
+      for (int i = 0; i < 3; i++) T.t[i] = s_scan[w * 12 + 9 + i];
+      if (w < wave) pre = xf_compose(pre, T);
+      tot = xf_compose(tot, T);
+    }
+    CSTAMP(11)  // NeRF: scan of rigid transforms (in-wave + across waves)
+    // frame of residue r = pre o (inclusive scan of the previous lane)
+    Xf prev = xf_shfl_up(P, 1);
+    Xf F = (lane == 0) ? pre : xf_compose(pre, prev);
+    carry = tot;
+    if (r < L) {
+      float so_, co_, s4, c4;
+      fast_sincosf(xt[k].y + gr.g2.x, &so_, &co_);  // dihedral N-CA-C-O = psi + t_O (ideal: pi)
+      fast_sincosf(gr.g1.w, &s4, &c4);
+      f3 lO = place_atom(lN, lCA, lC, gr.g1.z, c4, s4, co_, so_);
+      f3 N = xf_apply(F, lN), CA = xf_apply(F, lCA), C = xf_apply(F, lC), O = xf_apply(F, lO), CB = xf_apply(F, lCB);
+      float4 o0 = make_float4(N.x, N.y, N.z, CA.x), o1 = make_float4(CA.y, CA.z, C.x, C.y),
+             o2 = make_float4(C.z, O.x, O.y, O.z), o3 = make_float4(CB.x, CB.y, CB.z, 0);
+      float4* xo = reinterpret_cast<float4*>(A.xyz + (vb + r) * 16);
+      xo[0] = o0; xo[1] = o1; xo[2] = o2; xo[3] = o3;
+      const int grp = dec / A.BW, dd = dec % A.BW;
+      float4* xT = A.xyzT + ((size_t)(grp * L + r) * 4) * A.BW + dd;
+      xT[0] = o0; xT[A.BW] = o1; xT[2 * A.BW] = o2; xT[3 * A.BW] = o3;
+    }
+    CSTAMP(12)  // NeRF: atoms from frames, coordinate stores
+  }
+}
+
+// =================================================================================================
+// Cartesian-space minimiser step (MinMover.cartesian(True) on sf_cart, folding.py:83-84,100-102).  One workgroup per
+// decoy, one residue per thread (L <= 256).  DOFs = the 15 coordinates of a residue, stored as 4 float4 (16th = 0):
+// the trial vector IS the xyz buffer.  The pair kernel's gradient slabs are already Cartesian; added here: rama and
+// omega from coordinates, and the harmonic bonded term (cart_bonded surrogate, trx2_model.h).  Terms that span two
+// residues are evaluated by both owners, each keeping the gradient on its own atoms (no atomics).  When the run ends
+// the relaxed internal geometry is extracted so that later torsion-space runs continue from it (oracle:
+// orc_extract_internal).  The L-BFGS state machine is the one of k_chain on 4 float4 per residue.
+// =================================================================================================
+struct CartArgs {
+  int L, B, Bpad, BW, nsplit, nruns, max_evals;
+  const int* seq_ctr;
+  const trx2_run* runs;
+  int* st_i; double* st_d; float* rho;
+  float4 *CX, *CG, *CD;      // [B][L][4] accepted point, its gradient, direction
+  float4 *CS, *CY;           // [B][LBM][L][4]
+  float* xyz;                // [B][L][16] trial coordinates = trial DOF vector (in/out)
+  float4* xyzT;
+  float4 *X, *XT, *geom;     // torsions and internal geometry, written when the run ends
+  float* wcur;
+  const float* fpart; const float* epart;
+  double *e_last, *f_last;
+  int* done_count;
+};
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
+struct Res5 { f3 N, CA, C, O, CB; };
+__device__ __forceinline__ Res5 unpack5(const float* p) {
+  return Res5{mk3(p[0], p[1], p[2]), mk3(p[3], p[4], p[5]), mk3(p[6], p[7], p[8]), mk3(p[9], p[10], p[11]), mk3(p[12], p[13], p[14])};
+}
+__device__ __forceinline__ float wrap_pi_f(float x) { return x - 2.0f * TRX2_PI_F * rintf(x * (0.5f / TRX2_PI_F)); }
+// harmonic bond: energy, gradient on a (gradient on b is the negative)
+__device__ __forceinline__ float hbond(f3 a, f3 b, float d0, float k, f3& ga) {
+  f3 u = a - b; float d = sqrtf(dot(u, u)), dd = d - d0; ga = u * (2.0f * k * dd / d); return k * dd * dd;
+}
+__device__ __forceinline__ float hangle(f3 a, f3 b, f3 c, float a0, float k, f3& ga, f3& gb, f3& gc) {
+  float x = angle_grad(a, b, c, ga, gb, gc), dx = x - a0, sc = 2.0f * k * dx; ga = ga * sc; gb = gb * sc; gc = gc * sc; return k * dx * dx;
+}
+__device__ __forceinline__ float hdih(f3 a, f3 b, f3 c, f3 d, float t0, float k, f3& ga, f3& gb, f3& gc, f3& gd) {
+  float x = dihedral_grad(a, b, c, d, ga, gb, gc, gd), dx = wrap_pi_f(x - t0), sc = 2.0f * k * dx;
+  ga = ga * sc; gb = gb * sc; gc = gc * sc; gd = gd * sc; return k * dx * dx;
+}
+// link terms of the peptide bond P (residue i) -> Q (residue i+1): bond C-N', angles CA-C-N', C-N'-CA', O-C-N', improper CA-N'-C-O
+struct LinkGrad { f3 CA, C, O, Nn, CAn; float e; };
+__device__ __forceinline__ LinkGrad link_terms(const Res5& P, const Res5& Q) {
+  LinkGrad G; G.CA = G.C = G.O = G.Nn = G.CAn = mk3(0, 0, 0);
+  const float KL = (float)TRX2_CART_KLEN, KA = (float)TRX2_CART_KANG, KI = (float)TRX2_CART_KIMP;
+  f3 a, b, c, d;
+  float e = hbond(P.C, Q.N, (float)TRX2_B_C_N, KL, a); G.C += a; G.Nn += a * -1.0f;
+  e += hangle(P.CA, P.C, Q.N, (float)TRX2_A_CA_C_N * TRX2_DEG_F, KA, a, b, c); G.CA += a; G.C += b; G.Nn += c;
+  e += hangle(P.C, Q.N, Q.CA, (float)TRX2_A_C_N_CA * TRX2_DEG_F, KA, a, b, c); G.C += a; G.Nn += b; G.CAn += c;
+  e += hangle(P.O, P.C, Q.N, 2.0f * TRX2_PI_F - (float)(TRX2_A_CA_C_N + TRX2_A_CA_C_O) * TRX2_DEG_F, KA, a, b, c); G.O += a; G.C += b; G.Nn += c;
+  e += hdih(P.CA, Q.N, P.C, P.O, TRX2_PI_F, KI, a, b, c, d); G.CA += a; G.Nn += b; G.C += c; G.O += d;
+  G.e = e; return G;
+}
+
+template <int NT>
+__device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
+  constexpr int NW = NT / 64;  // one residue per thread: NT = 256 for chains up to 256 residues, 512 up to 512
+  const int L = A.L, tid = threadIdx.x, r = tid;
+  const bool act = r < L;
+  __shared__ double s_buf[2 * NW * 8];
+  int flip = 0;
+  __shared__ float s_alpha[LBM];
+  __shared__ int s_i[SI_N];
+  __shared__ double s_d[SD_N];
+  __shared__ float s_rho[LBM];
+  __shared__ float s_xyz[NT * 16];
+  __shared__ float s_dt[NT * 3];
+  int* gi = A.st_i + (size_t)dec * SI_N;
+  double* gd_ = A.st_d + (size_t)dec * SD_N;
+  KSTAMP_DECL
+  if (tid < SI_N && tid >= 2) s_i[tid] = gi[tid];
+  if (tid == 0) {  // (run, seq) in ONE 8-byte load
+    const unsigned long long rs = *reinterpret_cast<const volatile unsigned long long*>(gi);
+    s_i[SI_RUN] = (int)(unsigned)(rs & 0xffffffffull); s_i[SI_SEQ] = (int)(unsigned)(rs >> 32);
+  }
+  if (tid < SD_N) s_d[tid] = gd_[tid];
+  if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
+  __syncthreads();
+  int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
+  const int seq = *A.seq_ctr;
+  if (phase == PH_DONE || s_i[SI_SEQ] == seq) return;
+  const trx2_run R = A.runs[min(run, A.nruns - 1)];
+  if (!R.cartesian) return;
+  const size_t vb = (size_t)dec * L;
+  CSTAMP(16)  // state load, role test
+  CCOUNT(28)
+
+  // ---- trial coordinates; neighbours through LDS
+  float4 xt[4], gt[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { xt[q] = gt[q] = make_float4(0, 0, 0, 0); }
+  double esum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (act) {
+    const float4* xp = reinterpret_cast<const float4*>(A.xyz + (vb + r) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { xt[q] = xp[q]; reinterpret_cast<float4*>(s_xyz + r * 16)[q] = xt[q]; }
+    for (int s = 0; s < A.nsplit; s++) {
+      const size_t rec = ((size_t)s * A.Bpad + dec) * L + r;
+      const float4* fp = reinterpret_cast<const float4*>(A.fpart + rec * 16);
+#pragma unroll
+      for (int q = 0; q < 4; q++) { float4 v = fp[q]; gt[q].x += v.x; gt[q].y += v.y; gt[q].z += v.z; gt[q].w += v.w; }
+      const float4* ep = reinterpret_cast<const float4*>(A.epart + rec * 8);
+      float4 e0 = ep[0], e1 = ep[1];
+      esum[0] += e0.x; esum[1] += e0.y; esum[2] += e0.z; esum[3] += e0.w; esum[4] += e1.x;
+    }
+    gt[3].w = 0.0f;
+  }
+  __syncthreads();
+  CSTAMP(17)  // coordinates -> LDS, slab sums
+  f3 aN = mk3(0, 0, 0), aCA = aN, aC = aN, aO = aN, aCB = aN;  // gradient of the local terms on this residue's atoms
+  float dphi = 0, dpsi = 0, dom = 0;
+  Res5 Me = unpack5(s_xyz + (act ? r : 0) * 16), Pv = Me, Nx = Me;
+  if (act && r > 0) Pv = unpack5(s_xyz + (r - 1) * 16);
+  if (act && r + 1 < L) Nx = unpack5(s_xyz + (r + 1) * 16);
+  if (act) {
+    // rama (residues 2..L-1) and omega_bb (1..L-1): derivatives with respect to the torsion angles
+    f3 t1, t2, t3, t4;
+    if (r >= 1 && r < L - 1) {
+      const float ph = dihedral_grad(Pv.C, Me.N, Me.CA, Me.C, t1, t2, t3, t4), ps = dihedral_grad(Me.N, Me.CA, Me.C, Nx.N, t1, t2, t3, t4);
+      float sph, cph, sps, cps, sm = 0, a1 = 0, a2 = 0;
+      fast_sincosf(ph, &sph, &cph); fast_sincosf(ps, &sps, &cps);
+#pragma unroll
+      for (int j = 0; j < TRX2_RAMA_NB; j++) {
+        const float sk = c_rama_sc[j * 4], ck = c_rama_sc[j * 4 + 1], tk = c_rama_sc[j * 4 + 2], uk = c_rama_sc[j * 4 + 3];
+        const float sa = sph * ck - cph * sk, ca = cph * ck + sph * sk, sb = sps * uk - cps * tk, cb = cps * uk + sps * tk;
+        const float t = c_rama[j * 3 + 2] * expf((float)TRX2_RAMA_KAPPA * (ca + cb - 2.0f));
+        sm += t; a1 -= t * (float)TRX2_RAMA_KAPPA * sa; a2 -= t * (float)TRX2_RAMA_KAPPA * sb;
+      }
+      const float inv = 1.0f / (sm + (float)TRX2_RAMA_FLOOR);
+      esum[5] += -(double)logf((sm + (float)TRX2_RAMA_FLOOR) * (1.0f / (float)TRX2_RAMA_PREF));
+      dphi = -R.w[4] * a1 * inv; dpsi = -R.w[4] * a2 * inv;
+    }
+    if (r < L - 1) {
+      float dw = wrap_pi_f(dihedral_grad(Me.CA, Me.C, Nx.N, Nx.CA, t1, t2, t3, t4) - TRX2_PI_F) * (1.0f / TRX2_DEG_F);
+      esum[6] += (double)((float)TRX2_OMEGA_K * dw * dw);
+      dom = R.w[5] * 2.0f * (float)TRX2_OMEGA_K * dw * (1.0f / TRX2_DEG_F);
+    }
+    s_dt[r * 3] = dphi; s_dt[r * 3 + 1] = dpsi; s_dt[r * 3 + 2] = dom;
+  }
+  __syncthreads();
+  CSTAMP(18)  // rama / omega: angles and dE/dangle
+  if (act) {
+    f3 d1, d2, d3, d4;
+    if (dphi != 0.0f) { dihedral_grad(Pv.C, Me.N, Me.CA, Me.C, d1, d2, d3, d4); aN = fma3(d2, dphi, aN); aCA = fma3(d3, dphi, aCA); aC = fma3(d4, dphi, aC); }
+    if (dpsi != 0.0f) { dihedral_grad(Me.N, Me.CA, Me.C, Nx.N, d1, d2, d3, d4); aN = fma3(d1, dpsi, aN); aCA = fma3(d2, dpsi, aCA); aC = fma3(d3, dpsi, aC); }
+    if (dom != 0.0f) { dihedral_grad(Me.CA, Me.C, Nx.N, Nx.CA, d1, d2, d3, d4); aCA = fma3(d1, dom, aCA); aC = fma3(d2, dom, aC); }
+    if (r + 1 < L) {  // phi of the next residue moves C of this one
+      const float c = s_dt[(r + 1) * 3];
+      if (c != 0.0f) { Res5 N2 = Nx; dihedral_grad(Me.C, N2.N, N2.CA, N2.C, d1, d2, d3, d4); aC = fma3(d1, c, aC); }
+    }
+    if (r > 0) {      // psi and omega of the previous residue move N (and CA) of this one
+      const float c1 = s_dt[(r - 1) * 3 + 1], c2 = s_dt[(r - 1) * 3 + 2];
+      if (c1 != 0.0f) { dihedral_grad(Pv.N, Pv.CA, Pv.C, Me.N, d1, d2, d3, d4); aN = fma3(d4, c1, aN); }
+      if (c2 != 0.0f) { dihedral_grad(Pv.CA, Pv.C, Me.N, Me.CA, d1, d2, d3, d4); aN = fma3(d3, c2, aN); aCA = fma3(d4, c2, aCA); }
+    }
+    // bonded term: ideal CB geometry from the ideal local frame
+    CSTAMP(19)  // rama / omega gradients on atoms (up to 6 dihedral gradients)
+    const float wcb = R.w[6];
+    if (wcb != 0.0f) {
+      const float d_cacb = c_cb_ideal[0], a_ncacb = c_cb_ideal[1], a_ccacb = c_cb_ideal[2], t_cb = c_cb_ideal[3];
+      const float KL = (float)TRX2_CART_KLEN, KA = (float)TRX2_CART_KANG, KI = (float)TRX2_CART_KIMP;
+      f3 bN = mk3(0, 0, 0), bCA = bN, bC = bN, bO = bN, bCB = bN, a, b, c, d;
+      float eb = hbond(Me.N, Me.CA, (float)TRX2_B_N_CA, KL, a); bN += a; bCA += a * -1.0f;
+      eb += hbond(Me.CA, Me.C, (float)TRX2_B_CA_C, KL, a); bCA += a; bC += a * -1.0f;
+      eb += hbond(Me.C, Me.O, (float)TRX2_B_C_O, KL, a); bC += a; bO += a * -1.0f;
+      eb += hbond(Me.CA, Me.CB, d_cacb, KL, a); bCA += a; bCB += a * -1.0f;
+      eb += hangle(Me.N, Me.CA, Me.C, (float)TRX2_A_N_CA_C * TRX2_DEG_F, KA, a, b, c); bN += a; bCA += b; bC += c;
+      eb += hangle(Me.CA, Me.C, Me.O, (float)TRX2_A_CA_C_O * TRX2_DEG_F, KA, a, b, c); bCA += a; bC += b; bO += c;
+      eb += hangle(Me.N, Me.CA, Me.CB, a_ncacb, KA, a, b, c); bN += a; bCA += b; bCB += c;
+      eb += hangle(Me.C, Me.CA, Me.CB, a_ccacb, KA, a, b, c); bC += a; bCA += b; bCB += c;
+      eb += hdih(Me.N, Me.C, Me.CA, Me.CB, t_cb, KI, a, b, c, d); bN += a; bC += b; bCA += c; bCB += d;
+      if (r + 1 < L) { LinkGrad G = link_terms(Me, Nx); eb += G.e; bCA += G.CA; bC += G.C; bO += G.O; }
+      if (r > 0) { LinkGrad G = link_terms(Pv, Me); bN += G.Nn; bCA += G.CAn; }
+      esum[7] += (double)eb;
+      aN = fma3(bN, wcb, aN); aCA = fma3(bCA, wcb, aCA); aC = fma3(bC, wcb, aC); aO = fma3(bO, wcb, aO); aCB = fma3(bCB, wcb, aCB);
+    }
+    gt[0].x += aN.x; gt[0].y += aN.y; gt[0].z += aN.z; gt[0].w += aCA.x;
+    gt[1].x += aCA.y; gt[1].y += aCA.z; gt[1].z += aC.x; gt[1].w += aC.y;
+    gt[2].x += aC.z; gt[2].y += aO.x; gt[2].z += aO.y; gt[2].w += aO.z;
+    gt[3].x += aCB.x; gt[3].y += aCB.y; gt[3].z += aCB.z;
+  }
+  CSTAMP(20)  // bonded term
+  block_sum_n<8, NW>(esum, s_buf, flip);
+  const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] + (double)R.w[3] * esum[4] +
+                     (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[6] * esum[7];
+  if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
+  if (tid == 0) A.f_last[dec] = f_t;
+
+  // ------------------------------------------------------------------ minimiser state machine (as k_chain, 4 float4 per residue)
+  int iter = s_i[SI_ITER], nls = s_i[SI_NLS], hl = s_i[SI_HL], hh = s_i[SI_HH], nh = s_i[SI_NH];
+  int n_evals = s_i[SI_NEVALS] + 1, n_iters = s_i[SI_NITERS], status = s_i[SI_STATUS];
+  double f = s_d[SD_F], alpha = s_d[SD_ALPHA], gdir = s_d[SD_GD];
+  double fh[3] = {s_d[SD_FH0], s_d[SD_FH1], s_d[SD_FH2]};
+  double gamma_h = s_d[SD_GAMMA];
+  float4 x[4], g[4], dv[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    x[q] = g[q] = dv[q] = make_float4(0, 0, 0, 0);
+    if (act) { x[q] = A.CX[(vb + r) * 4 + q]; g[q] = A.CG[(vb + r) * 4 + q]; dv[q] = A.CD[(vb + r) * 4 + q]; }
+  }
+  bool next_run = false, new_dir = false, steepest = false, new_trial = false;
+  const bool finite_t = isfinite(f_t);
+  CSTAMP(21)  // energy reduction, loads of X, G, D
+  if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
+  else if (phase == PH_START) {
+    f = f_t;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { x[q] = xt[q]; g[q] = gt[q]; }
+    hl = 0; hh = 0; nh = 1; fh[0] = f; iter = 0;
+    steepest = true;
+  } else {
+    double fref = fh[0];
+    for (int k = 1; k < nh; k++) fref = fmax(fref, fh[k]);
+    const bool accept = finite_t && f_t <= fref + (double)TRX2_LS_C1 * alpha * gdir;
+    if (accept) {
+      double v3[3] = {0, 0, 0};
+      float4 sv[4], yv[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        sv[q] = make_float4(xt[q].x - x[q].x, xt[q].y - x[q].y, xt[q].z - x[q].z, xt[q].w - x[q].w);
+        yv[q] = make_float4(gt[q].x - g[q].x, gt[q].y - g[q].y, gt[q].z - g[q].z, gt[q].w - g[q].w);
+        v3[0] += (double)dot4(sv[q], yv[q]); v3[1] += (double)dot4(sv[q], sv[q]); v3[2] += (double)dot4(yv[q], yv[q]);
+      }
+      block_sum_n<3, NW>(v3, s_buf, flip);
+      if (v3[0] > 1e-12 * sqrt(v3[1] * v3[2])) {
+        if (act)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            A.CS[(((size_t)dec * LBM + hh) * L + r) * 4 + q] = sv[q];
+            A.CY[(((size_t)dec * LBM + hh) * L + r) * 4 + q] = yv[q];
+          }
+        __syncthreads();
+        if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
+        gamma_h = v3[0] / v3[2];
+        __syncthreads();
+        hh = (hh + 1) % LBM;
+        if (hl < LBM) hl++;
+      }
+      const double fprev = f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { x[q] = xt[q]; g[q] = gt[q]; }
+      f = f_t;
+      if (nh < TRX2_LS_PAST) fh[nh++] = f;
+      else { fh[0] = fh[1]; fh[1] = fh[2]; fh[2] = f; }
+      iter++; n_iters++;
+      const bool conv = 2.0 * fabs(fprev - f) <= (double)TRX2_MIN_TOL * (fabs(fprev) + fabs(f) + 1e-10);
+      if (conv || iter >= R.max_iter) next_run = true;
+      else new_dir = true;
+    } else {
+      nls++;
+      alpha *= (double)TRX2_LS_SHRINK;
+      if (nls > TRX2_LS_MAXTRIAL) {
+        if (hl > 0) { hl = 0; steepest = true; }
+        else next_run = true;
+      } else new_trial = true;
+    }
+  }
+  CSTAMP(22)  // Armijo / (s, y) pair
+  if (new_dir) {
+    CCOUNT(29)
+    // Two-loop recursion, 8 float4 per thread and stored pair.  Loads are branch-free (index clamped to the last residue; idle
+    // threads are masked out of the dot and the update instead) so that a pair's eight loads issue together -- guarded
+    // per element, each load had its own branch and wait (~2000 cycles per round, 57 % of a Cartesian step: s_memtime
+    // stamps, profiles/README.md).  Two named buffers and a loop unrolled by two keep the next pair in flight without a
+    // register copy (a copy makes the compiler wait for the load it has just issued).
+    float4 qv[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) qv[q] = g[q];
+    const int rc = min(r, L - 1);
+    auto pair_at = [&](int kk) { return (hh - 1 - kk + LBM) % LBM; };
+    auto load_pair = [&](int kk, float4 (&s_)[4], float4 (&y_)[4]) {
+      const size_t o = (((size_t)dec * LBM + pair_at(kk)) * L + rc) * 4;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { s_[q] = A.CS[o + q]; y_[q] = A.CY[o + q]; }
+    };
+    auto round1 = [&](int kk, const float4 (&s_)[4], const float4 (&y_)[4]) {
+      const int j = pair_at(kk);
+      double v1[1] = {0};
+#pragma unroll
+      for (int q = 0; q < 4; q++) v1[0] += (double)dot4(s_[q], qv[q]);  // qv is zero in idle threads
+      block_sum_n<1, NW>(v1, s_buf, flip);
+      const float al = s_rho[j] * (float)v1[0];
+      if (tid == 0) s_alpha[j] = al;
+      const float am = act ? al : 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { qv[q].x -= am * y_[q].x; qv[q].y -= am * y_[q].y; qv[q].z -= am * y_[q].z; qv[q].w -= am * y_[q].w; }
+    };
+    auto round2 = [&](int kk, const float4 (&s_)[4], const float4 (&y_)[4]) {
+      const int j = pair_at(kk);
+      double v1[1] = {0};
+#pragma unroll
+      for (int q = 0; q < 4; q++) v1[0] += (double)dot4(y_[q], qv[q]);
+      block_sum_n<1, NW>(v1, s_buf, flip);
+      const float c = act ? s_alpha[j] - s_rho[j] * (float)v1[0] : 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { qv[q].x += c * s_[q].x; qv[q].y += c * s_[q].y; qv[q].z += c * s_[q].z; qv[q].w += c * s_[q].w; }
+    };
+    float4 sa[4], ya[4], sb[4], yb[4];
+    if (hl > 0) load_pair(0, sa, ya);
+    for (int kk = 0; kk < hl; kk += 2) {  // pair kk in buffer a, pair kk+1 in buffer b
+      if (kk + 1 < hl) load_pair(kk + 1, sb, yb);
+      round1(kk, sa, ya);
+      if (kk + 1 < hl) {
+        if (kk + 2 < hl) load_pair(kk + 2, sa, ya);
+        round1(kk + 1, sb, yb);
+      }
+    }
+    CSTAMP(23)  // two-loop: first loop
+    if (hl > 0) {
+      const float gam = (float)gamma_h;
+#pragma unroll
+      for (int q = 0; q < 4; q++) { qv[q].x *= gam; qv[q].y *= gam; qv[q].z *= gam; qv[q].w *= gam; }
+    }
+    __syncthreads();
+    CSTAMP(24)  // two-loop: gamma
+    // backwards: the oldest pair (hl-1) is still in its buffer -- a if hl is odd, b if even
+    if (hl > 0) {
+      int kk = hl - 1;
+      if (kk & 1) {  // pair kk sits in b
+        if (kk > 0) load_pair(kk - 1, sa, ya);
+        round2(kk, sb, yb);
+        kk--;
+      }
+      for (; kk >= 0; kk -= 2) {  // pair kk in a, pair kk-1 goes to b
+        if (kk > 0) load_pair(kk - 1, sb, yb);
+        round2(kk, sa, ya);
+        if (kk > 0) {
+          if (kk > 1) load_pair(kk - 2, sa, ya);
+          round2(kk - 1, sb, yb);
+        }
+      }
+    }
+    CSTAMP(25)  // two-loop: second loop
+    double v2[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      dv[q] = make_float4(-qv[q].x, -qv[q].y, -qv[q].z, -qv[q].w);
+      v2[0] += (double)dot4(g[q], dv[q]); v2[1] += (double)dot4(g[q], g[q]);
+    }
+    block_sum_n<2, NW>(v2, s_buf, flip);
+    if (!(v2[1] > 0)) next_run = true;
+    else if (hl == 0 || !(v2[0] < 0)) { hl = 0; steepest = true; }
+    else { gdir = v2[0]; alpha = 1.0; nls = 0; new_trial = true; }
+  }
+  if (steepest) {
+    double v1[1] = {0};
+#pragma unroll
+    for (int q = 0; q < 4; q++) { dv[q] = make_float4(-g[q].x, -g[q].y, -g[q].z, -g[q].w); v1[0] += (double)dot4(g[q], g[q]); }
+    block_sum_n<1, NW>(v1, s_buf, flip);
+    if (!(v1[0] > 0)) next_run = true;
+    else { gdir = -v1[0]; alpha = fmin(1.0, 1.0 / sqrt(v1[0])); nls = 0; new_trial = true; }
+  }
+  if (next_run) {
+    run++;
+    phase = (run >= A.nruns) ? PH_DONE : PH_START;
+#pragma unroll
+    for (int q = 0; q < 4; q++) xt[q] = x[q];  // coordinates of the accepted point go back into the xyz buffer
+  }
+  if (new_trial) {
+    phase = PH_LS;
+    const float al = (float)alpha;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      xt[q] = make_float4(fmaf(al, dv[q].x, x[q].x), fmaf(al, dv[q].y, x[q].y), fmaf(al, dv[q].z, x[q].z), fmaf(al, dv[q].w, x[q].w));
+  }
+  if (phase != PH_DONE && n_evals >= A.max_evals) { status = TRX2_MAXEVAL; phase = PH_DONE; }
+  // ---- store state and the coordinates for the next pair launch
+  if (act) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { A.CX[(vb + r) * 4 + q] = x[q]; A.CG[(vb + r) * 4 + q] = g[q]; A.CD[(vb + r) * 4 + q] = dv[q]; }
+    float4* xo = reinterpret_cast<float4*>(A.xyz + (vb + r) * 16);
+    const int grp = dec / A.BW, dd = dec % A.BW;
+    float4* xT = A.xyzT + ((size_t)(grp * L + r) * 4) * A.BW + dd;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { xo[q] = xt[q]; xT[q * A.BW] = xt[q]; }
+  }
+  CSTAMP(26)  // direction test, trial point, state + coordinate stores
+  // ---- leaving Cartesian space (run finished, or the decoy stops here on its evaluation budget / divergence): torsions +
+  //      relaxed internal geometry of the ACCEPTED point, for the torsion-space runs after it and for the final report
+  if (next_run || phase == PH_DONE) {
+    __syncthreads();
+    if (act)
+#pragma unroll
+      for (int q = 0; q < 4; q++) reinterpret_cast<float4*>(s_xyz + r * 16)[q] = x[q];
+    __syncthreads();
+    if (act) {
+      const Res5 M2 = unpack5(s_xyz + r * 16);
+      f3 d1, d2, d3, d4;
+      ResGeom G = ideal_geom();
+      G.g0.x = sqrtf(dot(M2.CA - M2.N, M2.CA - M2.N)); G.g0.y = sqrtf(dot(M2.C - M2.CA, M2.C - M2.CA));
+      G.g0.w = angle_grad(M2.N, M2.CA, M2.C, d1, d2, d3);
+      G.g1.z = sqrtf(dot(M2.O - M2.C, M2.O - M2.C)); G.g1.w = angle_grad(M2.CA, M2.C, M2.O, d1, d2, d3);
+      {  // CB on the (b x c, b, c) basis
+        f3 b = M2.CA - M2.N, c = M2.C - M2.CA, a = cross(b, c), d = M2.CB - M2.CA;
+        const float bb = dot(b, b), cc = dot(c, c), bc = dot(b, c), det = bb * cc - bc * bc, db = dot(d, b), dc = dot(d, c);
+        G.g2.y = dot(d, a) / dot(a, a); G.g2.z = (db * cc - dc * bc) / det; G.g2.w = (dc * bb - db * bc) / det;
+      }
+      const float dO = dihedral_grad(M2.N, M2.CA, M2.C, M2.O, d1, d2, d3, d4);
+      float phi = TRX2_PI_F, psi = TRX2_PI_F, omg = TRX2_PI_F;
+      if (r > 0) { const Res5 P2 = unpack5(s_xyz + (r - 1) * 16); phi = dihedral_grad(P2.C, M2.N, M2.CA, M2.C, d1, d2, d3, d4); }
+      if (r + 1 < L) {
+        const Res5 N2 = unpack5(s_xyz + (r + 1) * 16);
+        G.g0.z = sqrtf(dot(N2.N - M2.C, N2.N - M2.C));
+        G.g1.x = angle_grad(M2.CA, M2.C, N2.N, d1, d2, d3); G.g1.y = angle_grad(M2.C, N2.N, N2.CA, d1, d2, d3);
+        psi = dihedral_grad(M2.N, M2.CA, M2.C, N2.N, d1, d2, d3, d4);
+        omg = dihedral_grad(M2.CA, M2.C, N2.N, N2.CA, d1, d2, d3, d4);
+      } else psi = dO - TRX2_PI_F;
+      G.g2.x = wrap_pi_f(dO - psi);
+      const float4 tv = make_float4(phi, psi, omg, 0);
+      A.X[vb + r] = tv; A.XT[vb + r] = tv;
+      A.geom[(vb + r) * 3] = G.g0; A.geom[(vb + r) * 3 + 1] = G.g1; A.geom[(vb + r) * 3 + 2] = G.g2;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
+    gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
+    *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
+    gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
+    gd_[SD_GAMMA] = gamma_h;
+    if (phase == PH_DONE) atomicAdd(A.done_count, 1);
+    const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
+    float* w = A.wcur + (size_t)dec * 8;
+    w[0] = Rn.w[0]; w[1] = Rn.w[1]; w[2] = Rn.w[2]; w[3] = Rn.w[3];
+    w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi; w[6] = (phase == PH_DONE) ? 0.0f : 1.0f; w[7] = 0;
+  }
+  if (tid < LBM) A.rho[(size_t)dec * LBM + tid] = s_rho[tid];
+}
+
+// ---- launchable forms.  k_chain: INIT / FINISH passes and protocols without a Cartesian run.  k_step: one launch of 2B
+// workgroups per evaluation -- workgroup d < B steps decoy d in torsion space, workgroup B + d steps it in Cartesian
+// space; whichever does not match the decoy's current run exits at once.  The two roles touch disjoint decoys, so they
+// run concurrently instead of as two half-empty launches back to back (k_cart alone was 22-27 % of GPU time).
+// The torsion role runs on TN threads, RPT residues each.
+template <int RPT, int TN>
+__global__ __launch_bounds__(TN) void k_chain(ChainArgs A) { chain_body<RPT, TN>(A, blockIdx.x); }
+template <int RPT, int TN, int NT>
+__global__ __launch_bounds__(NT) void k_step(ChainArgs A, CartArgs C) {
+  if ((int)blockIdx.x < A.B) {
+    if (NT == TN || threadIdx.x < TN) chain_body<RPT, TN>(A, blockIdx.x);  // the other waves of the workgroup exit at once
+  } else cart_body<NT>(C, (int)blockIdx.x - A.B);
+}
+
+// random start torsions: set_random_dihedral (utils_ros.py:656-696) with explicit (seed, decoy, residue) hashing
+__device__ __forceinline__ uint64_t splitmix64_dev(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ void k_init_torsions(int L, int B, uint64_t seed, uint32_t decoy0, const float* tors0, float4* X, float4* XT, float4* geom) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L * B) return;
+  const int dec = i / L, r = i % L;
+  float4 v;
+  if (tors0) v = make_float4(tors0[(size_t)i * 3], tors0[(size_t)i * 3 + 1], tors0[(size_t)i * 3 + 2], 0);
+  else {
+    float ph = 180.0f, ps = 180.0f;
+    if (r < L - 1) {
+      const double cum[6] = TRX2_RAND_CUM_INIT;
+      uint64_t hsh = splitmix64_dev(seed ^ splitmix64_dev(((uint64_t)(decoy0 + dec) << 32) | (uint32_t)r));
+      double u = (double)(hsh >> 11) * (1.0 / 9007199254740992.0);
+      int k = 0;
+      while (!(u <= cum[k])) k++;
+      v = make_float4(c_rama[k * 3], c_rama[k * 3 + 1], TRX2_PI_F, 0);
+    } else
+      v = make_float4(ph * TRX2_DEG_F, ps * TRX2_DEG_F, TRX2_PI_F, 0);
+  }
+  X[i] = v;
+  XT[i] = v;
+  const ResGeom gi = ideal_geom();  // pose_from_sequence: ideal bond geometry (folding.py:109)
+  geom[(size_t)i * 3] = gi.g0; geom[(size_t)i * 3 + 1] = gi.g1; geom[(size_t)i * 3 + 2] = gi.g2;
+}

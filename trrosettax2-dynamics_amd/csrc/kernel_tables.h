@@ -1,0 +1,131 @@
+// kernel_tables.h -- K2: restraint-table build (gen_rst + add_rst selection) -- included by trx2fold.hip.
+// Not a stand-alone header: it relies on the macros, constant tables and helpers defined above its #include.
+#pragma once
+// =================================================================================================
+// K2: restraint tables
+// =================================================================================================
+struct BuildArgs {
+  int L, use_orient;
+  const float *dist, *omega, *theta, *phi;
+  double ebase, erep[3], meff, pcut;
+  double bkgr[32];      // background (bins_k/DCUT)^ALPHA per contact bin; computed on the host: a device f64
+                        // pow() with a runtime exponent sends the gfx950 backend into a >10 min compile
+  const double* knots;  // [107] rounded knot positions: d(35) o(28) t(28) p(16)
+  float2 *Td, *To, *Tt, *Tp;
+  float *pd, *po, *pt, *pp;
+  unsigned char *gen, *sel;
+};
+
+__device__ float np_sum_f32_dev(const float* a, int n) {  // numpy pairwise_sum for 8 <= n <= 128
+  float r[8];
+  _Pragma("unroll 1") for (int j = 0; j < 8; j++) r[j] = a[j];
+  int i;
+  _Pragma("unroll 1") for (i = 8; i < n - (n % 8); i += 8)
+    _Pragma("unroll 1") for (int j = 0; j < 8; j++) r[j] += a[i + j];
+  float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  _Pragma("unroll 1") for (; i < n; i++) res += a[i];
+  return res;
+}
+
+// clamped cubic spline (end slopes 0) second derivatives, then store (y, y'') as float2
+__device__ __noinline__ void spline_store(int n, const double* x, const double* y, float2* out) {
+  double y2[KD], u[KD];
+  y2[0] = -0.5;
+  u[0] = (3.0 / (x[1] - x[0])) * ((y[1] - y[0]) / (x[1] - x[0]));
+  _Pragma("unroll 1") for (int i = 1; i < n - 1; i++) {
+    double sig = (x[i] - x[i - 1]) / (x[i + 1] - x[i - 1]);
+    double p = sig * y2[i - 1] + 2.0;
+    y2[i] = (sig - 1.0) / p;
+    double t = (y[i + 1] - y[i]) / (x[i + 1] - x[i]) - (y[i] - y[i - 1]) / (x[i] - x[i - 1]);
+    u[i] = (6.0 * t / (x[i + 1] - x[i - 1]) - sig * u[i - 1]) / p;
+  }
+  double un = (3.0 / (x[n - 1] - x[n - 2])) * (0.0 - (y[n - 1] - y[n - 2]) / (x[n - 1] - x[n - 2]));
+  y2[n - 1] = (un - 0.5 * u[n - 2]) / (0.5 * y2[n - 2] + 1.0);
+  _Pragma("unroll 1") for (int k = n - 2; k >= 0; k--) y2[k] = y2[k] * y2[k + 1] + u[k];
+  _Pragma("unroll 1") for (int k = 0; k < n; k++) out[k] = make_float2((float)y[k], (float)y2[k]);
+}
+
+__device__ __forceinline__ double round_dp(double v, double scale) { return rint(v * scale) / scale; }
+
+__global__ void k_build_tables(BuildArgs A) {
+  const int L = A.L;
+  size_t ab = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ab >= (size_t)L * L) return;
+  int a = (int)(ab / L), b = (int)(ab % L);
+  unsigned char gen = 0, sel = 0;
+  const float meff32 = (float)A.meff;
+  double y[KD];
+  {  // ---- dist (utils_ros.py:54-75)
+    const float* row = A.dist + ab * TRX2_ND_BINS;
+    float p = np_sum_f32_dev(row + 5, 32);
+    A.pd[ab] = p;
+    if ((double)p > TRX2_GEN_PCUT && b > a) {
+      double attr0 = 0;
+      _Pragma("unroll 1") for (int k = 0; k < 32; k++) {
+        double bk = A.bkgr[k];  // (bins_k / DCUT)^ALPHA, host libm pow like numpy (utils_ros.py:57)
+        float num = row[5 + k] + meff32;
+        double den = (double)row[36] * bk + 1e-6;
+        double at = -log((double)num / den) + A.ebase;
+        if (k == 0) attr0 = at;
+        y[3 + k] = round_dp(at, 1e3);
+      }
+      double rep0 = attr0 > 0.0 ? attr0 : 0.0;
+      _Pragma("unroll 1") for (int k = 0; k < 3; k++) y[k] = round_dp(rep0 + A.erep[k], 1e3);
+      spline_store(KD, A.knots, y, A.Td + ab * KD);
+      gen |= TRX2_M_DIST;
+      if ((double)p >= A.pcut) sel |= TRX2_M_DIST;
+    }
+  }
+  if (A.use_orient) {
+    _Pragma("unroll 1") for (int ch = 0; ch < 2; ch++) {  // ---- omega, theta (utils_ros.py:81-119), float32 like numpy
+      const float* row = (ch == 0 ? A.omega : A.theta) + ab * TRX2_NO_BINS;
+      float p = np_sum_f32_dev(row + 1, 24);
+      (ch == 0 ? A.po : A.pt)[ab] = p;
+      bool ok = (double)p > TRX2_GEN_PCUT && (ch == 0 ? b > a : b != a);
+      if (!ok) continue;
+      float v[TRX2_NO_BINS];
+      float den = row[24] + meff32;
+      _Pragma("unroll 1") for (int k = 0; k < TRX2_NO_BINS; k++) v[k] = -(float)log((double)((row[k] + meff32) / den));
+      double sc = ch == 0 ? 1e5 : 1e3;
+      y[0] = round_dp(v[23], sc);
+      y[1] = round_dp(v[24], sc);
+      _Pragma("unroll 1") for (int k = 1; k <= 24; k++) y[1 + k] = round_dp(v[k], sc);
+      y[26] = round_dp(v[1], sc);
+      y[27] = round_dp(v[2], sc);
+      spline_store(KO, A.knots + (ch == 0 ? KD : KD + KO), y, (ch == 0 ? A.To : A.Tt) + ab * KO);
+      unsigned char bit = ch == 0 ? TRX2_M_OMEGA : TRX2_M_THETA;
+      gen |= bit;
+      if ((double)p >= A.pcut + 0.5) sel |= bit;
+    }
+    {  // ---- phi (utils_ros.py:124-144)
+      const float* row = A.phi + ab * TRX2_NP_BINS;
+      float p = np_sum_f32_dev(row + 1, 12);
+      A.pp[ab] = p;
+      if ((double)p > TRX2_GEN_PCUT && a != b) {
+        float v[TRX2_NP_BINS];
+        float den = row[12] + meff32;
+        _Pragma("unroll 1") for (int k = 0; k < TRX2_NP_BINS; k++) v[k] = -(float)log((double)((row[k] + meff32) / den));
+        y[0] = round_dp(v[2], 1e3);
+        y[1] = round_dp(v[1], 1e3);
+        _Pragma("unroll 1") for (int k = 1; k <= 12; k++) y[1 + k] = round_dp(v[k], 1e3);
+        y[14] = round_dp(v[12], 1e3);
+        y[15] = round_dp(v[11], 1e3);
+        spline_store(KP, A.knots + KD + 2 * KO, y, A.Tp + ab * KP);
+        gen |= TRX2_M_PHI;
+        if ((double)p >= A.pcut + 0.6) sel |= TRX2_M_PHI;
+      }
+    }
+  }
+  A.gen[ab] = gen;
+  A.sel[ab] = sel;
+}
+
+// mask2[a][b] = sel[a][b] | sel[b][a] << 4 : both directions of an ordered pair in ONE row-contiguous byte.  k_pair used
+// to fetch sel[a][b] and sel[b][a] (a column access: a fresh cache line per visit) before it could even issue its
+// coordinate loads -- ~950 of ~3250 cycles per visit (s_memtime stamps, profiles/README.md).
+__global__ void k_pack_masks(int L, const unsigned char* sel, unsigned char* mask2) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)L * L) return;
+  const int a = (int)(i / L), b = (int)(i % L);
+  mask2[i] = (unsigned char)((sel[i] & 15) | ((sel[(size_t)b * L + a] & 15) << 4));
+}

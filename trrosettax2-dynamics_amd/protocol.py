@@ -35,7 +35,7 @@ def _declash(runs, w, max_iter, sep_lo, sep_hi):
         runs.append(_run(w, max_iter, sep_lo, sep_hi, precheck=1, skip_to=end))
 
 
-CART_MAX_L = 512  # the Cartesian step kernel handles one residue per thread, up to 512 threads (csrc/trx2fold.hip, cart_body)
+CART_MAX_L = 512  # the Cartesian step kernel handles one residue per thread, up to 512 threads (csrc/kernel_step.h, cart_body)
 
 
 def build_runs(L, mode=2, cartesian_stage=None):
