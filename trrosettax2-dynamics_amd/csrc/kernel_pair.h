@@ -81,7 +81,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
 
   STAMP_DECL
   __shared__ float s_kn[TRX2_KTOT], s_ikn[TRX2_KTOT];
-  __shared__ float s_red[PAIR_WAVES * 64 * RED_STRIDE];  // [slot][decoy][20 (+1 pad: bank-conflict-free)]
+  __shared__ float s_red[PAIR_WAVES * 64 * RED_STRIDE];  // [wave][decoy][20 (+1 pad: bank-conflict-free)]
   __shared__ unsigned char s_mask[1024];  // packed masks of this workgroup's residues b (chunk <= L <= 1024)
   // One evaluation = one sequence number.  Kept in device memory (not a kernel argument) so that a chunk of
   // (pair, step) launches is a STATIC graph that can be replayed.  The step kernel of this evaluation starts after this
@@ -265,16 +265,24 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   }
 
   STAMP(10) // loop exit
-  // ---- reduce over waves and over the PW residue sub-lanes; write decoy-major records.
-  // LDS image [slot][decoy][21]: a lane writes its own 20 values at stride 21 (no bank conflict); the readers are
+  // ---- reduce over the PW residue sub-lanes (inside the wave) and over the waves (through LDS); write decoy-major records.
+  // The sub-lanes of a decoy sit BW lanes apart: a butterfly over the lane distances BW, 2 BW, .. 32 leaves their sum in
+  // every one of them.  (Summing all PAIR_WAVES * PW slots from LDS instead made 6 threads add 256 slots each when one
+  // decoy is folded -- the case of every feedback iteration.)
+  // LDS image [wave][decoy][21]: the h = 0 lanes write 20 values at stride 21 (no bank conflict); the readers are
   // (decoy, quad) pairs, 4 lanes per decoy, so every store instruction writes whole 64-B (gradient) / 32-B (energy) runs.
   {
-    const int slot = wave * PW + h;
-    float* s = s_red + ((size_t)slot * BW + d) * RED_STRIDE;
-    const float vals[20] = {gN.x, gN.y, gN.z, gCA.x, gCA.y, gCA.z, gC.x, gC.y, gC.z, gO.x,
-                            gO.y, gO.z, gCB.x, gCB.y, gCB.z, e_d, e_o, e_t, e_p, e_v};
+    float vals[20] = {gN.x, gN.y, gN.z, gCA.x, gCA.y, gCA.z, gC.x, gC.y, gC.z, gO.x,
+                      gO.y, gO.z, gCB.x, gCB.y, gCB.z, e_d, e_o, e_t, e_p, e_v};
 #pragma unroll
-    for (int k = 0; k < 20; k++) s[k] = vals[k];
+    for (int o = BW; o < 64; o <<= 1)
+#pragma unroll
+      for (int k = 0; k < 20; k++) vals[k] += __shfl_xor(vals[k], o, 64);
+    if (h == 0) {
+      float* s = s_red + ((size_t)wave * BW + d) * RED_STRIDE;
+#pragma unroll
+      for (int k = 0; k < 20; k++) s[k] = vals[k];
+    }
   }
   __syncthreads();
   for (int t = threadIdx.x; t < 6 * BW; t += PAIR_THREADS) {  // 6 quads per decoy: 4 gradient (16 floats) + 2 energy (8)
@@ -288,7 +296,8 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       const int k = k0 + i;
       const bool real = q < 4 ? (k < 15) : (k < 20);  // gradient pad (16th float) and energy pads are zero
       if (real)
-        for (int sl = 0; sl < PAIR_WAVES * PW; sl++) acc[i] += s_red[((size_t)sl * BW + dd) * RED_STRIDE + k];
+#pragma unroll
+        for (int sl = 0; sl < PAIR_WAVES; sl++) acc[i] += s_red[((size_t)sl * BW + dd) * RED_STRIDE + k];
     }
     const size_t rec = ((size_t)split * A.Bpad + dc) * L + a;
     const float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
