@@ -89,6 +89,22 @@ int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint6
                     const float* tors0, int max_evals, float* tors_out, float* xyz_out, double* e_terms,
                     double* f_final, int* status, int* n_evals, int* n_iters);
 
+/* Feedback step between folds on the device (the caller on both sides of the fold).
+ * trx2_feedback_bins replaces get_neighbors + the one-hot binning of utils_trX2dy/utils.py:125-235,294-316: from the
+ * backbone of one decoy (xyz[L][5][3] N CA C O CB as read from its PDB file, NaN = absent; seq[L] one-letter, 'G' gets the
+ * virtual C-beta) to the realised bin of every ordered pair: jd (distance, 0 = no contact), jo, jt and jp -- jp from THETA on
+ * phi's edges, as the reference does (utils.py:226).  The edge arrays are passed in so that they are the very doubles numpy
+ * builds: np.arange(2, 20.5, 0.5), np.arange(-pi, pi, pi/12), np.arange(0, pi, pi/12); dmax = 20.  Outputs [L][L] int8.
+ * trx2_feedback_process replaces process_distribution_with_pred_distribution (utils.py:379-403, flag "0HD": mask
+ * max_k p < 0.5, decay 0.5 above 0.05, renormalise, Gaussian filter along the bins) for one channel in[L][L][K] with the
+ * bins of that channel; w9 = the nine weights of scipy's gaussian kernel for sigma (radius 4); norm = 0 gives the
+ * un-normalised cumulative `tmp` array.  All pointers are host memory; the context's stream and scratch are used. */
+int trx2_feedback_bins(trx2_ctx* ctx, int L, const char* seq, const float* xyz, const double* d_edges, int nd,
+                       const double* a_edges, int na, const double* p_edges, int np_, double dmax, signed char* jd,
+                       signed char* jo, signed char* jt, signed char* jp);
+int trx2_feedback_process(trx2_ctx* ctx, int L, int K, const float* in, const signed char* bins, const double* w9,
+                          int norm, int smooth, float* out);
+
 /* measurement helper (bench.py roofline leg): replays the pair-energy kernel n_rep times on the ctx stream
  * for the coordinates of the last eval/fold batch and returns the average launch duration in milliseconds
  * measured with hipEvents on that stream, plus the number of selected term-evaluations per launch. */

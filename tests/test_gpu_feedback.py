@@ -1,0 +1,83 @@
+"""GPU: the feedback step on the device (K7) against the host mirror feedback.py, which tests/test_host_boundary.py pins
+bit for bit to the reference (SHA-256 of its full outputs).  Inputs: the reference's own decoys and distograms."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  -- before libtrx2fold.so (see test_gpu_boundary.py)
+
+pytestmark = pytest.mark.gpu
+
+T = importlib.import_module("trrosettax2-dynamics_amd")
+FB = importlib.import_module("trrosettax2-dynamics_amd.feedback")
+P = importlib.import_module("trrosettax2-dynamics_amd.pdbio")
+
+
+def pdb_rounded(xyz, seq, tmp_path, name):
+    """what the pipeline hands to the feedback: coordinates after the PDB round trip (%8.3f)"""
+    path = str(tmp_path / name)
+    P.write_pdb(path, seq, np.nan_to_num(np.asarray(xyz, np.float32)))
+    return path, P.read_backbone(path)[0]
+
+
+@pytest.mark.parametrize("tag,decoys", [("NMR", ("conf_2_1", "conf_2_2")), ("Xray", ("conf_1_1", "conf_1_2"))])
+def test_device_feedback_equals_host_feedback(golden_dir, seq, tmp_path, tag, decoys):
+    m = dict(np.load(os.path.join(golden_dir, f"seq_{tag}.npz")))
+    ref = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    ctx = T.Context(0)
+    try:
+        cur_h = {k: m[k] for k in ("dist", "theta", "omega", "phi")}
+        cur_d = dict(cur_h)
+        for it, name in enumerate(decoys):                       # two chained iterations: the second one consumes `tmp`
+            path, xyz = pdb_rounded(ref[name], seq, tmp_path, f"{name}.pdb")
+            hb = FB.get_distribution_from_pdb(path)              # jd, jt, jo, jp
+            db = ctx.feedback_bins(xyz, seq)
+            diff = [int((np.asarray(a) != b).sum()) for a, b in zip(hb, db)]
+            print(f"\n{tag} {name}: pairs whose bin differs from the host's (dist, theta, omega, phi): {diff} of {90 * 89}")
+            # an angle within one ulp of a bin edge may fall on the other side (atan2f of glibc vs the device library)
+            assert diff[0] == 0 and max(diff) <= 2, diff
+            assert db[0].dtype == np.int8 and int(db[0].max()) <= 36 and int(db[2].max()) <= 24 and int(db[3].max()) <= 12
+            lab_h = FB.feedback_labels(cur_h, path, 1.0, True)
+            lab_d = ctx.feedback_labels(cur_d, xyz, seq, 1.0, True)
+            assert sorted(lab_h) == sorted(lab_d) == ["dist", "omega", "phi", "theta", "tmp"]
+            for k in lab_h:
+                same = np.array_equal(lab_h[k], lab_d[k])
+                rows = int((lab_h[k] != lab_d[k]).any(-1).sum())
+                print(f"   {k:5s}: bitwise equal {same}; pair rows that differ {rows}; max abs diff {np.abs(lab_h[k] - lab_d[k]).max():.2e}")
+                if max(diff) == 0:
+                    assert same, k                               # same bins -> same arithmetic -> same bits
+                else:
+                    assert rows <= 2 * max(diff)
+            cur_h, cur_d = lab_h, lab_d
+        # the individual variants of the reference's function
+        jd = np.asarray(hb[0])
+        for norm, smooth in ((True, False), (False, False)):
+            a = FB.process_distribution_with_pred_distribution(m["dist"], jd, norm=norm, smooth=smooth)
+            assert np.array_equal(a, ctx.feedback_process(m["dist"], jd, norm=norm, smooth=smooth)), (norm, smooth)
+    finally:
+        ctx.close()
+
+
+def test_device_feedback_glycine_missing_cb_and_errors(golden_dir, seq):
+    """virtual C-beta for glycine and for residues whose CB record is absent; argument checks fail loudly"""
+    ref = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    xyz = np.nan_to_num(ref["conf_1_1"].astype(np.float32)).round(3)
+    s2 = "G" + seq[1:10] + "G" + seq[11:]
+    xyz[20, 4] = np.nan                                          # a residue that lost its CB
+    ctx = T.Context(0)
+    try:
+        host = FB.bin_geometry(*FB.get_neighbors(xyz, s2))       # jd, jo, jt, jp
+        jd, jt, jo, jp = ctx.feedback_bins(xyz, s2)
+        assert np.array_equal(host[0], jd)
+        assert max(int((host[1] != jo).sum()), int((host[2] != jt).sum()), int((host[3] != jp).sum())) <= 2
+        with pytest.raises(ValueError):
+            ctx.feedback_bins(xyz, seq[:-1])
+        with pytest.raises(ValueError):
+            ctx.feedback_process(np.zeros((90, 90, 37), np.float32), np.zeros((90, 89), np.int8))
+        with pytest.raises(RuntimeError):
+            ctx.feedback_process(np.zeros((90, 90, 4), np.float32), np.zeros((90, 90), np.int8))   # fewer than 8 bins
+        with pytest.raises(ValueError):
+            T.Context.gaussian_weights(2.0)
+    finally:
+        ctx.close()

@@ -78,6 +78,8 @@ def load():
     L.trx2_get_tables.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.trx2_eval_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.trx2_fold_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_uint64, C.c_uint32, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.trx2_feedback_bins.argtypes = [vp, C.c_int, C.c_char_p, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_double, vp, vp, vp, vp]
+    L.trx2_feedback_process.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
     L.trx2_time_pair_kernel.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, dp, dp]
     L.trx2_last_fold_stats.argtypes = [vp, dp, ip]
     _lib = L
@@ -177,6 +179,60 @@ class Context:
         sec, nl = C.c_double(), C.c_int()
         self._l.trx2_last_fold_stats(self._h, C.byref(sec), C.byref(nl))
         return dict(tors=tors, xyz=xyz, e_terms=e, f=f, status=st, n_evals=ne, n_iters=ni, seconds=sec.value, launches=nl.value)
+
+    # ---- feedback step on the device; mirrors feedback.py, which is bit-identical to the reference
+    _D_EDGES = np.arange(2, 20.5, 0.5)
+    _A_EDGES = np.arange(-np.pi, np.pi, np.pi / 12)
+    _P_EDGES = np.arange(0, np.pi, np.pi / 12)
+
+    def feedback_bins(self, xyz, seq, dmax=20.0):
+        """xyz[L,5,3] float32 (as read from the decoy's PDB), seq -> realised bins (jd, jt, jo, jp), the return order of
+        get_distribution_from_pdb (utils_trX2dy/utils.py:294-316); int8 [L,L]"""
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        L = xyz.shape[0]
+        if xyz.shape != (L, 5, 3) or len(seq) != L:
+            raise ValueError("need xyz[L,5,3] and a sequence of the same length")
+        out = [np.empty((L, L), np.int8) for _ in range(4)]
+        self._chk(self._l.trx2_feedback_bins(self._h, L, seq.encode(), _p(xyz), _p(self._D_EDGES), len(self._D_EDGES), _p(self._A_EDGES),
+                                             len(self._A_EDGES), _p(self._P_EDGES), len(self._P_EDGES), float(dmax), *[_p(o) for o in out]),
+                  "trx2_feedback_bins")
+        jd, jo, jt, jp = out
+        return jd, jt, jo, jp
+
+    @staticmethod
+    def gaussian_weights(sigma, truncate=4.0):
+        """the kernel scipy.ndimage.gaussian_filter1d builds (_gaussian_kernel1d, order 0); radius 4 for sigma = 1"""
+        radius = int(truncate * float(sigma) + 0.5)
+        if radius != 4:
+            raise ValueError("the device filter is built for radius 4 (sigma = 1, the reference's value)")
+        x = np.arange(-radius, radius + 1)
+        phi = np.exp(-0.5 / (float(sigma) * float(sigma)) * x ** 2)
+        return np.ascontiguousarray((phi / phi.sum())[::-1], np.float64)
+
+    def feedback_process(self, unprocessed, bins, norm=True, smooth=True, sigma=1.0):
+        """process_distribution_with_pred_distribution (utils_trX2dy/utils.py:379-403) for one channel"""
+        a = np.ascontiguousarray(unprocessed, np.float32)
+        L, K = a.shape[0], a.shape[2]
+        b = np.ascontiguousarray(bins, np.int8)
+        if a.shape != (L, L, K) or b.shape != (L, L):
+            raise ValueError("need unprocessed[L,L,K] and bins[L,L]")
+        out = np.empty_like(a)
+        self._chk(self._l.trx2_feedback_process(self._h, L, K, _p(a), _p(b), _p(self.gaussian_weights(sigma)), int(bool(norm)),
+                                                int(bool(smooth)), _p(out)), "trx2_feedback_process")
+        return out
+
+    def feedback_labels(self, arrays, xyz, seq, sigma=1.0, angle=True):
+        """feedback.feedback_labels on the device: arrays (dist[/theta/omega/phi][/tmp]) + the decoy's backbone ->
+        dict dist[/theta/omega/phi]/tmp for the next fold"""
+        jd, jt, jo, jp = self.feedback_bins(xyz, seq)
+        labels = {"dist": self.feedback_process(arrays["dist"], jd, True, True, sigma)}
+        if angle:
+            labels["theta"] = self.feedback_process(arrays["theta"], jt, True, True, sigma)
+            labels["omega"] = self.feedback_process(arrays["omega"], jo, True, True, sigma)
+            labels["phi"] = self.feedback_process(arrays["phi"], jp, True, True, sigma)
+        base = arrays["tmp"] if "tmp" in arrays else arrays["dist"]
+        labels["tmp"] = self.feedback_process(base, jd, norm=False)
+        return labels
 
     def time_pair_kernel(self, B, w, sep_lo=1, sep_hi=None, n_rep=50):
         w = np.ascontiguousarray(w, np.float32)

@@ -1,0 +1,132 @@
+// kernel_feedback.h -- K7: the feedback step between folds on the device -- included by trx2fold.hip.
+// Not a stand-alone header: it relies on np_sum_f32_dev (kernel_tables.h) and the helpers above its #include.
+#pragma once
+// =================================================================================================
+// K7: decoy -> realised 6-D geometry -> bins (utils_trX2dy/utils.py:125-235) and the re-weighting of a distogram
+// channel with those bins (utils.py:379-403).  The host-side mirror (feedback.py) is bit-identical to the reference; these
+// kernels repeat ITS arithmetic: float32 where numpy computes in float32, in numpy's operation order with no fused
+// multiply-add, float64 for the neighbour test and inside the Gaussian filter as scipy does.  What cannot be promised
+// bit for bit is atan2f (glibc vs the device library, last ulp): a value within one ulp of a bin edge may fall on the
+// other side.  The parity test counts such pairs (none seen) and compares everything else exactly.
+// =================================================================================================
+struct FbBinsArgs {
+  int L;
+  const float* xyz;            // [L][5][3] N CA C O CB, NaN = absent
+  const unsigned char* gly;    // [L] 1 = glycine (virtual C-beta)
+  const double *d_edges, *a_edges, *p_edges;  // np.arange(2, 20.5, .5), np.arange(-pi, pi, pi/12), np.arange(0, pi, pi/12)
+  int nd, na, np_;
+  double dmax2;
+  signed char *jd, *jo, *jt, *jp;  // [L][L]
+};
+
+struct v3f { float x, y, z; };
+#pragma clang fp contract(off)
+__device__ __forceinline__ v3f fb_sub(v3f a, v3f b) { return v3f{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ float fb_sum3(float a, float b, float c) { return (a + b) + c; }          // np.sum over an axis of 3
+__device__ __forceinline__ float fb_dot(v3f a, v3f b) { return fb_sum3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ v3f fb_cross(v3f a, v3f b) {  // np.cross: multiply, multiply, subtract
+  return v3f{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ float fb_norm(v3f a) { return __fsqrt_rn(fb_dot(a, a)); }                    // np.linalg.norm, float32
+// get_dihedrals (utils.py:97-110) in float32
+__device__ __forceinline__ float fb_dihedral(v3f a, v3f b, v3f c, v3f d) {
+  v3f t = fb_sub(b, a);
+  v3f b0 = v3f{-1.0f * t.x, -1.0f * t.y, -1.0f * t.z}, b1 = fb_sub(c, b), b2 = fb_sub(d, c);
+  const float n = fb_norm(b1);
+  b1 = v3f{b1.x / n, b1.y / n, b1.z / n};
+  const float s0 = fb_dot(b0, b1), s2 = fb_dot(b2, b1);
+  const v3f v = v3f{b0.x - s0 * b1.x, b0.y - s0 * b1.y, b0.z - s0 * b1.z};
+  const v3f w = v3f{b2.x - s2 * b1.x, b2.y - s2 * b1.y, b2.z - s2 * b1.z};
+  const float x = fb_dot(v, w), y = fb_dot(fb_cross(b1, v), w);
+  return atan2f(y, x);
+}
+__device__ __forceinline__ v3f fb_cbeta(const FbBinsArgs& A, int i) {
+  const float* p = A.xyz + (size_t)i * 15;
+  const v3f N{p[0], p[1], p[2]}, Ca{p[3], p[4], p[5]}, C{p[6], p[7], p[8]}, real{p[12], p[13], p[14]};
+  const v3f b = fb_sub(Ca, N), c = fb_sub(C, Ca), a = fb_cross(b, c);
+  const float k0 = -0.58273431f, k1 = 0.56802827f, k2 = -0.54067466f;  // utils.py:135, as float32 like numpy's weak scalars
+  const v3f virt{((k0 * a.x + k1 * b.x) + k2 * c.x) + Ca.x, ((k0 * a.y + k1 * b.y) + k2 * c.y) + Ca.y, ((k0 * a.z + k1 * b.z) + k2 * c.z) + Ca.z};
+  const bool use = !A.gly[i] && isfinite(real.x) && isfinite(real.y) && isfinite(real.z);
+  return use ? real : virt;
+}
+__device__ __forceinline__ int fb_count(const double* edges, int n, double x) {  // (edges < x).sum()
+  int c = 0;
+  for (int k = 0; k < n; k++) c += edges[k] < x;
+  return c;
+}
+__global__ void k_fb_bins(FbBinsArgs A) {
+  const size_t ij = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ij >= (size_t)A.L * A.L) return;
+  const int i = (int)(ij / A.L), j = (int)(ij % A.L);
+  int jd = 0, jo = 0, jt = 0, jp = 0;
+  if (i != j) {
+    const v3f cbi = fb_cbeta(A, i), cbj = fb_cbeta(A, j);
+    const double dx = (double)cbi.x - (double)cbj.x, dy = (double)cbi.y - (double)cbj.y, dz = (double)cbi.z - (double)cbj.z;
+    const double d2 = (dx * dx + dy * dy) + dz * dz;
+    if (d2 <= A.dmax2) {
+      const float* pi_ = A.xyz + (size_t)i * 15;
+      const float* pj_ = A.xyz + (size_t)j * 15;
+      const v3f Ni{pi_[0], pi_[1], pi_[2]}, Cai{pi_[3], pi_[4], pi_[5]}, Caj{pj_[3], pj_[4], pj_[5]};
+      const float dist = fb_norm(fb_sub(cbj, cbi));
+      jd = fb_count(A.d_edges, A.nd, (double)dist);
+      if (jd >= 37) jd = 0;
+      if (jd != 0) {
+        const float om = fb_dihedral(Cai, cbi, cbj, Caj), th = fb_dihedral(Ni, Cai, cbi, cbj);
+        jo = fb_count(A.a_edges, A.na, (double)om);
+        jt = fb_count(A.a_edges, A.na, (double)th);
+        jp = fb_count(A.p_edges, A.np_, (double)th);  // the reference bins THETA on phi's edges (utils.py:226)
+      }
+    }
+  }
+  A.jd[ij] = (signed char)jd; A.jo[ij] = (signed char)jo; A.jt[ij] = (signed char)jt; A.jp[ij] = (signed char)jp;
+}
+
+struct FbProcArgs {
+  int L, K, norm, smooth;
+  const float* in;           // [L][L][K]
+  const signed char* bins;   // [L][L]
+  double w[9];               // Gaussian weights, radius 4 (scipy _gaussian_kernel1d)
+  float* out;                // [L][L][K]
+};
+// process_distribution_with_pred_distribution (utils.py:379-403): one thread per pair
+__global__ void k_fb_process(FbProcArgs A) {
+  const size_t ij = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ij >= (size_t)A.L * A.L) return;
+  const int K = A.K;
+  const float* src = A.in + ij * K;
+  float* dst = A.out + ij * K;
+  float row[40];
+  float mx = src[0];
+  for (int k = 0; k < K; k++) { row[k] = src[k]; mx = fmaxf(mx, src[k]); }
+  if (!(mx < 0.5f)) {  // pairs the network is sure about are left alone
+    for (int k = 0; k < K; k++) dst[k] = row[k];
+    return;
+  }
+  const int idx = A.bins[ij];
+  if (idx < K - 1) {  // realised bin = last bin: the reference's slice is empty, no decay
+    const float v = row[idx];
+    row[idx] = v < 0.05f ? v : v * 0.5f;
+  }
+  if (!A.norm) {  // the cumulative `tmp` array: decayed, not normalised
+    for (int k = 0; k < K; k++) dst[k] = row[k];
+    return;
+  }
+  const float s = np_sum_f32_dev(row, K);
+  for (int k = 0; k < K; k++) row[k] = row[k] / s;
+  if (!A.smooth) {
+    for (int k = 0; k < K; k++) dst[k] = row[k];
+    return;
+  }
+  // scipy.ndimage.gaussian_filter1d(mode="reflect"): double line with 4 reflected samples on each side, symmetric
+  // correlation accumulated from the outermost pair inwards (NI_Correlate1D), result cast to float32
+  double line[48];
+  for (int k = 0; k < K; k++) line[4 + k] = (double)row[k];
+  for (int m = 1; m <= 4; m++) { line[4 - m] = (double)row[m - 1]; line[4 + K - 1 + m] = (double)row[K - m]; }
+  for (int l = 0; l < K; l++) {
+    const double* c = line + 4 + l;
+    double t = c[0] * A.w[4];
+    for (int jj = -4; jj < 0; jj++) t += (c[jj] + c[-jj]) * A.w[4 + jj];
+    dst[l] = (float)t;
+  }
+}
+#pragma clang fp contract(fast)

@@ -57,6 +57,7 @@ __constant__ float c_cb_ideal[4];
 #include "kernel_tables.h"
 #include "kernel_pair.h"
 #include "kernel_step.h"
+#include "kernel_feedback.h"
 
 // =================================================================================================
 // host side
@@ -97,6 +98,8 @@ struct trx2_ctx {
   // one job can run as two half-batches whose pair and step kernels overlap
   trx2_ctx* child = nullptr;
   bool borrows_map = false;
+  // feedback scratch (trx2_feedback_*): grows on demand
+  void* fb_buf = nullptr; size_t fb_cap = 0;
 };
 
 #define HIPCHK(expr)                                                                                        \
@@ -262,6 +265,7 @@ extern "C" void trx2_ctx_destroy(trx2_ctx* ctx) {
   if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
   free_map(ctx);
   free_batch(ctx);
+  if (ctx->fb_buf) (void)hipFree(ctx->fb_buf);
   if (ctx->h_done) (void)hipHostFree(ctx->h_done);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -661,6 +665,79 @@ extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int n
   ctx->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   ctx->last_launches = ctx->last_launches > k->last_launches ? ctx->last_launches : k->last_launches;
   return rc0 != 0 ? rc0 : rc1;
+}
+
+// ---- K7: feedback step.  Host arrays in and out; the device buffers are scratch owned by the context.
+static int fb_reserve(trx2_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->fb_cap) return 0;
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (ctx->fb_buf) (void)hipFree(ctx->fb_buf);
+  ctx->fb_buf = nullptr; ctx->fb_cap = 0;
+  HIPCHK(hipMalloc(&ctx->fb_buf, bytes));
+  ctx->fb_cap = bytes;
+  return 0;
+}
+static size_t al256(size_t n) { return (n + 255) / 256 * 256; }
+
+extern "C" int trx2_feedback_bins(trx2_ctx* ctx, int L, const char* seq, const float* xyz, const double* d_edges, int nd,
+                                  const double* a_edges, int na, const double* p_edges, int np_, double dmax,
+                                  signed char* jd, signed char* jo, signed char* jt, signed char* jp) {
+  if (!ctx) return 1;
+  if (L < 2 || L > 4096 || !seq || !xyz || !d_edges || !a_edges || !p_edges || nd < 1 || nd > 64 || na < 1 || na > 64 || np_ < 1 || np_ > 64 ||
+      !jd || !jo || !jt || !jp || strnlen(seq, (size_t)L) != (size_t)L) {
+    ctx->err = "trx2_feedback_bins: bad arguments (need L residues of sequence and coordinates, edge arrays, four outputs)";
+    return 1;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t LL = (size_t)L * L;
+  const size_t o_xyz = 0, o_gly = al256((size_t)L * 15 * 4), o_ed = o_gly + al256(L), o_bins = o_ed + al256((size_t)(nd + na + np_) * 8);
+  if (fb_reserve(ctx, o_bins + 4 * al256(LL))) return 1;
+  char* base = (char*)ctx->fb_buf;
+  std::vector<unsigned char> gly(L);
+  for (int i = 0; i < L; i++) gly[i] = seq[i] == 'G';
+  std::vector<double> ed((size_t)nd + na + np_);
+  memcpy(ed.data(), d_edges, nd * 8); memcpy(ed.data() + nd, a_edges, na * 8); memcpy(ed.data() + nd + na, p_edges, np_ * 8);
+  HIPCHK(hipMemcpyAsync(base + o_xyz, xyz, (size_t)L * 15 * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(base + o_gly, gly.data(), L, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(base + o_ed, ed.data(), ed.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  FbBinsArgs A;
+  A.L = L; A.xyz = (const float*)(base + o_xyz); A.gly = (const unsigned char*)(base + o_gly);
+  A.d_edges = (const double*)(base + o_ed); A.a_edges = A.d_edges + nd; A.p_edges = A.a_edges + na;
+  A.nd = nd; A.na = na; A.np_ = np_; A.dmax2 = dmax * dmax;
+  signed char* b0 = (signed char*)(base + o_bins);
+  A.jd = b0; A.jo = b0 + al256(LL); A.jt = b0 + 2 * al256(LL); A.jp = b0 + 3 * al256(LL);
+  hipLaunchKernelGGL(k_fb_bins, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, ctx->stream, A);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(jd, A.jd, LL, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(jo, A.jo, LL, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(jt, A.jt, LL, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(jp, A.jp, LL, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+extern "C" int trx2_feedback_process(trx2_ctx* ctx, int L, int K, const float* in, const signed char* bins, const double* w9,
+                                     int norm, int smooth, float* out) {
+  if (!ctx) return 1;
+  if (L < 2 || L > 4096 || K < 8 || K > 40 || !in || !bins || !w9 || !out) {
+    ctx->err = "trx2_feedback_process: bad arguments (8 <= K <= 40 bins per pair)";
+    return 1;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t LL = (size_t)L * L, nb = LL * K * 4;
+  if (fb_reserve(ctx, 2 * al256(nb) + al256(LL))) return 1;
+  char* base = (char*)ctx->fb_buf;
+  FbProcArgs A;
+  A.L = L; A.K = K; A.norm = norm; A.smooth = smooth;
+  A.in = (const float*)base; A.out = (float*)(base + al256(nb)); A.bins = (const signed char*)(base + 2 * al256(nb));
+  memcpy(A.w, w9, sizeof A.w);
+  HIPCHK(hipMemcpyAsync(base, in, nb, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(base + 2 * al256(nb), bins, LL, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_fb_process, dim3((unsigned)((LL + 127) / 128)), dim3(128), 0, ctx->stream, A);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, A.out, nb, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
 }
 
 extern "C" int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int sep_lo, int sep_hi, int n_rep,

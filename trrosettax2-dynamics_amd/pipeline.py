@@ -21,13 +21,13 @@ import numpy as np
 
 from . import sched
 from .feedback import calculate_reliability_score, feedback_labels
-from .fold import fold_arrays_to_pdb
-from .pdbio import read_fasta
+from .fold import fold_arrays_to_pdb, get_context
+from .pdbio import read_backbone, read_fasta
 
 
 def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz, fasta, N=10, Nmax=500, begin_num=0,
                          sigma=1.0, tta_opt="-m 2 -r no-idp --orient ", angle=True, device=0, seed=None, lanes=2,
-                         write_tmp_npz=False):
+                         write_tmp_npz=False, device_feedback=True):
     """N initial decoys as one GPU batch -> best by reliability -> feedback -> one decoy per iteration until the
     cumulative `tmp` array moves by < 0.01 or Nmax iterations (run_inference.py:97-139).  Returns the last index.
 
@@ -36,8 +36,19 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     np.savez instead of np.savez_compressed: compressing 3 MB of float32 took 95 ms per iteration at L=90, more than the
     fold (54 ms) or the feedback (25 ms), and run_single deletes tmp_npz/ at the end (run_inference.py:334).  Nothing reads
     those files any more, and even uncompressed they cost 9 ms of a 50 ms iteration: they are written only with
-    write_tmp_npz=True (`run_inference.py --keep_tmp_npz`)."""
+    write_tmp_npz=True (`run_inference.py --keep_tmp_npz`).
+
+    device_feedback: the feedback step (decoy -> bins -> re-weighted distograms) runs on the GPU (Context.feedback_labels,
+    csrc/kernel_feedback.h) instead of in numpy (feedback.feedback_labels, 20 ms per iteration at L=90).  Tested bitwise
+    equal to the numpy path, which is pinned bit for bit to the reference; sigma other than 1 falls back to numpy."""
     os.makedirs(processed_npz_dir, exist_ok=True)
+
+    def feedback(arrays, pdb):
+        if device_feedback and float(sigma) == 1.0:
+            xyz, s_pdb = read_backbone(pdb)                 # the decoy as the reference sees it: through its PDB file
+            return get_context(device, lanes).feedback_labels(arrays, xyz, s_pdb, sigma, angle)
+        return feedback_labels(arrays, pdb, sigma, angle)
+
     seq = read_fasta(fasta)
     init = dict(np.load(initial_npz))
     print("Start generating the initial structures")
@@ -53,7 +64,7 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     pattern = os.path.join(processed_npz_dir, pdb_name + "{}.npz")
     base = {k: init[k] for k in (("dist", "theta", "omega", "phi") if angle else ("dist",))}   # no "tmp": falls back to dist
     old_tmp = init["dist"]
-    cur = feedback_labels(base, best_pdb, sigma, angle)
+    cur = feedback(base, best_pdb)
     if write_tmp_npz:
         np.savez(pattern.format(begin_num + 1), **cur)
     iter_n = begin_num
@@ -66,7 +77,7 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
         print("Done generating structure", iter_n)
         if iter_n - begin_num >= Nmax:
             break
-        cur = feedback_labels(cur, os.path.join(pred_pdb_dir, f"{pdb_name}{iter_n}.pdb"), sigma, angle)
+        cur = feedback(cur, os.path.join(pred_pdb_dir, f"{pdb_name}{iter_n}.pdb"))
         if write_tmp_npz:
             np.savez(pattern.format(iter_n + 1), **cur)
         if np.max(np.abs(old_tmp - cur["tmp"])) < 0.01:
