@@ -139,7 +139,9 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
     rsc[k * 4] = (float)sin(ph); rsc[k * 4 + 1] = (float)cos(ph); rsc[k * 4 + 2] = (float)sin(ps); rsc[k * 4 + 3] = (float)cos(ps);
   }
   // the step kernels of short chains stage the L-BFGS history in 96 KB of dynamic LDS (above the 64 KB default limit)
-  if (hipFuncSetAttribute((const void*)k_chain<1, CHAIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(CHAIN_THREADS)) != hipSuccess ||
+  if (hipFuncSetAttribute((const void*)k_chain<1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(128)) != hipSuccess ||
+      hipFuncSetAttribute((const void*)k_step<1, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(128)) != hipSuccess ||
+      hipFuncSetAttribute((const void*)k_chain<1, CHAIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(CHAIN_THREADS)) != hipSuccess ||
       hipFuncSetAttribute((const void*)k_step<1, CHAIN_THREADS, CHAIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(CHAIN_THREADS)) != hipSuccess) {
     delete ctx;
     return 4;
@@ -489,7 +491,10 @@ static void launch_chain(trx2_ctx* c, int B, int mode, int nruns, int max_evals)
   ChainArgs A = chain_args(c, B, mode, nruns, max_evals);
   const dim3 grid(B);
   const int L = c->L;
-  if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_chain<1, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), HIST_LDS_BYTES(CHAIN_THREADS), c->stream, A);
+  // chains of up to 128 residues (the reference's example has 90) run the step on two waves: every workgroup reduction and
+  // scan combines two partials instead of four
+  if (L <= 128) hipLaunchKernelGGL((k_chain<1, 128>), grid, dim3(128), HIST_LDS_BYTES(128), c->stream, A);
+  else if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_chain<1, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), HIST_LDS_BYTES(CHAIN_THREADS), c->stream, A);
   else if (L <= 2 * CHAIN_THREADS) hipLaunchKernelGGL((k_chain<2, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), 0, c->stream, A);
   else hipLaunchKernelGGL((k_chain<4, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), 0, c->stream, A);
 }
@@ -573,7 +578,8 @@ static int fold_impl(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint
         const ChainArgs ca = chain_args(ctx, B, MODE_STEP, nruns, max_evals);
         const CartArgs cc = cart_args(ctx, B, nruns, max_evals);
         const dim3 g2(2 * B), b1(CHAIN_THREADS), b2(2 * CHAIN_THREADS);
-        if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS>), g2, b1, HIST_LDS_BYTES(CHAIN_THREADS), ctx->stream, ca, cc);
+        if (L <= 128) hipLaunchKernelGGL((k_step<1, 128, 128>), g2, dim3(128), HIST_LDS_BYTES(128), ctx->stream, ca, cc);
+        else if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS>), g2, b1, HIST_LDS_BYTES(CHAIN_THREADS), ctx->stream, ca, cc);
         else hipLaunchKernelGGL((k_step<2, CHAIN_THREADS, 2 * CHAIN_THREADS>), g2, b2, 0, ctx->stream, ca, cc);
       } else
         launch_chain(ctx, B, MODE_STEP, nruns, max_evals);
