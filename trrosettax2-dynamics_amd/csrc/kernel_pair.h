@@ -69,7 +69,9 @@ __device__ unsigned long long g_stamp[32];
 #define FAM_ASYM 2  /* theta + phi (both directions): needs N, CA, CB */
 #define FAM_VDW 4   /* soft-sphere repulsion: needs all five atoms, no tables */
 #define FAM_ALL 7
-template <int BW, int FAM>
+#define VDW_RES_STRIDE 17 /* 15 gradient floats + energy, +1: a lane's record starts in its own LDS bank */
+// SHARE: the repulsion contacts of a block are shared by the wave's lanes (below) instead of walked lane by lane
+template <int BW, int FAM, bool SHARE>
 __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs A) {
   constexpr int PW = 64 / BW;
   const int L = A.L;
@@ -83,6 +85,8 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   __shared__ float s_kn[TRX2_KTOT], s_ikn[TRX2_KTOT];
   __shared__ float s_red[PAIR_WAVES * 64 * RED_STRIDE];  // [wave][decoy][20 (+1 pad: bank-conflict-free)]
   __shared__ unsigned char s_mask[1024];  // packed masks of this workgroup's residues b (chunk <= L <= 1024)
+  __shared__ unsigned short s_item[PAIR_WAVES * 64 * 32];   // per wave: contact items (owner lane << 5 | visit) of one block
+  __shared__ float s_res[PAIR_WAVES * 64 * VDW_RES_STRIDE];  // per wave: one result record per lane and round
   // One evaluation = one sequence number.  Kept in device memory (not a kernel argument) so that a chunk of
   // (pair, step) launches is a STATIC graph that can be replayed.  The step kernel of this evaluation starts after this
   // kernel has finished (same stream), so every one of its workgroups reads the same, final value.
@@ -231,35 +235,116 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       if (dot(dca, dca) < (float)TRX2_VDW_CUT2) vmask |= 1u << v;
     }
   }
-  while (vmask) {  // per-lane trip count; lanes without further contacts idle
-    const int v = __ffs((int)vmask) - 1;
-    vmask &= vmask - 1;
-    const int b = bb + v * VSTRIDE + h;
-    const float4* xb = A.xyzT + ((size_t)(grp * L + b) * 4) * BW + d;
-    float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW];
-    const f3 pa[5] = {Na, CAa, Ca, Oa, CBa};
-    const f3 pb[5] = {mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), mk3(r2.y, r2.z, r2.w),
-                      mk3(r3.x, r3.y, r3.z)};
-    f3 ga[5] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
-    float ev = 0;
-#pragma unroll
-    for (int p = 0; p < 5; p++)
-#pragma unroll
-      for (int q = 0; q < 5; q++) {
-        f3 u = pa[p] - pb[q];
-        constexpr VdwTab T = make_vdw_tab();
-        const float r02 = T.r0sq[p * 5 + q], ir = T.ir0sq[p * 5 + q];
-        float c = fmaxf(r02 - dot(u, u), 0.0f);
-        ev = fmaf(c * c, ir, ev);
-        ga[p] = fma3(u, -4.0f * c * ir, ga[p]);
+  if (SHARE) {
+    // ---- the block's contacts, shared by the whole wave.  A lane walking only its own bits made the wave take
+    // max-over-lanes steps (5.1 on a distance-only fold) where the contacts would fill ceil(total / 64) = 2.0 rounds of 64
+    // (tools/vdw_walk_stats.py).  So: every lane publishes its contacts as items (owner lane, visit) at the positions an
+    // exclusive prefix sum of the counts assigns; in round r lane l computes item 64 r + l for WHICHEVER decoy owns it
+    // (coordinates of a and b of that decoy come from L1 / L2) and leaves the 15 gradient components and the energy in LDS;
+    // each owner then adds its own items in index (= visit) order.  Fixed order, no atomics: still deterministic.
+    {
+      const int cnt = __popc(vmask);
+      int incl = cnt;
+  #pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
       }
-    const float s = w_vdw * (float)TRX2_VDW_SCALE;
-    if (a < b) e_v += (float)TRX2_VDW_SCALE * ev;  // symmetric energy: counted from the lower row only
-    gN = fma3(ga[0], s, gN);
-    gCA = fma3(ga[1], s, gCA);
-    gC = fma3(ga[2], s, gC);
-    gO = fma3(ga[3], s, gO);
-    gCB = fma3(ga[4], s, gCB);
+      const int first_item = incl - cnt;
+      const int total = __builtin_amdgcn_readlane(incl, 63);  // wave-uniform
+      if (total > 0) {
+        unsigned short* item = s_item + wave * (64 * 32);
+        float* res = s_res + wave * (64 * VDW_RES_STRIDE);
+        {
+          unsigned m = vmask;
+          int g = first_item;
+          while (m) {
+            const int v = __ffs((int)m) - 1;
+            m &= m - 1;
+            item[g++] = (unsigned short)((lane << 5) | v);
+          }
+        }
+        wave_lds_sync();
+        const float sw = w_vdw * (float)TRX2_VDW_SCALE;
+        for (int r0 = 0; r0 < total; r0 += 64) {
+          const int g = r0 + lane;
+          if (g < total) {
+            const unsigned it = item[g];
+            const int o = (int)(it >> 5), v = (int)(it & 31u);
+            const int od = o % BW, ob = bb + v * VSTRIDE + o / BW;
+            const float4* xo = A.xyzT + ((size_t)(grp * L + a) * 4) * BW + od;
+            const float4* xb = A.xyzT + ((size_t)(grp * L + ob) * 4) * BW + od;
+            const float4 p0 = xo[0], p1 = xo[BW], p2 = xo[2 * BW], p3 = xo[3 * BW];
+            const float4 r0_ = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW];
+            const f3 pa[5] = {mk3(p0.x, p0.y, p0.z), mk3(p0.w, p1.x, p1.y), mk3(p1.z, p1.w, p2.x), mk3(p2.y, p2.z, p2.w), mk3(p3.x, p3.y, p3.z)};
+            const f3 pb[5] = {mk3(r0_.x, r0_.y, r0_.z), mk3(r0_.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), mk3(r2.y, r2.z, r2.w), mk3(r3.x, r3.y, r3.z)};
+            f3 ga[5] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
+            float ev = 0;
+  #pragma unroll
+            for (int p = 0; p < 5; p++)
+  #pragma unroll
+              for (int q = 0; q < 5; q++) {
+                f3 u = pa[p] - pb[q];
+                constexpr VdwTab T = make_vdw_tab();
+                const float r02 = T.r0sq[p * 5 + q], ir = T.ir0sq[p * 5 + q];
+                float c = fmaxf(r02 - dot(u, u), 0.0f);
+                ev = fmaf(c * c, ir, ev);
+                ga[p] = fma3(u, -4.0f * c * ir, ga[p]);
+              }
+            float* w = res + lane * VDW_RES_STRIDE;
+  #pragma unroll
+            for (int p = 0; p < 5; p++) { w[p * 3] = ga[p].x; w[p * 3 + 1] = ga[p].y; w[p * 3 + 2] = ga[p].z; }
+            w[15] = ev;
+          }
+          wave_lds_sync();
+          const int q_hi = min(first_item + cnt, r0 + 64);
+          for (int q = max(first_item, r0); q < q_hi; q++) {  // this lane's items of the round, in visit order
+            const float* rr = res + (q - r0) * VDW_RES_STRIDE;
+            const int ob = bb + (int)(item[q] & 31u) * VSTRIDE + h;
+            gN = fma3(mk3(rr[0], rr[1], rr[2]), sw, gN);
+            gCA = fma3(mk3(rr[3], rr[4], rr[5]), sw, gCA);
+            gC = fma3(mk3(rr[6], rr[7], rr[8]), sw, gC);
+            gO = fma3(mk3(rr[9], rr[10], rr[11]), sw, gO);
+            gCB = fma3(mk3(rr[12], rr[13], rr[14]), sw, gCB);
+            if (a < ob) e_v += (float)TRX2_VDW_SCALE * rr[15];  // symmetric energy: counted from the lower row only
+          }
+          wave_lds_sync();  // before the next round overwrites the records
+        }
+      }
+    }
+  } else {
+    // per-lane walk: every lane follows its own contact bits (max-over-lanes steps).  Kept for maps with angle channels,
+    // where the shared walk's extra state cost the restraint terms more than it saved (profiles/README.md).
+    while (vmask) {  // per-lane trip count; lanes without further contacts idle
+      const int v = __ffs((int)vmask) - 1;
+      vmask &= vmask - 1;
+      const int b = bb + v * VSTRIDE + h;
+      const float4* xb = A.xyzT + ((size_t)(grp * L + b) * 4) * BW + d;
+      float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW];
+      const f3 pa[5] = {Na, CAa, Ca, Oa, CBa};
+      const f3 pb[5] = {mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), mk3(r2.y, r2.z, r2.w),
+                        mk3(r3.x, r3.y, r3.z)};
+      f3 ga[5] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
+      float ev = 0;
+  #pragma unroll
+      for (int p = 0; p < 5; p++)
+  #pragma unroll
+        for (int q = 0; q < 5; q++) {
+          f3 u = pa[p] - pb[q];
+          constexpr VdwTab T = make_vdw_tab();
+          const float r02 = T.r0sq[p * 5 + q], ir = T.ir0sq[p * 5 + q];
+          float c = fmaxf(r02 - dot(u, u), 0.0f);
+          ev = fmaf(c * c, ir, ev);
+          ga[p] = fma3(u, -4.0f * c * ir, ga[p]);
+        }
+      const float s = w_vdw * (float)TRX2_VDW_SCALE;
+      if (a < b) e_v += (float)TRX2_VDW_SCALE * ev;  // symmetric energy: counted from the lower row only
+      gN = fma3(ga[0], s, gN);
+      gCA = fma3(ga[1], s, gCA);
+      gC = fma3(ga[2], s, gC);
+      gO = fma3(ga[3], s, gO);
+      gCB = fma3(ga[4], s, gCB);
+    }
   }
   STAMP(9)  // vdw
   }

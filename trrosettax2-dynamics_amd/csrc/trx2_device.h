@@ -143,6 +143,13 @@ __device__ __forceinline__ float angle_grad(f3 p1, f3 p2, f3 p3, f3& d1, f3& d2,
   return ang;
 }
 
+// LDS hand-off between the lanes of ONE wave: its LDS instructions execute in program order, so only the compiler has to be
+// kept from moving them across this point
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ---- wave-wide sum, total in every lane; all 64 lanes must be active.
 // __shfl_xor is a ds_bpermute through the LDS crossbar (~120 cycles, two per double): six dependent rounds made one
 // reduction ~1000+ cycles, and a minimiser step has ~27 of them (s_memtime stamps, profiles/README.md).  DPP row operations

@@ -463,14 +463,20 @@ static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_eva
 
 template <int FAM>
 static void launch_pair_fam(trx2_ctx* c, const PairArgs& P, dim3 grid, dim3 block, hipStream_t st) {
+  // shared repulsion walk: distance-only maps with full decoy groups (measured: 25.6 -> 23.3 us at L=150, B=64; with the
+  // angle channels on the same change cost 3 us, and one decoy per group gains nothing)
+  const bool share = !c->use_orient && c->BW == 64;  // at 32 decoys per group it measured slower (two lanes: 286 -> 266 decoys/s)
   switch (c->BW) {
-    case 64: hipLaunchKernelGGL((k_pair<64, FAM>), grid, block, 0, st, P); break;
-    case 32: hipLaunchKernelGGL((k_pair<32, FAM>), grid, block, 0, st, P); break;
-    case 16: hipLaunchKernelGGL((k_pair<16, FAM>), grid, block, 0, st, P); break;
-    case 8: hipLaunchKernelGGL((k_pair<8, FAM>), grid, block, 0, st, P); break;
-    case 4: hipLaunchKernelGGL((k_pair<4, FAM>), grid, block, 0, st, P); break;
-    case 2: hipLaunchKernelGGL((k_pair<2, FAM>), grid, block, 0, st, P); break;
-    default: hipLaunchKernelGGL((k_pair<1, FAM>), grid, block, 0, st, P); break;
+    case 64:
+      if (share) hipLaunchKernelGGL((k_pair<64, FAM, true>), grid, block, 0, st, P);
+      else hipLaunchKernelGGL((k_pair<64, FAM, false>), grid, block, 0, st, P);
+      break;
+    case 32: hipLaunchKernelGGL((k_pair<32, FAM, false>), grid, block, 0, st, P); break;
+    case 16: hipLaunchKernelGGL((k_pair<16, FAM, false>), grid, block, 0, st, P); break;
+    case 8: hipLaunchKernelGGL((k_pair<8, FAM, false>), grid, block, 0, st, P); break;
+    case 4: hipLaunchKernelGGL((k_pair<4, FAM, false>), grid, block, 0, st, P); break;
+    case 2: hipLaunchKernelGGL((k_pair<2, FAM, false>), grid, block, 0, st, P); break;
+    default: hipLaunchKernelGGL((k_pair<1, FAM, false>), grid, block, 0, st, P); break;
   }
 }
 static void launch_pair(trx2_ctx* c, int B) {
