@@ -91,6 +91,15 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   // (pair, step) launches is a STATIC graph that can be replayed.  The step kernel of this evaluation starts after this
   // kernel has finished (same stream), so every one of its workgroups reads the same, final value.
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && A.seq_ctr) *A.seq_ctr += 1;
+  // this lane's weights and residue a: requested first, so that their latency (they were written by the step kernel on
+  // other CUs a moment ago) runs under the LDS fill and its barrier instead of after it
+  float4 w0 = make_float4(0, 0, 0, 0), w1 = w0;
+  if (live) {
+    const float4* wp = reinterpret_cast<const float4*>(A.wcur + (size_t)dec * 8);
+    w0 = wp[0]; w1 = wp[1];
+  }
+  const float4* xa = A.xyzT + ((size_t)(grp * L + a) * 4) * BW + d;
+  const float4 q0 = xa[0], q1 = xa[BW], q2 = xa[2 * BW], q3 = xa[3 * BW];
   for (int i = threadIdx.x; i < TRX2_KTOT; i += PAIR_THREADS) {
     s_kn[i] = A.knots[i];
     s_ikn[i] = i + 1 < TRX2_KTOT ? 1.0f / (A.knots[i + 1] - A.knots[i]) : 0.0f;  // entries straddling two tables are never read
@@ -107,20 +116,11 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   const float *iknd = s_ikn, *ikno = s_ikn + KD, *iknt = s_ikn + KD + KO, *iknp = s_ikn + KD + 2 * KO;
   const float inv_o = 1.0f / (kno[1] - kno[0]), inv_p = 1.0f / (knp[1] - knp[0]);
 
-  float w_ap = 0, w_dih = 0, w_ang = 0, w_vdw = 0;
-  int sep_lo = 0, sep_hi = 0;
-  bool active = false;
-  if (live) {
-    const float4* wp = reinterpret_cast<const float4*>(A.wcur + (size_t)dec * 8);
-    float4 w0 = wp[0], w1 = wp[1];
-    w_ap = w0.x; w_dih = w0.y; w_ang = w0.z; w_vdw = w0.w;
-    sep_lo = (int)w1.x; sep_hi = (int)w1.y;
-    active = w1.z != 0.0f;
-  }
+  const float w_ap = w0.x, w_dih = w0.y, w_ang = w0.z, w_vdw = w0.w;
+  const int sep_lo = (int)w1.x, sep_hi = (int)w1.y;
+  const bool active = live && w1.z != 0.0f;
 
   // residue a
-  const float4* xa = A.xyzT + ((size_t)(grp * L + a) * 4) * BW + d;
-  float4 q0 = xa[0], q1 = xa[BW], q2 = xa[2 * BW], q3 = xa[3 * BW];
   const f3 Na = mk3(q0.x, q0.y, q0.z), CAa = mk3(q0.w, q1.x, q1.y), Ca = mk3(q1.z, q1.w, q2.x),
            Oa = mk3(q2.y, q2.z, q2.w), CBa = mk3(q3.x, q3.y, q3.z);
 
