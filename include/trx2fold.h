@@ -105,6 +105,15 @@ int trx2_feedback_bins(trx2_ctx* ctx, int L, const char* seq, const float* xyz, 
 int trx2_feedback_process(trx2_ctx* ctx, int L, int K, const float* in, const signed char* bins, const double* w9,
                           int norm, int smooth, float* out);
 
+/* The same step on the distograms RESIDENT in the context (those of the last trx2_set_map, or of the previous step): bins of
+ * the decoy, the cumulative `tmp` array, the re-weighted channels (dist only, or all four with angle != 0) and new restraint
+ * tables -- everything run_inference.py:75-131 does between two folds.  Only the decoy's coordinates go in;
+ * max_tmp_change = max |tmp_new - tmp_old|, the reference's convergence measure (stop below 0.01, run_inference.py:133).
+ * trx2_get_map downloads a resident array: channel 0..3 = dist, omega, theta, phi; 4 = tmp. */
+int trx2_feedback_step(trx2_ctx* ctx, const char* seq, const float* xyz, const double* d_edges, int nd, const double* a_edges,
+                       int na, const double* p_edges, int np_, double dmax, const double* w9, int angle, float* max_tmp_change);
+int trx2_get_map(trx2_ctx* ctx, int channel, float* out);
+
 /* measurement helper (bench.py roofline leg): replays the pair-energy kernel n_rep times on the ctx stream
  * for the coordinates of the last eval/fold batch and returns the average launch duration in milliseconds
  * measured with hipEvents on that stream, plus the number of selected term-evaluations per launch. */

@@ -81,3 +81,35 @@ def test_device_feedback_glycine_missing_cb_and_errors(golden_dir, seq):
             T.Context.gaussian_weights(2.0)
     finally:
         ctx.close()
+
+
+def test_resident_feedback_chain_equals_the_host_chain(golden_dir, tmp_path):
+    """pipeline.generate_npz_and_pdb three ways -- distograms resident on the device (default), device kernels on host
+    arrays, numpy -- must produce the same decoys, the same number of iterations and the same intermediate arrays."""
+    PL = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
+    npz, fa = os.path.join(golden_dir, "seq_NMR.npz"), os.path.join(golden_dir, "seq.fasta")
+    runs = {}
+    for tag, mode in (("resident", True), ("arrays", "arrays"), ("numpy", False)):
+        tmpd, pdbd = str(tmp_path / tag / "tmp"), str(tmp_path / tag / "pdb")
+        last = PL.generate_npz_and_pdb("s", tmpd, pdbd, npz, fa, N=4, Nmax=4, seed=21, device_feedback=mode, write_tmp_npz=True)
+        runs[tag] = (last, {f: open(os.path.join(pdbd, f)).read() for f in sorted(os.listdir(pdbd))},
+                     {f: dict(np.load(os.path.join(tmpd, f))) for f in sorted(os.listdir(tmpd))})
+    ref = runs["numpy"]
+    assert ref[0] >= 2 and len(ref[2]) >= 2
+    for tag in ("resident", "arrays"):
+        last, pdbs, arrs = runs[tag]
+        assert last == ref[0] and sorted(pdbs) == sorted(ref[1]) and sorted(arrs) == sorted(ref[2]), tag
+        assert all(pdbs[f] == ref[1][f] for f in pdbs), tag                       # every decoy, byte for byte
+        for f in arrs:
+            assert sorted(arrs[f]) == sorted(ref[2][f]) == ["dist", "omega", "phi", "theta", "tmp"]
+            assert all(np.array_equal(arrs[f][k], ref[2][f][k]) for k in arrs[f]), (tag, f)
+    # dist-only iteration (--no-angle): only dist and tmp move
+    a = PL.generate_npz_and_pdb("t", str(tmp_path / "a" / "tmp"), str(tmp_path / "a" / "pdb"), npz, fa, N=2, Nmax=3, seed=5, angle=False,
+                                tta_opt="-m 2 --no-orient -r no-idp", write_tmp_npz=True)
+    b = PL.generate_npz_and_pdb("t", str(tmp_path / "b" / "tmp"), str(tmp_path / "b" / "pdb"), npz, fa, N=2, Nmax=3, seed=5, angle=False,
+                                tta_opt="-m 2 --no-orient -r no-idp", write_tmp_npz=True, device_feedback=False)
+    assert a == b
+    for f in sorted(os.listdir(tmp_path / "b" / "tmp")):
+        za, zb = np.load(tmp_path / "a" / "tmp" / f), np.load(tmp_path / "b" / "tmp" / f)
+        assert sorted(za.files) == sorted(zb.files) == ["dist", "tmp"] and all(np.array_equal(za[k], zb[k]) for k in za.files)
+    assert open(tmp_path / "a" / "pdb" / f"t{a}.pdb").read() == open(tmp_path / "b" / "pdb" / f"t{b}.pdb").read()

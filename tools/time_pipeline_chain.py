@@ -12,7 +12,7 @@ def chain(n, **kw):
     return time.perf_counter() - t, last
 chain(2)
 t0, _ = chain(0 + 1)
-for kw in ({}, {"device_feedback": False}, {"device_feedback": False, "write_tmp_npz": True}):
+for kw in ({}, {"device_feedback": "arrays"}, {"device_feedback": False}, {"device_feedback": False, "write_tmp_npz": True}):
     t, last = chain(nmax, **kw)
     print(f"{kw or 'default'}: {last} iterations in {t*1e3:.0f} ms; first iteration + 10 initial decoys {t0*1e3:.0f} ms; "
           f"{(t - t0) / max(last - 1, 1) * 1e3:.1f} ms per further iteration")

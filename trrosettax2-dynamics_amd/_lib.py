@@ -79,6 +79,8 @@ def load():
     L.trx2_eval_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.trx2_fold_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_uint64, C.c_uint32, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     L.trx2_feedback_bins.argtypes = [vp, C.c_int, C.c_char_p, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_double, vp, vp, vp, vp]
+    L.trx2_feedback_step.argtypes = [vp, C.c_char_p, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_double, vp, C.c_int, C.POINTER(C.c_float)]
+    L.trx2_get_map.argtypes = [vp, C.c_int, vp]
     L.trx2_feedback_process.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
     L.trx2_time_pair_kernel.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, dp, dp]
     L.trx2_last_fold_stats.argtypes = [vp, dp, ip]
@@ -233,6 +235,26 @@ class Context:
         base = arrays["tmp"] if "tmp" in arrays else arrays["dist"]
         labels["tmp"] = self.feedback_process(base, jd, norm=False)
         return labels
+
+    def feedback_step(self, xyz, seq, sigma=1.0, angle=True, dmax=20.0):
+        """One feedback iteration on the distograms resident in this context (trx2_feedback_step): re-weights them with the
+        decoy's realised geometry, updates the cumulative tmp array and rebuilds the restraint tables; the next fold_batch
+        uses them.  -> max |tmp_new - tmp_old| (the reference stops below 0.01)"""
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        if xyz.shape != (self.L, 5, 3) or len(seq) != self.L:
+            raise ValueError("need xyz[L,5,3] and a sequence of the length of the current map")
+        d = C.c_float()
+        self._chk(self._l.trx2_feedback_step(self._h, seq.encode(), _p(xyz), _p(self._D_EDGES), len(self._D_EDGES), _p(self._A_EDGES),
+                                             len(self._A_EDGES), _p(self._P_EDGES), len(self._P_EDGES), float(dmax),
+                                             _p(self.gaussian_weights(sigma)), int(bool(angle)), C.byref(d)), "trx2_feedback_step")
+        return float(d.value)
+
+    def get_map(self, channel):
+        """the resident distogram: "dist" / "omega" / "theta" / "phi", or "tmp" after a feedback step"""
+        k = ("dist", "omega", "theta", "phi", "tmp").index(channel)
+        out = np.empty((self.L, self.L, (37, 25, 25, 13, 37)[k]), np.float32)
+        self._chk(self._l.trx2_get_map(self._h, k, _p(out)), "trx2_get_map")
+        return out
 
     def time_pair_kernel(self, B, w, sep_lo=1, sep_hi=None, n_rep=50):
         w = np.ascontiguousarray(w, np.float32)

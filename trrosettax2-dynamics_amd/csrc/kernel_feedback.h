@@ -87,6 +87,7 @@ struct FbProcArgs {
   const signed char* bins;   // [L][L]
   double w[9];               // Gaussian weights, radius 4 (scipy _gaussian_kernel1d)
   float* out;                // [L][L][K]
+  unsigned* max_diff_bits;   // optional: max |out - in| over everything, as the bits of a non-negative float (atomicMax)
 };
 // process_distribution_with_pred_distribution (utils.py:379-403): one thread per pair
 __global__ void k_fb_process(FbProcArgs A) {
@@ -101,6 +102,13 @@ __global__ void k_fb_process(FbProcArgs A) {
   if (!(mx < 0.5f)) {  // pairs the network is sure about are left alone
     for (int k = 0; k < K; k++) dst[k] = row[k];
     return;
+  }
+  if (A.max_diff_bits && !A.norm) {  // the convergence measure of the iteration: max |tmp_new - tmp_old| (run_inference.py:133)
+    const int i0 = A.bins[ij];
+    if (i0 < K - 1) {
+      const float v = row[i0], nv = v < 0.05f ? v : v * 0.5f;
+      atomicMax(A.max_diff_bits, __float_as_uint(fabsf(nv - v)));
+    }
   }
   const int idx = A.bins[ij];
   if (idx < K - 1) {  // realised bin = last bin: the reference's slice is empty, no decay

@@ -100,6 +100,13 @@ struct trx2_ctx {
   bool borrows_map = false;
   // feedback scratch (trx2_feedback_*): grows on demand
   void* fb_buf = nullptr; size_t fb_cap = 0;
+  // the current distograms stay resident (dist, omega, theta, phi) so that the feedback step can re-weight them in place and
+  // rebuild the tables without a host round trip; alt = output buffers of that step, tmp = the cumulative convergence array
+  float* cur[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* alt[4] = {nullptr, nullptr, nullptr, nullptr};
+  float *tmp_cur = nullptr, *tmp_alt = nullptr;
+  bool has_tmp = false;
+  trx2_params prm;
 };
 
 #define HIPCHK(expr)                                                                                        \
@@ -183,9 +190,12 @@ static void free_map(trx2_ctx* c) {
     k->Td = k->To = k->Tt = k->Tp = nullptr; k->pd = k->po = k->pt = k->pp = nullptr;
     k->gen = k->sel = k->mask2 = nullptr; k->knots_f = nullptr; k->knots_d = nullptr; k->L = 0; k->alloc_epoch++;
   }
-  void* p[] = {c->Td, c->To, c->Tt, c->Tp, c->pd, c->po, c->pt, c->pp, c->gen, c->sel, c->mask2, c->knots_f, c->knots_d};
+  void* p[] = {c->Td, c->To, c->Tt, c->Tp, c->pd, c->po, c->pt, c->pp, c->gen, c->sel, c->mask2, c->knots_f, c->knots_d,
+               c->cur[0], c->cur[1], c->cur[2], c->cur[3], c->alt[0], c->alt[1], c->alt[2], c->alt[3], c->tmp_cur, c->tmp_alt};
   for (void* q : p)
     if (q && !c->borrows_map) (void)hipFree(q);
+  for (int k = 0; k < 4; k++) c->cur[k] = c->alt[k] = nullptr;
+  c->tmp_cur = c->tmp_alt = nullptr; c->has_tmp = false;
   c->Td = c->To = c->Tt = c->Tp = nullptr;
   c->pd = c->po = c->pt = c->pp = nullptr;
   c->gen = c->sel = c->mask2 = nullptr;
@@ -275,6 +285,33 @@ extern "C" void trx2_ctx_destroy(trx2_ctx* ctx) {
 
 extern "C" const char* trx2_last_error(const trx2_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
+// restraint tables, selection masks and packed masks from the resident distograms (ctx->cur) and parameters (ctx->prm)
+static int build_tables(trx2_ctx* ctx) {
+  const int L = ctx->L;
+  const size_t LL = (size_t)L * L;
+  const trx2_params* prm = &ctx->prm;
+  HIPCHK(hipMemsetAsync(ctx->Td, 0, LL * KD * sizeof(float2), ctx->stream));
+  if (ctx->use_orient) {
+    HIPCHK(hipMemsetAsync(ctx->To, 0, LL * KO * sizeof(float2), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->Tt, 0, LL * KO * sizeof(float2), ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->Tp, 0, LL * KP * sizeof(float2), ctx->stream));
+  }
+  BuildArgs A;
+  A.L = L; A.use_orient = ctx->use_orient;
+  A.dist = ctx->cur[0]; A.omega = ctx->cur[1]; A.theta = ctx->cur[2]; A.phi = ctx->cur[3];
+  A.ebase = prm->ebase; for (int k = 0; k < 3; k++) A.erep[k] = prm->erep[k];
+  A.meff = prm->meff; A.pcut = prm->pcut;
+  for (int k = 0; k < 32; k++) A.bkgr[k] = std::pow((4.25 + prm->dstep * k) / prm->dcut, prm->alpha);
+  A.knots = ctx->knots_d;
+  A.Td = ctx->Td; A.To = ctx->To; A.Tt = ctx->Tt; A.Tp = ctx->Tp;
+  A.pd = ctx->pd; A.po = ctx->po; A.pt = ctx->pt; A.pp = ctx->pp; A.gen = ctx->gen; A.sel = ctx->sel;
+  hipLaunchKernelGGL(k_build_tables, dim3((unsigned)((LL + 127) / 128)), dim3(128), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_pack_masks, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, ctx->stream, L, ctx->sel, ctx->mask2);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
 static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist, const float* omega, const float* theta,
                         const float* phi, const trx2_params* prm, bool device_ptrs) {
   if (!ctx) return 1;
@@ -313,7 +350,6 @@ static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist
   HIPCHK(hipMalloc((void**)&ctx->gen, LL));
   HIPCHK(hipMalloc((void**)&ctx->sel, LL));
   HIPCHK(hipMalloc((void**)&ctx->mask2, LL));
-  HIPCHK(hipMemsetAsync(ctx->Td, 0, LL * KD * sizeof(float2), ctx->stream));
   if (orient) {
     HIPCHK(hipMalloc((void**)&ctx->To, LL * KO * sizeof(float2)));
     HIPCHK(hipMalloc((void**)&ctx->Tt, LL * KO * sizeof(float2)));
@@ -321,37 +357,16 @@ static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist
     HIPCHK(hipMalloc((void**)&ctx->po, LL * 4));
     HIPCHK(hipMalloc((void**)&ctx->pt, LL * 4));
     HIPCHK(hipMalloc((void**)&ctx->pp, LL * 4));
-    HIPCHK(hipMemsetAsync(ctx->To, 0, LL * KO * sizeof(float2), ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->Tt, 0, LL * KO * sizeof(float2), ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->Tp, 0, LL * KP * sizeof(float2), ctx->stream));
   }
   const float* src[4] = {dist, omega, theta, phi};
-  float* dev[4] = {nullptr, nullptr, nullptr, nullptr};
   const int nb[4] = {TRX2_ND_BINS, TRX2_NO_BINS, TRX2_NO_BINS, TRX2_NP_BINS};
-  for (int c = 0; c < 4; c++) {
+  for (int c = 0; c < 4; c++) {  // the distograms stay resident: the feedback step re-weights them in place
     if (!src[c]) continue;
-    if (device_ptrs) dev[c] = const_cast<float*>(src[c]);
-    else {
-      HIPCHK(hipMalloc((void**)&dev[c], LL * nb[c] * 4));
-      HIPCHK(hipMemcpyAsync(dev[c], src[c], LL * nb[c] * 4, hipMemcpyHostToDevice, ctx->stream));
-    }
+    HIPCHK(hipMalloc((void**)&ctx->cur[c], LL * nb[c] * 4));
+    HIPCHK(hipMemcpyAsync(ctx->cur[c], src[c], LL * nb[c] * 4, device_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
   }
-  BuildArgs A;
-  A.L = L; A.use_orient = orient;
-  A.dist = dev[0]; A.omega = dev[1]; A.theta = dev[2]; A.phi = dev[3];
-  A.ebase = prm->ebase; for (int k = 0; k < 3; k++) A.erep[k] = prm->erep[k];
-  A.meff = prm->meff; A.pcut = prm->pcut;
-  for (int k = 0; k < 32; k++) A.bkgr[k] = std::pow((4.25 + prm->dstep * k) / prm->dcut, prm->alpha);
-  A.knots = ctx->knots_d;
-  A.Td = ctx->Td; A.To = ctx->To; A.Tt = ctx->Tt; A.Tp = ctx->Tp;
-  A.pd = ctx->pd; A.po = ctx->po; A.pt = ctx->pt; A.pp = ctx->pp; A.gen = ctx->gen; A.sel = ctx->sel;
-  hipLaunchKernelGGL(k_build_tables, dim3((unsigned)((LL + 127) / 128)), dim3(128), 0, ctx->stream, A);
-  hipLaunchKernelGGL(k_pack_masks, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, ctx->stream, L, ctx->sel, ctx->mask2);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (!device_ptrs)
-    for (int c = 0; c < 4; c++)
-      if (dev[c]) HIPCHK(hipFree(dev[c]));
+  ctx->prm = *prm;
+  if (build_tables(ctx)) return 1;
   if (ctx->child) { HIPCHK(hipStreamSynchronize(ctx->stream)); lend_map(ctx); }  // tables complete before the other stream reads them
   return 0;
 }
@@ -691,19 +706,13 @@ static int fb_reserve(trx2_ctx* ctx, size_t bytes) {
 }
 static size_t al256(size_t n) { return (n + 255) / 256 * 256; }
 
-extern "C" int trx2_feedback_bins(trx2_ctx* ctx, int L, const char* seq, const float* xyz, const double* d_edges, int nd,
-                                  const double* a_edges, int na, const double* p_edges, int np_, double dmax,
-                                  signed char* jd, signed char* jo, signed char* jt, signed char* jp) {
-  if (!ctx) return 1;
-  if (L < 2 || L > 4096 || !seq || !xyz || !d_edges || !a_edges || !p_edges || nd < 1 || nd > 64 || na < 1 || na > 64 || np_ < 1 || np_ > 64 ||
-      !jd || !jo || !jt || !jp || strnlen(seq, (size_t)L) != (size_t)L) {
-    ctx->err = "trx2_feedback_bins: bad arguments (need L residues of sequence and coordinates, edge arrays, four outputs)";
-    return 1;
-  }
-  HIPCHK(hipSetDevice(ctx->device));
+// bins of one decoy on the device; the four [L][L] int8 arrays stay in the context's scratch (returned pointers)
+static int fb_bins_device(trx2_ctx* ctx, int L, const char* seq, const float* xyz, const double* d_edges, int nd, const double* a_edges,
+                          int na, const double* p_edges, int np_, double dmax, size_t extra_bytes, signed char* (&bins)[4], char*& extra) {
   const size_t LL = (size_t)L * L;
   const size_t o_xyz = 0, o_gly = al256((size_t)L * 15 * 4), o_ed = o_gly + al256(L), o_bins = o_ed + al256((size_t)(nd + na + np_) * 8);
-  if (fb_reserve(ctx, o_bins + 4 * al256(LL))) return 1;
+  const size_t o_extra = o_bins + 4 * al256(LL);
+  if (fb_reserve(ctx, o_extra + extra_bytes)) return 1;
   char* base = (char*)ctx->fb_buf;
   std::vector<unsigned char> gly(L);
   for (int i = 0; i < L; i++) gly[i] = seq[i] == 'G';
@@ -712,6 +721,7 @@ extern "C" int trx2_feedback_bins(trx2_ctx* ctx, int L, const char* seq, const f
   HIPCHK(hipMemcpyAsync(base + o_xyz, xyz, (size_t)L * 15 * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(base + o_gly, gly.data(), L, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(base + o_ed, ed.data(), ed.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // the staging vectors above go out of scope
   FbBinsArgs A;
   A.L = L; A.xyz = (const float*)(base + o_xyz); A.gly = (const unsigned char*)(base + o_gly);
   A.d_edges = (const double*)(base + o_ed); A.a_edges = A.d_edges + nd; A.p_edges = A.a_edges + na;
@@ -720,10 +730,87 @@ extern "C" int trx2_feedback_bins(trx2_ctx* ctx, int L, const char* seq, const f
   A.jd = b0; A.jo = b0 + al256(LL); A.jt = b0 + 2 * al256(LL); A.jp = b0 + 3 * al256(LL);
   hipLaunchKernelGGL(k_fb_bins, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, ctx->stream, A);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpyAsync(jd, A.jd, LL, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(jo, A.jo, LL, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(jt, A.jt, LL, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipMemcpyAsync(jp, A.jp, LL, hipMemcpyDeviceToHost, ctx->stream));
+  bins[0] = A.jd; bins[1] = A.jo; bins[2] = A.jt; bins[3] = A.jp;
+  extra = base + o_extra;
+  return 0;
+}
+static bool fb_bins_args_ok(int L, const char* seq, const float* xyz, const double* d_edges, int nd, const double* a_edges, int na,
+                            const double* p_edges, int np_) {
+  return L >= 2 && L <= 4096 && seq && xyz && d_edges && a_edges && p_edges && nd >= 1 && nd <= 64 && na >= 1 && na <= 64 && np_ >= 1 &&
+         np_ <= 64 && strnlen(seq, (size_t)L) == (size_t)L;
+}
+
+extern "C" int trx2_feedback_bins(trx2_ctx* ctx, int L, const char* seq, const float* xyz, const double* d_edges, int nd,
+                                  const double* a_edges, int na, const double* p_edges, int np_, double dmax,
+                                  signed char* jd, signed char* jo, signed char* jt, signed char* jp) {
+  if (!ctx) return 1;
+  if (!fb_bins_args_ok(L, seq, xyz, d_edges, nd, a_edges, na, p_edges, np_) || !jd || !jo || !jt || !jp) {
+    ctx->err = "trx2_feedback_bins: bad arguments (need L residues of sequence and coordinates, edge arrays, four outputs)";
+    return 1;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t LL = (size_t)L * L;
+  signed char* bins[4]; char* extra;
+  if (fb_bins_device(ctx, L, seq, xyz, d_edges, nd, a_edges, na, p_edges, np_, dmax, 0, bins, extra)) return 1;
+  signed char* out[4] = {jd, jo, jt, jp};
+  for (int c = 0; c < 4; c++) HIPCHK(hipMemcpyAsync(out[c], bins[c], LL, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// One feedback iteration on the RESIDENT distograms of the context (those of the last trx2_set_map, or of the previous
+// step): bins of the decoy, the cumulative `tmp` array (from the previous tmp, or from dist the first time), the
+// re-weighted channels, and new restraint tables -- what run_inference.py:75-131 does between two folds, with nothing but
+// the decoy's coordinates going in and one float coming back.
+extern "C" int trx2_feedback_step(trx2_ctx* ctx, const char* seq, const float* xyz, const double* d_edges, int nd,
+                                  const double* a_edges, int na, const double* p_edges, int np_, double dmax, const double* w9,
+                                  int angle, float* max_tmp_change) {
+  if (!ctx) return 1;
+  const int L = ctx->L;
+  if (!L || !ctx->cur[0] || ctx->borrows_map) { ctx->err = "trx2_feedback_step: set a map first"; return 1; }
+  if (!fb_bins_args_ok(L, seq, xyz, d_edges, nd, a_edges, na, p_edges, np_) || !w9) { ctx->err = "trx2_feedback_step: bad arguments"; return 1; }
+  if (angle && !ctx->use_orient) { ctx->err = "trx2_feedback_step: angle channels requested but the map has none"; return 1; }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (ctx->child && ctx->child->stream) HIPCHK(hipStreamSynchronize(ctx->child->stream));  // it reads the tables rebuilt below
+  const size_t LL = (size_t)L * L;
+  signed char* bins[4]; char* extra;
+  if (fb_bins_device(ctx, L, seq, xyz, d_edges, nd, a_edges, na, p_edges, np_, dmax, 256, bins, extra)) return 1;
+  unsigned* dmax_bits = (unsigned*)extra;
+  HIPCHK(hipMemsetAsync(dmax_bits, 0, 4, ctx->stream));
+  const int nb[4] = {TRX2_ND_BINS, TRX2_NO_BINS, TRX2_NO_BINS, TRX2_NP_BINS};
+  auto process = [&](const float* in, float* out, int K, const signed char* b, int norm, unsigned* diff) {
+    FbProcArgs A;
+    A.L = L; A.K = K; A.norm = norm; A.smooth = norm; A.in = in; A.out = out; A.bins = b; A.max_diff_bits = diff;
+    memcpy(A.w, w9, sizeof A.w);
+    hipLaunchKernelGGL(k_fb_process, dim3((unsigned)((LL + 127) / 128)), dim3(128), 0, ctx->stream, A);
+  };
+  // tmp first: the first time its base is the dist array BEFORE this step re-weights it (run_inference.py:101-102, R11)
+  if (!ctx->tmp_alt) HIPCHK(hipMalloc((void**)&ctx->tmp_alt, LL * nb[0] * 4));
+  process(ctx->has_tmp ? ctx->tmp_cur : ctx->cur[0], ctx->tmp_alt, nb[0], bins[0], 0, dmax_bits);
+  { float* t = ctx->tmp_cur; ctx->tmp_cur = ctx->tmp_alt; ctx->tmp_alt = t; ctx->has_tmp = true; }
+  // channels: dist with jd; with angles omega with jo, theta with jt, phi with jp (= theta on phi's edges)
+  const int chan_bins[4] = {0, 1, 2, 3};
+  for (int c = 0; c < (angle ? 4 : 1); c++) {
+    if (!ctx->alt[c]) HIPCHK(hipMalloc((void**)&ctx->alt[c], LL * nb[c] * 4));
+    process(ctx->cur[c], ctx->alt[c], nb[c], bins[chan_bins[c]], 1, nullptr);
+    float* t = ctx->cur[c]; ctx->cur[c] = ctx->alt[c]; ctx->alt[c] = t;
+  }
+  HIPCHK(hipGetLastError());
+  unsigned bits = 0;
+  HIPCHK(hipMemcpyAsync(&bits, dmax_bits, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (max_tmp_change) memcpy(max_tmp_change, &bits, 4);
+  return build_tables(ctx);
+}
+
+// current resident distogram: channel 0..3 = dist, omega, theta, phi; 4 = the cumulative tmp array (after a feedback step)
+extern "C" int trx2_get_map(trx2_ctx* ctx, int channel, float* out) {
+  if (!ctx) return 1;
+  const int nb[5] = {TRX2_ND_BINS, TRX2_NO_BINS, TRX2_NO_BINS, TRX2_NP_BINS, TRX2_ND_BINS};
+  const float* src = (channel >= 0 && channel < 4) ? ctx->cur[channel] : (channel == 4 && ctx->has_tmp ? ctx->tmp_cur : nullptr);
+  if (!ctx->L || !src || !out) { ctx->err = "trx2_get_map: no such resident array"; return 1; }
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(out, src, (size_t)ctx->L * ctx->L * nb[channel] * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
@@ -742,6 +829,7 @@ extern "C" int trx2_feedback_process(trx2_ctx* ctx, int L, int K, const float* i
   FbProcArgs A;
   A.L = L; A.K = K; A.norm = norm; A.smooth = smooth;
   A.in = (const float*)base; A.out = (float*)(base + al256(nb)); A.bins = (const signed char*)(base + 2 * al256(nb));
+  A.max_diff_bits = nullptr;
   memcpy(A.w, w9, sizeof A.w);
   HIPCHK(hipMemcpyAsync(base, in, nb, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(base + 2 * al256(nb), bins, LL, hipMemcpyHostToDevice, ctx->stream));

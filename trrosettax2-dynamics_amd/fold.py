@@ -103,6 +103,25 @@ def folding_with_pred_npz(base_npz, base_fasta, base_out, out_name, options="-m 
     return r
 
 
+def fold_resident_to_pdb(ctx, seq, base_out, names, options="", seed=None, decoy0=0):
+    """fold_arrays_to_pdb for the map already resident in `ctx` (after Context.feedback_step): no upload, no table build"""
+    args = parse_options(options)
+    if ctx.L != len(seq) or bool(ctx.use_orient) != bool(args.use_orient):
+        raise ValueError("the resident map does not match the sequence / the --orient option")
+    if seed is None:
+        with _SEED_LOCK:
+            seed = _SEED[0]
+            _SEED[0] += 1
+    os.makedirs(base_out, exist_ok=True)
+    r = ctx.fold_batch(len(names), protocol.build_runs(len(seq), args.mode), seed=seed, decoy0=decoy0)
+    bad = np.nonzero((r["status"] != 0) | ~np.isfinite(r["xyz"]).all(axis=(1, 2, 3)))[0]
+    if len(bad):
+        raise RuntimeError(f"fold failed for decoys {bad.tolist()} (status {r['status'][bad].tolist()})")
+    for k, name in enumerate(names):
+        write_pdb(os.path.join(base_out, name), seq, r["xyz"][k], remarks=[f"trx2fold decoy {k} seed {seed} evals {int(r['n_evals'][k])}"])
+    return r
+
+
 def fold_arrays_to_pdb(arrays, seq, base_out, names, options="", device=0, seed=None, decoy0=0, lanes=2):
     """folding_with_pred_npz for distograms already in memory: writes base_out/name for every name"""
     os.makedirs(base_out, exist_ok=True)

@@ -21,7 +21,7 @@ import numpy as np
 
 from . import sched
 from .feedback import calculate_reliability_score, feedback_labels
-from .fold import fold_arrays_to_pdb, get_context
+from .fold import fold_arrays_to_pdb, fold_resident_to_pdb, get_context
 from .pdbio import read_backbone, read_fasta
 
 
@@ -38,10 +38,15 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     those files any more, and even uncompressed they cost 9 ms of a 50 ms iteration: they are written only with
     write_tmp_npz=True (`run_inference.py --keep_tmp_npz`).
 
-    device_feedback: the feedback step (decoy -> bins -> re-weighted distograms) runs on the GPU (Context.feedback_labels,
-    csrc/kernel_feedback.h) instead of in numpy (feedback.feedback_labels, 20 ms per iteration at L=90).  Tested bitwise
-    equal to the numpy path, which is pinned bit for bit to the reference; sigma other than 1 falls back to numpy."""
+    device_feedback: the feedback step (decoy -> bins -> re-weighted distograms) runs on the GPU (csrc/kernel_feedback.h)
+    instead of in numpy (feedback.feedback_labels, 20 ms per iteration at L=90).  True: on the distograms RESIDENT in the
+    fold context (Context.feedback_step: only the decoy's coordinates go in, the convergence measure comes back, the next
+    fold uses the rebuilt tables without any upload).  "arrays": same kernels on host arrays (Context.feedback_labels).
+    Both are tested bitwise equal to the numpy path, which is pinned bit for bit to the reference; sigma other than 1
+    falls back to numpy."""
     os.makedirs(processed_npz_dir, exist_ok=True)
+
+    resident = device_feedback is True and float(sigma) == 1.0
 
     def feedback(arrays, pdb):
         if device_feedback and float(sigma) == 1.0:
@@ -62,6 +67,29 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
             best_score, best_pdb = score, pdb
 
     pattern = os.path.join(processed_npz_dir, pdb_name + "{}.npz")
+    if resident:
+        # The initial batch left its map in this thread's context.  From here on the distograms never leave the device.
+        ctx = get_context(device, lanes)
+
+        def step(pdb, k):
+            xyz, s_pdb = read_backbone(pdb)                 # the decoy as the reference sees it: through its PDB file
+            delta = ctx.feedback_step(xyz, s_pdb, sigma, angle)
+            if write_tmp_npz:
+                np.savez(pattern.format(k), **{c: ctx.get_map(c) for c in ((("dist", "theta", "omega", "phi") if angle else ("dist",)) + ("tmp",))})
+            return delta
+
+        step(best_pdb, begin_num + 1)
+        iter_n = begin_num
+        while True:
+            iter_n += 1
+            print(f"Start generating structure {iter_n}")
+            fold_resident_to_pdb(ctx, seq, pred_pdb_dir, [f"{pdb_name}{iter_n}.pdb"], tta_opt, seed=None if seed is None else seed + iter_n)
+            print("Done generating structure", iter_n)
+            if iter_n - begin_num >= Nmax:
+                break
+            if step(os.path.join(pred_pdb_dir, f"{pdb_name}{iter_n}.pdb"), iter_n + 1) < 0.01:
+                break
+        return iter_n
     base = {k: init[k] for k in (("dist", "theta", "omega", "phi") if angle else ("dist",))}   # no "tmp": falls back to dist
     old_tmp = init["dist"]
     cur = feedback(base, best_pdb)
