@@ -139,3 +139,24 @@ def test_single_parse_feedback_equals_the_two_reference_calls(golden_dir, tmp_pa
     want2 = dict(zip(("dist", "omega", "theta", "phi"), ref2)) if angle else {"dist": ref2}
     want2["tmp"] = F.get_npz_from_pred_pdb(it2, pdb2, tmp=True, angle=angle)
     assert all(np.array_equal(lab2[k], want2[k]) for k in want2)
+
+
+def test_pdb_round_trip_without_the_file(tmp_path, golden_dir):
+    """pdbio.as_read_from_pdb(seq, xyz) must equal read_backbone(write_pdb(seq, xyz)) bit for bit: the device feedback
+    consumes the decoy "as the reference sees it" without reading the file back.  Includes exact .0005 ties and glycine."""
+    P = importlib.import_module("trrosettax2-dynamics_amd.pdbio")
+    rng = np.random.default_rng(3)
+    seq = "GASTGVLKDEGNQRHFWYCMPI" * 4
+    xyz = (rng.normal(size=(len(seq), 5, 3)) * 30).astype(np.float32)
+    ties = np.array([0.0005, -0.0005, 1.0005, 2.0015, -3.0025, 12.3455, 0.0, -0.0, 123.4565, -99.9995, 7.1245, 0.00049999], np.float32)
+    xyz.reshape(-1)[:len(ties)] = ties
+    xyz.reshape(-1)[40:52] = (np.arange(12) * 0.001 + 0.0005).astype(np.float32)
+    path = str(tmp_path / "x.pdb")
+    P.write_pdb(path, seq, xyz)
+    a, sa = P.read_backbone(path)
+    b, sb = P.as_read_from_pdb(seq, xyz)
+    assert sa == sb == seq
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.isnan(a).sum() == 3 * seq.count("G")
+    assert np.array_equal(np.nan_to_num(a).view(np.uint32), np.nan_to_num(b).view(np.uint32))     # bits, including signed zeros
+    with pytest.raises(ValueError):
+        P.as_read_from_pdb("A@A", xyz[:3])

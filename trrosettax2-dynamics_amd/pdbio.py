@@ -61,6 +61,19 @@ def write_pdb(path, seq, xyz, remarks=()):
     os.replace(tmp, path)
 
 
+def as_read_from_pdb(seq, xyz):
+    """What read_backbone(path) returns for a file write_pdb(path, seq, xyz) has written, without the file: coordinates after
+    the "%8.3f" round trip (float32 -> exact double -> nearest multiple of 0.001, ties to even as the formatter does ->
+    nearest double -> float32; x * 1000 is exact in double for a float32 x) and NaN for glycine's absent CB.  Standard
+    residues only (the writer's UNK records are skipped by the reader)."""
+    if any(a.upper() not in AA3 for a in seq):
+        raise ValueError("non-standard residue: parse the file instead")
+    v = np.rint(np.asarray(xyz, np.float32).astype(np.float64) * 1000.0) / 1000.0
+    out = v.astype(np.float32)
+    out[np.array([a.upper() == "G" for a in seq]), ATOMS.index("CB")] = np.nan
+    return out, "".join(a.upper() for a in seq)
+
+
 def read_backbone(path):
     """-> (xyz[L,5,3] float32 with NaN for absent atoms, one-letter sequence)"""
     rows, names, index = [], [], {}

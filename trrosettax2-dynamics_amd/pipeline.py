@@ -22,7 +22,7 @@ import numpy as np
 from . import sched
 from .feedback import calculate_reliability_score, feedback_labels
 from .fold import fold_arrays_to_pdb, fold_resident_to_pdb, get_context
-from .pdbio import read_backbone, read_fasta
+from .pdbio import as_read_from_pdb, read_backbone, read_fasta
 
 
 def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz, fasta, N=10, Nmax=500, begin_num=0,
@@ -57,37 +57,38 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     seq = read_fasta(fasta)
     init = dict(np.load(initial_npz))
     print("Start generating the initial structures")
-    fold_arrays_to_pdb(init, seq, pred_pdb_dir, [f"initial{i}.pdb" for i in range(N)], tta_opt, device=device, seed=seed, lanes=lanes)
+    r_init = fold_arrays_to_pdb(init, seq, pred_pdb_dir, [f"initial{i}.pdb" for i in range(N)], tta_opt, device=device, seed=seed, lanes=lanes)
     print("Done generating initial structures")
-    best_score, best_pdb = -np.inf, None
+    best_score, best_pdb, best_i = -np.inf, None, 0
     for i in range(N):                                   # strict '>' : the first maximum wins (run_inference.py:67)
         pdb = os.path.join(pred_pdb_dir, f"initial{i}.pdb")
         score = calculate_reliability_score(pdb)
         if score > best_score:
-            best_score, best_pdb = score, pdb
+            best_score, best_pdb, best_i = score, pdb, i
 
     pattern = os.path.join(processed_npz_dir, pdb_name + "{}.npz")
     if resident:
         # The initial batch left its map in this thread's context.  From here on the distograms never leave the device.
         ctx = get_context(device, lanes)
 
-        def step(pdb, k):
-            xyz, s_pdb = read_backbone(pdb)                 # the decoy as the reference sees it: through its PDB file
+        def step(xyz_fold, k):
+            # the decoy as the reference sees it -- through its PDB file -- without reading the file back
+            xyz, s_pdb = as_read_from_pdb(seq, xyz_fold)
             delta = ctx.feedback_step(xyz, s_pdb, sigma, angle)
             if write_tmp_npz:
                 np.savez(pattern.format(k), **{c: ctx.get_map(c) for c in ((("dist", "theta", "omega", "phi") if angle else ("dist",)) + ("tmp",))})
             return delta
 
-        step(best_pdb, begin_num + 1)
+        step(r_init["xyz"][best_i], begin_num + 1)
         iter_n = begin_num
         while True:
             iter_n += 1
             print(f"Start generating structure {iter_n}")
-            fold_resident_to_pdb(ctx, seq, pred_pdb_dir, [f"{pdb_name}{iter_n}.pdb"], tta_opt, seed=None if seed is None else seed + iter_n)
+            r = fold_resident_to_pdb(ctx, seq, pred_pdb_dir, [f"{pdb_name}{iter_n}.pdb"], tta_opt, seed=None if seed is None else seed + iter_n)
             print("Done generating structure", iter_n)
             if iter_n - begin_num >= Nmax:
                 break
-            if step(os.path.join(pred_pdb_dir, f"{pdb_name}{iter_n}.pdb"), iter_n + 1) < 0.01:
+            if step(r["xyz"][0], iter_n + 1) < 0.01:
                 break
         return iter_n
     base = {k: init[k] for k in (("dist", "theta", "omega", "phi") if angle else ("dist",))}   # no "tmp": falls back to dist
