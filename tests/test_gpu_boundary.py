@@ -199,3 +199,30 @@ def test_two_lanes_fold_the_two_halves_of_a_batch(golden_dir, seq):
     with pytest.raises(RuntimeError):
         one.set_lanes(3)
     one.close(); two.close()
+
+
+def test_batch_mode_command_line_on_one_rank(golden_dir, tmp_path):
+    """`run_inference.py --fasta_dir D --name_lst names.txt --save_dir out` (run_inference.py:339-348): two targets whose
+    distograms are already in place, one model each, through the real fold; a third name without a distogram must be reported
+    and turn the exit code non-zero while the other two finish."""
+    import shutil
+    RI = importlib.import_module("run_inference")
+    fasta_dir, save = tmp_path / "fa", tmp_path / "out"
+    fasta_dir.mkdir()
+    for name in ("t1", "t2", "missing"):
+        shutil.copyfile(os.path.join(golden_dir, "seq.fasta"), fasta_dir / f"{name}.fasta")
+    for name in ("t1", "t2"):
+        os.makedirs(save / name / "pred_npz")
+        shutil.copyfile(os.path.join(golden_dir, "seq_NMR.npz"), save / name / "pred_npz" / f"{name}_NMR.npz")
+    (tmp_path / "names.txt").write_text("t1\nt2\nmissing\n")
+    rc = RI.main(["--fasta_dir", str(fasta_dir), "--name_lst", str(tmp_path / "names.txt"), "--save_dir", str(save), "--init_num", "2",
+                  "--Nmax", "2", "--no-mult_two_models", "--seed", "4"])
+    assert rc == 1                                                     # "missing" has no distogram
+    for name in ("t1", "t2"):
+        files = sorted(os.listdir(save / name / "pred_pdb"))
+        assert len(files) in (3, 4) and all(f.startswith("conf_") for f in files), files   # 2 initial + 1 or 2 iterations
+    assert not os.path.exists(save / "missing" / "pred_pdb" / "conf_1_1.pdb")
+    # same seed, same outputs: the two targets share the map and the seed
+    a = open(save / "t1" / "pred_pdb" / sorted(os.listdir(save / "t1" / "pred_pdb"))[0]).read()
+    b = open(save / "t2" / "pred_pdb" / sorted(os.listdir(save / "t2" / "pred_pdb"))[0]).read()
+    assert a == b
