@@ -161,8 +161,10 @@ def main():
     # ---- G3 / G4: feedback -----------------------------------------------------------------------------
     # provenance: conf_2_1 = NMR/initial0, conf_1_1 = Xray/initial0
     for tag, decoy in (("NMR", "conf_2_1"), ("Xray", "conf_1_1")):
-        xyz = dec[decoy].astype(np.float64)  # what Biopython would hand over (float32 coords -> arrays)
-        xyzs = {"N": dec[decoy][:, 0], "CA": dec[decoy][:, 1], "C": dec[decoy][:, 2], "CB": dec[decoy][:, 4]}
+        # What get_atom_positions_pdb hands over (utils.py:252-291): float64 arrays (np.nan * np.zeros) holding Biopython's
+        # float32 coordinates -- so the reference's geometry arithmetic runs in float64.
+        xyz = dec[decoy].astype(np.float64)
+        xyzs = {"N": xyz[:, 0], "CA": xyz[:, 1], "C": xyz[:, 2], "CB": xyz[:, 4]}
         import io, contextlib
         with contextlib.redirect_stdout(io.StringIO()):
             key, d6, o6, t6, p6 = U.get_neighbors({k: v.copy() for k, v in xyzs.items()}, seq, 20)

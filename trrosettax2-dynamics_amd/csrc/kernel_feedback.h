@@ -4,10 +4,11 @@
 // =================================================================================================
 // K7: decoy -> realised 6-D geometry -> bins (utils_trX2dy/utils.py:125-235) and the re-weighting of a distogram
 // channel with those bins (utils.py:379-403).  The host-side mirror (feedback.py) is bit-identical to the reference; these
-// kernels repeat ITS arithmetic: float32 where numpy computes in float32, in numpy's operation order with no fused
-// multiply-add, float64 for the neighbour test and inside the Gaussian filter as scipy does.  What cannot be promised
-// bit for bit is atan2f (glibc vs the device library, last ulp): a value within one ulp of a bin edge may fall on the
-// other side.  The parity test counts such pairs (none seen) and compares everything else exactly.
+// kernels repeat ITS arithmetic in numpy's operation order with no fused multiply-add: float64 geometry (on float32-valued
+// coordinates, as the reference's reader hands them over), float32 for the distogram rows with numpy's pairwise sums,
+// float64 inside the Gaussian filter as scipy does.  What cannot be promised bit for bit is atan2 (glibc vs the device
+// library, last ulp): a value within one ulp of a bin edge may fall on the other side.  The parity test counts such pairs
+// (none seen) and compares everything else exactly.
 // =================================================================================================
 struct FbBinsArgs {
   int L;
@@ -19,33 +20,38 @@ struct FbBinsArgs {
   signed char *jd, *jo, *jt, *jp;  // [L][L]
 };
 
-struct v3f { float x, y, z; };
+// Geometry in float64 on float32-valued coordinates: the reference's reader fills float64 arrays with Biopython's float32
+// coordinates (utils.py:270,283), so get_neighbors computes in float64.
+struct v3d { double x, y, z; };
 #pragma clang fp contract(off)
-__device__ __forceinline__ v3f fb_sub(v3f a, v3f b) { return v3f{a.x - b.x, a.y - b.y, a.z - b.z}; }
-__device__ __forceinline__ float fb_sum3(float a, float b, float c) { return (a + b) + c; }          // np.sum over an axis of 3
-__device__ __forceinline__ float fb_dot(v3f a, v3f b) { return fb_sum3(a.x * b.x, a.y * b.y, a.z * b.z); }
-__device__ __forceinline__ v3f fb_cross(v3f a, v3f b) {  // np.cross: multiply, multiply, subtract
-  return v3f{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+__device__ __forceinline__ v3d fb_sub(v3d a, v3d b) { return v3d{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ double fb_sum3(double a, double b, double c) { return (a + b) + c; }       // np.sum over an axis of 3
+__device__ __forceinline__ double fb_dot(v3d a, v3d b) { return fb_sum3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ v3d fb_cross(v3d a, v3d b) {  // np.cross: multiply, multiply, subtract
+  return v3d{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-__device__ __forceinline__ float fb_norm(v3f a) { return __fsqrt_rn(fb_dot(a, a)); }                    // np.linalg.norm, float32
-// get_dihedrals (utils.py:97-110) in float32
-__device__ __forceinline__ float fb_dihedral(v3f a, v3f b, v3f c, v3f d) {
-  v3f t = fb_sub(b, a);
-  v3f b0 = v3f{-1.0f * t.x, -1.0f * t.y, -1.0f * t.z}, b1 = fb_sub(c, b), b2 = fb_sub(d, c);
-  const float n = fb_norm(b1);
-  b1 = v3f{b1.x / n, b1.y / n, b1.z / n};
-  const float s0 = fb_dot(b0, b1), s2 = fb_dot(b2, b1);
-  const v3f v = v3f{b0.x - s0 * b1.x, b0.y - s0 * b1.y, b0.z - s0 * b1.z};
-  const v3f w = v3f{b2.x - s2 * b1.x, b2.y - s2 * b1.y, b2.z - s2 * b1.z};
-  const float x = fb_dot(v, w), y = fb_dot(fb_cross(b1, v), w);
-  return atan2f(y, x);
+__device__ __forceinline__ double fb_norm(v3d a) { return __dsqrt_rn(fb_dot(a, a)); }                   // np.linalg.norm
+// get_dihedrals (utils.py:97-110)
+__device__ __forceinline__ double fb_dihedral(v3d a, v3d b, v3d c, v3d d) {
+  v3d t = fb_sub(b, a);
+  v3d b0 = v3d{-1.0 * t.x, -1.0 * t.y, -1.0 * t.z}, b1 = fb_sub(c, b), b2 = fb_sub(d, c);
+  const double n = fb_norm(b1);
+  b1 = v3d{b1.x / n, b1.y / n, b1.z / n};
+  const double s0 = fb_dot(b0, b1), s2 = fb_dot(b2, b1);
+  const v3d v = v3d{b0.x - s0 * b1.x, b0.y - s0 * b1.y, b0.z - s0 * b1.z};
+  const v3d w = v3d{b2.x - s2 * b1.x, b2.y - s2 * b1.y, b2.z - s2 * b1.z};
+  const double x = fb_dot(v, w), y = fb_dot(fb_cross(b1, v), w);
+  return atan2(y, x);
 }
-__device__ __forceinline__ v3f fb_cbeta(const FbBinsArgs& A, int i) {
-  const float* p = A.xyz + (size_t)i * 15;
-  const v3f N{p[0], p[1], p[2]}, Ca{p[3], p[4], p[5]}, C{p[6], p[7], p[8]}, real{p[12], p[13], p[14]};
-  const v3f b = fb_sub(Ca, N), c = fb_sub(C, Ca), a = fb_cross(b, c);
-  const float k0 = -0.58273431f, k1 = 0.56802827f, k2 = -0.54067466f;  // utils.py:135, as float32 like numpy's weak scalars
-  const v3f virt{((k0 * a.x + k1 * b.x) + k2 * c.x) + Ca.x, ((k0 * a.y + k1 * b.y) + k2 * c.y) + Ca.y, ((k0 * a.z + k1 * b.z) + k2 * c.z) + Ca.z};
+__device__ __forceinline__ v3d fb_atom(const FbBinsArgs& A, int i, int k) {
+  const float* p = A.xyz + (size_t)i * 15 + k * 3;
+  return v3d{(double)p[0], (double)p[1], (double)p[2]};
+}
+__device__ __forceinline__ v3d fb_cbeta(const FbBinsArgs& A, int i) {
+  const v3d N = fb_atom(A, i, 0), Ca = fb_atom(A, i, 1), C = fb_atom(A, i, 2), real = fb_atom(A, i, 4);
+  const v3d b = fb_sub(Ca, N), c = fb_sub(C, Ca), a = fb_cross(b, c);
+  const double k0 = -0.58273431, k1 = 0.56802827, k2 = -0.54067466;  // utils.py:135
+  const v3d virt{((k0 * a.x + k1 * b.x) + k2 * c.x) + Ca.x, ((k0 * a.y + k1 * b.y) + k2 * c.y) + Ca.y, ((k0 * a.z + k1 * b.z) + k2 * c.z) + Ca.z};
   const bool use = !A.gly[i] && isfinite(real.x) && isfinite(real.y) && isfinite(real.z);
   return use ? real : virt;
 }
@@ -60,21 +66,19 @@ __global__ void k_fb_bins(FbBinsArgs A) {
   const int i = (int)(ij / A.L), j = (int)(ij % A.L);
   int jd = 0, jo = 0, jt = 0, jp = 0;
   if (i != j) {
-    const v3f cbi = fb_cbeta(A, i), cbj = fb_cbeta(A, j);
-    const double dx = (double)cbi.x - (double)cbj.x, dy = (double)cbi.y - (double)cbj.y, dz = (double)cbi.z - (double)cbj.z;
+    const v3d cbi = fb_cbeta(A, i), cbj = fb_cbeta(A, j);
+    const double dx = cbi.x - cbj.x, dy = cbi.y - cbj.y, dz = cbi.z - cbj.z;
     const double d2 = (dx * dx + dy * dy) + dz * dz;
     if (d2 <= A.dmax2) {
-      const float* pi_ = A.xyz + (size_t)i * 15;
-      const float* pj_ = A.xyz + (size_t)j * 15;
-      const v3f Ni{pi_[0], pi_[1], pi_[2]}, Cai{pi_[3], pi_[4], pi_[5]}, Caj{pj_[3], pj_[4], pj_[5]};
-      const float dist = fb_norm(fb_sub(cbj, cbi));
-      jd = fb_count(A.d_edges, A.nd, (double)dist);
+      const v3d Ni = fb_atom(A, i, 0), Cai = fb_atom(A, i, 1), Caj = fb_atom(A, j, 1);
+      const double dist = fb_norm(fb_sub(cbj, cbi));
+      jd = fb_count(A.d_edges, A.nd, dist);
       if (jd >= 37) jd = 0;
       if (jd != 0) {
-        const float om = fb_dihedral(Cai, cbi, cbj, Caj), th = fb_dihedral(Ni, Cai, cbi, cbj);
-        jo = fb_count(A.a_edges, A.na, (double)om);
-        jt = fb_count(A.a_edges, A.na, (double)th);
-        jp = fb_count(A.p_edges, A.np_, (double)th);  // the reference bins THETA on phi's edges (utils.py:226)
+        const double om = fb_dihedral(Cai, cbi, cbj, Caj), th = fb_dihedral(Ni, Cai, cbi, cbj);
+        jo = fb_count(A.a_edges, A.na, om);
+        jt = fb_count(A.a_edges, A.na, th);
+        jp = fb_count(A.p_edges, A.np_, th);  // the reference bins THETA on phi's edges (utils.py:226)
       }
     }
   }

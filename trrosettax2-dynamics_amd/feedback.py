@@ -45,7 +45,10 @@ def get_angles(a, b, c):
 def get_neighbors(xyz, seq, dmax=DMAX):
     """xyz[L,5,3] (N CA C O CB) -> dense dist6d, omega6d, theta6d, phi6d [L,L], 0 outside dmax (utils.py:125-182).
     C-beta: the real atom for non-Gly residues, the virtual one (utils.py:132-135) for Gly or when the atom is absent
-    (the reference drops such rows from its KD-tree and mis-indexes; this package's decoys always carry CB)."""
+    (the reference drops such rows from its KD-tree and mis-indexes; this package's decoys always carry CB).
+    Arithmetic in float64: the reference's reader fills float64 arrays (np.nan * np.zeros, utils.py:270) with Biopython's
+    float32 coordinates, so its geometry runs in float64 on float32-valued inputs -- read_backbone's float32 is widened here."""
+    xyz = np.asarray(xyz).astype(np.float64)
     N, Ca, C = xyz[:, 0], xyz[:, 1], xyz[:, 2]
     L = len(Ca)
     if L != len(seq):
