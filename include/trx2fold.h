@@ -114,6 +114,12 @@ int trx2_feedback_step(trx2_ctx* ctx, const char* seq, const float* xyz, const d
                        int na, const double* p_edges, int np_, double dmax, const double* w9, int angle, float* max_tmp_change);
 int trx2_get_map(trx2_ctx* ctx, int channel, float* out);
 
+/* GloCon matrix for clustering (get_glocon_matrix, utils_trX2dy/utils.py:543-569): for every pair of n
+ * decoys of the same length, the sum over the upper triangle of |dist6d_p - dist6d_q| with differences <= 3 A dropped,
+ * divided by L (L - 1) / 2; dist6d = C-beta distances within dmax (20), 0 elsewhere, as get_neighbors builds them.
+ * seqs = n * L one-letter codes (glycines get the virtual C-beta), xyz[n][L][5][3] as read from the PDB files, out[n][n]. */
+int trx2_glocon_matrix(trx2_ctx* ctx, int n, int L, const char* seqs, const float* xyz, double dmax, double* out);
+
 /* measurement helper (bench.py roofline leg): replays the pair-energy kernel n_rep times on the ctx stream
  * for the coordinates of the last eval/fold batch and returns the average launch duration in milliseconds
  * measured with hipEvents on that stream, plus the number of selected term-evaluations per launch. */

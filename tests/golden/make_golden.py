@@ -14,6 +14,7 @@ Fixtures written:
   feedback_{NMR,Xray}.npz                     G3+G4: get_neighbors / pros / process_distribution outputs
   random_dihedral.json                        G5: random_dihedral() draws under random.seed(s)
   constants.json                              G6: params.json + *.wts (data)
+  glocon.json                                 G7: get_glocon_matrix() on the 8 committed example decoys
 """
 import hashlib
 import json
@@ -190,6 +191,28 @@ def main():
             save[f"{ch}_sum"] = np.float64(arr.astype(np.float64).sum())
         np.savez_compressed(os.path.join(OUT, f"feedback_{tag}.npz"), **save)
         print(tag, "feedback", {k: str(v.dtype) for k, v in outs.items()})
+
+    # ---- G7: GloCon matrix of the reference's own 8 example decoys (utils.py:543-569) ----------------------------
+    # The reference's function is called as is; only its PDB reader (Biopython, absent) is replaced by one that returns
+    # what get_atom_positions_pdb returns: float64 arrays holding float32 coordinates, the residue ids, the sequence.
+    ex_pdb = os.path.join(REF, "example", "output", "seq", "pred_pdb")
+    res1 = {"ALA": "A", "ARG": "R", "ASN": "N", "ASP": "D", "CYS": "C", "GLN": "Q", "GLU": "E", "GLY": "G", "HIS": "H", "ILE": "I",
+            "LEU": "L", "LYS": "K", "MET": "M", "PHE": "F", "PRO": "P", "SER": "S", "THR": "T", "TRP": "W", "TYR": "Y", "VAL": "V"}
+
+    def reader(pdb_file, model=0, retain_all_res=True):
+        xyz, names = parse_pdb_backbone(pdb_file)
+        xyz = xyz.astype(np.float32).astype(np.float64)
+        return {"N": xyz[:, 0], "CA": xyz[:, 1], "C": xyz[:, 2], "CB": xyz[:, 4]}, np.arange(len(xyz)), "".join(res1[n] for n in names)
+
+    U.get_atom_positions_pdb = reader
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        gm, gfiles = U.get_glocon_matrix(ex_pdb)
+    order = np.argsort(gfiles)
+    gm = gm[np.ix_(order, order)]
+    json.dump({"files": [gfiles[i] for i in order], "matrix": [[float.hex(float(v)) for v in row] for row in gm]},
+              open(os.path.join(OUT, "glocon.json"), "w"), indent=1)
+    print("glocon", [gfiles[i] for i in order], np.round(gm[0], 4))
 
     # ---- G5: random_dihedral ---------------------------------------------------------------------------
     rd = {}

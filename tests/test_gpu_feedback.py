@@ -113,3 +113,19 @@ def test_resident_feedback_chain_equals_the_host_chain(golden_dir, tmp_path):
         za, zb = np.load(tmp_path / "a" / "tmp" / f), np.load(tmp_path / "b" / "tmp" / f)
         assert sorted(za.files) == sorted(zb.files) == ["dist", "tmp"] and all(np.array_equal(za[k], zb[k]) for k in za.files)
     assert open(tmp_path / "a" / "pdb" / f"t{a}.pdb").read() == open(tmp_path / "b" / "pdb" / f"t{b}.pdb").read()
+
+
+def test_device_glocon_matrix_equals_host(golden_dir, seq, tmp_path):
+    """trx2_glocon_matrix sums in numpy's pairwise order: bitwise the host matrix (which is pinned to the reference's)"""
+    CL = importlib.import_module("trrosettax2-dynamics_amd.cluster")
+    ref = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    d = tmp_path / "pdb"
+    d.mkdir()
+    for name in ("conf_1_1", "conf_1_2", "conf_1_3", "conf_1_4", "conf_2_1", "conf_2_2", "conf_2_3", "conf_2_4"):
+        P.write_pdb(str(d / f"{name}.pdb"), seq, np.nan_to_num(ref[name].astype(np.float32)))
+    host, files = CL.get_glocon_matrix(str(d))
+    dev, files2 = CL.get_glocon_matrix(str(d), device=0)
+    assert files == files2 and np.array_equal(host, dev), np.abs(host - dev).max()
+    assert np.allclose(np.diag(dev), 0) and np.array_equal(dev, dev.T)
+    out = CL.save_cluster_result(str(d), n_clusters=2, n_files=2, mode="glocon", device=0)
+    assert sorted(len(v) for v in out.values()) == [4, 4]

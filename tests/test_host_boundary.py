@@ -160,3 +160,26 @@ def test_pdb_round_trip_without_the_file(tmp_path, golden_dir):
     assert np.array_equal(np.nan_to_num(a).view(np.uint32), np.nan_to_num(b).view(np.uint32))     # bits, including signed zeros
     with pytest.raises(ValueError):
         P.as_read_from_pdb("A@A", xyz[:3])
+
+
+def test_glocon_matrix_is_bit_identical_to_reference(golden_dir, tmp_path, seq):
+    """cluster.get_glocon_matrix (utils_trX2dy/utils.py:543-569) on the reference's eight example decoys against the matrix its
+    own function returned (tests/golden/glocon.json: get_glocon_matrix called as is, only the Biopython reader substituted);
+    plus the RMSD matrix against SURVEY.md section 4 and the clustering front end."""
+    import json
+    CL = importlib.import_module("trrosettax2-dynamics_amd.cluster")
+    g = json.load(open(os.path.join(golden_dir, "glocon.json")))
+    d = tmp_path / "pdb"
+    d.mkdir()
+    for f in g["files"]:
+        decoy_pdb(golden_dir, d, seq, f[:-4])
+    m, got_files = CL.get_glocon_matrix(str(d))
+    assert got_files == g["files"]                                             # sorted order on both sides
+    want = np.array([[float.fromhex(v) for v in row] for row in g["matrix"]])
+    assert np.array_equal(m, want)
+    r, _ = CL.get_rmsd_matrix(str(d))
+    assert abs(r[0, 1] - 0.62) < 0.01 and abs(r[4, 5] - 0.86) < 0.01          # SURVEY.md section 4: conf_1_1/1_2, conf_2_1/2_2
+    out = CL.save_cluster_result(str(d), n_clusters=2, n_files=1, mode="glocon")
+    assert sorted(len(v) for v in out.values()) == [4, 4] and len(os.listdir(d / "clusters_result")) == 2   # the two models separate
+    with pytest.raises(NotImplementedError):
+        CL.save_cluster_result(str(d), mode="tmscore")

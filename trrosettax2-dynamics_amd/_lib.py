@@ -81,6 +81,7 @@ def load():
     L.trx2_feedback_bins.argtypes = [vp, C.c_int, C.c_char_p, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_double, vp, vp, vp, vp]
     L.trx2_feedback_step.argtypes = [vp, C.c_char_p, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_double, vp, C.c_int, C.POINTER(C.c_float)]
     L.trx2_get_map.argtypes = [vp, C.c_int, vp]
+    L.trx2_glocon_matrix.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, vp, C.c_double, vp]
     L.trx2_feedback_process.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
     L.trx2_time_pair_kernel.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, dp, dp]
     L.trx2_last_fold_stats.argtypes = [vp, dp, ip]
@@ -254,6 +255,17 @@ class Context:
         k = ("dist", "omega", "theta", "phi", "tmp").index(channel)
         out = np.empty((self.L, self.L, (37, 25, 25, 13, 37)[k]), np.float32)
         self._chk(self._l.trx2_get_map(self._h, k, _p(out)), "trx2_get_map")
+        return out
+
+    def glocon_matrix(self, xyz, seqs, dmax=20.0):
+        """GloCon matrix of n structures of one length (get_glocon_matrix, utils_trX2dy/utils.py:543-569): xyz[n,L,5,3] as read
+        from the PDB files, seqs = n sequences -> float64 [n,n]"""
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        n, L = xyz.shape[0], xyz.shape[1]
+        if xyz.shape != (n, L, 5, 3) or len(seqs) != n or any(len(s) != L for s in seqs):
+            raise ValueError("need xyz[n,L,5,3] and n sequences of length L")
+        out = np.empty((n, n), np.float64)
+        self._chk(self._l.trx2_glocon_matrix(self._h, n, L, "".join(seqs).encode(), _p(xyz), float(dmax), _p(out)), "trx2_glocon_matrix")
         return out
 
     def time_pair_kernel(self, B, w, sep_lo=1, sep_hi=None, n_rep=50):

@@ -1,0 +1,100 @@
+"""Clustering of generated structures: GloCon / RMSD matrices + KMeans, the reference's cluster.py.
+
+Mirrors /root/reference/utils_trX2dy/utils.py:514-616 (get_glocon_matrix, kmeans_clustering, save_cluster_result) and
+/root/reference/cluster.py.  SURVEY.md 8f4.  Differences, deliberate:
+  D  files are taken in sorted order (the reference uses os.listdir order, so its matrix rows depend on the file system)
+  D  mode "rmsd" uses this package's Kabsch C-alpha RMSD; mode "tmscore" is rejected: both call the prebuilt ./bin/TMscore
+     ELF in the reference (utils.py:514-541), which has no source in the tree
+  D  selected files are copied with shutil instead of `os.system("cp ...")`
+The GloCon matrix is O(n^2 L^2) numpy passes on the host; device=<gpu index> computes it with trx2_glocon_matrix, summing in
+numpy's pairwise order (bitwise the same matrix in the tests).
+"""
+import os
+import shutil
+
+import numpy as np
+
+from .feedback import get_neighbors
+from .pdbio import read_backbone
+
+
+def _pdb_files(pdb_dir):
+    return sorted(f for f in os.listdir(pdb_dir) if f.endswith(".pdb"))
+
+
+def glocon_score(dist1, dist2):
+    """utils.py:560-563 for one pair of dist6d matrices"""
+    dist_diff = np.abs(dist1 - dist2)
+    dist_diff[dist_diff <= 3] = 0
+    return np.sum(np.triu(dist_diff)) / (len(dist_diff) * (len(dist_diff) - 1) / 2)
+
+
+def get_glocon_matrix(pdb_dir, device=None):
+    """-> (matrix[n,n] float64, pdb_files); utils.py:543-569"""
+    pdb_files = _pdb_files(pdb_dir)
+    parsed = [read_backbone(os.path.join(pdb_dir, f)) for f in pdb_files]
+    n = len(pdb_files)
+    if device is not None:
+        from ._lib import Context
+        lens = {len(s) for _, s in parsed}
+        if len(lens) != 1:
+            raise ValueError("the device GloCon matrix needs structures of one length")
+        ctx = Context(int(device))
+        try:
+            return ctx.glocon_matrix(np.stack([x for x, _ in parsed]), [s for _, s in parsed]), pdb_files
+        finally:
+            ctx.close()
+    dist = [get_neighbors(x, s)[0] for x, s in parsed]
+    m = np.zeros((n, n))
+    for i in range(n):
+        for j in range(i):
+            m[i][j] = glocon_score(dist[i], dist[j])
+    return m + m.T, pdb_files
+
+
+def get_rmsd_matrix(pdb_dir):
+    """C-alpha RMSD after optimal superposition for every pair (stands in for TMscore's "RMSD of the common residues")"""
+    pdb_files = _pdb_files(pdb_dir)
+    ca = [read_backbone(os.path.join(pdb_dir, f))[0][:, 1].astype(np.float64) for f in pdb_files]
+    n = len(ca)
+    m = np.zeros((n, n))
+    for i in range(n):
+        for j in range(i):
+            a, b = ca[i] - ca[i].mean(0), ca[j] - ca[j].mean(0)
+            u, s, vt = np.linalg.svd(a.T @ b)
+            s[-1] *= np.sign(np.linalg.det(u @ vt))
+            m[i][j] = np.sqrt(max(0.0, (np.sum(a * a) + np.sum(b * b) - 2.0 * s.sum()) / len(a)))
+    return m + m.T, pdb_files
+
+
+def kmeans_clustering(matrix, pdb_files, n_clusters=10):
+    """utils.py:572-592 (without the plot)"""
+    from sklearn.cluster import KMeans
+    labels = KMeans(n_clusters=n_clusters, n_init=10, random_state=0).fit(matrix).labels_
+    clusters = {}
+    for i, label in enumerate(labels):
+        clusters.setdefault(int(label), []).append(pdb_files[i])
+    return clusters
+
+
+def save_cluster_result(pdb_dir, n_clusters=10, n_files=5, output_dir=None, mode="glocon", device=None):
+    """utils.py:595-616: cluster on the rows of the chosen matrix, keep the first n_files of every cluster"""
+    if mode == "glocon":
+        matrix, pdb_files = get_glocon_matrix(pdb_dir, device=device)
+    elif mode == "rmsd":
+        matrix, pdb_files = get_rmsd_matrix(pdb_dir)
+    elif mode == "tmscore":
+        raise NotImplementedError("mode tmscore needs the reference's prebuilt ./bin/TMscore binary; use glocon or rmsd")
+    else:
+        raise ValueError(f"unknown mode {mode!r}")
+    if output_dir is None:
+        output_dir = os.path.join(pdb_dir, "clusters_result")
+    os.makedirs(output_dir, exist_ok=True)
+    try:
+        clusters = kmeans_clustering(matrix, pdb_files, n_clusters=n_clusters)
+    except ValueError:
+        return "no_cluster"
+    for files in clusters.values():
+        for f in files[:n_files]:
+            shutil.copyfile(os.path.join(pdb_dir, f), os.path.join(output_dir, f))
+    return clusters

@@ -142,3 +142,72 @@ __global__ void k_fb_process(FbProcArgs A) {
   }
 }
 #pragma clang fp contract(fast)
+
+// =================================================================================================
+// GloCon matrix for clustering (utils_trX2dy/utils.py:543-569): score(p, q) = sum over the upper triangle of
+// |dist6d_p - dist6d_q| with differences <= 3 A dropped, divided by L (L - 1) / 2.
+// =================================================================================================
+#pragma clang fp contract(off)
+struct GloArgs {
+  int n, L;
+  const float* xyz;          // [n][L][5][3]
+  const unsigned char* gly;  // [n][L]
+  double dmax2;
+  double* d6;                // [n][L][L] dist6d of every decoy (0 outside dmax), float64 like the reference's arrays
+  double* out;               // [n][n]
+};
+__global__ void k_glocon_dist(GloArgs A) {  // dist6d of every decoy: get_neighbors' first output
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t LL = (size_t)A.L * A.L;
+  if (t >= (size_t)A.n * LL) return;
+  const int p = (int)(t / LL), i = (int)((t % LL) / A.L), j = (int)(t % A.L);
+  FbBinsArgs B;
+  B.L = A.L; B.xyz = A.xyz + (size_t)p * A.L * 15; B.gly = A.gly + (size_t)p * A.L;
+  double v = 0.0;
+  if (i != j) {
+    const v3d cbi = fb_cbeta(B, i), cbj = fb_cbeta(B, j);
+    const double dx = cbi.x - cbj.x, dy = cbi.y - cbj.y, dz = cbi.z - cbj.z;
+    if ((dx * dx + dy * dy) + dz * dz <= A.dmax2) v = fb_norm(fb_sub(cbj, cbi));
+  }
+  A.d6[t] = v;
+}
+// element k of np.triu(np.abs(d1 - d2) with values <= 3 zeroed), flattened
+__device__ __forceinline__ double glo_elem(const double* a, const double* b, int L, int k) {
+  const int i = k / L, j = k % L;
+  if (j < i) return 0.0;
+  const double d = fabs(a[k] - b[k]);
+  return d <= 3.0 ? 0.0 : d;
+}
+// numpy's pairwise_sum over the flattened array (blocks of <= 128 with eight running sums, halves recursively)
+__device__ double glo_pairwise(const double* a, const double* b, int L, int k0, int n) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; i++) r += glo_elem(a, b, L, k0 + i);
+    return r;
+  }
+  if (n <= 128) {
+    double r[8];
+    for (int q = 0; q < 8; q++) r[q] = glo_elem(a, b, L, k0 + q);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int q = 0; q < 8; q++) r[q] += glo_elem(a, b, L, k0 + i + q);
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += glo_elem(a, b, L, k0 + i);
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return glo_pairwise(a, b, L, k0, n2) + glo_pairwise(a, b, L, k0 + n2, n - n2);
+}
+__global__ void k_glocon_pairs(GloArgs A) {  // one thread per ordered pair p > q; the matrix is symmetric, diagonal 0
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)A.n * A.n) return;
+  const int p = (int)(t / A.n), q = (int)(t % A.n);
+  if (p <= q) return;
+  const size_t LL = (size_t)A.L * A.L;
+  const double s = glo_pairwise(A.d6 + (size_t)p * LL, A.d6 + (size_t)q * LL, A.L, 0, (int)LL);
+  const double score = s / ((double)A.L * (double)(A.L - 1) / 2.0);
+  A.out[(size_t)p * A.n + q] = score;
+  A.out[(size_t)q * A.n + p] = score;
+}
+#pragma clang fp contract(fast)

@@ -840,6 +840,34 @@ extern "C" int trx2_feedback_process(trx2_ctx* ctx, int L, int K, const float* i
   return 0;
 }
 
+// GloCon matrix of n decoys (utils_trX2dy/utils.py:543-569); host arrays in and out
+extern "C" int trx2_glocon_matrix(trx2_ctx* ctx, int n, int L, const char* seqs, const float* xyz, double dmax, double* out) {
+  if (!ctx) return 1;
+  if (n < 1 || n > 4096 || L < 2 || L > 4096 || !seqs || !xyz || !out || strnlen(seqs, (size_t)n * L) != (size_t)n * L) {
+    ctx->err = "trx2_glocon_matrix: need n decoys of L residues (sequence letters n*L, coordinates [n][L][5][3]) and an [n][n] output";
+    return 1;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t LL = (size_t)L * L, nL = (size_t)n * L;
+  const size_t o_xyz = 0, o_gly = al256(nL * 15 * 4), o_d6 = o_gly + al256(nL), o_out = o_d6 + al256((size_t)n * LL * 8);
+  if (fb_reserve(ctx, o_out + al256((size_t)n * n * 8))) return 1;
+  char* base = (char*)ctx->fb_buf;
+  std::vector<unsigned char> gly(nL);
+  for (size_t i = 0; i < nL; i++) gly[i] = seqs[i] == 'G';
+  HIPCHK(hipMemcpyAsync(base + o_xyz, xyz, nL * 15 * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(base + o_gly, gly.data(), nL, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(base + o_out, 0, (size_t)n * n * 8, ctx->stream));
+  GloArgs A;
+  A.n = n; A.L = L; A.xyz = (const float*)(base + o_xyz); A.gly = (const unsigned char*)(base + o_gly); A.dmax2 = dmax * dmax;
+  A.d6 = (double*)(base + o_d6); A.out = (double*)(base + o_out);
+  hipLaunchKernelGGL(k_glocon_dist, dim3((unsigned)(((size_t)n * LL + 255) / 256)), dim3(256), 0, ctx->stream, A);
+  hipLaunchKernelGGL(k_glocon_pairs, dim3((unsigned)(((size_t)n * n + 63) / 64)), dim3(64), 0, ctx->stream, A);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, A.out, (size_t)n * n * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
 extern "C" int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int sep_lo, int sep_hi, int n_rep,
                                      double* ms_avg, double* term_evals) {
   if (!ctx) return 1;
