@@ -178,26 +178,48 @@ __device__ __forceinline__ double glo_elem(const double* a, const double* b, int
   const double d = fabs(a[k] - b[k]);
   return d <= 3.0 ? 0.0 : d;
 }
-// numpy's pairwise_sum over the flattened array (blocks of <= 128 with eight running sums, halves recursively)
-__device__ double glo_pairwise(const double* a, const double* b, int L, int k0, int n) {
+// numpy's pairwise_sum over the flattened array: blocks of <= 128 elements with eight running sums; above that the range
+// is halved (first half rounded down to a multiple of 8) and the two sums added.  Written with an explicit stack: device
+// recursion makes the runtime reserve a dynamic stack for every wave slot (1.2 GB here).
+__device__ __forceinline__ double glo_leaf(const double* a, const double* b, int L, int k0, int n) {
   if (n < 8) {
     double r = 0.0;
     for (int i = 0; i < n; i++) r += glo_elem(a, b, L, k0 + i);
     return r;
   }
-  if (n <= 128) {
-    double r[8];
-    for (int q = 0; q < 8; q++) r[q] = glo_elem(a, b, L, k0 + q);
-    int i;
-    for (i = 8; i < n - (n % 8); i += 8)
-      for (int q = 0; q < 8; q++) r[q] += glo_elem(a, b, L, k0 + i + q);
-    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-    for (; i < n; i++) res += glo_elem(a, b, L, k0 + i);
-    return res;
+  double r[8];
+  for (int q = 0; q < 8; q++) r[q] = glo_elem(a, b, L, k0 + q);
+  int i;
+  for (i = 8; i < n - (n % 8); i += 8)
+    for (int q = 0; q < 8; q++) r[q] += glo_elem(a, b, L, k0 + i + q);
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; i++) res += glo_elem(a, b, L, k0 + i);
+  return res;
+}
+__device__ double glo_pairwise(const double* a, const double* b, int L, int k0_, int n_) {
+  int fk0[24], fn[24], fstate[24];  // depth <= log2(4096^2 / 128) + 1 = 18
+  double fleft[24];
+  int sp = 0;
+  fk0[0] = k0_; fn[0] = n_; fstate[0] = 0;
+  double ret = 0.0;
+  while (sp >= 0) {
+    const int k0 = fk0[sp], n = fn[sp];
+    if (n <= 128) { ret = glo_leaf(a, b, L, k0, n); sp--; continue; }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    if (fstate[sp] == 0) {        // descend into the first half
+      fstate[sp] = 1;
+      sp++; fk0[sp] = k0; fn[sp] = n2; fstate[sp] = 0;
+    } else if (fstate[sp] == 1) { // first half done: keep it, descend into the second
+      fleft[sp] = ret;
+      fstate[sp] = 2;
+      sp++; fk0[sp] = k0 + n2; fn[sp] = n - n2; fstate[sp] = 0;
+    } else {                      // both done
+      ret = fleft[sp] + ret;
+      sp--;
+    }
   }
-  int n2 = n / 2;
-  n2 -= n2 % 8;
-  return glo_pairwise(a, b, L, k0, n2) + glo_pairwise(a, b, L, k0 + n2, n - n2);
+  return ret;
 }
 __global__ void k_glocon_pairs(GloArgs A) {  // one thread per ordered pair p > q; the matrix is symmetric, diagonal 0
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
