@@ -183,3 +183,28 @@ def test_glocon_matrix_is_bit_identical_to_reference(golden_dir, tmp_path, seq):
     assert sorted(len(v) for v in out.values()) == [4, 4] and len(os.listdir(d / "clusters_result")) == 2   # the two models separate
     with pytest.raises(NotImplementedError):
         CL.save_cluster_result(str(d), mode="tmscore")
+
+
+def test_evaluation_reproduces_the_reference_summary(golden_dir, tmp_path, seq):
+    """evaluate.py / run_score (evaluate_utils.py:33-100) without the external TM-score binary: on the reference's committed
+    example (eight decoys against apo and holo) the summary must carry the numbers of its committed summary.txt:
+      holo best_RMSD: 3.931 ... best_TM_score: 0.6269   apo best_RMSD: 3.018 ... best_TM_score: 0.6661
+      Mean RMSD: 3.47  Mean TM-score: 0.65  Min RMSD: 3.02  Max TM-score: 0.67"""
+    EV = importlib.import_module("trrosettax2-dynamics_amd.evaluate")
+    CLI = importlib.import_module("evaluate")
+    nat, pred = tmp_path / "native", tmp_path / "pred"
+    nat.mkdir(); pred.mkdir()
+    for k in ("apo", "holo"):
+        decoy_pdb(golden_dir, nat, seq, k)
+    for k in ("conf_1_1", "conf_1_2", "conf_1_3", "conf_1_4", "conf_2_1", "conf_2_2", "conf_2_3", "conf_2_4"):
+        decoy_pdb(golden_dir, pred, seq, k)
+    assert CLI.main(["-n", str(nat), "-p", str(pred), "-o", str(tmp_path / "out" / "s.txt")]) == 0
+    txt = open(tmp_path / "out" / "s.txt").read().splitlines()
+    rows = {l.split()[0]: l.split() for l in txt[:2]}
+    assert (rows["apo"][2], rows["apo"][6]) == ("3.018", "0.6661") and rows["apo"][4] == rows["apo"][8] == "conf_2_3"
+    assert (rows["holo"][2], rows["holo"][6]) == ("3.931", "0.6269")
+    assert txt[2:] == ["Mean RMSD: 3.47", "Mean TM-score: 0.65", "Min RMSD: 3.02", "Max TM-score: 0.67"]
+    x = np.load(os.path.join(golden_dir, "ref_decoys.npz"))["conf_1_1"][:, 1].astype(np.float64)
+    assert EV.tm_score(x, x) == pytest.approx(1.0) and EV.rmsd_common(x, x[::-1].copy()[::-1]) == pytest.approx(0.0, abs=1e-9)
+    with pytest.raises(NotImplementedError):
+        EV.run_score(str(nat), str(pred), align=True)
