@@ -932,16 +932,22 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
 #pragma unroll
       for (int q = 0; q < 4; q++) { qv[q].x += c * s_[q].x; qv[q].y += c * s_[q].y; qv[q].z += c * s_[q].z; qv[q].w += c * s_[q].w; }
     };
-    float4 sa[4], ya[4], sb[4], yb[4];
-    if (hl > 0) load_pair(0, sa, ya);
-    for (int kk = 0; kk < hl; kk += 2) {  // pair kk in buffer a, pair kk+1 in buffer b
-      if (kk + 1 < hl) load_pair(kk + 1, sb, yb);
-      round1(kk, sa, ya);
-      if (kk + 1 < hl) {
-        if (kk + 2 < hl) load_pair(kk + 2, sa, ya);
-        round1(kk + 1, sb, yb);
+    // Three rotating buffers, loops advancing in groups of three so that the buffer of pair kk (kk % 3) is a compile-time
+    // choice: two pairs are always in flight.  With 64 decoys the histories (460 KB each at L=150) do not stay in L2 and a
+    // round is shorter than one memory round trip, so one pair ahead was not enough (profiles/README.md).
+    float4 sb[3][4], yb[3][4];
+    if (hl > 0) load_pair(0, sb[0], yb[0]);
+    if (hl > 1) load_pair(1, sb[1], yb[1]);
+#pragma unroll 1
+    for (int k0 = 0; k0 < hl; k0 += 3)
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int kk = k0 + u;
+        if (kk < hl) {
+          if (kk + 2 < hl) load_pair(kk + 2, sb[(u + 2) % 3], yb[(u + 2) % 3]);
+          round1(kk, sb[u], yb[u]);
+        }
       }
-    }
     CSTAMP(23)  // two-loop: first loop
     if (hl > 0) {
       const float gam = (float)gamma_h;
@@ -950,23 +956,17 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     }
     __syncthreads();
     CSTAMP(24)  // two-loop: gamma
-    // backwards: the oldest pair (hl-1) is still in its buffer -- a if hl is odd, b if even
-    if (hl > 0) {
-      int kk = hl - 1;
-      if (kk & 1) {  // pair kk sits in b
-        if (kk > 0) load_pair(kk - 1, sa, ya);
-        round2(kk, sb, yb);
-        kk--;
-      }
-      for (; kk >= 0; kk -= 2) {  // pair kk in a, pair kk-1 goes to b
-        if (kk > 0) load_pair(kk - 1, sb, yb);
-        round2(kk, sa, ya);
-        if (kk > 0) {
-          if (kk > 1) load_pair(kk - 2, sa, ya);
-          round2(kk - 1, sb, yb);
+    // backwards: the three oldest pairs are still in their buffers; a buffer is refilled (pair kk - 3) as soon as it is done
+#pragma unroll 1
+    for (int k0 = (hl - 1) / 3 * 3; k0 >= 0; k0 -= 3)
+#pragma unroll
+      for (int u = 2; u >= 0; u--) {
+        const int kk = k0 + u;
+        if (kk < hl) {
+          round2(kk, sb[u], yb[u]);
+          if (kk >= 3) load_pair(kk - 3, sb[u], yb[u]);
         }
       }
-    }
     CSTAMP(25)  // two-loop: second loop
     double v2[2] = {0, 0};
 #pragma unroll
