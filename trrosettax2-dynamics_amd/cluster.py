@@ -9,6 +9,7 @@ Mirrors /root/reference/utils_trX2dy/utils.py:514-616 (get_glocon_matrix, kmeans
 The GloCon matrix is O(n^2 L^2) numpy passes on the host; device=<gpu index> computes it with trx2_glocon_matrix, summing in
 numpy's pairwise order (bitwise the same matrix in the tests).
 """
+import argparse
 import os
 import shutil
 
@@ -98,3 +99,19 @@ def save_cluster_result(pdb_dir, n_clusters=10, n_files=5, output_dir=None, mode
         for f in files[:n_files]:
             shutil.copyfile(os.path.join(pdb_dir, f), os.path.join(output_dir, f))
     return clusters
+
+
+def main(argv=None):
+    """command line of the reference's cluster.py: -d/--pdb_dir, -m/--mode, -o/--output_dir, --n_clusters, --n_files"""
+    ap = argparse.ArgumentParser(prog="cluster.py", description="Group generated models by KMeans on a pairwise matrix.")
+    ap.add_argument("-d", "--pdb_dir", required=True, help="folder holding the .pdb models")
+    ap.add_argument("-m", "--mode", default="glocon", choices=("glocon", "tmscore", "rmsd"), help="matrix to cluster on")
+    ap.add_argument("-o", "--output_dir", default=None, help="where the kept models go (<pdb_dir>/clusters_result if omitted)")
+    ap.add_argument("--n_clusters", type=int, default=10, help="KMeans k")
+    ap.add_argument("--n_files", type=int, default=5, help="models kept from every cluster")
+    ap.add_argument("--device", type=int, default=None, help="compute the GloCon matrix on this GPU (extension; numpy if omitted)")
+    a = ap.parse_args(argv)
+    target = a.output_dir if a.output_dir else os.path.join(a.pdb_dir, "clusters_result")
+    res = save_cluster_result(a.pdb_dir, n_clusters=a.n_clusters, n_files=a.n_files, output_dir=target, mode=a.mode, device=a.device)
+    print("Clustering failed or not possible." if res == "no_cluster" else f"Clustering completed. Results saved in {target}.")
+    return 0

@@ -10,7 +10,9 @@ sum 1 / (1 + (d_i / d0)^2) / L_norm wins, d0 = 1.24 (L_norm - 15)^(1/3) - 1.8, L
 Pinned by the reference's committed example summary (tests): apo 3.018 A / 0.6661, holo 3.931 A / 0.6269.
 Not mirrored: `--align` (TM-score's -seq sequence alignment) -> NotImplementedError.
 """
+import argparse
 import os
+import shutil
 
 import numpy as np
 
@@ -120,3 +122,24 @@ def run_score(native_pdb_dir, pred_pdb_dir, align=False, save_summary=False, sav
         with open(os.path.join(d, "summary.txt"), "w") as f:
             f.write("".join(lines))
     return out
+
+
+def main(argv=None):
+    """command line of the reference's evaluate.py: -n/--native_dir, -p/--pred_dir, -o/--output (file or folder), --align"""
+    ap = argparse.ArgumentParser(prog="evaluate.py", description="Best RMSD and TM-score of a set of models against every native structure.")
+    ap.add_argument("-n", "--native_dir", required=True, help="folder of native .pdb files")
+    ap.add_argument("-p", "--pred_dir", required=True, help="folder of model .pdb files")
+    ap.add_argument("-o", "--output", default=None, help="summary file (*.txt) or folder; the model folder if omitted")
+    ap.add_argument("--align", action="store_true", help="TM-score's -seq alignment: not implemented, raises")
+    a = ap.parse_args(argv)
+    folder, name = a.pred_dir, "summary.txt"
+    if a.output:
+        folder, name = (os.path.dirname(a.output) or os.getcwd(), os.path.basename(a.output)) if a.output.endswith(".txt") else (a.output, name)
+    stats = run_score(a.native_dir, a.pred_dir, align=a.align, save_summary=True, save_dir=folder)
+    if name != "summary.txt":
+        shutil.move(os.path.join(folder, "summary.txt"), os.path.join(folder, name))
+    print("Evaluation Summary:")
+    for label, v in zip(("Min RMSD", "Max TM-score", "Mean RMSD", "Mean TM-score"), stats):
+        print(f"  {label}: {round(v, 3)}")
+    print(f"Full summary saved to: {os.path.join(folder, name)}")
+    return 0
