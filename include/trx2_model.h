@@ -126,6 +126,14 @@ enum {
 #define TRX2_LS_MAXTRIAL 20
 #define TRX2_MIN_TOL 1.0e-6  /* folding.py:91 fractional tolerance: 2|f0-f1| <= tol (|f0|+|f1|+eps) */
 #define TRX2_CLASH_BREAK 10.0 /* utils_ros.py:701 */
+/* Offset per rama residue used ONLY in that guard (not in the minimised energy).  Rosetta's rama is negative in favoured
+ * regions, so a clash-free pose passes `rama + vdw < 10` and remove_clash stops; this surrogate is >= 0 (about +1.4 per
+ * residue on folded decoys), so without an offset the guard can never fire.  0 = current behaviour (all five rounds run);
+ * any value <= -1.6 makes it fire on clash-free poses: 7-11 % fewer evaluations, outcome within noise to slightly worse
+ * (512-decoy samples, DESIGN.md section 2, deviation 5).  Rosetta's own values are not available, so 0 stays. */
+#ifndef TRX2_RAMA_GUARD_OFFSET
+#define TRX2_RAMA_GUARD_OFFSET 0.0
+#endif
 #define TRX2_MAX_RUNS 32
 
 /* one minimiser run of the staged protocol (folding.py:119,164-171; utils_ros.py:699-703) */

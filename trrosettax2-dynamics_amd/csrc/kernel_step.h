@@ -336,7 +336,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
     CSTAMP(3)  // energy reduction + loads of X, G, D
     if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
     else if (phase == PH_START) {
-      if (R.precheck && esum[5] + esum[4] < (double)TRX2_CLASH_BREAK) {
+      if (R.precheck && esum[5] + (double)TRX2_RAMA_GUARD_OFFSET * (double)max(L - 2, 0) + esum[4] < (double)TRX2_CLASH_BREAK) {
         run = R.skip_to;
         if (run >= A.nruns) phase = PH_DONE;
         need_nerf = false;
