@@ -124,7 +124,9 @@ enum {
 #define TRX2_LS_C1 1.0e-4
 #define TRX2_LS_SHRINK 0.5
 #define TRX2_LS_MAXTRIAL 20
+#ifndef TRX2_MIN_TOL
 #define TRX2_MIN_TOL 1.0e-6  /* folding.py:91 fractional tolerance: 2|f0-f1| <= tol (|f0|+|f1|+eps) */
+#endif
 #define TRX2_CLASH_BREAK 10.0 /* utils_ros.py:701 */
 /* Offset per rama residue used ONLY in that guard (not in the minimised energy).  Rosetta's rama is negative in favoured
  * regions, so a clash-free pose passes `rama + vdw < 10` and remove_clash stops; this surrogate is >= 0 (about +1.4 per
