@@ -119,7 +119,9 @@ enum {
 #define TRX2_CART_KIMP 300.0   /* per rad^2 */
 
 /* ---- minimiser (own design; Rosetta's lbfgs_armijo_nonmonotone is not in the tree) --------------- */
+#ifndef TRX2_LBFGS_M
 #define TRX2_LBFGS_M 12
+#endif
 #define TRX2_LS_PAST 3       /* non-monotone window */
 #define TRX2_LS_C1 1.0e-4
 #define TRX2_LS_SHRINK 0.5
