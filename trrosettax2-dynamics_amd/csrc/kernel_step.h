@@ -47,7 +47,7 @@ __device__ __forceinline__ void bsync() {
 // Sum over the workgroup, total in every thread.  Consecutive calls alternate between two LDS buffers (`flip`), so one
 // barrier per call is enough: a wave can be at most one call ahead of the slowest, and then it writes the OTHER buffer.
 // (With one buffer every call needed a second barrier just to protect the previous call's reads; the two-loop recursion
-// makes 2 x 12 dependent calls per step.)  Every wave must make the same sequence of calls.
+// makes 2 x LBM dependent calls per step.)  Every wave must make the same sequence of calls.
 template <int K, int NW>
 __device__ __forceinline__ void block_sum_n(double (&v)[K], double* s_buf /* [2][NW*8] */, int& flip) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -116,7 +116,7 @@ __device__ unsigned long long g_cstamp[32];
 #endif
 // L-BFGS history of the decoy staged in LDS for the duration of one step: [LBM][s | y][NT] float4, dynamic shared memory
 // (HIST_LDS_BYTES, only the one-residue-per-thread instantiations; gfx950 has 160 KB of LDS per CU).  The two-loop
-// recursion is 2 x 12 DEPENDENT rounds; read from global memory every round exposed an L2 round trip (~500-700 of its
+// recursion is 2 x LBM DEPENDENT rounds; read from global memory every round exposed an L2 round trip (~500-700 of its
 // ~1000 cycles; the compiler turns a register prefetch into a wait on the load just issued).  Instead the whole history is
 // requested at the top of the step with LDS-DMA loads (global_load_lds_dwordx4: no registers, nothing waits on them until
 // the recursion starts a phase later) and every round reads the thread's own slot from LDS.

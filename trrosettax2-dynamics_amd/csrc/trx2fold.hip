@@ -145,7 +145,7 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
     rm[k * 3 + 2] = (float)rama[k][2];
     rsc[k * 4] = (float)sin(ph); rsc[k * 4 + 1] = (float)cos(ph); rsc[k * 4 + 2] = (float)sin(ps); rsc[k * 4 + 3] = (float)cos(ps);
   }
-  // the step kernels of short chains stage the L-BFGS history in 96 KB of dynamic LDS (above the 64 KB default limit)
+  // the step kernels of short chains stage the L-BFGS history in dynamic LDS (HIST_LDS_BYTES: 64 KB with 8 pairs and 256 threads)
   if (hipFuncSetAttribute((const void*)k_chain<1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(128)) != hipSuccess ||
       hipFuncSetAttribute((const void*)k_step<1, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(128)) != hipSuccess ||
       hipFuncSetAttribute((const void*)k_chain<1, CHAIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(CHAIN_THREADS)) != hipSuccess ||
