@@ -164,6 +164,34 @@ def test_eval_other_widths_and_long_chains(ctx, L, B):
         assert np.abs(g[d] - go).max() <= 1e-2 * np.abs(go).max(), ("grad", L, d, np.abs(g[d] - go).max(), np.abs(go).max())
 
 
+@pytest.mark.parametrize("L,B,orient", [(4, 1, True), (5, 2, True), (17, 5, True), (64, 64, False), (65, 33, True), (129, 9, True),
+                                         (200, 70, False)])
+def test_eval_edge_shapes(ctx, L, B, orient):
+    """The smallest chain the ABI accepts (4 residues), chain lengths around the wave size, a partial second decoy group
+    (B = 70: 64 + 6 live lanes), distance-only maps with full groups (the pair kernel's shared repulsion walk, with dead lanes
+    in the second group at B = 70), and a 128-thread / 256-thread step boundary (L = 129).  Energy terms, gradient and
+    coordinates against the oracle."""
+    S = importlib.import_module("trrosettax2-dynamics_amd.synth")
+    m = S.make_map(L, seed=1000 + L, n_moves=60)
+    ang = [m["omega"], m["theta"], m["phi"]] if orient else []
+    ctx.set_map(m["dist"], *ang, seq=m["seq"])
+    Tb = O.Tables(m["dist"], *(ang if orient else [None, None, None]))
+    rng = np.random.default_rng(L * 100 + B)
+    tors = np.stack([m["tors"] + rng.normal(size=(L, 3)) * 0.1 for _ in range(B)])
+    f, e, g, xyz = ctx.eval_batch(tors, SF)
+    assert np.all(np.isfinite(f)) and np.all(np.isfinite(g))
+    for d in sorted({0, B // 2, B - 1}):
+        fo, eo, go, xo = O.evaluate(Tb, tors[d].astype(np.float32).astype(np.float64), SF)
+        assert np.abs(xyz[d] - xo).max() < 2e-3, ("xyz", L, B, d)
+        assert np.all(np.abs(e[d, :7] - eo[:7]) <= 2e-4 * np.abs(eo[:7]) + 0.1), ("terms", L, B, d, e[d], eo)
+        assert np.abs(g[d] - go).max() <= 1e-2 * max(np.abs(go).max(), 1.0), ("grad", L, B, d, np.abs(g[d] - go).max(), np.abs(go).max())
+    if L <= 64:   # a short fold must run through every stage and every role at these sizes too
+        r = ctx.fold_batch(B, T.protocol.build_runs(L, 2), seed=3, max_evals=300)
+        assert np.all(np.isfinite(r["xyz"])) and np.all(np.isfinite(r["f"])) and np.all((r["status"] == 0) | (r["n_evals"] == 300))
+        again = ctx.fold_batch(B, T.protocol.build_runs(L, 2), seed=3, max_evals=300)
+        assert np.array_equal(r["xyz"], again["xyz"])                            # and reproducibly
+
+
 def test_minimiser_on_a_chain_longer_than_512(ctx):
     """L = 520: four residues per thread in the step kernel, history read from global memory (the LDS-staged history is for
     L <= 256), more than 64 visits per wave in the pair kernel (three blocks of its contact-bit walk).  Torsion-space
