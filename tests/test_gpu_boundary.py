@@ -226,3 +226,23 @@ def test_batch_mode_command_line_on_one_rank(golden_dir, tmp_path):
     a = open(save / "t1" / "pred_pdb" / sorted(os.listdir(save / "t1" / "pred_pdb"))[0]).read()
     b = open(save / "t2" / "pred_pdb" / sorted(os.listdir(save / "t2" / "pred_pdb"))[0]).read()
     assert a == b
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_staged_modes_fold_the_example(golden_dir, seq, mode):
+    """`-m 0` (short -> medium -> long range, folding.py:125-147) and `-m 1` (short+medium -> long, :149-162): the separation
+    windows of the run table reach the pair kernel per decoy; the example map must fold to the reference decoys as in mode 2."""
+    m = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
+    dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    runs = T.protocol.build_runs(90, mode)
+    assert len({(q["sep_lo"], q["sep_hi"]) for q in runs if q["sep_hi"]}) == (3 if mode == 0 else 2)
+    ctx = T.Context(0)
+    try:
+        ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+        r = ctx.fold_batch(32, runs, seed=8)
+        assert np.all(r["status"] == 0)
+        best = np.array([min(kabsch_rmsd(r["xyz"][i, :, 1], dec[k][:, 1]) for k in ("conf_2_1", "conf_2_2")) for i in range(32)])
+        print("\nmode %d: median RMSD to the reference decoys %.2f A, evaluations median %d" % (mode, np.median(best), np.median(r["n_evals"])))
+        assert np.median(best) < 1.3, np.sort(best)
+    finally:
+        ctx.close()
