@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""bench.py -- decoys/sec of the MI355X-native fold, with the pair-kernel roofline and a CPU baseline.
+"""bench.py -- decoys/sec of the MI355X-native fold, with kernel rooflines and a CPU baseline.
 
 Contract:  python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank per GPU)
 prints ONE JSON line on rank 0.
@@ -7,13 +7,16 @@ prints ONE JSON line on rank 0.
 A "step" = one call of the hot path over one batch: fold B decoys of one distogram through the full staged protocol
 (folding/folding.py:118-171 mode 2), timed from tables-resident-in-HBM to the last coordinates on the host.
 Workload at N=1 = BASELINE.json configs[1]: L=150 single target, init_num=64, dist-only restraints (synthetic map,
-SURVEY.md 8d -- the reference ships data for L=90 only).  Other configs: --config 3 (all channels), --config 4 (L=400,
-B=32), --config 5 (eight targets L=100..400, 32 decoys each, assigned to ranks longest-first: strong scaling).
-N>1: every rank folds its own B decoys of the same target (independent units, no data-path collective): weak scaling.
+SURVEY.md 8d -- the reference ships data for L=90 only).  Other configs: --config 3 (all channels, two models),
+--config 4 (L=400, B=32), --config 5 (eight targets L=100..400, 32 decoys each, assigned to ranks longest-first: strong
+scaling).  N>1: every rank folds its own B decoys of the same target (independent units, no data-path collective): weak
+scaling; the same line then also carries the config-5 batch-mode record ("batch_mode", strong scaling), which is the
+north star's multi-GPU mode.  At N=1 the line carries compact sub-records for configs 3 and 4 ("sub_records").
 
 Nothing here reads /root/reference.  The oracle is imported ONLY for the cpu_baseline leg (rank 0, N=1).
 """
 import argparse
+import hashlib
 import importlib
 import json
 import os
@@ -39,6 +42,17 @@ CONFIGS = {
             name="eight targets L in {100,140,180,220,260,300,350,400}, init_num=32 each, dist+omega+theta+phi, synthetic maps "
                  "seed L; (target, decoy-block) items assigned to ranks longest-processing-time-first"),
 }
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+KERNEL_SOURCES = ("kernel_pair.h", "trx2_device.h")
+
+
+def kernel_source_sha():
+    """identifies the pair-kernel build a committed PMC record belongs to (records must not go stale silently)"""
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "trrosettax2-dynamics_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(B, n_terms_per_decoy, L):
@@ -46,22 +60,103 @@ def algorithmic_bytes(B, n_terms_per_decoy, L):
     return B * (16.0 * n_terms_per_decoy + 96.0 * L)
 
 
-def cpu_baseline(m, cfg, runs, budget_s=20.0):
-    """oracle (CPU restatement, single thread) on a bounded sample of the same workload"""
+def step_algorithmic_bytes(B, L, slabs, m):
+    """Step kernel (torsion role), bytes one launch must move per active decoy: gradient + energy slabs in (slabs x L x 96 B),
+    trial coordinates in (64 B per residue), accepted point / gradient / direction / trial torsions in and out (4 + 4 float4),
+    the stored correction pairs in (m pairs x 2 x 16 B per residue) and the new pair out (2 x 16 B), internal geometry in
+    (48 B), coordinates out twice (decoy-major + decoy-minor copy for the pair kernel, 2 x 64 B).  DESIGN.md section 4."""
+    per_res = slabs * 96.0 + 64.0 + 8 * 16.0 + m * 32.0 + 32.0 + 48.0 + 128.0
+    return B * L * per_res
+
+
+def cpu_baseline(m, cfg, runs, budget_s=10.0):
+    """oracle (CPU restatement of the same fold) on a bounded sample of the same workload: one thread, then OpenMP over decoys on
+    every core this process may use.  `value` is the all-core figure."""
     from oracle import oracle as O
-    Tb = O.Tables(m["dist"], *( [m["omega"], m["theta"], m["phi"]] if cfg["orient"] else [None, None, None]))
+    Tb = O.Tables(m["dist"], *([m["omega"], m["theta"], m["phi"]] if cfg["orient"] else [None, None, None]))
+    L = cfg["L"]
     n, t0 = 0, time.time()
     while True:
-        O.fold(Tb, O.random_torsions(cfg["L"], 12345, n), runs)
+        O.fold(Tb, O.random_torsions(L, 12345, n), runs)
         n += 1
         el = time.time() - t0
         if el + el / n > budget_s or n >= 16:
             break
-    return dict(value=n / el, unit="decoys/sec", cores=1, kind="port",
-                sample=f"{n} decoys of the same map and protocol, oracle/trx2_oracle.c -O3 -march=native, 1 thread, {el:.1f} s")
+    one = dict(value=n / el, unit="decoys/sec", cores=1, sample=f"{n} decoys, 1 thread, {el:.1f} s")
+    cores = O.usable_cores()
+    per = max(1, min(4, int(budget_s / (el / n))))  # decoys per thread within the budget
+    nb = cores * per
+    t0 = time.time()
+    _, _, st, used = O.fold_batch(Tb, np.stack([O.random_torsions(L, 12345, 100 + d) for d in range(nb)]), runs, nthreads=cores)
+    el2 = time.time() - t0
+    return dict(value=nb / el2, unit="decoys/sec", cores=used, kind="port",
+                sample=f"{nb} decoys of the same map and protocol, oracle/trx2_oracle.c (gcc -O3 -march=native -fopenmp), "
+                       f"OpenMP over decoys on {used} threads, {el2:.1f} s",
+                single_thread=one, host_cores_available=os.cpu_count(), host_cores_usable=cores)
 
 
-def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced):
+def traffic_record(config):
+    """HBM-side bytes of the pair kernel per launch: PMC counters cannot be collected from inside this process, so the value is the
+    one measured with rocprofv3 for THIS kernel source and config and committed under profiles/ (null when the sources changed)"""
+    if not os.path.exists(TRAFFIC_FILE):
+        return None
+    rec = json.load(open(TRAFFIC_FILE))
+    if rec.get("kernel_src_sha") != kernel_source_sha():
+        return None
+    return rec.get(str(config))
+
+
+def pair_roofline(ctx, T, B, L, config, fold_times=None):
+    w = np.array(T.protocol.SF, np.float32)
+    ms, term_evals = ctx.time_pair_kernel(B, w, 1, L, n_rep=200)
+    n_terms = term_evals / B
+    abytes = algorithmic_bytes(B, n_terms, L)
+    achieved = abytes / (ms * 1e-3) / 1e9
+    rec = traffic_record(config)
+    traffic, valu = None, None
+    if rec:
+        traffic = rec["hbm_bytes_per_launch"]
+        # The kernel computes in f32 on the vector ALUs (nothing to contract on MFMA): next to the contract's HBM figure, how busy
+        # the SIMDs' VALUs are.  SQ_ACTIVE_INST_VALU counts units of 4 cycles summed over waves; one wave64 f32 instruction holds
+        # its SIMD for 4 cycles.
+        cyc = rec["valu_active_quad_cycles"] * 4.0 / SIMDS
+        valu = {"insts_per_launch": rec["valu_insts_per_launch"], "busy_cycles_per_simd": cyc, "busy_frac": cyc / (ms * 1e-3 * CLOCK_HZ),
+                "clock_hz_assumed": CLOCK_HZ, "wave_time_waiting_frac": rec["wait_any_quad_cycles"] / rec["wave_quad_cycles"]}
+    bw = int(ctx.info(0))
+    out = {"bound": "hbm", "kernel": f"k_pair<{bw}>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": (rec or {}).get("method"),
+           "avg_launch_ms": ms, "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": n_terms, "valu": valu,
+           "binding_limit": "vector-ALU issue + dependent-load latency, not HBM bandwidth (DESIGN.md section 5)"}
+    if fold_times and fold_times[2]:
+        out["avg_launch_ms_over_fold"] = fold_times[0]
+    return out
+
+
+def step_roofline(ctx, B, L, fold_times):
+    """second roofline record: the fused step kernel, live average over a whole (untimed, event-sampled) fold"""
+    if not fold_times or not fold_times[2]:
+        return None
+    slabs, m = int(ctx.info(1)), int(ctx.info(2))
+    ms = fold_times[1]
+    abytes = step_algorithmic_bytes(B, L, slabs, m)
+    ach = abytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "k_step (torsion + Cartesian roles, one workgroup per decoy and role)", "achieved": ach,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+            "algorithmic_bytes_per_launch": abytes, "samples": fold_times[2],
+            "binding_limit": "latency of ~25 dependent phases on one workgroup per decoy (DESIGN.md section 4), not bandwidth"}
+
+
+def sampled_fold(ctx, B, runs, seed, decoy0):
+    """one extra, UNTIMED fold with every 8th evaluation bracketed by HIP events -> (pair ms, step ms, samples)"""
+    ctx.set_profiling(8)
+    try:
+        ctx.fold_batch(B, runs, seed=seed, decoy0=decoy0)
+        return ctx.last_fold_kernel_times()
+    finally:
+        ctx.set_profiling(0)
+
+
+def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, with_cpu):
     """a list of targets of different length.  Work item = (target, decoy block); every rank
     derives the same longest-first plan (sched.lpt_assign splits decoy blocks while ranks would idle or the load is uneven)
     and folds its items, up to three at a time on separate contexts (streams).  Total work is fixed: strong scaling."""
@@ -107,9 +202,6 @@ def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced):
     stats = sched.gather_stats(dict(decoys=sum(it.n for it in mine) * args.steps, seconds=elapsed, failed=0 if ok else 1), dist)
     out = None
     if rank == 0:
-        it = mine[0]  # rank 0's heaviest item: its pair kernel on the coordinates of the last batch
-        ms, term_evals = ctxs[0].time_pair_kernel(it.n, np.array(T.protocol.SF, np.float32), 1, it.L, n_rep=100)
-        abytes = algorithmic_bytes(it.n, term_evals / it.n, it.L)
         total = len(cfg["targets"]) * B
         out = {
             "metric": "decoys/sec", "value": args.steps * total / elapsed, "unit": "decoys/sec", "n_gpus": world, "steps": args.steps,
@@ -119,60 +211,25 @@ def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced):
                        "parallelism": f"{len(items)} targets -> {sum(len(p) for p in sched.lpt_assign(items, world))} items over {world} rank(s), "
                                       "no collective on the data path",
                        "items_rank0": [(i.target, i.decoy0, i.n) for i in mine]},
-            "roofline": {"bound": "hbm", "kernel": f"k_pair<{min(64, 1 << (it.n - 1).bit_length())}> of target {it.target}",
-                         "achieved": abytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
-                         "algorithmic_bytes_per_launch": abytes},
             "all_decoys_converged": bool(all(p["failed"] == 0 for p in stats)),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if mine:
+            it = mine[0]  # rank 0's heaviest item: its pair kernel on the coordinates of the last batch
+            out["roofline"] = pair_roofline(ctxs[0], T, it.n, it.L, 5)
+            out["roofline"]["kernel"] += f" of target {it.target}"
+        if with_cpu:
             L0 = min(cfg["targets"])
             out["cpu_baseline"] = cpu_baseline(synth.make_map(L0, seed=L0), dict(L=L0, orient=True), T.protocol.build_runs(L0, 2))
             out["cpu_baseline"]["sample"] += f" (the L={L0} target only)"
-            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
     for c in ctxs:
         c.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out))
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-    cfg = CONFIGS[args.config]
+def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, forced, steps, warmup, full):
+    """one target (configs 2, 3, 4): B decoys per chain and step on every rank.  full: roofline records, two-lane leg"""
     L, B = cfg["L"], cfg["B"]
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    # Rehearsal on a box with fewer GPUs than ranks: TRX2_BENCH_FORCE_DEVICE=0 puts every rank on that GPU and uses gloo
-    # (NCCL refuses two ranks on one device).  It exercises the multi-rank control flow, not multi-GPU performance.
-    forced = os.environ.get("TRX2_BENCH_FORCE_DEVICE")
-    if forced is not None:
-        local_rank = int(forced)
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if forced is not None:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    T = importlib.import_module("trrosettax2-dynamics_amd")
-    synth = importlib.import_module("trrosettax2-dynamics_amd.synth")
     n_chains = cfg.get("chains", 1)
-    if "targets" in cfg:
-        return multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced)
     ms_ = [synth.make_map(L, seed=L + c) for c in range(n_chains)]
     m = ms_[0]
     runs = T.protocol.build_runs(L, 2)
@@ -197,11 +254,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(900 + i)
     sync()
     t0 = time.perf_counter()
-    res = [r for i in range(args.steps) for r in step(i)]  # fold_batch returns with the coordinates on the host
+    res = [r for i in range(steps) for r in step(i)]  # fold_batch returns with the coordinates on the host
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -213,45 +270,22 @@ def main():
     ok = all(np.all(r["status"] == 0) and np.all(np.isfinite(r["xyz"])) for r in res)
     evals = np.concatenate([r["n_evals"] for r in res])
     launches = sum(r["launches"] for r in res)
-
-    # ---- roofline of the dominant kernel (pair terms), HIP events on the ctx stream, coordinates of the last batch
-    w = np.array(T.protocol.SF, np.float32)
-    ms, term_evals = ctx.time_pair_kernel(B, w, 1, L, n_rep=200)
-    n_terms = term_evals / B
-    abytes = algorithmic_bytes(B, n_terms, L)
-    achieved = abytes / (ms * 1e-3) / 1e9
-
-    # HBM-side bytes of that kernel per launch: PMC counters cannot be collected from inside this process, so the value is the
-    # one measured with rocprofv3 for this kernel build and config and committed under profiles/ (null if absent)
-    traffic, traffic_src, valu = None, None, None
-    tf = os.path.join(ROOT, "profiles", "r01_final_traffic.json")
-    if os.path.exists(tf):
-        rec = json.load(open(tf)).get(str(args.config))
-        if rec:
-            traffic, traffic_src = rec["hbm_bytes_per_launch"], "profiles/r01_final_traffic.json: " + rec["method"]
-            # The kernel computes in f32 on the vector ALUs (no contraction to put on MFMA): next to the contract's HBM figure,
-            # how busy the SIMDs' VALUs are.  Counter SQ_ACTIVE_INST_VALU (units of 4 cycles, summed over waves; one wave64
-            # f32 instruction occupies its SIMD for 4 cycles) from the same PMC run, over 1024 SIMDs and the LIVE duration.
-            cyc = rec["valu_active_quad_cycles"] * 4.0 / SIMDS
-            valu = {"insts_per_launch": rec["valu_insts_per_launch"], "busy_cycles_per_simd": cyc,
-                    "busy_frac": cyc / (ms * 1e-3 * CLOCK_HZ), "clock_hz_assumed": CLOCK_HZ,
-                    "wave_time_waiting_frac": rec["wait_any_quad_cycles"] / rec["wave_quad_cycles"]}
-
     out = None
     if rank == 0:
+        ft = sampled_fold(ctx, B, runs, 150, 901 * B)  # untimed; live per-kernel averages over a whole fold
         out = {
-            "metric": "decoys/sec", "value": world * args.steps * B * n_chains / elapsed, "unit": "decoys/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "metric": "decoys/sec", "value": world * steps * B * n_chains / elapsed, "unit": "decoys/sec",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "L": L, "decoys_per_step": B * n_chains, "protocol": "mode 2, full staged minimisation",
                        "parallelism": f"decoys sharded over {world} rank(s), no collective on the data path"},
-            "roofline": {"bound": "hbm", "kernel": f"k_pair<{min(64, 1 << (B - 1).bit_length())}>", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": ms, "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": n_terms, "valu": valu},
+            "roofline": pair_roofline(ctx, T, B, L, config, ft),
+            "roofline_step": step_roofline(ctx, B, L, ft),
             "all_decoys_converged": bool(ok), "evals_per_decoy": {"min": int(evals.min()), "median": float(np.median(evals)), "max": int(evals.max())},
-            "pair_launches_per_step": launches / args.steps / n_chains,
+            "pair_launches_per_step": launches / steps / n_chains,
+            "slot_efficiency": float(evals.sum()) / (launches * B),  # sum of evaluations over decoys / (launches x decoy slots)
         }
-        if world == 1 and n_chains == 1:
+        if full and world == 1 and n_chains == 1:
             # The same job with the library's two lanes (trx2_ctx_set_lanes: two half-batches on two streams, one half's step
             # kernel overlapping the other's pair kernel).  Reported beside `value`, which stays the single-stream figure so
             # that the per-kernel roofline above and the committed kernel trace describe the launches that were timed.
@@ -259,17 +293,84 @@ def main():
             c2.set_map(m["dist"], *([m["omega"], m["theta"], m["phi"]] if cfg["orient"] else []), seq=m["seq"])
             c2.fold_batch(B, runs, seed=150, decoy0=900 * B)
             t1 = time.perf_counter()
-            r2 = [c2.fold_batch(B, runs, seed=150, decoy0=i * B) for i in range(args.steps)]
+            r2 = [c2.fold_batch(B, runs, seed=150, decoy0=i * B) for i in range(steps)]
             e2 = time.perf_counter() - t1
             c2.close()
-            out["two_lanes"] = {"value": args.steps * B / e2, "unit": "decoys/sec", "ms_per_step": 1e3 * e2 / args.steps,
+            out["two_lanes"] = {"value": steps * B / e2, "unit": "decoys/sec", "ms_per_step": 1e3 * e2 / steps,
                                 "all_decoys_converged": bool(all(np.all(r["status"] == 0) for r in r2)),
                                 "note": f"same job, Context(lanes=2): halves of {(B + 1) // 2} and {B // 2} decoys on two streams"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(m, cfg, runs)
-            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
     for c_ in ctxs:
         c_.close()
+    return out, m, runs
+
+
+def compact(rec):
+    """sub-record of another config inside the default line: value, time per step, convergence, the kernel records"""
+    keys = ("value", "unit", "steps", "ms_per_step", "all_decoys_converged", "evals_per_decoy", "pair_launches_per_step", "slot_efficiency")
+    out = {k: rec[k] for k in keys if k in rec}
+    out["workload"] = rec["config"]["workload"]
+    for k in ("roofline", "roofline_step"):
+        r = rec.get(k)
+        if r:
+            out[k] = {q: r[q] for q in ("kernel", "achieved", "frac", "unit", "avg_launch_ms", "algorithmic_bytes_per_launch", "traffic") if q in r}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-records", action="store_true", help="skip the config 3 / 4 sub-records (N=1) and the batch-mode record (N>1)")
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    # Rehearsal on a box with fewer GPUs than ranks: TRX2_BENCH_FORCE_DEVICE=0 puts every rank on that GPU and uses gloo
+    # (NCCL refuses two ranks on one device).  It exercises the multi-rank control flow, not multi-GPU performance.
+    forced = os.environ.get("TRX2_BENCH_FORCE_DEVICE")
+    if forced is not None:
+        local_rank = int(forced)
+    if world > 1:
+        import datetime
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        if forced is not None:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(hours=2))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(hours=2))
+
+    T = importlib.import_module("trrosettax2-dynamics_amd")
+    synth = importlib.import_module("trrosettax2-dynamics_amd.synth")
+    with_cpu = world == 1 and not args.no_cpu_baseline
+    if "targets" in cfg:
+        out = multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, with_cpu)
+    else:
+        out, m, runs = single_target(args, cfg, args.config, T, synth, rank, local_rank, world, dist, forced, args.steps, args.warmup, True)
+        if rank == 0 and with_cpu:
+            out["cpu_baseline"] = cpu_baseline(m, cfg, runs)
+        if args.config == 2 and not args.no_sub_records:
+            if world == 1:
+                # the other single-GPU configs of BASELINE.json, shorter legs of the same measurement
+                sub = {}
+                for c in (3, 4):
+                    r, _, _ = single_target(args, CONFIGS[c], c, T, synth, rank, local_rank, world, dist, forced, max(1, min(2, args.steps)), 1, False)
+                    sub[f"config{c}"] = compact(r)
+                out["sub_records"] = sub
+            else:
+                # the north star's multi-GPU mode: independent targets sharded over the ranks (config 5, strong scaling)
+                a5 = argparse.Namespace(steps=1, warmup=0)
+                bm = multi_target(a5, CONFIGS[5], T, synth, rank, local_rank, world, dist, forced, False)
+                if rank == 0:
+                    out["batch_mode"] = {k: bm[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "all_decoys_converged")}
+                    out["batch_mode"]["workload"] = bm["config"]["workload"]
+                    out["batch_mode"]["parallelism"] = bm["config"]["parallelism"]
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -126,6 +126,19 @@ int trx2_glocon_matrix(trx2_ctx* ctx, int n, int L, const char* seqs, const floa
 int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int sep_lo, int sep_hi, int n_rep, double* ms_avg,
                           double* term_evals);
 
+/* measurement helpers (bench.py): with every > 0, every `every`-th evaluation of a fold on this ctx is bracketed by HIP events
+ * on the ctx stream (before the pair kernel | between | after the step kernel); trx2_last_fold_kernel_times returns the
+ * averages over the sampled evaluations of the last fold -- the live launch durations of both kernels over a whole fold,
+ * not only on final coordinates.  Sampling inserts event records into the stream: use it in an untimed fold.
+ * trx2_ctx_info: layout facts the roofline arithmetic needs (key TRX2_INFO_*), valid after a fold/eval on the ctx. */
+#define TRX2_INFO_GROUP_WIDTH 0 /* decoys per wave of the pair kernel */
+#define TRX2_INFO_SLABS 1       /* gradient slabs the step kernel sums per residue */
+#define TRX2_INFO_LBFGS_M 2     /* stored correction pairs */
+#define TRX2_INFO_L 3
+int trx2_ctx_set_profiling(trx2_ctx* ctx, int every);
+int trx2_last_fold_kernel_times(trx2_ctx* ctx, double* pair_ms_avg, double* step_ms_avg, int* n_samples);
+int trx2_ctx_info(const trx2_ctx* ctx, int key, double* value);
+
 /* seconds spent inside the last trx2_fold_batch between first launch and results on host, and the number of
  * pair-kernel launches it made */
 int trx2_last_fold_stats(trx2_ctx* ctx, double* seconds, int* n_launches);

@@ -85,6 +85,8 @@ def lib():
         L.orc_random_torsions.argtypes = [C.c_int, C.c_uint64, C.c_uint32, vp]
         L.orc_fold.restype = C.c_int
         L.orc_fold.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+        L.orc_fold_batch.restype = C.c_int
+        L.orc_fold_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int]
         _lib = L
     return _lib
 
@@ -245,3 +247,37 @@ def fold(tab, tors0, runs, max_evals=200000):
     lib().orc_fold(tab.h, _p(tors), arr, len(runs), int(max_evals), C.byref(st), _p(xyz))
     return tors, xyz, dict(n_evals=st.n_evals, n_iters=st.n_iters, runs_done=st.runs_done, status=st.status,
                            e_final=np.array(st.e_final[:]), f_final=st.f_final)
+
+
+def usable_cores():
+    """cores this process may actually use: the scheduler affinity mask, capped by a cgroup CPU quota if one is set"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def fold_batch(tab, tors0, runs, max_evals=200000, nthreads=0):
+    """fold B decoys, OpenMP over decoys (orc_fold_batch); tors0[B,L,3] -> (torsions[B,L,3], xyz[B,L,5,3], stats list, threads used)"""
+    tors = np.ascontiguousarray(tors0, np.float64).copy()
+    B = tors.shape[0]
+    arr = make_runs(runs)
+    st = (FoldStats * B)()
+    xyz = np.zeros((B, tab.L, 5, 3))
+    used = lib().orc_fold_batch(tab.h, B, _p(tors), arr, len(runs), int(max_evals), st, _p(xyz), int(nthreads))
+    stats = [dict(n_evals=s.n_evals, n_iters=s.n_iters, runs_done=s.runs_done, status=s.status, e_final=np.array(s.e_final[:]),
+                  f_final=s.f_final) for s in st]
+    return tors, xyz, stats, used
+

@@ -44,13 +44,17 @@ def main(argv=None):
         rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
         dist = None
         if world > 1:
+            import datetime
             import torch
             import torch.distributed as dist
+            # no collective runs on the data path; the long timeout covers the final barrier of ranks that finish hours apart
+            # (the summary itself is gathered on a gloo group, sched.summary_group)
+            long_ = datetime.timedelta(hours=24)
             if torch.cuda.is_available():
                 torch.cuda.set_device(local)
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=long_)
             else:
-                dist.init_process_group("gloo")
+                dist.init_process_group("gloo", timeout=long_)
             kw["device"] = local
         dev_ = kw.pop("device")
         res = pipe.run_batch(names, a.fasta_dir, a.save_dir, rank=rank, world=world, dist=dist, device=dev_, **kw)

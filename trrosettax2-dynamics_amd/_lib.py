@@ -85,6 +85,9 @@ def load():
     L.trx2_feedback_process.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
     L.trx2_time_pair_kernel.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, dp, dp]
     L.trx2_last_fold_stats.argtypes = [vp, dp, ip]
+    L.trx2_ctx_set_profiling.argtypes = [vp, C.c_int]
+    L.trx2_last_fold_kernel_times.argtypes = [vp, dp, dp, ip]
+    L.trx2_ctx_info.argtypes = [vp, C.c_int, dp]
     _lib = L
     return L
 
@@ -267,6 +270,23 @@ class Context:
         out = np.empty((n, n), np.float64)
         self._chk(self._l.trx2_glocon_matrix(self._h, n, L, "".join(seqs).encode(), _p(xyz), float(dmax), _p(out)), "trx2_glocon_matrix")
         return out
+
+    def set_profiling(self, every):
+        """every > 0: bracket every `every`-th evaluation of the following folds by HIP events (trx2_ctx_set_profiling)"""
+        self._chk(self._l.trx2_ctx_set_profiling(self._h, int(every)), "trx2_ctx_set_profiling")
+
+    def last_fold_kernel_times(self):
+        """-> (pair kernel ms, step kernel ms, samples): live averages over the sampled evaluations of the last fold"""
+        a, b, n = C.c_double(), C.c_double(), C.c_int()
+        self._chk(self._l.trx2_last_fold_kernel_times(self._h, C.byref(a), C.byref(b), C.byref(n)), "trx2_last_fold_kernel_times")
+        return a.value, b.value, n.value
+
+    def info(self, key):
+        """layout facts for the roofline arithmetic: 0 decoys per wave, 1 gradient slabs per residue, 2 L-BFGS pairs, 3 L"""
+        v = C.c_double()
+        if self._l.trx2_ctx_info(self._h, int(key), C.byref(v)) != 0:
+            raise RuntimeError(f"trx2_ctx_info: unknown key {key}")
+        return v.value
 
     def time_pair_kernel(self, B, w, sep_lo=1, sep_hi=None, n_rep=50):
         w = np.ascontiguousarray(w, np.float32)

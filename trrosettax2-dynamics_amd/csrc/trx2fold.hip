@@ -94,6 +94,10 @@ struct trx2_ctx {
   trx2_run* runs = nullptr;
   int* h_done = nullptr;  // pinned
   double last_seconds = 0; int last_launches = 0;
+  // trx2_ctx_set_profiling: every prof_every-th evaluation of a fold is bracketed by HIP events on the stream (pair | step)
+  int prof_every = 0;
+  std::vector<hipEvent_t> prof_ev;
+  double prof_pair_ms = 0, prof_step_ms = 0; int prof_n = 0;
   // second lane (trx2_ctx_set_lanes): a context of its own stream and batch buffers that BORROWS this one's tables, so that
   // one job can run as two half-batches whose pair and step kernels overlap
   trx2_ctx* child = nullptr;
@@ -275,6 +279,7 @@ extern "C" void trx2_ctx_destroy(trx2_ctx* ctx) {
   if (ctx->child) { trx2_ctx* k = ctx->child; ctx->child = nullptr; trx2_ctx_destroy(k); }
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
+  for (auto& e : ctx->prof_ev) (void)hipEventDestroy(e);
   free_map(ctx);
   free_batch(ctx);
   if (ctx->fb_buf) (void)hipFree(ctx->fb_buf);
@@ -591,9 +596,19 @@ static int fold_impl(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint
   // hard cap on launches: every decoy stops by itself at max_evals; the extra margin covers skipped runs
   const long cap = (long)max_evals + 64;
   HIPCHK(hipMemsetAsync(ctx->seq_ctr, 0, sizeof(int), ctx->stream));
+  const int pe = ctx->prof_every;
+  int prof_used = 0;
+  ctx->prof_pair_ms = ctx->prof_step_ms = 0; ctx->prof_n = 0;
+  if (pe > 0 && ctx->prof_ev.empty()) {
+    ctx->prof_ev.resize(3 * (size_t)(chunk / 1));
+    for (auto& e : ctx->prof_ev) HIPCHK(hipEventCreate(&e));
+  }
   auto enqueue_chunk = [&]() {
     for (int i = 0; i < chunk; i++) {
+      const bool samp = pe > 0 && (i % pe) == 0 && (size_t)(3 * prof_used + 2) < ctx->prof_ev.size();
+      if (samp) (void)hipEventRecord(ctx->prof_ev[3 * prof_used], ctx->stream);
       launch_pair(ctx, B);  // bumps the device-side evaluation counter
+      if (samp) (void)hipEventRecord(ctx->prof_ev[3 * prof_used + 1], ctx->stream);
       if (has_cart) {
         // fused launch: workgroups of 256 (512 for 256 < L <= 512) threads, one residue per thread in the Cartesian role
         const ChainArgs ca = chain_args(ctx, B, MODE_STEP, nruns, max_evals);
@@ -604,6 +619,7 @@ static int fold_impl(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint
         else hipLaunchKernelGGL((k_step<2, CHAIN_THREADS, 2 * CHAIN_THREADS>), g2, b2, 0, ctx->stream, ca, cc);
       } else
         launch_chain(ctx, B, MODE_STEP, nruns, max_evals);
+      if (samp) { (void)hipEventRecord(ctx->prof_ev[3 * prof_used + 2], ctx->stream); prof_used++; }
     }
   };
   // The chunk is a static graph (its only per-evaluation input, the sequence number, lives in device memory): capture it
@@ -631,6 +647,14 @@ static int fold_impl(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ctx->h_done, ctx->done_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < prof_used; k++) {  // the sampled evaluations of this chunk
+      float a = 0, b = 0;
+      if (hipEventElapsedTime(&a, ctx->prof_ev[3 * k], ctx->prof_ev[3 * k + 1]) == hipSuccess &&
+          hipEventElapsedTime(&b, ctx->prof_ev[3 * k + 1], ctx->prof_ev[3 * k + 2]) == hipSuccess) {
+        ctx->prof_pair_ms += a; ctx->prof_step_ms += b; ctx->prof_n++;
+      }
+    }
+    prof_used = 0;
     if (*ctx->h_done >= B || launches >= cap) break;
   }
   // final report: energies of the accepted point X under the last run's weights
@@ -908,6 +932,32 @@ extern "C" int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int s
     *term_evals = n * B;
   }
   return 0;
+}
+
+extern "C" int trx2_ctx_set_profiling(trx2_ctx* ctx, int every) {
+  if (!ctx) return 1;
+  if (every < 0 || every > 64) { ctx->err = "trx2_ctx_set_profiling: every in 0..64"; return 1; }
+  ctx->prof_every = every;
+  if (ctx->child) ctx->child->prof_every = 0;  // the second lane is never sampled: its events would time overlapped kernels
+  return 0;
+}
+extern "C" int trx2_last_fold_kernel_times(trx2_ctx* ctx, double* pair_ms_avg, double* step_ms_avg, int* n_samples) {
+  if (!ctx) return 1;
+  const int n = ctx->prof_n;
+  if (pair_ms_avg) *pair_ms_avg = n ? ctx->prof_pair_ms / n : 0.0;
+  if (step_ms_avg) *step_ms_avg = n ? ctx->prof_step_ms / n : 0.0;
+  if (n_samples) *n_samples = n;
+  return 0;
+}
+extern "C" int trx2_ctx_info(const trx2_ctx* ctx, int key, double* value) {
+  if (!ctx || !value) return 1;
+  switch (key) {
+    case TRX2_INFO_GROUP_WIDTH: *value = ctx->BW; return 0;
+    case TRX2_INFO_SLABS: *value = ctx->nsplit; return 0;
+    case TRX2_INFO_LBFGS_M: *value = LBM; return 0;
+    case TRX2_INFO_L: *value = ctx->L; return 0;
+    default: return 1;
+  }
 }
 
 extern "C" int trx2_last_fold_stats(trx2_ctx* ctx, double* seconds, int* n_launches) {

@@ -219,8 +219,15 @@ def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, 
     n_chain = 2 if kw.get("mult_two_models", True) else 1
     init_num = kw.get("init_num", 10)
     fasta = {n: os.path.join(fasta_dir, n + ".fasta") for n in names}
-    items = [sched.Item(n, "all", len(read_fasta(fasta[n])), 0, init_num * n_chain) for n in names]
+    # Cost of a target = its initial batch + its feedback iterations.  The iterations are SEQUENTIAL single-decoy folds
+    # (run_inference.py:75-139) and dominate a target's wall time: one of them costs about as much time as ITER_DECOYS decoys
+    # of a batch (a fold is latency-bound: 37 ms for 1 decoy against 230 ms for 64 at L=150), and a chain
+    # runs ITER_EST of them before its convergence test fires (2-20 on the maps seen so far), never more than Nmax.
+    ITER_DECOYS, ITER_EST = 10, 10
+    n_eff = init_num * n_chain + n_chain * min(int(kw.get("Nmax", 300)), ITER_EST) * ITER_DECOYS
+    items = [sched.Item(n, "all", len(read_fasta(fasta[n])), 0, n_eff) for n in names]
     mine = sched.lpt_assign(items, world, min_block=1 << 30)[rank]   # min_block: never split a target
+    group = sched.summary_group(dist)                                # created up front: new_group is itself a collective
     local = dict(decoys=0, seconds=0.0, failed=0, targets=[], errors=[])
     for it in mine:
         t0 = time.perf_counter()
@@ -231,6 +238,6 @@ def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, 
             local["failed"] += 1
             local["errors"].append(f"{it.target}: {type(e).__name__}: {e}")
         local["seconds"] += time.perf_counter() - t0
-    per = sched.gather_stats(local, dist)
+    per = sched.gather_stats(local, dist, group)   # gloo, 24 h timeout: ranks arrive as they finish
     return dict(decoys=sum(p["decoys"] for p in per), seconds=max(p["seconds"] for p in per), failed=sum(p["failed"] for p in per),
                 errors=[e for p in per for e in p["errors"]], per_rank=per)

@@ -61,12 +61,26 @@ def shard_range(n, rank, world):
     return rank * base + min(rank, extra), base + (1 if rank < extra else 0)
 
 
-def gather_stats(local, dist=None):
-    """local: dict(decoys, seconds, failed).  -> list of per-rank dicts on every rank (all_gather_object)."""
+GATHER_TIMEOUT_H = 24  # ranks finish hours apart on long name lists; the summary gather must outwait the slowest one
+
+
+def summary_group(dist):
+    """A gloo group with a long timeout for the end-of-job summary gather.  Ranks reach that gather as they finish, possibly
+    hours apart; on the default NCCL group (10 min timeout) the watchdog would abort the early ranks and the summary and exit
+    code would be lost although every PDB file is written.  Collective: every rank must call it, once."""
+    import datetime
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    return dist.new_group(backend="gloo", timeout=datetime.timedelta(hours=GATHER_TIMEOUT_H))
+
+
+def gather_stats(local, dist=None, group=None):
+    """local: dict(decoys, seconds, failed).  -> list of per-rank dicts on every rank (all_gather_object on `group`,
+    a summary_group() for jobs whose ranks finish far apart; the default group otherwise)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return [dict(local)]
     out = [None] * dist.get_world_size()
-    dist.all_gather_object(out, dict(local))
+    dist.all_gather_object(out, dict(local), group=group)
     return out
 
 
