@@ -43,7 +43,7 @@ CONFIGS = {
                  "seed L; (target, decoy-block) items assigned to ranks longest-processing-time-first"),
 }
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
-KERNEL_SOURCES = ("kernel_pair.h", "trx2_device.h")
+KERNEL_SOURCES = ("kernel_pair2.h", "trx2_device.h")
 
 
 def kernel_source_sha():
@@ -60,12 +60,13 @@ def algorithmic_bytes(B, n_terms_per_decoy, L):
     return B * (16.0 * n_terms_per_decoy + 96.0 * L)
 
 
-def step_algorithmic_bytes(B, L, slabs, m):
-    """Step kernel (torsion role), bytes one launch must move per active decoy: gradient + energy slabs in (slabs x L x 96 B),
-    trial coordinates in (64 B per residue), accepted point / gradient / direction / trial torsions in and out (4 + 4 float4),
-    the stored correction pairs in (m pairs x 2 x 16 B per residue) and the new pair out (2 x 16 B), internal geometry in
-    (48 B), coordinates out twice (decoy-major + decoy-minor copy for the pair kernel, 2 x 64 B).  DESIGN.md section 4."""
-    per_res = slabs * 96.0 + 64.0 + 8 * 16.0 + m * 32.0 + 32.0 + 48.0 + 128.0
+def step_algorithmic_bytes(B, L, record_bytes, m):
+    """Step kernel (torsion role), bytes one launch must move per active decoy and residue: the pair kernel's gradient / energy
+    records in (record_bytes: 96 B per tile of the residue's row + 80 B per tile of its column, library-reported average), trial
+    coordinates in (80 B: six atoms), accepted point / gradient / direction / trial torsions in and out (4 + 4 float4), the stored
+    correction pairs in (m pairs x 2 x 16 B) and the new pair out (2 x 16 B), internal geometry in (48 B), coordinates out
+    (80 B).  DESIGN.md section 4."""
+    per_res = record_bytes + 80.0 + 8 * 16.0 + m * 32.0 + 32.0 + 48.0 + 80.0
     return B * L * per_res
 
 
@@ -123,7 +124,7 @@ def pair_roofline(ctx, T, B, L, config, fold_times=None):
         valu = {"insts_per_launch": rec["valu_insts_per_launch"], "busy_cycles_per_simd": cyc, "busy_frac": cyc / (ms * 1e-3 * CLOCK_HZ),
                 "clock_hz_assumed": CLOCK_HZ, "wave_time_waiting_frac": rec["wait_any_quad_cycles"] / rec["wave_quad_cycles"]}
     bw = int(ctx.info(0))
-    out = {"bound": "hbm", "kernel": f"k_pair<{bw}>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    out = {"bound": "hbm", "kernel": (f"k_pair<{bw}>" if B >= 3 else "k_pair2<1>") + f" ({int(ctx.info(4))} workgroups)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": (rec or {}).get("method"),
            "avg_launch_ms": ms, "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": n_terms, "valu": valu,
            "binding_limit": "vector-ALU issue + dependent-load latency, not HBM bandwidth (DESIGN.md section 5)"}
@@ -136,9 +137,9 @@ def step_roofline(ctx, B, L, fold_times):
     """second roofline record: the fused step kernel, live average over a whole (untimed, event-sampled) fold"""
     if not fold_times or not fold_times[2]:
         return None
-    slabs, m = int(ctx.info(1)), int(ctx.info(2))
+    rec_bytes, m = ctx.info(1), int(ctx.info(2))
     ms = fold_times[1]
-    abytes = step_algorithmic_bytes(B, L, slabs, m)
+    abytes = step_algorithmic_bytes(B, L, rec_bytes, m)
     ach = abytes / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": "k_step (torsion + Cartesian roles, one workgroup per decoy and role)", "achieved": ach,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
@@ -154,6 +155,26 @@ def sampled_fold(ctx, B, runs, seed, decoy0):
         return ctx.last_fold_kernel_times()
     finally:
         ctx.set_profiling(0)
+
+
+def fold_quality(synth, m, results):
+    """Does the workload FOLD?  C-alpha RMSD of every decoy of the timed steps to the synthetic map's own target structure and to
+    its mirror image (computed after the timed region): a throughput figure on a fold that fails is a cost-per-evaluation
+    figure, not a fold."""
+    ca = synth.nerf_backbone(m["tors"])[1]
+    xyz = np.concatenate([r["xyz"][:, :, 1] for r in results]).astype(np.float64)
+
+    def rmsd(P, Q):
+        P = P - P.mean(0); Q = Q - Q.mean(0)
+        U, S_, Vt = np.linalg.svd(P.T @ Q)
+        dsign = np.sign(np.linalg.det(U @ Vt))
+        return float(np.sqrt(max(0.0, ((P ** 2).sum() + (Q ** 2).sum() - 2 * (S_[0] + S_[1] + dsign * S_[2])) / len(P))))
+
+    rm = np.array([rmsd(x, ca) for x in xyz])
+    mir = np.array([rmsd(x * np.array([1.0, 1.0, -1.0]), ca) for x in xyz])
+    return {"decoys": len(rm), "rmsd_to_target_median": float(np.median(rm)), "frac_within_2A_of_target": float((rm < 2.0).mean()),
+            "frac_within_3.5A_of_mirror_image": float((mir < 3.5).mean()),
+            "note": "synthetic helical-bundle target (synth.py); distance-only maps cannot fix handedness"}
 
 
 def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, with_cpu):
@@ -282,6 +303,7 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
             "roofline": pair_roofline(ctx, T, B, L, config, ft),
             "roofline_step": step_roofline(ctx, B, L, ft),
             "all_decoys_converged": bool(ok), "evals_per_decoy": {"min": int(evals.min()), "median": float(np.median(evals)), "max": int(evals.max())},
+            "fold_quality": fold_quality(synth, m, res[::n_chains]),
             "pair_launches_per_step": launches / steps / n_chains,
             "slot_efficiency": float(evals.sum()) / (launches * B),  # sum of evaluations over decoys / (launches x decoy slots)
         }
@@ -306,7 +328,7 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
 
 def compact(rec):
     """sub-record of another config inside the default line: value, time per step, convergence, the kernel records"""
-    keys = ("value", "unit", "steps", "ms_per_step", "all_decoys_converged", "evals_per_decoy", "pair_launches_per_step", "slot_efficiency")
+    keys = ("value", "unit", "steps", "ms_per_step", "all_decoys_converged", "evals_per_decoy", "pair_launches_per_step", "slot_efficiency", "fold_quality")
     out = {k: rec[k] for k in keys if k in rec}
     out["workload"] = rec["config"]["workload"]
     for k in ("roofline", "roofline_step"):

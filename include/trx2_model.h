@@ -67,10 +67,11 @@ enum {
   TRX2_E_RAMA,     /* -ln mixture over the reference's 6 basins         */
   TRX2_E_OMEGA_BB, /* peptide-bond planarity tether (Rosetta "omega")   */
   TRX2_E_CART,     /* harmonic bonded geometry (Cartesian stage only)   */
+  TRX2_E_HB,       /* backbone hydrogen bonds (surrogate of cen_hb / hbond_sr_bb + hbond_lr_bb) */
   TRX2_NTERMS
 };
 /* weight vector layout: w[0]=atom_pair, w[1]=dihedral (omega & theta), w[2]=angle (phi), w[3]=vdw,
- * w[4]=rama, w[5]=omega_bb, w[6]=cart_bonded, w[7]=unused */
+ * w[4]=rama, w[5]=omega_bb, w[6]=cart_bonded, w[7]=backbone hydrogen bonds */
 #define TRX2_NW 8
 
 /* soft-sphere: E = VDW_SCALE * sum_{|i-j|>=VDW_MINSEP} max(0, r0^2 - d^2)^2 / r0^2 */
@@ -88,6 +89,23 @@ enum {
       3.72, 4.02, 3.97, 3.25, 4.15                                                                     \
     }                                                                                                  \
   }
+
+/* backbone hydrogen bond N-H(i) ... O=C(j), |i-j| >= HB_MINSEP, donor i >= 1 and not proline.  Surrogate of the terms the
+ * reference weights with cen_hb 5.0 (folding/data/scorefxn.wts:1, scorefxn1.wts:1) and hbond_sr_bb / hbond_lr_bb 3.0 each
+ * (scorefxn_cart.wts:1-2; equal weights, so the |i-j| <= 4 split is not needed).  Rosetta's potentials are not in the tree:
+ *   H   = N + HB_B_NH * unit( unit(N - C(i-1)) + unit(N - CA) )          in-plane bisector
+ *   E   = -HB_SCALE * f_d(|H-O|) * max(0, cos(N-H..O))^2 * max(0, cos(H..O=C))^2
+ *   f_d = (1 - ((d - HB_D0) / HB_R)^2)^2  inside |d - HB_D0| < HB_R, 0 outside  (C1, compact support 0.9 .. 3.0 A)
+ * cos(N-H..O) = unit(H-N).unit(O-H) and cos(H..O=C) = unit(O-C).unit(H-O) are both +1 for a straight N-H...O=C.
+ * The well sits where the reference's decoys put their closest N...O approaches (2.69 min / 2.83 A at the 0.1 percentile,
+ * |N-O| = 1.01 + 1.95 for a straight bond). */
+#define TRX2_HB_B_NH 1.01
+#define TRX2_HB_D0 1.95
+#define TRX2_HB_R 1.05
+#define TRX2_HB_MINSEP 3
+#ifndef TRX2_HB_SCALE
+#define TRX2_HB_SCALE 1.0
+#endif
 
 /* rama surrogate: E_i = -ln( (sum_k p_k exp(KAPPA (cos(phi-phi_k) + cos(psi-psi_k) - 2)) + FLOOR) / P_REF )
  * for residues 2..L-1; basins = the reference's start table (utils_ros.py:667-673), degrees */

@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-NTERMS = 8
+NTERMS = 9
 NW = 8
 KD, KO, KP = 35, 28, 16
 
@@ -60,6 +60,10 @@ def lib():
         L.orc_build_tables.restype = vp
         L.orc_build_tables.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_double]
         L.orc_tables_free.argtypes = [vp]
+        L.orc_tables_set_seq.argtypes = [vp, C.c_char_p]
+        L.orc_place_h.argtypes = [vp, vp, vp, vp]
+        L.orc_hbond_term.restype = C.c_double
+        L.orc_hbond_term.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_tables_ptr.restype = dp
         L.orc_tables_ptr.argtypes = [vp, C.c_int]
         L.orc_tables_prob.restype = fp
@@ -108,12 +112,16 @@ def params_vec(p=None):
 class Tables:
     """orc_build_tables: gen_rst + add_rst selection, dense."""
 
-    def __init__(self, dist, omega=None, theta=None, phi=None, params=None, pcut=0.05):
+    def __init__(self, dist, omega=None, theta=None, phi=None, params=None, pcut=0.05, seq=None):
         self.L = int(dist.shape[0])
         arrs = [np.ascontiguousarray(a, dtype=np.float32) if a is not None else None for a in (dist, omega, theta, phi)]
         self._keep = arrs
         self.use_orient = all(a is not None for a in arrs)
         self.h = lib().orc_build_tables(self.L, *[_p(a) for a in arrs], _p(params_vec(params)), float(pcut))
+        if seq is not None:   # prolines donate no backbone hydrogen bond
+            if len(seq) != self.L:
+                raise ValueError("sequence length does not match the map")
+            lib().orc_tables_set_seq(self.h, seq.encode())
 
     def __del__(self):
         try:

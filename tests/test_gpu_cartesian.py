@@ -30,7 +30,7 @@ def test_cartesian_run_tracks_oracle_over_a_short_horizon(ctx, golden_dir, seq):
     float32 and float64 trajectories are still together; the relaxed geometry comes back through the internal coordinates."""
     m = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
     ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
-    Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"])
+    Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
     rng = np.random.default_rng(5)
     B = 6
     t0 = np.stack([O.random_torsions(90, 31, d) + rng.normal(size=(90, 3)) * 0.05 for d in range(B)]).astype(np.float32)

@@ -9,8 +9,9 @@ L, B, orient = {2: (150, 64, False), 3: (150, 64, True), 4: (400, 32, True)}[int
 m = S.make_map(L); ctx = T.Context(0)
 ctx.set_map(m["dist"], *([m["omega"], m["theta"], m["phi"]] if orient else []), seq=m["seq"])
 ctx.fold_batch(B, T.protocol.build_runs(L, 2), seed=150)
-w = np.array(T.protocol.SF, np.float32); w0 = w.copy(); w0[3] = 0
-rows = [("everything", w, 1, L), ("vdw off", w0, 1, L), ("restraints off (vdw only)", w, 0, 0), ("both off (skeleton)", w0, 0, 0)]
+w = np.array(T.protocol.SF, np.float32); w0 = w.copy(); w0[3] = 0; w0[7] = 0; wv = w.copy(); wv[7] = 0; wh = w.copy(); wh[3] = 0
+rows = [("everything", w, 1, L), ("contacts off (vdw, hb)", w0, 1, L), ("hb off", wv, 1, L), ("vdw off", wh, 1, L), ("restraints off (contacts only)", w, 0, 0),
+        ("both off (skeleton)", w0, 0, 0)]
 for rep in range(2):
     for name, ww, lo, hi in rows:
         ms, _ = ctx.time_pair_kernel(B, ww, lo, hi, n_rep=100)

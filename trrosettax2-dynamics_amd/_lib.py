@@ -11,9 +11,9 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # TRX2FOLD_LIB selects an alternative build of the SAME library (A/B timing of kernel variants); never a CPU path
 LIB_PATH = os.environ.get("TRX2FOLD_LIB") or os.path.join(_HERE, "libtrx2fold.so")
-NTERMS, NW = 8, 8
+NTERMS, NW = 9, 8
 K = (35, 28, 28, 16)
-TERM_NAMES = ("dist", "omega", "theta", "phi", "vdw", "rama", "omega_bb", "cart")
+TERM_NAMES = ("dist", "omega", "theta", "phi", "vdw", "rama", "omega_bb", "cart", "hb")
 
 
 class Params(C.Structure):
@@ -282,7 +282,8 @@ class Context:
         return a.value, b.value, n.value
 
     def info(self, key):
-        """layout facts for the roofline arithmetic: 0 decoys per wave, 1 gradient slabs per residue, 2 L-BFGS pairs, 3 L"""
+        """layout facts for the roofline arithmetic: 0 decoys per wave of the pair kernel, 1 bytes of pair-kernel records summed
+        per residue by the step kernel, 2 L-BFGS pairs, 3 L, 4 workgroups per pair-kernel launch"""
         v = C.c_double()
         if self._l.trx2_ctx_info(self._h, int(key), C.byref(v)) != 0:
             raise RuntimeError(f"trx2_ctx_info: unknown key {key}")

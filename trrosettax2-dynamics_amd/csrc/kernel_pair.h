@@ -1,4 +1,5 @@
-// kernel_pair.h -- K3/K4: pair-term kernel (restraint splines + soft-sphere repulsion) -- included by trx2fold.hip.
+// kernel_pair.h -- K3/K4 for batches: pair-term kernel with lane = decoy (restraint splines, soft-sphere repulsion, backbone
+// hydrogen bonds) -- included by trx2fold.hip after kernel_pair2.h (shared helpers: spline_eval_dev, hbond_dev, P2_AREC).
 // Not a stand-alone header: it relies on the macros, constant tables and helpers defined above its #include.
 #pragma once
 // =================================================================================================
@@ -8,39 +9,15 @@
 // =================================================================================================
 struct PairArgs {
   int L, B, nsplit, Bpad;
-  const float4* xyzT;  // [ngrp][L][4][BW] float4 : residue record (N CA C O CB + pad), decoy-minor
+  const float4* xyzT;  // [ngrp][L][5][BW] float4 : residue record N CA C O CB (+pad) | H, hasH ; decoy-minor
   const float2 *Td, *To, *Tt, *Tp;
   const unsigned char* mask;  // [L][L] packed: low nibble = selected bits of (a,b), high nibble = those of (b,a)
   const float* knots;         // [107] float
-  const float* wcur;          // [Bpad][8] : w_ap w_dih w_ang w_vdw sep_lo sep_hi active -
-  float* fpart;               // [nsplit][Bpad][L][16] gradient on N CA C O CB (+pad)
-  float* epart;               // [nsplit][Bpad][L][8]  raw energies dist omega theta phi vdw
+  const float* wcur;          // [B][8] : w_ap w_dih w_ang w_vdw sep_lo sep_hi active w_hb
+  float* FA;                  // [nsplit][B][L][24] per (slab, decoy, residue a): gradient on N CA C O CB H, then the raw energies
+                              // dist omega theta phi vdw hb (P2_AREC; the step kernel sums the slabs: sum_pair_records)
   int* seq_ctr;               // evaluation counter in device memory: bumped here, read by the step kernel that follows
 };
-
-// ikn[i] = 1 / (kn[i+1] - kn[i]), precomputed once per workgroup: the same correctly rounded quotient the evaluator used
-// to compute per term (an IEEE division = ~10 vector instructions, six times per visit)
-__device__ __forceinline__ void spline_eval_dev(const float2* __restrict__ row, const float* kn, const float* ikn, int K,
-                                                int idx, float x, float& e, float& de) {
-  // idx is a guess; fix up against the (rounded, slightly non-uniform) knots
-  idx = max(0, min(K - 2, idx));
-  if (x < kn[idx]) idx = max(0, idx - 1);
-  else if (x >= kn[idx + 1]) idx = min(K - 2, idx + 1);
-  float lo = kn[idx], hi = kn[idx + 1];
-  float2 k0 = row[idx], k1 = row[idx + 1];
-  // the segment's cubic in t = x - lo, formed from (y, y'') of its two knots and evaluated by Horner (17 operations; the
-  // symmetric a/b form of the textbook needs ~30):  c1 = (y1-y0)/h - h (2 y0'' + y1'')/6,  c2 = y0''/2,  c3 = (y1''-y0'')/(6h)
-  float h = hi - lo, ih = ikn[idx], t = x - lo;
-  bool inside = (x > kn[0]) && (x < kn[K - 1]);
-  float c1 = fmaf(-h * (1.0f / 6.0f), fmaf(2.0f, k0.y, k1.y), (k1.x - k0.x) * ih);
-  float c3 = (k1.y - k0.y) * (ih * (1.0f / 6.0f));
-  float ev = fmaf(fmaf(fmaf(c3, t, 0.5f * k0.y), t, c1), t, k0.x);
-  float dv = fmaf(fmaf(3.0f * c3, t, k0.y), t, c1);
-  // outside the knot range: constant end value, zero slope (SplineFunc).  The end knots are the ones already fetched:
-  // x <= kn[0] => idx == 0 => k0 is row[0];  x >= kn[K-1] => idx == K-2 => k1 is row[K-1]
-  e = inside ? ev : (x <= kn[0] ? k0.x : k1.x);
-  de = inside ? dv : 0.0f;
-}
 
 // PAIR_MIN_WAVES (waves per SIMD the register allocator must admit) is a build-time knob so that occupancy-vs-spill
 // variants can be A/B-timed on hardware: 2 = no spills (220 VGPRs), 3 = 62 spilled, 4 = 104 spilled (profiles/README.md)
@@ -69,9 +46,7 @@ __device__ unsigned long long g_stamp[32];
 #define FAM_ASYM 2  /* theta + phi (both directions): needs N, CA, CB */
 #define FAM_VDW 4   /* soft-sphere repulsion: needs all five atoms, no tables */
 #define FAM_ALL 7
-#define VDW_RES_STRIDE 17 /* 15 gradient floats + energy, +1: a lane's record starts in its own LDS bank */
-// SHARE: the repulsion contacts of a block are shared by the wave's lanes (below) instead of walked lane by lane
-template <int BW, int FAM, bool SHARE>
+template <int BW, int FAM>
 __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs A) {
   constexpr int PW = 64 / BW;
   const int L = A.L;
@@ -80,26 +55,22 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   const int d = lane % BW, h = lane / BW;
   const int dec = grp * BW + d;
   const bool live = dec < A.B;
+  const int decc = min(dec, A.B - 1);
 
   STAMP_DECL
   __shared__ float s_kn[TRX2_KTOT], s_ikn[TRX2_KTOT];
-  __shared__ float s_red[PAIR_WAVES * 64 * RED_STRIDE];  // [wave][decoy][20 (+1 pad: bank-conflict-free)]
+  __shared__ float s_red[PAIR_WAVES * 64 * RED_STRIDE];  // [wave][decoy][24 (+1 pad: bank-conflict-free)]
   __shared__ unsigned char s_mask[1024];  // packed masks of this workgroup's residues b (chunk <= L <= 1024)
-  __shared__ unsigned short s_item[PAIR_WAVES * 64 * 32];   // per wave: contact items (owner lane << 5 | visit) of one block
-  __shared__ float s_res[PAIR_WAVES * 64 * VDW_RES_STRIDE];  // per wave: one result record per lane and round
   // One evaluation = one sequence number.  Kept in device memory (not a kernel argument) so that a chunk of
   // (pair, step) launches is a STATIC graph that can be replayed.  The step kernel of this evaluation starts after this
   // kernel has finished (same stream), so every one of its workgroups reads the same, final value.
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && A.seq_ctr) *A.seq_ctr += 1;
   // this lane's weights and residue a: requested first, so that their latency (they were written by the step kernel on
   // other CUs a moment ago) runs under the LDS fill and its barrier instead of after it
-  float4 w0 = make_float4(0, 0, 0, 0), w1 = w0;
-  if (live) {
-    const float4* wp = reinterpret_cast<const float4*>(A.wcur + (size_t)dec * 8);
-    w0 = wp[0]; w1 = wp[1];
-  }
-  const float4* xa = A.xyzT + ((size_t)(grp * L + a) * 4) * BW + d;
-  const float4 q0 = xa[0], q1 = xa[BW], q2 = xa[2 * BW], q3 = xa[3 * BW];
+  const float4* wp = reinterpret_cast<const float4*>(A.wcur + (size_t)decc * 8);
+  const float4 w0 = wp[0], w1 = wp[1];
+  const float4* xa = A.xyzT + ((size_t)(grp * L + a) * 5) * BW + d;
+  const float4 q0 = xa[0], q1 = xa[BW], q2 = xa[2 * BW], q3 = xa[3 * BW], q4 = xa[4 * BW];
   for (int i = threadIdx.x; i < TRX2_KTOT; i += PAIR_THREADS) {
     s_kn[i] = A.knots[i];
     s_ikn[i] = i + 1 < TRX2_KTOT ? 1.0f / (A.knots[i + 1] - A.knots[i]) : 0.0f;  // entries straddling two tables are never read
@@ -116,16 +87,17 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   const float *iknd = s_ikn, *ikno = s_ikn + KD, *iknt = s_ikn + KD + KO, *iknp = s_ikn + KD + 2 * KO;
   const float inv_o = 1.0f / (kno[1] - kno[0]), inv_p = 1.0f / (knp[1] - knp[0]);
 
-  const float w_ap = w0.x, w_dih = w0.y, w_ang = w0.z, w_vdw = w0.w;
+  const float w_ap = w0.x, w_dih = w0.y, w_ang = w0.z, w_vdw = w0.w, w_hb = w1.w;
   const int sep_lo = (int)w1.x, sep_hi = (int)w1.y;
   const bool active = live && w1.z != 0.0f;
 
   // residue a
   const f3 Na = mk3(q0.x, q0.y, q0.z), CAa = mk3(q0.w, q1.x, q1.y), Ca = mk3(q1.z, q1.w, q2.x),
-           Oa = mk3(q2.y, q2.z, q2.w), CBa = mk3(q3.x, q3.y, q3.z);
+           Oa = mk3(q2.y, q2.z, q2.w), CBa = mk3(q3.x, q3.y, q3.z), Ha = mk3(q4.x, q4.y, q4.z);
+  const bool donor_a = q4.w != 0.0f;
 
-  f3 gN = mk3(0, 0, 0), gCA = gN, gC = gN, gO = gN, gCB = gN;
-  float e_d = 0, e_o = 0, e_t = 0, e_p = 0, e_v = 0;
+  f3 gN = mk3(0, 0, 0), gCA = gN, gC = gN, gO = gN, gCB = gN, gH = gN;
+  float e_d = 0, e_o = 0, e_t = 0, e_p = 0, e_v = 0, e_h = 0;
 
   const int chunk = (L + A.nsplit - 1) / A.nsplit;
   const int b_lo = split * chunk, b_hi = min(L, b_lo + chunk);
@@ -157,14 +129,13 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
     if (!(FAM & FAM_SYM)) { m_ab &= ~(TRX2_M_DIST | TRX2_M_OMEGA); m_ba &= ~(TRX2_M_DIST | TRX2_M_OMEGA); }
     if (!(FAM & FAM_ASYM)) { m_ab &= ~(TRX2_M_THETA | TRX2_M_PHI); m_ba &= ~(TRX2_M_THETA | TRX2_M_PHI); }
     const unsigned msym = (a < bc) ? m_ab : m_ba;  // DIST / OMEGA bits live on the (min,max) row
-    const bool dovdw = (FAM & FAM_VDW) && valid && sep >= TRX2_VDW_MINSEP && w_vdw != 0.0f;
+    const bool dovdw = (FAM & FAM_VDW) && valid && sep >= TRX2_VDW_MINSEP && (w_vdw != 0.0f || w_hb != 0.0f);
     STAMP(1)  // masks (2 byte loads) + loop control
     if (!__any((int)(m_ab | m_ba | (unsigned)dovdw))) continue;
 
-    const float4* xb = A.xyzT + ((size_t)(grp * L + bc) * 4) * BW + d;
-    float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW];
-    const f3 Nb = mk3(r0.x, r0.y, r0.z), CAb = mk3(r0.w, r1.x, r1.y), Cb = mk3(r1.z, r1.w, r2.x),
-             Ob = mk3(r2.y, r2.z, r2.w), CBb = mk3(r3.x, r3.y, r3.z);
+    const float4* xb = A.xyzT + ((size_t)(grp * L + bc) * 5) * BW + d;
+    float4 r0 = xb[0], r1 = xb[BW], r3 = xb[3 * BW];
+    const f3 Nb = mk3(r0.x, r0.y, r0.z), CAb = mk3(r0.w, r1.x, r1.y), CBb = mk3(r3.x, r3.y, r3.z);
     STAMP(2)  // coordinates of residue b (4 x 16 B per lane)
     const size_t iab = (size_t)a * L + bc, iba = (size_t)bc * L + a;
     const size_t isym = (a < bc) ? iab : iba;
@@ -235,115 +206,45 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       if (dot(dca, dca) < (float)TRX2_VDW_CUT2) vmask |= 1u << v;
     }
   }
-  if (SHARE) {
-    // ---- the block's contacts, shared by the whole wave.  A lane walking only its own bits made the wave take
-    // max-over-lanes steps (5.1 on a distance-only fold) where the contacts would fill ceil(total / 64) = 2.0 rounds of 64
-    // (tools/vdw_walk_stats.py).  So: every lane publishes its contacts as items (owner lane, visit) at the positions an
-    // exclusive prefix sum of the counts assigns; in round r lane l computes item 64 r + l for WHICHEVER decoy owns it
-    // (coordinates of a and b of that decoy come from L1 / L2) and leaves the 15 gradient components and the energy in LDS;
-    // each owner then adds its own items in index (= visit) order.  Fixed order, no atomics: still deterministic.
-    {
-      const int cnt = __popc(vmask);
-      int incl = cnt;
-  #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-      }
-      const int first_item = incl - cnt;
-      const int total = __builtin_amdgcn_readlane(incl, 63);  // wave-uniform
-      if (total > 0) {
-        unsigned short* item = s_item + wave * (64 * 32);
-        float* res = s_res + wave * (64 * VDW_RES_STRIDE);
-        {
-          unsigned m = vmask;
-          int g = first_item;
-          while (m) {
-            const int v = __ffs((int)m) - 1;
-            m &= m - 1;
-            item[g++] = (unsigned short)((lane << 5) | v);
-          }
-        }
-        wave_lds_sync();
-        const float sw = w_vdw * (float)TRX2_VDW_SCALE;
-        for (int r0 = 0; r0 < total; r0 += 64) {
-          const int g = r0 + lane;
-          if (g < total) {
-            const unsigned it = item[g];
-            const int o = (int)(it >> 5), v = (int)(it & 31u);
-            const int od = o % BW, ob = bb + v * VSTRIDE + o / BW;
-            const float4* xo = A.xyzT + ((size_t)(grp * L + a) * 4) * BW + od;
-            const float4* xb = A.xyzT + ((size_t)(grp * L + ob) * 4) * BW + od;
-            const float4 p0 = xo[0], p1 = xo[BW], p2 = xo[2 * BW], p3 = xo[3 * BW];
-            const float4 r0_ = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW];
-            const f3 pa[5] = {mk3(p0.x, p0.y, p0.z), mk3(p0.w, p1.x, p1.y), mk3(p1.z, p1.w, p2.x), mk3(p2.y, p2.z, p2.w), mk3(p3.x, p3.y, p3.z)};
-            const f3 pb[5] = {mk3(r0_.x, r0_.y, r0_.z), mk3(r0_.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), mk3(r2.y, r2.z, r2.w), mk3(r3.x, r3.y, r3.z)};
-            f3 ga[5] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
-            float ev = 0;
-  #pragma unroll
-            for (int p = 0; p < 5; p++)
-  #pragma unroll
-              for (int q = 0; q < 5; q++) {
-                f3 u = pa[p] - pb[q];
-                constexpr VdwTab T = make_vdw_tab();
-                const float r02 = T.r0sq[p * 5 + q], ir = T.ir0sq[p * 5 + q];
-                float c = fmaxf(r02 - dot(u, u), 0.0f);
-                ev = fmaf(c * c, ir, ev);
-                ga[p] = fma3(u, -4.0f * c * ir, ga[p]);
-              }
-            float* w = res + lane * VDW_RES_STRIDE;
-  #pragma unroll
-            for (int p = 0; p < 5; p++) { w[p * 3] = ga[p].x; w[p * 3 + 1] = ga[p].y; w[p * 3 + 2] = ga[p].z; }
-            w[15] = ev;
-          }
-          wave_lds_sync();
-          const int q_hi = min(first_item + cnt, r0 + 64);
-          for (int q = max(first_item, r0); q < q_hi; q++) {  // this lane's items of the round, in visit order
-            const float* rr = res + (q - r0) * VDW_RES_STRIDE;
-            const int ob = bb + (int)(item[q] & 31u) * VSTRIDE + h;
-            gN = fma3(mk3(rr[0], rr[1], rr[2]), sw, gN);
-            gCA = fma3(mk3(rr[3], rr[4], rr[5]), sw, gCA);
-            gC = fma3(mk3(rr[6], rr[7], rr[8]), sw, gC);
-            gO = fma3(mk3(rr[9], rr[10], rr[11]), sw, gO);
-            gCB = fma3(mk3(rr[12], rr[13], rr[14]), sw, gCB);
-            if (a < ob) e_v += (float)TRX2_VDW_SCALE * rr[15];  // symmetric energy: counted from the lower row only
-          }
-          wave_lds_sync();  // before the next round overwrites the records
-        }
-      }
-    }
-  } else {
-    // per-lane walk: every lane follows its own contact bits (max-over-lanes steps).  Kept for maps with angle channels,
-    // where the shared walk's extra state cost the restraint terms more than it saved (profiles/README.md).
+  {
+    // per-lane walk: every lane follows its own contact bits (max-over-lanes steps): repulsion over the 5 x 5 atom pairs and
+    // the two hydrogen-bond candidates of the pair, gradient on residue a's atoms; symmetric energies counted from the lower row
     while (vmask) {  // per-lane trip count; lanes without further contacts idle
       const int v = __ffs((int)vmask) - 1;
       vmask &= vmask - 1;
       const int b = bb + v * VSTRIDE + h;
-      const float4* xb = A.xyzT + ((size_t)(grp * L + b) * 4) * BW + d;
-      float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW];
-      const f3 pa[5] = {Na, CAa, Ca, Oa, CBa};
-      const f3 pb[5] = {mk3(r0.x, r0.y, r0.z), mk3(r0.w, r1.x, r1.y), mk3(r1.z, r1.w, r2.x), mk3(r2.y, r2.z, r2.w),
-                        mk3(r3.x, r3.y, r3.z)};
-      f3 ga[5] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
-      float ev = 0;
+      const float4* xb = A.xyzT + ((size_t)(grp * L + b) * 5) * BW + d;
+      const float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW], r4 = xb[4 * BW];
+      const f3 Nb = mk3(r0.x, r0.y, r0.z), Cb = mk3(r1.z, r1.w, r2.x), Ob = mk3(r2.y, r2.z, r2.w), Hb = mk3(r4.x, r4.y, r4.z);
+      if (w_vdw != 0.0f) {
+        const f3 pa[5] = {Na, CAa, Ca, Oa, CBa};
+        const f3 pb[5] = {Nb, mk3(r0.w, r1.x, r1.y), Cb, Ob, mk3(r3.x, r3.y, r3.z)};
+        f3 ga[5] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
+        float ev = 0;
   #pragma unroll
-      for (int p = 0; p < 5; p++)
+        for (int p = 0; p < 5; p++)
   #pragma unroll
-        for (int q = 0; q < 5; q++) {
-          f3 u = pa[p] - pb[q];
-          constexpr VdwTab T = make_vdw_tab();
-          const float r02 = T.r0sq[p * 5 + q], ir = T.ir0sq[p * 5 + q];
-          float c = fmaxf(r02 - dot(u, u), 0.0f);
-          ev = fmaf(c * c, ir, ev);
-          ga[p] = fma3(u, -4.0f * c * ir, ga[p]);
-        }
-      const float s = w_vdw * (float)TRX2_VDW_SCALE;
-      if (a < b) e_v += (float)TRX2_VDW_SCALE * ev;  // symmetric energy: counted from the lower row only
-      gN = fma3(ga[0], s, gN);
-      gCA = fma3(ga[1], s, gCA);
-      gC = fma3(ga[2], s, gC);
-      gO = fma3(ga[3], s, gO);
-      gCB = fma3(ga[4], s, gCB);
+          for (int q = 0; q < 5; q++) {
+            f3 u = pa[p] - pb[q];
+            constexpr VdwTab T = make_vdw_tab();
+            const float r02 = T.r0sq[p * 5 + q], ir = T.ir0sq[p * 5 + q];
+            float c = fmaxf(r02 - dot(u, u), 0.0f);
+            ev = fmaf(c * c, ir, ev);
+            ga[p] = fma3(u, -4.0f * c * ir, ga[p]);
+          }
+        const float s = w_vdw * (float)TRX2_VDW_SCALE;
+        if (a < b) e_v += (float)TRX2_VDW_SCALE * ev;
+        gN = fma3(ga[0], s, gN);
+        gCA = fma3(ga[1], s, gCA);
+        gC = fma3(ga[2], s, gC);
+        gO = fma3(ga[3], s, gO);
+        gCB = fma3(ga[4], s, gCB);
+      }
+      if (w_hb != 0.0f && abs(a - b) >= TRX2_HB_MINSEP) {
+        f3 dump = mk3(0, 0, 0);  // the other residue's share: its own row computes it
+        if (donor_a) { const float e = hbond_dev(Na, Ha, Ob, Cb, w_hb, gN, gH, dump, dump); if (a < b) e_h += e; }
+        if (r4.w != 0.0f) { const float e = hbond_dev(Nb, Hb, Oa, Ca, w_hb, dump, dump, gO, gC); if (a < b) e_h += e; }
+      }
     }
   }
   STAMP(9)  // vdw
@@ -357,37 +258,29 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   // LDS image [wave][decoy][21]: the h = 0 lanes write 20 values at stride 21 (no bank conflict); the readers are
   // (decoy, quad) pairs, 4 lanes per decoy, so every store instruction writes whole 64-B (gradient) / 32-B (energy) runs.
   {
-    float vals[20] = {gN.x, gN.y, gN.z, gCA.x, gCA.y, gCA.z, gC.x, gC.y, gC.z, gO.x,
-                      gO.y, gO.z, gCB.x, gCB.y, gCB.z, e_d, e_o, e_t, e_p, e_v};
+    float vals[P2_AREC] = {gN.x, gN.y, gN.z, gCA.x, gCA.y, gCA.z, gC.x, gC.y, gC.z, gO.x, gO.y, gO.z,
+                           gCB.x, gCB.y, gCB.z, gH.x, gH.y, gH.z, e_d, e_o, e_t, e_p, e_v, e_h};
 #pragma unroll
     for (int o = BW; o < 64; o <<= 1)
 #pragma unroll
-      for (int k = 0; k < 20; k++) vals[k] += __shfl_xor(vals[k], o, 64);
+      for (int k = 0; k < P2_AREC; k++) vals[k] += __shfl_xor(vals[k], o, 64);
     if (h == 0) {
       float* s = s_red + ((size_t)wave * BW + d) * RED_STRIDE;
 #pragma unroll
-      for (int k = 0; k < 20; k++) s[k] = vals[k];
+      for (int k = 0; k < P2_AREC; k++) s[k] = vals[k];
     }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < 6 * BW; t += PAIR_THREADS) {  // 6 quads per decoy: 4 gradient (16 floats) + 2 energy (8)
+  for (int t = threadIdx.x; t < 6 * BW; t += PAIR_THREADS) {  // 6 quads per decoy = one 24-float record
     const int dd = t / 6, q = t % 6;
     const int dc = grp * BW + dd;
     if (dc >= A.B) continue;
     float acc[4] = {0, 0, 0, 0};
-    const int k0 = q < 4 ? q * 4 : 15 + (q - 4) * 4;  // first value of this quad in the 20-value record
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int k = k0 + i;
-      const bool real = q < 4 ? (k < 15) : (k < 20);  // gradient pad (16th float) and energy pads are zero
-      if (real)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int sl = 0; sl < PAIR_WAVES; sl++) acc[i] += s_red[((size_t)sl * BW + dd) * RED_STRIDE + k];
-    }
-    const size_t rec = ((size_t)split * A.Bpad + dc) * L + a;
-    const float4 v = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    if (q < 4) reinterpret_cast<float4*>(A.fpart + rec * 16)[q] = v;
-    else reinterpret_cast<float4*>(A.epart + rec * 8)[q - 4] = v;
+      for (int sl = 0; sl < PAIR_WAVES; sl++) acc[i] += s_red[((size_t)sl * BW + dd) * RED_STRIDE + q * 4 + i];
+    reinterpret_cast<float4*>(A.FA + (((size_t)split * A.B + dc) * L + a) * P2_AREC)[q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
   STAMP(11)  // epilogue: LDS image, barrier, column sums, stores
   STAMP_FLUSH

@@ -16,7 +16,7 @@ enum { SI_RUN = 0, SI_SEQ, SI_PHASE, SI_ITER, SI_NLS, SI_HL, SI_HH, SI_NH, SI_ST
 enum { SD_F = 0, SD_ALPHA, SD_GD, SD_FH0, SD_FH1, SD_FH2, SD_GAMMA, SD_N = 8 };
 
 struct ChainArgs {
-  int L, B, Bpad, BW, nsplit, mode, nruns, max_evals;
+  int L, B, mode, nruns, max_evals;
   const int* seq_ctr;  // evaluation number (device counter bumped by k_pair): a decoy is stepped once per evaluation, by the
                        // torsion OR the Cartesian role (SI_SEQ)
   const trx2_run* runs;
@@ -25,17 +25,57 @@ struct ChainArgs {
   float* rho;      // [B][LBM]
   float4 *X, *G, *D, *XT;  // [B][L] (phi, psi, omega, -)
   float4 *S, *Y;           // [B][LBM][L]
-  float* xyz;              // [B][L][16] trial coordinates, decoy-major
+  float4* P;               // [B][L][5] trial coordinates, decoy-major: N CA C O CB (15 floats + pad) | backbone H, hasH
+  float4* xyzT;            // [ngrp][L][5][BW] decoy-minor copy for the batch pair kernel (kernel_pair.h), or NULL
+  int BW;
   const float4* geom;      // [B][L][3] internal geometry per residue (ResGeom)
-  float4* xyzT;            // decoy-minor copy for k_pair
-  float* wcur;             // [Bpad][8]
-  const float* fpart;      // [nsplit][Bpad][L][16]
-  const float* epart;      // [nsplit][Bpad][L][8]
+  float* wcur;             // [B][8]
+  const float* FA;         // [nJ][B][L][24] pair-kernel records of a residue as the lower member of its pairs (+ energies)
+  const float* FB;         // [nI][B][L][20] ... as the upper member
+  int TA, TB, nI, nJ;      // tile geometry of the pair kernel (kernel_pair2.h)
+  const unsigned char* hasH;  // [L] residue donates a backbone hydrogen bond (has a predecessor, not proline)
   double* e_last;          // [B][NTERMS] raw terms of the last evaluation
   double* f_last;          // [B]
   float* grad_out;         // [B][L][3] (MODE_FINISH)
   int* done_count;
 };
+
+// tile (it, jt) of the pair matrix holds a pair a < b  <=>  its first a is below its last b (host: same test, trx2fold.hip)
+__host__ __device__ __forceinline__ bool tile_exists(int it, int jt, int TA, int TB, int L) {
+  const int bmax = ((jt + 1) * TB < L ? (jt + 1) * TB : L) - 1;
+  return it * TA < bmax;
+}
+// Sum of the pair kernel's records of residue r of decoy dec: a-records of the tiles in its row (24 floats: 18 gradient
+// components + 6 energies), b-records of the tiles in its column (20 floats).  Fixed order: deterministic.
+__device__ __forceinline__ void sum_pair_records(const float* FA, const float* FB, int TA, int TB, int nI, int nJ, int B, int L,
+                                                 int dec, int r, float (&g)[P2_NCOMP], float (&e)[6]) {
+#pragma unroll
+  for (int i = 0; i < P2_NCOMP; i++) g[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 6; i++) e[i] = 0.0f;
+  const int it_r = r / TA, jt_r = r / TB;
+  for (int jt = 0; jt < nJ; jt++) {
+    if (!tile_exists(it_r, jt, TA, TB, L)) continue;
+    const float4* f = reinterpret_cast<const float4*>(FA + (((size_t)jt * B + dec) * L + r) * P2_AREC);
+    const float4 v0 = f[0], v1 = f[1], v2 = f[2], v3 = f[3], v4 = f[4], v5 = f[5];
+    g[0] += v0.x; g[1] += v0.y; g[2] += v0.z; g[3] += v0.w; g[4] += v1.x; g[5] += v1.y; g[6] += v1.z; g[7] += v1.w;
+    g[8] += v2.x; g[9] += v2.y; g[10] += v2.z; g[11] += v2.w; g[12] += v3.x; g[13] += v3.y; g[14] += v3.z; g[15] += v3.w;
+    g[16] += v4.x; g[17] += v4.y; e[0] += v4.z; e[1] += v4.w; e[2] += v5.x; e[3] += v5.y; e[4] += v5.z; e[5] += v5.w;
+  }
+  for (int it = 0; it < nI; it++) {
+    if (!tile_exists(it, jt_r, TA, TB, L)) break;  // tiles of a column exist for it = 0 .. some bound
+    const float4* f = reinterpret_cast<const float4*>(FB + (((size_t)it * B + dec) * L + r) * P2_BREC);
+    const float4 v0 = f[0], v1 = f[1], v2 = f[2], v3 = f[3], v4 = f[4];
+    g[0] += v0.x; g[1] += v0.y; g[2] += v0.z; g[3] += v0.w; g[4] += v1.x; g[5] += v1.y; g[6] += v1.z; g[7] += v1.w;
+    g[8] += v2.x; g[9] += v2.y; g[10] += v2.z; g[11] += v2.w; g[12] += v3.x; g[13] += v3.y; g[14] += v3.z; g[15] += v3.w;
+    g[16] += v4.x; g[17] += v4.y;
+  }
+}
+// backbone H from C of the previous residue, N, CA: in-plane bisector (trx2_model.h; oracle: orc_place_h)
+__device__ __forceinline__ f3 place_h(f3 Cp, f3 N, f3 CA) {
+  const f3 u = unit(N - Cp) + unit(N - CA);
+  return N + u * ((float)TRX2_HB_B_NH * rsqrtf(dot(u, u)));
+}
 
 // workgroup barrier of an NW-wave role.  One wave: its LDS operations execute in program order, so only the compiler has
 // to be kept from reordering them.
@@ -48,13 +88,14 @@ __device__ __forceinline__ void bsync() {
 // barrier per call is enough: a wave can be at most one call ahead of the slowest, and then it writes the OTHER buffer.
 // (With one buffer every call needed a second barrier just to protect the previous call's reads; the two-loop recursion
 // makes 2 x LBM dependent calls per step.)  Every wave must make the same sequence of calls.
+#define SBUF_K 12 /* values per wave in the reduction buffers (the energy reduction carries 9) */
 template <int K, int NW>
-__device__ __forceinline__ void block_sum_n(double (&v)[K], double* s_buf /* [2][NW*8] */, int& flip) {
+__device__ __forceinline__ void block_sum_n(double (&v)[K], double* s_buf /* [2][NW*SBUF_K] */, int& flip) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < K; k++) v[k] = wave_sum(v[k]);
   if (NW == 1) return;  // the in-wave sum leaves the total in every lane
-  double* buf = s_buf + flip * (NW * 8);
+  double* buf = s_buf + flip * (NW * SBUF_K);
   flip ^= 1;
   if (lane == 0)
 #pragma unroll
@@ -133,7 +174,7 @@ template <int RPT, int NT>
 __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   constexpr int NW = NT / 64;
   const int L = A.L, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __shared__ double s_buf[2 * NW * 8];
+  __shared__ double s_buf[2 * NW * SBUF_K];
   int flip = 0;
   __shared__ float s_scan[NW * 12];
   __shared__ float s_alpha[LBM];
@@ -186,7 +227,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       x[k] = g[k] = dv[k] = make_float4(0, 0, 0, 0);
       if (r < L && A.mode == MODE_STEP) { x[k] = A.X[vb + r]; g[k] = A.G[vb + r]; dv[k] = A.D[vb + r]; }
     }
-    double esum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double esum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     f3 g2[RPT], g1[RPT];       // per-residue sums of gradient / x cross gradient
     f3 gO_[RPT], gC_[RPT], gCB_[RPT], pN[RPT], pCA[RPT], pC[RPT], pO[RPT], pCB[RPT];
 #pragma unroll
@@ -197,29 +238,20 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       g2[k] = g1[k] = gO_[k] = gC_[k] = gCB_[k] = pN[k] = pCA[k] = pC[k] = pO[k] = pCB[k] = mk3(0, 0, 0);
       if (r < L) {
         xt[k] = A.XT[vb + r];
-        float g[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) g[i] = 0;
-        for (int s = 0; s < A.nsplit; s++) {
-          const size_t rec = ((size_t)s * A.Bpad + dec) * L + r;
-          const float4* fp = reinterpret_cast<const float4*>(A.fpart + rec * 16);
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            float4 v = fp[q];
-            g[q * 4] += v.x; g[q * 4 + 1] += v.y; g[q * 4 + 2] += v.z; g[q * 4 + 3] += v.w;
-          }
-          const float4* ep = reinterpret_cast<const float4*>(A.epart + rec * 8);
-          float4 e0 = ep[0], e1 = ep[1];
-          esum[0] += e0.x; esum[1] += e0.y; esum[2] += e0.z; esum[3] += e0.w; esum[4] += e1.x;
-        }
-        const float4* xp = reinterpret_cast<const float4*>(A.xyz + (vb + r) * 16);
-        float4 c0 = xp[0], c1 = xp[1], c2 = xp[2], c3 = xp[3];
+        const float4* xp = A.P + (vb + r) * 5;
+        const float4 c0 = xp[0], c1 = xp[1], c2 = xp[2], c3 = xp[3], c4 = xp[4];
+        float g[P2_NCOMP], ep[6];
+        sum_pair_records(A.FA, A.FB, A.TA, A.TB, A.nI, A.nJ, A.B, L, dec, r, g, ep);
+        esum[0] += ep[0]; esum[1] += ep[1]; esum[2] += ep[2]; esum[3] += ep[3]; esum[4] += ep[4]; esum[8] += ep[5];
         pN[k] = mk3(c0.x, c0.y, c0.z); pCA[k] = mk3(c0.w, c1.x, c1.y); pC[k] = mk3(c1.z, c1.w, c2.x);
         pO[k] = mk3(c2.y, c2.z, c2.w); pCB[k] = mk3(c3.x, c3.y, c3.z);
+        const f3 pH = mk3(c4.x, c4.y, c4.z), gH = mk3(g[15], g[16], g[17]);
         f3 gN = mk3(g[0], g[1], g[2]), gCA = mk3(g[3], g[4], g[5]);
         gC_[k] = mk3(g[6], g[7], g[8]); gO_[k] = mk3(g[9], g[10], g[11]); gCB_[k] = mk3(g[12], g[13], g[14]);
-        g2[k] = gN + gCA + gC_[k] + gO_[k] + gCB_[k];
-        g1[k] = cross(pN[k], gN) + cross(pCA[k], gCA) + cross(pC[k], gC_[k]) + cross(pO[k], gO_[k]) + cross(pCB[k], gCB_[k]);
+        // the backbone H rides on its residue: it is placed from C(r-1), N, CA, all upstream of this residue's own torsions,
+        // so it belongs to the suffix sums (every torsion before r moves it) and to none of the residue's own moved sets
+        g2[k] = gN + gCA + gC_[k] + gO_[k] + gCB_[k] + gH;
+        g1[k] = cross(pN[k], gN) + cross(pCA[k], gCA) + cross(pC[k], gC_[k]) + cross(pO[k], gO_[k]) + cross(pCB[k], gCB_[k]) + cross(pH, gH);
         // torsion-space terms: rama (residues 2..L-1) and omega_bb (1..L-1)
         if (r >= 1 && r < L - 1) {
           float s = 0, dph = 0, dps = 0;
@@ -285,8 +317,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       if (r < L) {
         // omega_r: axis C_r -> N_{r+1}
         if (r + 1 < L) {
-          const float* nx = A.xyz + (vb + r + 1) * 16;
-          f3 Nn = mk3(nx[0], nx[1], nx[2]);
+          const float4 nx = A.P[(vb + r + 1) * 5];
+          f3 Nn = mk3(nx.x, nx.y, nx.z);
           f3 n = unit(Nn - pC[k]);
           gt[k].z += dot(n, ex1) - dot(cross(n, pC[k]), ex2);
         }
@@ -306,9 +338,9 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       car1 = car1 + mk3(tot[3], tot[4], tot[5]);
     }
     CSTAMP(2)  // suffix scan + torsion gradient
-    block_sum_n<8, NW>(esum, s_buf, flip);
+    block_sum_n<9, NW>(esum, s_buf, flip);
     const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] +
-                       (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6];
+                       (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[7] * esum[8];
     if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
     if (tid == 0) A.f_last[dec] = f_t;
 
@@ -542,7 +574,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
     w[0] = Rn.w[0]; w[1] = Rn.w[1]; w[2] = Rn.w[2]; w[3] = Rn.w[3];
     w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi;
     w[6] = (phase == PH_DONE && A.mode == MODE_STEP) ? 0.0f : 1.0f;
-    w[7] = 0;
+    w[7] = Rn.w[7];
   }
   if (!need_nerf) return;
 
@@ -565,7 +597,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
     const int r = k * NT + tid;
     Xf M = xf_identity();
     ResGeom gr = ideal_geom();
-    f3 lN = mk3(0, 0, 0), lCA = lN, lC = lN, lCB = lN;
+    f3 lN = mk3(0, 0, 0), lCA = lN, lC = lN, lCB = lN, lNn = lN, lCAn = lN;
     if (r < L) {
       gr.g0 = gq[r * 3]; gr.g1 = gq[r * 3 + 1]; gr.g2 = gq[r * 3 + 2];
       local_atoms(gr, lN, lCA, lC, lCB);
@@ -582,6 +614,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         f3 CAn = place_atom(lCA, lC, Nn, n0.x, c2, s2, co, so);
         f3 Cn = place_atom(lC, Nn, CAn, n0.y, c3, s3, cp, sp);
         M = xf_from_atoms(Nn, CAn, Cn);
+        lNn = Nn; lCAn = CAn;
       }
     }
     CSTAMP(10)  // NeRF: geometry loads, sincos, local frames
@@ -624,11 +657,25 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       f3 N = xf_apply(F, lN), CA = xf_apply(F, lCA), C = xf_apply(F, lC), O = xf_apply(F, lO), CB = xf_apply(F, lCB);
       float4 o0 = make_float4(N.x, N.y, N.z, CA.x), o1 = make_float4(CA.y, CA.z, C.x, C.y),
              o2 = make_float4(C.z, O.x, O.y, O.z), o3 = make_float4(CB.x, CB.y, CB.z, 0);
-      float4* xo = reinterpret_cast<float4*>(A.xyz + (vb + r) * 16);
+      float4* xo = A.P + (vb + r) * 5;
       xo[0] = o0; xo[1] = o1; xo[2] = o2; xo[3] = o3;
-      const int grp = dec / A.BW, dd = dec % A.BW;
-      float4* xT = A.xyzT + ((size_t)(grp * L + r) * 4) * A.BW + dd;
-      xT[0] = o0; xT[A.BW] = o1; xT[2 * A.BW] = o2; xT[3 * A.BW] = o3;
+      // backbone H of the NEXT residue: its three parents C(r), N(r+1), CA(r+1) are all known in this residue's frame
+      float4* xT = nullptr;
+      if (A.xyzT) {
+        xT = A.xyzT + ((size_t)((dec / A.BW) * L + r) * 5) * A.BW + dec % A.BW;
+        xT[0] = o0; xT[A.BW] = o1; xT[2 * A.BW] = o2; xT[3 * A.BW] = o3;
+      }
+      if (r + 1 < L) {
+        const f3 Hn = xf_apply(F, place_h(lC, lNn, lCAn));
+        const float4 hv = make_float4(Hn.x, Hn.y, Hn.z, A.hasH[r + 1] ? 1.0f : 0.0f);
+        xo[5 + 4] = hv;
+        if (xT) xT[(5 + 4) * A.BW] = hv;
+      }
+      if (r == 0) {  // residue 1 has no predecessor: no H, a harmless position
+        const float4 hv = make_float4(N.x + 1.0f, N.y, N.z, 0.0f);
+        xo[4] = hv;
+        if (xT) xT[4 * A.BW] = hv;
+      }
     }
     CSTAMP(12)  // NeRF: atoms from frames, coordinate stores
   }
@@ -644,17 +691,18 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
 // orc_extract_internal).  The L-BFGS state machine is the one of k_chain on 4 float4 per residue.
 // =================================================================================================
 struct CartArgs {
-  int L, B, Bpad, BW, nsplit, nruns, max_evals;
+  int L, B, nruns, max_evals;
   const int* seq_ctr;
   const trx2_run* runs;
   int* st_i; double* st_d; float* rho;
   float4 *CX, *CG, *CD;      // [B][L][4] accepted point, its gradient, direction
   float4 *CS, *CY;           // [B][LBM][L][4]
-  float* xyz;                // [B][L][16] trial coordinates = trial DOF vector (in/out)
-  float4* xyzT;
+  float4* P;                 // [B][L][5]: the first 4 float4 of a record = trial coordinates = trial DOF vector (in/out), 5th = H
+  float4* xyzT; int BW;      // decoy-minor copy for the batch pair kernel, or NULL
   float4 *X, *XT, *geom;     // torsions and internal geometry, written when the run ends
   float* wcur;
-  const float* fpart; const float* epart;
+  const float* FA; const float* FB; int TA, TB, nI, nJ;
+  const unsigned char* hasH;
   double *e_last, *f_last;
   int* done_count;
 };
@@ -694,7 +742,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   constexpr int NW = NT / 64;  // one residue per thread: NT = 256 for chains up to 256 residues, 512 up to 512
   const int L = A.L, tid = threadIdx.x, r = tid;
   const bool act = r < L;
-  __shared__ double s_buf[2 * NW * 8];
+  __shared__ double s_buf[2 * NW * SBUF_K];
   int flip = 0;
   __shared__ float s_alpha[LBM];
   __shared__ int s_i[SI_N];
@@ -702,6 +750,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   __shared__ float s_rho[LBM];
   __shared__ float s_xyz[NT * 16];
   __shared__ float s_dt[NT * 3];
+  __shared__ float s_gp[NT * 3];  // gradient a residue's backbone H sends to C of the residue before it
   int* gi = A.st_i + (size_t)dec * SI_N;
   double* gd_ = A.st_d + (size_t)dec * SD_N;
   KSTAMP_DECL
@@ -726,21 +775,18 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   float4 xt[4], gt[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) { xt[q] = gt[q] = make_float4(0, 0, 0, 0); }
-  double esum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double esum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  f3 gH = mk3(0, 0, 0);
   if (act) {
-    const float4* xp = reinterpret_cast<const float4*>(A.xyz + (vb + r) * 16);
+    const float4* xp = A.P + (vb + r) * 5;
 #pragma unroll
     for (int q = 0; q < 4; q++) { xt[q] = xp[q]; reinterpret_cast<float4*>(s_xyz + r * 16)[q] = xt[q]; }
-    for (int s = 0; s < A.nsplit; s++) {
-      const size_t rec = ((size_t)s * A.Bpad + dec) * L + r;
-      const float4* fp = reinterpret_cast<const float4*>(A.fpart + rec * 16);
-#pragma unroll
-      for (int q = 0; q < 4; q++) { float4 v = fp[q]; gt[q].x += v.x; gt[q].y += v.y; gt[q].z += v.z; gt[q].w += v.w; }
-      const float4* ep = reinterpret_cast<const float4*>(A.epart + rec * 8);
-      float4 e0 = ep[0], e1 = ep[1];
-      esum[0] += e0.x; esum[1] += e0.y; esum[2] += e0.z; esum[3] += e0.w; esum[4] += e1.x;
-    }
-    gt[3].w = 0.0f;
+    float g[P2_NCOMP], ep[6];
+    sum_pair_records(A.FA, A.FB, A.TA, A.TB, A.nI, A.nJ, A.B, L, dec, r, g, ep);
+    esum[0] += ep[0]; esum[1] += ep[1]; esum[2] += ep[2]; esum[3] += ep[3]; esum[4] += ep[4]; esum[8] += ep[5];
+    gt[0] = make_float4(g[0], g[1], g[2], g[3]); gt[1] = make_float4(g[4], g[5], g[6], g[7]);
+    gt[2] = make_float4(g[8], g[9], g[10], g[11]); gt[3] = make_float4(g[12], g[13], g[14], 0.0f);
+    gH = mk3(g[15], g[16], g[17]);
   }
   __syncthreads();
   CSTAMP(17)  // coordinates -> LDS, slab sums
@@ -749,6 +795,23 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   Res5 Me = unpack5(s_xyz + (act ? r : 0) * 16), Pv = Me, Nx = Me;
   if (act && r > 0) Pv = unpack5(s_xyz + (r - 1) * 16);
   if (act && r + 1 < L) Nx = unpack5(s_xyz + (r + 1) * 16);
+  // The pair kernel's gradient on the backbone H goes to the three atoms H is built from (transpose of the Jacobian of
+  // place_h; oracle: hb_spread_h): N and CA of this residue, C of the previous one (handed over through LDS).
+  f3 hN = mk3(0, 0, 0), hCA = hN;
+  if (act) {
+    f3 gp1 = mk3(0, 0, 0);
+    if (R.w[7] != 0.0f && r > 0) {
+      const f3 d1 = Me.N - Pv.C, d2 = Me.N - Me.CA;
+      const float il1 = rsqrtf(dot(d1, d1)), il2 = rsqrtf(dot(d2, d2));
+      const f3 e1 = d1 * il1, e2 = d2 * il2, u = e1 + e2;
+      const float ilu = rsqrtf(dot(u, u));
+      const f3 uh = u * ilu;
+      const f3 gp = (gH - uh * dot(uh, gH)) * ((float)TRX2_HB_B_NH * ilu);
+      const f3 g1 = (gp - e1 * dot(e1, gp)) * il1, g2 = (gp - e2 * dot(e2, gp)) * il2;
+      hN = gH + g1 + g2; hCA = g2 * -1.0f; gp1 = g1 * -1.0f;
+    }
+    s_gp[r * 3] = gp1.x; s_gp[r * 3 + 1] = gp1.y; s_gp[r * 3 + 2] = gp1.z;
+  }
   if (act) {
     // rama (residues 2..L-1) and omega_bb (1..L-1): derivatives with respect to the torsion angles
     f3 t1, t2, t3, t4;
@@ -811,15 +874,17 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
       esum[7] += (double)eb;
       aN = fma3(bN, wcb, aN); aCA = fma3(bCA, wcb, aCA); aC = fma3(bC, wcb, aC); aO = fma3(bO, wcb, aO); aCB = fma3(bCB, wcb, aCB);
     }
+    aN += hN; aCA += hCA;
+    if (r + 1 < L) aC += mk3(s_gp[(r + 1) * 3], s_gp[(r + 1) * 3 + 1], s_gp[(r + 1) * 3 + 2]);  // from the next residue's H
     gt[0].x += aN.x; gt[0].y += aN.y; gt[0].z += aN.z; gt[0].w += aCA.x;
     gt[1].x += aCA.y; gt[1].y += aCA.z; gt[1].z += aC.x; gt[1].w += aC.y;
     gt[2].x += aC.z; gt[2].y += aO.x; gt[2].z += aO.y; gt[2].w += aO.z;
     gt[3].x += aCB.x; gt[3].y += aCB.y; gt[3].z += aCB.z;
   }
   CSTAMP(20)  // bonded term
-  block_sum_n<8, NW>(esum, s_buf, flip);
+  block_sum_n<9, NW>(esum, s_buf, flip);
   const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] + (double)R.w[3] * esum[4] +
-                     (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[6] * esum[7];
+                     (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[6] * esum[7] + (double)R.w[7] * esum[8];
   if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
   if (tid == 0) A.f_last[dec] = f_t;
 
@@ -1005,11 +1070,32 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   if (act) {
 #pragma unroll
     for (int q = 0; q < 4; q++) { A.CX[(vb + r) * 4 + q] = x[q]; A.CG[(vb + r) * 4 + q] = g[q]; A.CD[(vb + r) * 4 + q] = dv[q]; }
-    float4* xo = reinterpret_cast<float4*>(A.xyz + (vb + r) * 16);
-    const int grp = dec / A.BW, dd = dec % A.BW;
-    float4* xT = A.xyzT + ((size_t)(grp * L + r) * 4) * A.BW + dd;
+    float4* xo = A.P + (vb + r) * 5;
 #pragma unroll
-    for (int q = 0; q < 4; q++) { xo[q] = xt[q]; xT[q * A.BW] = xt[q]; }
+    for (int q = 0; q < 4; q++) xo[q] = xt[q];
+    if (A.xyzT) {
+      float4* xT = A.xyzT + ((size_t)((dec / A.BW) * L + r) * 5) * A.BW + dec % A.BW;
+#pragma unroll
+      for (int q = 0; q < 4; q++) xT[q * A.BW] = xt[q];
+    }
+  }
+  {  // backbone H of the new trial point: C of the previous residue comes through LDS
+    __syncthreads();
+    if (act)
+#pragma unroll
+      for (int q = 0; q < 4; q++) reinterpret_cast<float4*>(s_xyz + r * 16)[q] = xt[q];
+    __syncthreads();
+    if (act) {
+      const Res5 M3 = unpack5(s_xyz + r * 16);
+      float4 hv = make_float4(M3.N.x + 1.0f, M3.N.y, M3.N.z, 0.0f);
+      if (r > 0) {
+        const Res5 P3 = unpack5(s_xyz + (r - 1) * 16);
+        const f3 Hn = place_h(P3.C, M3.N, M3.CA);
+        hv = make_float4(Hn.x, Hn.y, Hn.z, A.hasH[r] ? 1.0f : 0.0f);
+      }
+      A.P[(vb + r) * 5 + 4] = hv;
+      if (A.xyzT) A.xyzT[((size_t)((dec / A.BW) * L + r) * 5 + 4) * A.BW + dec % A.BW] = hv;
+    }
   }
   CSTAMP(26)  // direction test, trial point, state + coordinate stores
   // ---- leaving Cartesian space (run finished, or the decoy stops here on its evaluation budget / divergence): torsions +
@@ -1059,7 +1145,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
     float* w = A.wcur + (size_t)dec * 8;
     w[0] = Rn.w[0]; w[1] = Rn.w[1]; w[2] = Rn.w[2]; w[3] = Rn.w[3];
-    w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi; w[6] = (phase == PH_DONE) ? 0.0f : 1.0f; w[7] = 0;
+    w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi; w[6] = (phase == PH_DONE) ? 0.0f : 1.0f; w[7] = Rn.w[7];
   }
   if (tid < LBM) A.rho[(size_t)dec * LBM + tid] = s_rho[tid];
 }

@@ -4,18 +4,21 @@ Mirrors /root/reference/folding/folding.py:74-104 (four score functions, four Mi
 :118-119 (random start + declash), :125-186 (modes 0-3) and folding/utils_ros/utils_ros.py:699-703
 (remove_clash: at most 5 x { if sf_vdw(pose) < 10: break; mover.apply(pose) }).
 
-Weight vector layout (include/trx2_model.h): [atom_pair, dihedral, angle, vdw, rama, omega, cart_bonded, -].
-Weights are the reference's folding/data/*.wts files; cen_hb / hbond_* have no surrogate yet.
+Weight vector layout (include/trx2_model.h): [atom_pair, dihedral, angle, vdw, rama, omega, cart_bonded, hbond].
+Weights are the reference's folding/data/*.wts files.  The last slot carries cen_hb (5.0 in scorefxn.wts / scorefxn1.wts) in
+the torsion-space score functions and hbond_sr_bb = hbond_lr_bb (3.0 each in scorefxn_cart.wts; equal, so one weight) in the
+Cartesian one, all applied to ONE backbone hydrogen-bond surrogate (trx2_model.h TRX2_HB_*): Rosetta's potentials are not in
+the reference tree.  Measured effect on the outcome: none within sampling noise.
 """
 
 # folding/data/scorefxn.wts
-SF = [5.0, 4.0, 4.0, 1.0, 1.0, 0.5, 0.0, 0.0]
+SF = [5.0, 4.0, 4.0, 1.0, 1.0, 0.5, 0.0, 5.0]
 # folding/data/scorefxn1.wts
-SF1 = [3.0, 1.0, 1.0, 3.0, 1.0, 0.5, 0.0, 0.0]
+SF1 = [3.0, 1.0, 1.0, 3.0, 1.0, 0.5, 0.0, 5.0]
 # folding/data/scorefxn_vdw.wts
 SF_VDW = [0.0, 0.0, 0.0, 1.0, 1.0, 0.0, 0.0, 0.0]
 # folding/data/scorefxn_cart.wts
-SF_CART = [5.0, 4.0, 4.0, 0.5, 1.0, 0.5, 0.1, 0.0]
+SF_CART = [5.0, 4.0, 4.0, 0.5, 1.0, 0.5, 0.1, 3.0]
 
 MAX_ITER = 1000      # folding.py:92,95,101
 MAX_ITER_VDW = 500   # folding.py:98
@@ -62,7 +65,7 @@ def build_runs(L, mode=2, cartesian_stage=None):
         for _ in range(N_REPEAT):                # repeat_mover.apply
             runs.append(_run(SF, MAX_ITER, lo, hi))
         # min_mover_cart.apply: Cartesian-space L-BFGS on sf_cart
-        w_cart = SF_CART if cartesian_stage else SF_CART[:6] + [0.0, 0.0]  # no bonded term in torsion space
+        w_cart = SF_CART if cartesian_stage else SF_CART[:6] + [0.0, SF_CART[7]]  # no bonded term in torsion space
         runs.append(_run(w_cart, MAX_ITER, lo, hi, cartesian=1 if cartesian_stage else 0))
         _declash(runs, SF1, MAX_ITER, lo, hi)    # remove_clash(sf_vdw, min_mover1, pose)
     return runs

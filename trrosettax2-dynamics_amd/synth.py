@@ -1,13 +1,24 @@
 """Synthetic distograms for chain lengths the reference ships no data for (its only example is L=90,
 BASELINE.json's L=150 / L=400 configs need synthetic maps).  numpy only, deterministic in (L, seed).
 
-Recipe: a backbone is built by NeRF from torsions drawn from the reference's start table
+Two kinds of target structure:
+  "bundle" (default): a protein-like helical bundle -- rigid alpha-helices of 12-24 residues joined by loops of 3-6, compacted by
+      pivot Monte-Carlo on the loop torsions only (simulated annealing on radius of gyration + C-alpha clashes).  Rigid rods
+      joined by short loops cannot thread through each other, so the target is free of the knots and entanglements that made
+      the round-1 random-coil targets unfoldable from random starts (measured: DESIGN.md section 2).
+  "coil": the round-1 recipe below, kept for the evaluation-parity tests (any structure will do there).
+
+Recipe ("coil"): a backbone is built by NeRF from torsions drawn from the reference's start table
 (folding/utils_ros/utils_ros.py:667-696) and compacted by a short Monte-Carlo over that table (radius of gyration +
 CA clash count), so the target is exactly realisable by the fold's ideal geometry.  Its C-beta 6-D geometry
 (formulae of utils_trX2dy/utils.py:97-182) is one-hot binned on the reference's bin edges (utils.py:191,203,215,227,
 with the TRUE phi -- the reference's phi-from-theta label bug is a property of its trained network, not of geometry),
-blurred along bins (Gaussian, sigma 1.5 bins), mixed 0.9 blur + 0.1 uniform, renormalised, cast to float32;
-dist and omega are symmetrised.
+blurred along bins (Gaussian, sigma 1.5 bins), mixed 0.96 blur + 0.04 uniform, renormalised, cast to float32;
+dist and omega are symmetrised.  (SURVEY.md 8d proposed 0.1 uniform.  That puts 0.086 of contact probability on every pair
+that is NOT in contact in the target, above gen_rst's 0.05 threshold, so every far pair got a restraint whose only shape is
+the background term -- a mild attraction towards short distances, on half of all pairs; distance-only folds then collapsed
+into wrong globules, 0 of 16 within 7 A of the target or its mirror image.  With 0.04, far pairs get no restraint, as in
+the reference's own maps, and distance-only folds reach the target or its mirror image: DESIGN.md section 2.)
 """
 import os
 import tempfile
@@ -92,6 +103,62 @@ def compact_torsions(L, seed, n_moves=None):
     return np.concatenate([BASINS[basin], np.full((L, 1), np.pi)], axis=1), cur
 
 
+def _rot(points, origin, axis, ang):
+    """rotate points about the line origin + t * axis (Rodrigues), vectorised"""
+    k = axis / np.linalg.norm(axis)
+    v = points - origin
+    c, s_ = np.cos(ang), np.sin(ang)
+    return origin + v * c + np.cross(k, v) * s_ + np.outer(v @ k, k) * (1 - c)
+
+
+def bundle_torsions(L, seed, n_moves=None):
+    """Helical-bundle target: secondary-structure layout from the seed, then pivot Monte-Carlo over the loop torsions."""
+    rng = np.random.default_rng(seed + 7919)
+    ss = np.zeros(L, bool)                      # True = helix
+    i = int(rng.integers(1, 4))
+    while i < L - 8:
+        n = int(rng.integers(12, 25))
+        ss[i:min(L - 2, i + n)] = True
+        i += n + int(rng.integers(3, 7))
+    loops = np.nonzero(~ss)[0]
+    loops = loops[(loops > 0) & (loops < L - 1)]
+    loop_basins = BASINS[[0, 1, 2, 3]]          # beta / PPII / bridge regions of the reference's start table
+    tors = np.empty((L, 3))
+    tors[:, 2] = np.pi
+    tors[:, :2] = BASINS[4]                     # (-61, -41): alpha helix
+    for r in np.nonzero(~ss)[0]:
+        tors[r, :2] = loop_basins[rng.integers(0, 4)] + rng.normal(size=2) * np.radians(10)
+    N, CA, C, _ = nerf_backbone(tors)
+    iu = np.triu_indices(L, 3)
+
+    def score(ca):
+        d2 = ((ca[:, None] - ca[None]) ** 2).sum(-1)[iu]
+        clash = np.clip(4.6 - np.sqrt(d2), 0, None)
+        return ((ca - ca.mean(0)) ** 2).sum(1).mean() + 30.0 * (clash ** 2).sum()
+
+    cur = score(CA)
+    n_moves = n_moves if n_moves is not None else 40 * len(loops) + 2000
+    for it in range(n_moves):
+        temp = 4.0 * (1 - it / n_moves) + 0.05
+        r = int(loops[rng.integers(0, len(loops))])
+        new = loop_basins[rng.integers(0, 4)] + rng.normal(size=2) * np.radians(12) if rng.random() < 0.5 else tors[r, :2] + rng.normal(size=2) * np.radians(8)
+        dphi, dpsi = new[0] - tors[r, 0], new[1] - tors[r, 1]
+        N2, CA2, C2 = N.copy(), CA.copy(), C.copy()
+        # phi_r: axis N_r -> CA_r moves C_r and everything after; psi_r: axis CA_r -> C_r moves every later residue
+        C2[r:] = _rot(C2[r:], N2[r], CA2[r] - N2[r], dphi)
+        N2[r + 1:] = _rot(N2[r + 1:], N2[r], CA2[r] - N2[r], dphi)
+        CA2[r + 1:] = _rot(CA2[r + 1:], N2[r], CA2[r] - N2[r], dphi)
+        ax, org = C2[r] - CA2[r], CA2[r].copy()
+        N2[r + 1:] = _rot(N2[r + 1:], org, ax, dpsi)
+        CA2[r + 1:] = _rot(CA2[r + 1:], org, ax, dpsi)
+        C2[r + 1:] = _rot(C2[r + 1:], org, ax, dpsi)
+        sc = score(CA2)
+        if sc <= cur or rng.random() < np.exp((cur - sc) / temp):
+            cur, N, CA, C = sc, N2, CA2, C2
+            tors[r, :2] = new
+    return tors, cur
+
+
 def _dihedral(a, b, c, d):
     b0, b1, b2 = a - b, c - b, d - c
     b1 = b1 / np.linalg.norm(b1, axis=-1, keepdims=True)
@@ -107,7 +174,8 @@ def _angle(a, b, c):
     return np.arccos(np.clip((v * w).sum(-1), -1, 1))
 
 
-def _blur_mix(onehot, sigma=1.5, mix=0.1):
+def _blur_mix(onehot, sigma=1.5, mix=None):
+    mix = float(os.environ.get("TRX2_SYNTH_MIX", "0.04")) if mix is None else mix
     K = onehot.shape[-1]
     k = np.arange(K)
     G = np.exp(-0.5 * ((k[:, None] - k[None]) / sigma) ** 2)
@@ -116,15 +184,17 @@ def _blur_mix(onehot, sigma=1.5, mix=0.1):
     return (p / p.sum(-1, keepdims=True)).astype(np.float32)
 
 
-def make_map(L, seed=None, n_moves=None):
-    """-> dict(dist[L,L,37], omega[L,L,25], theta[L,L,25], phi[L,L,13], tors[L,3], seq)"""
+def make_map(L, seed=None, n_moves=None, kind=None):
+    """-> dict(dist[L,L,37], omega[L,L,25], theta[L,L,25], phi[L,L,13], tors[L,3], seq).  kind: "bundle" (default) or "coil"
+    (default when n_moves is given: the short-Monte-Carlo coils of the evaluation-parity tests)."""
     seed = L if seed is None else seed
+    kind = kind or ("coil" if n_moves is not None else "bundle")
     cache = os.path.join(os.environ.get("TRX2_SYNTH_CACHE", os.path.join(tempfile.gettempdir(), "trx2_synth")),
-                         f"map_L{L}_s{seed}_m{n_moves}.npz")
+                         f"map_{kind}_L{L}_s{seed}_m{n_moves}.npz")
     if os.path.exists(cache):
         with np.load(cache) as z:
             return {k: (z[k].item() if z[k].ndim == 0 else z[k]) for k in z.files}
-    out = _make_map(L, seed, n_moves)
+    out = _make_map(L, seed, n_moves, kind)
     try:
         os.makedirs(os.path.dirname(cache), exist_ok=True)
         tmp = f"{cache}.{os.getpid()}.tmp.npz"
@@ -135,8 +205,8 @@ def make_map(L, seed=None, n_moves=None):
     return out
 
 
-def _make_map(L, seed, n_moves):
-    tors, _ = compact_torsions(L, seed, n_moves)
+def _make_map(L, seed, n_moves, kind="bundle"):
+    tors, _ = (bundle_torsions if kind == "bundle" else compact_torsions)(L, seed, n_moves)
     N, CA, C, CB = nerf_backbone(tors)
     i, j = np.meshgrid(np.arange(L), np.arange(L), indexing="ij")
     with np.errstate(invalid="ignore", divide="ignore"):
