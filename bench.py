@@ -43,7 +43,7 @@ CONFIGS = {
                  "seed L; (target, decoy-block) items assigned to ranks longest-processing-time-first"),
 }
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
-KERNEL_SOURCES = ("kernel_pair2.h", "trx2_device.h")
+KERNEL_SOURCES = ("kernel_pair.h", "trx2_device.h")
 
 
 def kernel_source_sha():
@@ -124,7 +124,7 @@ def pair_roofline(ctx, T, B, L, config, fold_times=None):
         valu = {"insts_per_launch": rec["valu_insts_per_launch"], "busy_cycles_per_simd": cyc, "busy_frac": cyc / (ms * 1e-3 * CLOCK_HZ),
                 "clock_hz_assumed": CLOCK_HZ, "wave_time_waiting_frac": rec["wait_any_quad_cycles"] / rec["wave_quad_cycles"]}
     bw = int(ctx.info(0))
-    out = {"bound": "hbm", "kernel": (f"k_pair<{bw}>" if B >= 3 else "k_pair2<1>") + f" ({int(ctx.info(4))} workgroups)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    out = {"bound": "hbm", "kernel": f"k_pair<{bw}> ({int(ctx.info(4))} workgroups)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": (rec or {}).get("method"),
            "avg_launch_ms": ms, "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": n_terms, "valu": valu,
            "binding_limit": "vector-ALU issue + dependent-load latency, not HBM bandwidth (DESIGN.md section 5)"}

@@ -1,5 +1,5 @@
-// kernel_pair.h -- K3/K4 for batches: pair-term kernel with lane = decoy (restraint splines, soft-sphere repulsion, backbone
-// hydrogen bonds) -- included by trx2fold.hip after kernel_pair2.h (shared helpers: spline_eval_dev, hbond_dev, P2_AREC).
+// kernel_pair.h -- K3/K4: pair-term kernel, lane = decoy (restraint splines, soft-sphere repulsion, backbone hydrogen bonds)
+// -- included by trx2fold.hip.
 // Not a stand-alone header: it relies on the macros, constant tables and helpers defined above its #include.
 #pragma once
 // =================================================================================================
@@ -7,6 +7,9 @@
 // wave, 64/BW residues b per wave step).  Each ORDERED pair (a,b) is visited from a's row and only the
 // gradient on a's atoms is kept -> no atomics, no cross-workgroup reduction, deterministic.
 // =================================================================================================
+#define PR_NCOMP 18 /* gradient components per residue: N CA C O CB H */
+#define PR_REC 24   /* floats per record: 18 gradient + 6 energies (dist omega theta phi vdw hb) */
+
 struct PairArgs {
   int L, B, nsplit, Bpad;
   const float4* xyzT;  // [ngrp][L][5][BW] float4 : residue record N CA C O CB (+pad) | H, hasH ; decoy-minor
@@ -15,9 +18,50 @@ struct PairArgs {
   const float* knots;         // [107] float
   const float* wcur;          // [B][8] : w_ap w_dih w_ang w_vdw sep_lo sep_hi active w_hb
   float* FA;                  // [nsplit][B][L][24] per (slab, decoy, residue a): gradient on N CA C O CB H, then the raw energies
-                              // dist omega theta phi vdw hb (P2_AREC; the step kernel sums the slabs: sum_pair_records)
+                              // dist omega theta phi vdw hb (PR_REC; the step kernel sums the slabs: sum_pair_records)
   int* seq_ctr;               // evaluation counter in device memory: bumped here, read by the step kernel that follows
 };
+
+// ikn[i] = 1 / (kn[i+1] - kn[i]), precomputed once per workgroup
+__device__ __forceinline__ void spline_eval_dev(const float2* __restrict__ row, const float* kn, const float* ikn, int K,
+                                                int idx, float x, float& e, float& de) {
+  // idx is a guess; fix up against the (rounded, slightly non-uniform) knots
+  idx = max(0, min(K - 2, idx));
+  if (x < kn[idx]) idx = max(0, idx - 1);
+  else if (x >= kn[idx + 1]) idx = min(K - 2, idx + 1);
+  float lo = kn[idx], hi = kn[idx + 1];
+  float2 k0 = row[idx], k1 = row[idx + 1];
+  // the segment's cubic in t = x - lo, formed from (y, y'') of its two knots and evaluated by Horner:
+  //   c1 = (y1-y0)/h - h (2 y0'' + y1'')/6,  c2 = y0''/2,  c3 = (y1''-y0'')/(6h)
+  float h = hi - lo, ih = ikn[idx], t = x - lo;
+  bool inside = (x > kn[0]) && (x < kn[K - 1]);
+  float c1 = fmaf(-h * (1.0f / 6.0f), fmaf(2.0f, k0.y, k1.y), (k1.x - k0.x) * ih);
+  float c3 = (k1.y - k0.y) * (ih * (1.0f / 6.0f));
+  float ev = fmaf(fmaf(fmaf(c3, t, 0.5f * k0.y), t, c1), t, k0.x);
+  float dv = fmaf(fmaf(3.0f * c3, t, k0.y), t, c1);
+  // outside the knot range: constant end value, zero slope (SplineFunc)
+  e = inside ? ev : (x <= kn[0] ? k0.x : k1.x);
+  de = inside ? dv : 0.0f;
+}
+
+// one donor -> acceptor candidate of a backbone hydrogen bond (trx2_model.h TRX2_HB_*; oracle: orc_hbond_term): N-H of one
+// residue, O=C of the other.  Returns the raw energy (<= 0) and ADDS its gradient scaled by s to gN, gH, gO, gC.
+__device__ __forceinline__ float hbond_dev(f3 N, f3 H, f3 O, f3 C, float s, f3& gN, f3& gH, f3& gO, f3& gC) {
+  const f3 u = H - N, v = O - H, w = O - C;
+  const float d2 = dot(v, v), id = rsqrtf(d2), d = d2 * id, x = (d - (float)TRX2_HB_D0) * (1.0f / (float)TRX2_HB_R);
+  if (!(x > -1.0f && x < 1.0f)) return 0.0f;
+  const float ilu = rsqrtf(dot(u, u)), ilw = rsqrtf(dot(w, w));
+  const f3 uh = u * ilu, vh = v * id, wh = w * ilw;
+  const float ct = dot(uh, vh), cp = -dot(wh, vh);
+  if (!(ct > 0.0f && cp > 0.0f)) return 0.0f;
+  const float q = 1.0f - x * x, fd = q * q, dfd = -4.0f * q * x * (1.0f / (float)TRX2_HB_R);
+  const float S = (float)TRX2_HB_SCALE, ct2 = ct * ct, cp2 = cp * cp;
+  const float kd = -S * dfd * ct2 * cp2 * s, kt = -S * fd * 2.0f * ct * cp2 * s, kp = -S * fd * ct2 * 2.0f * cp * s;
+  const f3 tu = (vh - uh * ct) * ilu, tv = (uh - vh * ct) * id, pw = (vh + wh * cp) * (-ilw), pv = (wh + vh * cp) * (-id);
+  const f3 gv = vh * kd + tv * kt + pv * kp, gu = tu * kt, gw = pw * kp;
+  gO += gv + gw; gH += gu - gv; gN += gu * -1.0f; gC += gw * -1.0f;
+  return -S * fd * ct2 * cp2;
+}
 
 // PAIR_MIN_WAVES (waves per SIMD the register allocator must admit) is a build-time knob so that occupancy-vs-spill
 // variants can be A/B-timed on hardware: 2 = no spills (220 VGPRs), 3 = 62 spilled, 4 = 104 spilled (profiles/README.md)
@@ -258,16 +302,16 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   // LDS image [wave][decoy][21]: the h = 0 lanes write 20 values at stride 21 (no bank conflict); the readers are
   // (decoy, quad) pairs, 4 lanes per decoy, so every store instruction writes whole 64-B (gradient) / 32-B (energy) runs.
   {
-    float vals[P2_AREC] = {gN.x, gN.y, gN.z, gCA.x, gCA.y, gCA.z, gC.x, gC.y, gC.z, gO.x, gO.y, gO.z,
+    float vals[PR_REC] = {gN.x, gN.y, gN.z, gCA.x, gCA.y, gCA.z, gC.x, gC.y, gC.z, gO.x, gO.y, gO.z,
                            gCB.x, gCB.y, gCB.z, gH.x, gH.y, gH.z, e_d, e_o, e_t, e_p, e_v, e_h};
 #pragma unroll
     for (int o = BW; o < 64; o <<= 1)
 #pragma unroll
-      for (int k = 0; k < P2_AREC; k++) vals[k] += __shfl_xor(vals[k], o, 64);
+      for (int k = 0; k < PR_REC; k++) vals[k] += __shfl_xor(vals[k], o, 64);
     if (h == 0) {
       float* s = s_red + ((size_t)wave * BW + d) * RED_STRIDE;
 #pragma unroll
-      for (int k = 0; k < P2_AREC; k++) s[k] = vals[k];
+      for (int k = 0; k < PR_REC; k++) s[k] = vals[k];
     }
   }
   __syncthreads();
@@ -280,7 +324,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
     for (int i = 0; i < 4; i++)
 #pragma unroll
       for (int sl = 0; sl < PAIR_WAVES; sl++) acc[i] += s_red[((size_t)sl * BW + dd) * RED_STRIDE + q * 4 + i];
-    reinterpret_cast<float4*>(A.FA + (((size_t)split * A.B + dc) * L + a) * P2_AREC)[q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    reinterpret_cast<float4*>(A.FA + (((size_t)split * A.B + dc) * L + a) * PR_REC)[q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
   STAMP(11)  // epilogue: LDS image, barrier, column sums, stores
   STAMP_FLUSH

@@ -26,13 +26,12 @@ struct ChainArgs {
   float4 *X, *G, *D, *XT;  // [B][L] (phi, psi, omega, -)
   float4 *S, *Y;           // [B][LBM][L]
   float4* P;               // [B][L][5] trial coordinates, decoy-major: N CA C O CB (15 floats + pad) | backbone H, hasH
-  float4* xyzT;            // [ngrp][L][5][BW] decoy-minor copy for the batch pair kernel (kernel_pair.h), or NULL
+  float4* xyzT;            // [ngrp][L][5][BW] decoy-minor copy for the pair kernel (its lanes are decoys)
   int BW;
   const float4* geom;      // [B][L][3] internal geometry per residue (ResGeom)
   float* wcur;             // [B][8]
-  const float* FA;         // [nJ][B][L][24] pair-kernel records of a residue as the lower member of its pairs (+ energies)
-  const float* FB;         // [nI][B][L][20] ... as the upper member
-  int TA, TB, nI, nJ;      // tile geometry of the pair kernel (kernel_pair2.h)
+  const float* FA;         // [nsplit][B][L][24] pair-kernel records: gradient on the six atoms + the pair energies
+  int nsplit;
   const unsigned char* hasH;  // [L] residue donates a backbone hydrogen bond (has a predecessor, not proline)
   double* e_last;          // [B][NTERMS] raw terms of the last evaluation
   double* f_last;          // [B]
@@ -40,35 +39,19 @@ struct ChainArgs {
   int* done_count;
 };
 
-// tile (it, jt) of the pair matrix holds a pair a < b  <=>  its first a is below its last b (host: same test, trx2fold.hip)
-__host__ __device__ __forceinline__ bool tile_exists(int it, int jt, int TA, int TB, int L) {
-  const int bmax = ((jt + 1) * TB < L ? (jt + 1) * TB : L) - 1;
-  return it * TA < bmax;
-}
-// Sum of the pair kernel's records of residue r of decoy dec: a-records of the tiles in its row (24 floats: 18 gradient
-// components + 6 energies), b-records of the tiles in its column (20 floats).  Fixed order: deterministic.
-__device__ __forceinline__ void sum_pair_records(const float* FA, const float* FB, int TA, int TB, int nI, int nJ, int B, int L,
-                                                 int dec, int r, float (&g)[P2_NCOMP], float (&e)[6]) {
+// Sum of the pair kernel's records of residue r of decoy dec over the b-range slabs (24 floats: gradient on N CA C O CB H,
+// then the energies dist omega theta phi vdw hb).  Fixed order: deterministic.
+__device__ __forceinline__ void sum_pair_records(const float* FA, int nsplit, int B, int L, int dec, int r, float (&g)[PR_NCOMP], float (&e)[6]) {
 #pragma unroll
-  for (int i = 0; i < P2_NCOMP; i++) g[i] = 0.0f;
+  for (int i = 0; i < PR_NCOMP; i++) g[i] = 0.0f;
 #pragma unroll
   for (int i = 0; i < 6; i++) e[i] = 0.0f;
-  const int it_r = r / TA, jt_r = r / TB;
-  for (int jt = 0; jt < nJ; jt++) {
-    if (!tile_exists(it_r, jt, TA, TB, L)) continue;
-    const float4* f = reinterpret_cast<const float4*>(FA + (((size_t)jt * B + dec) * L + r) * P2_AREC);
+  for (int sl = 0; sl < nsplit; sl++) {
+    const float4* f = reinterpret_cast<const float4*>(FA + (((size_t)sl * B + dec) * L + r) * PR_REC);
     const float4 v0 = f[0], v1 = f[1], v2 = f[2], v3 = f[3], v4 = f[4], v5 = f[5];
     g[0] += v0.x; g[1] += v0.y; g[2] += v0.z; g[3] += v0.w; g[4] += v1.x; g[5] += v1.y; g[6] += v1.z; g[7] += v1.w;
     g[8] += v2.x; g[9] += v2.y; g[10] += v2.z; g[11] += v2.w; g[12] += v3.x; g[13] += v3.y; g[14] += v3.z; g[15] += v3.w;
     g[16] += v4.x; g[17] += v4.y; e[0] += v4.z; e[1] += v4.w; e[2] += v5.x; e[3] += v5.y; e[4] += v5.z; e[5] += v5.w;
-  }
-  for (int it = 0; it < nI; it++) {
-    if (!tile_exists(it, jt_r, TA, TB, L)) break;  // tiles of a column exist for it = 0 .. some bound
-    const float4* f = reinterpret_cast<const float4*>(FB + (((size_t)it * B + dec) * L + r) * P2_BREC);
-    const float4 v0 = f[0], v1 = f[1], v2 = f[2], v3 = f[3], v4 = f[4];
-    g[0] += v0.x; g[1] += v0.y; g[2] += v0.z; g[3] += v0.w; g[4] += v1.x; g[5] += v1.y; g[6] += v1.z; g[7] += v1.w;
-    g[8] += v2.x; g[9] += v2.y; g[10] += v2.z; g[11] += v2.w; g[12] += v3.x; g[13] += v3.y; g[14] += v3.z; g[15] += v3.w;
-    g[16] += v4.x; g[17] += v4.y;
   }
 }
 // backbone H from C of the previous residue, N, CA: in-plane bisector (trx2_model.h; oracle: orc_place_h)
@@ -240,8 +223,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         xt[k] = A.XT[vb + r];
         const float4* xp = A.P + (vb + r) * 5;
         const float4 c0 = xp[0], c1 = xp[1], c2 = xp[2], c3 = xp[3], c4 = xp[4];
-        float g[P2_NCOMP], ep[6];
-        sum_pair_records(A.FA, A.FB, A.TA, A.TB, A.nI, A.nJ, A.B, L, dec, r, g, ep);
+        float g[PR_NCOMP], ep[6];
+        sum_pair_records(A.FA, A.nsplit, A.B, L, dec, r, g, ep);
         esum[0] += ep[0]; esum[1] += ep[1]; esum[2] += ep[2]; esum[3] += ep[3]; esum[4] += ep[4]; esum[8] += ep[5];
         pN[k] = mk3(c0.x, c0.y, c0.z); pCA[k] = mk3(c0.w, c1.x, c1.y); pC[k] = mk3(c1.z, c1.w, c2.x);
         pO[k] = mk3(c2.y, c2.z, c2.w); pCB[k] = mk3(c3.x, c3.y, c3.z);
@@ -698,10 +681,10 @@ struct CartArgs {
   float4 *CX, *CG, *CD;      // [B][L][4] accepted point, its gradient, direction
   float4 *CS, *CY;           // [B][LBM][L][4]
   float4* P;                 // [B][L][5]: the first 4 float4 of a record = trial coordinates = trial DOF vector (in/out), 5th = H
-  float4* xyzT; int BW;      // decoy-minor copy for the batch pair kernel, or NULL
+  float4* xyzT; int BW;      // decoy-minor copy for the pair kernel
   float4 *X, *XT, *geom;     // torsions and internal geometry, written when the run ends
   float* wcur;
-  const float* FA; const float* FB; int TA, TB, nI, nJ;
+  const float* FA; int nsplit;
   const unsigned char* hasH;
   double *e_last, *f_last;
   int* done_count;
@@ -781,8 +764,8 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     const float4* xp = A.P + (vb + r) * 5;
 #pragma unroll
     for (int q = 0; q < 4; q++) { xt[q] = xp[q]; reinterpret_cast<float4*>(s_xyz + r * 16)[q] = xt[q]; }
-    float g[P2_NCOMP], ep[6];
-    sum_pair_records(A.FA, A.FB, A.TA, A.TB, A.nI, A.nJ, A.B, L, dec, r, g, ep);
+    float g[PR_NCOMP], ep[6];
+    sum_pair_records(A.FA, A.nsplit, A.B, L, dec, r, g, ep);
     esum[0] += ep[0]; esum[1] += ep[1]; esum[2] += ep[2]; esum[3] += ep[3]; esum[4] += ep[4]; esum[8] += ep[5];
     gt[0] = make_float4(g[0], g[1], g[2], g[3]); gt[1] = make_float4(g[4], g[5], g[6], g[7]);
     gt[2] = make_float4(g[8], g[9], g[10], g[11]); gt[3] = make_float4(g[12], g[13], g[14], 0.0f);

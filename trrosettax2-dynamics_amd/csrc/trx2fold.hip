@@ -3,14 +3,13 @@
 // Replaces the per-decoy PyRosetta process of /root/reference/folding/folding.py (+ folding/utils_ros) by a
 // device-resident batched minimiser.  Kernel inventory ("native work-list"):
 //   K2 k_build_tables : gen_rst + add_rst selection -> dense (y, y'') spline tables  (utils_ros.py:6-146,706-723)
-//   K3/K4 k_pair2<DW> : CB-CB distance / omega / theta / phi spline restraints + soft-sphere repulsion + backbone hydrogen
-//                       bonds, every unordered residue pair once, energy and Cartesian gradient on both residues
-//                       (folding.py:74-84 score terms)
+//   K3/K4 k_pair<BW>  : CB-CB distance / omega / theta / phi spline restraints + soft-sphere repulsion + backbone hydrogen
+//                       bonds, energy and Cartesian gradient, lane = decoy                 (folding.py:74-84 score terms)
 //   K1/K5/K6 k_chain  : per decoy: gradient slabs -> torsion gradient (suffix scan of force/torque), rama/omega
 //                       terms, non-monotone Armijo L-BFGS state machine over the staged protocol, new trial
 //                       torsions -> backbone by a parallel rigid-transform scan (NeRF) (folding.py:86-119,164-171)
 // Data layout in HBM: see DESIGN.md.  No CPU fallback exists: every entry point runs on the GPU or fails.
-// One translation unit: kernel_tables.h (K2), kernel_pair2.h (K3/K4), kernel_step.h (K1/K5/K6 + Cartesian role) are
+// One translation unit: kernel_tables.h (K2), kernel_pair.h (K3/K4), kernel_step.h (K1/K5/K6 + Cartesian role) are
 // included below the shared macros and constant tables; this file holds those and the host side (context, C ABI).
 #include <hip/hip_runtime.h>
 
@@ -56,7 +55,6 @@ __constant__ float c_rama_sc[TRX2_RAMA_NB * 4];  // sin phi_k, cos phi_k, sin ps
 __constant__ float c_cb_ideal[4];
 
 #include "kernel_tables.h"
-#include "kernel_pair2.h"
 #include "kernel_pair.h"
 #include "kernel_step.h"
 #include "kernel_feedback.h"
@@ -78,20 +76,11 @@ struct trx2_ctx {
   double* knots_d = nullptr;
   double knots_h[TRX2_KTOT];
   // batch
-  int Bcap = 0, Lcap = 0;
-  // pair-kernel geometry (kernel_pair2.h): DW decoys per wave, tiles of TA x TB residues, RA residues a per wave, nI x nJ tiles,
-  // ntp listed tiles (padded to a multiple of 8), G decoy groups
-  int DW = 4, TA = 0, TB = 0, RA = 1, nI = 0, nJ = 0, ntp = 0, NG = 0;
-  // batches (B >= 3) use the lane = decoy kernel (kernel_pair.h): groups of BW decoys, nsplit slabs; its records are the FA
-  // array with one "tile row" (TA = L, nI = 0).  Folds of one or two decoys use kernel_pair2.h (DW = 1).
-  bool ordered = true; int BW = 64, Bpad = 0, nsplit = 1; size_t xt_cap = 0;
-  float4* xyzT = nullptr;
-  size_t fa_cap = 0, fbrec_cap = 0; int tiles_cap = 0;
-  double slab_bytes_per_res = 0;
+  int Bcap = 0, Lcap = 0, BW = 64, Bpad = 0, nsplit = 1, nsplit_cap = 0;
   int* st_i = nullptr; double* st_d = nullptr; float* rho = nullptr;
   float4 *X = nullptr, *G = nullptr, *D = nullptr, *XT = nullptr, *S = nullptr, *Y = nullptr;
-  float4* P = nullptr; float* wcur = nullptr; float4* geom = nullptr;
-  float *FA = nullptr, *FB = nullptr; short2* tiles = nullptr;
+  float4* P = nullptr; float4* xyzT = nullptr; float* wcur = nullptr; float4* geom = nullptr;
+  float* FA = nullptr;
   double *e_last = nullptr, *f_last = nullptr;
   float* grad = nullptr; float* tors0 = nullptr;
   float4 *CX = nullptr, *CG = nullptr, *CD = nullptr, *CS = nullptr, *CY = nullptr;  // Cartesian runs (allocated on first use)
@@ -219,13 +208,12 @@ static void free_map(trx2_ctx* c) {
 }
 static void free_batch(trx2_ctx* c) {
   void* p[] = {c->st_i, c->st_d, c->rho, c->X, c->G, c->D, c->XT, c->S, c->Y, c->P, c->xyzT, c->geom, c->wcur, c->FA,
-               c->FB, c->tiles, c->e_last, c->f_last, c->grad, c->tors0, c->done_count, c->seq_ctr, c->runs};
+               c->e_last, c->f_last, c->grad, c->tors0, c->done_count, c->seq_ctr, c->runs};
   for (void* q : p)
     if (q) (void)hipFree(q);
   c->st_i = nullptr; c->st_d = nullptr; c->rho = nullptr;
   c->X = c->G = c->D = c->XT = c->S = c->Y = nullptr;
-  c->P = nullptr; c->xyzT = nullptr; c->xt_cap = 0; c->geom = nullptr; c->wcur = nullptr; c->FA = c->FB = nullptr; c->tiles = nullptr;
-  c->fa_cap = c->fbrec_cap = 0; c->tiles_cap = 0;
+  c->P = nullptr; c->xyzT = nullptr; c->geom = nullptr; c->wcur = nullptr; c->FA = nullptr;
   c->e_last = c->f_last = nullptr; c->grad = nullptr; c->tors0 = nullptr; c->done_count = nullptr; c->seq_ctr = nullptr; c->runs = nullptr;
   c->Bcap = c->Lcap = 0;
   c->alloc_epoch++;
@@ -421,75 +409,35 @@ extern "C" int trx2_get_tables(trx2_ctx* ctx, int channel, float* y_y2, float* k
   return 0;
 }
 
-// ---- pair-kernel geometry (kernel_pair2.h).  Decoy groups of 4 for batches, 1 for folds of one or two decoys (every feedback
-// iteration).  TB is fixed by the group width; RA (residues a per wave, TA = 4 RA) is the knob: a larger tile means fewer
-// records per residue for the step kernel to sum, a smaller one more workgroups.  Rule: the largest RA in {8, 4, 2, 1} that
-// still gives at least P2_MIN_WGS workgroups (256 CUs; measured: profiles/README.md round 2).
-#ifndef P2_MIN_WGS
-#define P2_MIN_WGS 320
-#endif
-static int count_tiles(int L, int TA, int TB, std::vector<short2>* out) {
-  const int nI = (L + TA - 1) / TA, nJ = (L + TB - 1) / TB;
-  int n = 0;
-  for (int jt = 0; jt < nJ; jt++)      // column-major: consecutive workgroups share the rows b of the tables
-    for (int it = 0; it < nI; it++)
-      if (tile_exists(it, jt, TA, TB, L)) { if (out) out->push_back(short2{(short)it, (short)jt}); n++; }
-  return n;
-}
 static int pick_bw(int B) {
   int bw = 1;
   while (bw < B && bw < 64) bw <<= 1;
   return bw;
 }
+
 static int ensure_batch(trx2_ctx* ctx, int B) {
   const int L = ctx->L;
-  const bool ordered = B >= 3;
-  int DW = 1, TB, G, RA = 1, TA, nI, nJ, ntp = 0, BW = 1, Bpad = B, nsplit = 1;
-  std::vector<short2> tl;
-  if (ordered) {
-    // lane = decoy kernel: workgroup = (residue a, slice of b, decoy group).  b-range splits: enough workgroups (>= ~2 per CU)
-    // while every wave keeps a few residues b.  EMPIRICAL rule from profiles/README.md round 1 (L=150, B=64, splits 2/3/4/6 timed
-    // on MI355X): with distances only the largest split whose grid fits one round of 512 resident workgroups is fastest; with
-    // the angle channels on, 600 smaller workgroups win despite the partial second round.
-    BW = pick_bw(B);
-    const int ngrp = (B + BW - 1) / BW;
-    Bpad = ngrp * BW;
+  const int BW = pick_bw(B);
+  const int ngrp = (B + BW - 1) / BW;
+  const int Bpad = ngrp * BW;
+  // b-range splits: enough workgroups (>= ~2 per CU) while every wave keeps a few residues b
+  int nsplit = 1;
+  {
+    // k_pair holds 2 workgroups per CU (232 VGPRs): 512 resident slots.  EMPIRICAL rule from profiles/README.md
+    // (L=150, B=64, splits 2/3/4/6 timed on MI355X): with distances only, the largest split whose grid fits one
+    // round is fastest; with the angle channels on, 600 smaller workgroups win despite the partial second round.
+    // Every wave keeps at least two residues b.
     const int PW = 64 / BW;
     const long slots = ctx->use_orient ? 640 : 512;
     for (int n = 1; n <= 16; n++)
       if ((long)L * n * ngrp <= slots && L / n >= PAIR_WAVES * PW * 2) nsplit = n;
     if (const char* e = getenv("TRX2_NSPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) nsplit = v; }  // A/B timing only
-    TA = L; TB = (L + nsplit - 1) / nsplit; nI = 0; nJ = nsplit; G = ngrp; DW = BW;
-  } else {
-    DW = 1; TB = P2_NW * 64; G = B;
-    RA = 8;
-    while (RA > 1 && (long)G * count_tiles(L, P2_NW * RA, TB, nullptr) < P2_MIN_WGS) RA >>= 1;
-    if (const char* e = getenv("TRX2_RA")) { int v = atoi(e); if (v >= 1 && v <= 64) RA = v; }  // A/B timing only
-    TA = P2_NW * RA; nI = (L + TA - 1) / TA; nJ = (L + TB - 1) / TB;
-    const int nt = count_tiles(L, TA, TB, &tl);
-    ntp = (nt + 7) / 8 * 8;
-    tl.resize((size_t)ntp, short2{-1, -1});
   }
-  const bool geom_changed = ordered != ctx->ordered || DW != ctx->DW || TA != ctx->TA || TB != ctx->TB || nI != ctx->nI || nJ != ctx->nJ ||
-                            ntp != ctx->ntp || BW != ctx->BW;
-  ctx->ordered = ordered; ctx->BW = BW; ctx->Bpad = Bpad; ctx->nsplit = nsplit;
-  ctx->DW = DW; ctx->TA = TA; ctx->TB = TB; ctx->RA = RA; ctx->nI = nI; ctx->nJ = nJ; ctx->ntp = ntp; ctx->NG = G;
-  {  // average bytes of pair-kernel records the step kernel sums per residue (bench.py's step roofline)
-    double bytes = 0;
-    for (int r = 0; r < L; r++) {
-      for (int jt = 0; jt < nJ; jt++) if (tile_exists(r / TA, jt, TA, TB, L)) bytes += P2_AREC * 4;
-      for (int it = 0; it < nI; it++) if (tile_exists(it, r / TB, TA, TB, L)) bytes += P2_BREC * 4;
-    }
-    ctx->slab_bytes_per_res = bytes / L;
-  }
-  const size_t fa = (size_t)nJ * B * L * P2_AREC, fb = (size_t)nI * B * L * P2_BREC + 4;
-  const size_t xt = ordered ? (size_t)Bpad * L * 5 : 0;
-  const int ntp_alloc = ntp > 8 ? ntp : 8;
-  if (B <= ctx->Bcap && L <= ctx->Lcap && fa <= ctx->fa_cap && fb <= ctx->fbrec_cap && ntp <= ctx->tiles_cap && xt <= ctx->xt_cap) {
-    if (geom_changed) {
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      if (ntp) HIPCHK(hipMemcpy(ctx->tiles, tl.data(), sizeof(short2) * ntp, hipMemcpyHostToDevice));
-      if (xt) HIPCHK(hipMemsetAsync(ctx->xyzT, 0, sizeof(float4) * xt, ctx->stream));  // the pad lanes of a group layout must hold finite numbers
+  const bool layout_changed = BW != ctx->BW || Bpad != ctx->Bpad;
+  ctx->BW = BW; ctx->Bpad = Bpad; ctx->nsplit = nsplit;
+  if (B <= ctx->Bcap && L <= ctx->Lcap && nsplit <= ctx->nsplit_cap) {
+    if (layout_changed) {  // the pad lanes of a group layout must hold finite numbers
+      HIPCHK(hipMemsetAsync(ctx->xyzT, 0, sizeof(float4) * (size_t)Bpad * L * 5, ctx->stream));
       ctx->alloc_epoch++;
     }
     return 0;
@@ -508,15 +456,11 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
   HIPCHK(hipMalloc((void**)&ctx->Y, sizeof(float4) * BL * LBM));
   HIPCHK(hipMalloc((void**)&ctx->P, sizeof(float4) * BL * 5));
   HIPCHK(hipMalloc((void**)&ctx->geom, sizeof(float4) * BL * 3));
-  HIPCHK(hipMalloc((void**)&ctx->wcur, sizeof(float) * B * 8));
-  HIPCHK(hipMalloc((void**)&ctx->FA, sizeof(float) * fa));
-  HIPCHK(hipMalloc((void**)&ctx->FB, sizeof(float) * fb));
-  HIPCHK(hipMalloc((void**)&ctx->tiles, sizeof(short2) * ntp_alloc));
-  if (ntp) HIPCHK(hipMemcpy(ctx->tiles, tl.data(), sizeof(short2) * ntp, hipMemcpyHostToDevice));
-  // the decoy-minor copy is sized for the widest group layout of this many decoys, so that a later, smaller batch fits
+  // the decoy-minor copy is sized for the widest group layout of this many decoys, so that any later, smaller batch fits
   const size_t xt_alloc = (size_t)((B + 63) / 64 * 64) * L * 5;
   HIPCHK(hipMalloc((void**)&ctx->xyzT, sizeof(float4) * xt_alloc));
-  HIPCHK(hipMemsetAsync(ctx->xyzT, 0, sizeof(float4) * xt_alloc, ctx->stream));
+  HIPCHK(hipMalloc((void**)&ctx->wcur, sizeof(float) * B * 8));
+  HIPCHK(hipMalloc((void**)&ctx->FA, sizeof(float) * (size_t)nsplit * B * L * PR_REC));
   HIPCHK(hipMalloc((void**)&ctx->e_last, sizeof(double) * B * TRX2_NTERMS));
   HIPCHK(hipMalloc((void**)&ctx->f_last, sizeof(double) * B));
   HIPCHK(hipMalloc((void**)&ctx->grad, sizeof(float) * BL * 3));
@@ -526,18 +470,18 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
   HIPCHK(hipMemsetAsync(ctx->seq_ctr, 0, sizeof(int), ctx->stream));
   HIPCHK(hipMalloc((void**)&ctx->runs, sizeof(trx2_run) * TRX2_MAX_RUNS));
   HIPCHK(hipMemsetAsync(ctx->P, 0, sizeof(float4) * BL * 5, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->xyzT, 0, sizeof(float4) * xt_alloc, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->wcur, 0, sizeof(float) * B * 8, ctx->stream));
-  ctx->Bcap = B; ctx->Lcap = L; ctx->fa_cap = fa; ctx->fbrec_cap = fb; ctx->tiles_cap = ntp_alloc; ctx->xt_cap = xt_alloc;
+  ctx->Bcap = B; ctx->Lcap = L; ctx->nsplit_cap = nsplit;
   ctx->alloc_epoch++;
   return 0;
 }
 
-static Pair2Args pair_args(trx2_ctx* c, int B) {
-  Pair2Args P;
-  P.L = c->L; P.B = B; P.RA = c->RA; P.TA = c->TA; P.nI = c->nI; P.nJ = c->nJ; P.ntp = c->ntp; P.G = c->NG;
-  P.P = c->P; P.Td = c->Td; P.To = c->To; P.Tt = c->Tt; P.Tp = c->Tp;
-  P.mask = c->mask2; P.knots = c->knots_f; P.wcur = c->wcur; P.FA = c->FA; P.FB = c->FB; P.tiles = c->tiles;
-  P.seq_ctr = c->seq_ctr;
+static PairArgs pair_args(trx2_ctx* c, int B) {
+  PairArgs P;
+  P.L = c->L; P.B = B; P.nsplit = c->nsplit; P.Bpad = c->Bpad;
+  P.xyzT = c->xyzT; P.Td = c->Td; P.To = c->To; P.Tt = c->Tt; P.Tp = c->Tp;
+  P.mask = c->mask2; P.knots = c->knots_f; P.wcur = c->wcur; P.FA = c->FA; P.seq_ctr = c->seq_ctr;
   return P;
 }
 static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_evals) {
@@ -546,30 +490,23 @@ static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_eva
   A.L = c->L; A.B = B; A.mode = mode; A.nruns = nruns;
   A.max_evals = max_evals; A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho;
   A.X = c->X; A.G = c->G; A.D = c->D; A.XT = c->XT; A.S = c->S; A.Y = c->Y; A.P = c->P; A.geom = c->geom;
-  A.wcur = c->wcur; A.FA = c->FA; A.FB = c->FB; A.TA = c->TA; A.TB = c->TB; A.nI = c->nI; A.nJ = c->nJ; A.hasH = c->hasH;
-  A.xyzT = c->ordered ? c->xyzT : nullptr; A.BW = c->BW;
+  A.xyzT = c->xyzT; A.BW = c->BW;
+  A.wcur = c->wcur; A.FA = c->FA; A.nsplit = c->nsplit; A.hasH = c->hasH;
   A.e_last = c->e_last; A.f_last = c->f_last;
   A.grad_out = c->grad; A.done_count = c->done_count;
   return A;
 }
 static void launch_pair(trx2_ctx* c, int B) {
-  if (!c->ordered) {
-    const Pair2Args P = pair_args(c, B);
-    const dim3 grid((unsigned)(c->ntp * c->NG)), block(P2_THREADS);
-    hipLaunchKernelGGL((k_pair2<1>), grid, block, 0, c->stream, P);
-    return;
-  }
-  PairArgs P;
-  P.L = c->L; P.B = B; P.nsplit = c->nsplit; P.Bpad = c->Bpad;
-  P.xyzT = c->xyzT; P.Td = c->Td; P.To = c->To; P.Tt = c->Tt; P.Tp = c->Tp;
-  P.mask = c->mask2; P.knots = c->knots_f; P.wcur = c->wcur; P.FA = c->FA; P.seq_ctr = c->seq_ctr;
+  const PairArgs P = pair_args(c, B);
   const dim3 grid(c->L, c->nsplit, c->Bpad / c->BW), block(PAIR_THREADS);
   switch (c->BW) {
     case 64: hipLaunchKernelGGL((k_pair<64, FAM_ALL>), grid, block, 0, c->stream, P); break;
     case 32: hipLaunchKernelGGL((k_pair<32, FAM_ALL>), grid, block, 0, c->stream, P); break;
     case 16: hipLaunchKernelGGL((k_pair<16, FAM_ALL>), grid, block, 0, c->stream, P); break;
     case 8: hipLaunchKernelGGL((k_pair<8, FAM_ALL>), grid, block, 0, c->stream, P); break;
-    default: hipLaunchKernelGGL((k_pair<4, FAM_ALL>), grid, block, 0, c->stream, P); break;
+    case 4: hipLaunchKernelGGL((k_pair<4, FAM_ALL>), grid, block, 0, c->stream, P); break;
+    case 2: hipLaunchKernelGGL((k_pair<2, FAM_ALL>), grid, block, 0, c->stream, P); break;
+    default: hipLaunchKernelGGL((k_pair<1, FAM_ALL>), grid, block, 0, c->stream, P); break;
   }
 }
 static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals) {
@@ -577,9 +514,8 @@ static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals) {
   A.L = c->L; A.B = B; A.nruns = nruns; A.max_evals = max_evals; A.seq_ctr = c->seq_ctr;
   A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho;
   A.CX = c->CX; A.CG = c->CG; A.CD = c->CD; A.CS = c->CS; A.CY = c->CY;
-  A.P = c->P; A.X = c->X; A.XT = c->XT; A.geom = c->geom; A.wcur = c->wcur;
-  A.FA = c->FA; A.FB = c->FB; A.TA = c->TA; A.TB = c->TB; A.nI = c->nI; A.nJ = c->nJ; A.hasH = c->hasH;
-  A.xyzT = c->ordered ? c->xyzT : nullptr; A.BW = c->BW;
+  A.P = c->P; A.xyzT = c->xyzT; A.BW = c->BW; A.X = c->X; A.XT = c->XT; A.geom = c->geom; A.wcur = c->wcur;
+  A.FA = c->FA; A.nsplit = c->nsplit; A.hasH = c->hasH;
   A.e_last = c->e_last; A.f_last = c->f_last; A.done_count = c->done_count;
   return A;
 }
@@ -698,7 +634,7 @@ static int fold_impl(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint
   // TRX2_GRAPH=1 opts in.
   static const bool no_graph = getenv("TRX2_GRAPH") == nullptr;
   if (!no_graph) {
-    const long key[8] = {B, nruns, max_evals, has_cart ? 1 : 0, L, ctx->TA, ctx->DW, ctx->alloc_epoch};
+    const long key[8] = {B, nruns, max_evals, has_cart ? 1 : 0, L, ctx->nsplit, ctx->BW, ctx->alloc_epoch};
     if (!ctx->gexec || memcmp(key, ctx->g_key, sizeof key) != 0) {
       if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
       hipGraph_t graph = nullptr;
@@ -1022,9 +958,9 @@ extern "C" int trx2_last_fold_kernel_times(trx2_ctx* ctx, double* pair_ms_avg, d
 extern "C" int trx2_ctx_info(const trx2_ctx* ctx, int key, double* value) {
   if (!ctx || !value) return 1;
   switch (key) {
-    case TRX2_INFO_GROUP_WIDTH: *value = ctx->DW; return 0;  // = BW for the batch kernel
-    case TRX2_INFO_SLAB_BYTES: *value = ctx->slab_bytes_per_res; return 0;
-    case TRX2_INFO_PAIR_WGS: *value = ctx->ordered ? (double)ctx->L * ctx->nsplit * ctx->NG : (double)ctx->ntp * ctx->NG; return 0;
+    case TRX2_INFO_GROUP_WIDTH: *value = ctx->BW; return 0;
+    case TRX2_INFO_SLAB_BYTES: *value = (double)ctx->nsplit * PR_REC * 4; return 0;
+    case TRX2_INFO_PAIR_WGS: *value = (double)ctx->L * ctx->nsplit * (ctx->Bpad / ctx->BW); return 0;
     case TRX2_INFO_LBFGS_M: *value = LBM; return 0;
     case TRX2_INFO_L: *value = ctx->L; return 0;
     default: return 1;
