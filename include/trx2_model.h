@@ -31,9 +31,11 @@
 #define TRX2_NO_BINS 25 /* omega, theta */
 #define TRX2_NP_BINS 13 /* phi */
 #define TRX2_KD 35      /* knots of the distance spline: 3 repulsive + 32 contact bins (utils_ros.py:60-64) */
+#define TRX2_KD_AF2 60  /* ... of gen_rst_af2's C-alpha tables: 3 repulsive + 57 AlphaFold bin edges (utils_ros.py:174-181) */
 #define TRX2_KO 28      /* knots of omega / theta splines: 24 + 4 wrap-pad (utils_ros.py:81-87)          */
 #define TRX2_KP 16      /* knots of phi spline: 12 + 4 mirror-pad (utils_ros.py:124-130)                */
 #define TRX2_KTOT (TRX2_KD + TRX2_KO + TRX2_KO + TRX2_KP) /* 107 knots per ordered pair */
+#define TRX2_KTOT_MAX (TRX2_KD_AF2 + TRX2_KO + TRX2_KO + TRX2_KP)
 #define TRX2_GEN_PCUT 0.05 /* utils_ros.py:18 (literal, ignores -pd) */
 
 /* selection mask bits per ORDERED pair (a,b) */
@@ -170,7 +172,9 @@ typedef struct trx2_run {
   int precheck;     /* 1: before running, if rama+vdw (raw) < CLASH_BREAK jump to skip_to      */
   int skip_to;      /* run index to continue with when the precheck fires                      */
   int cartesian;    /* 1: minimise Cartesian coordinates (MinMover.cartesian(True))            */
-  int pad0, pad1;
+  int pair_filter;  /* 1: only restraints of pairs NOT flagged in the map's idr mask (add_idr_rst with the complement, mode 3's
+                       first stage, folding.py:173-179); 0: all selected restraints */
+  int pad1;
 } trx2_run;
 
 #endif

@@ -66,8 +66,24 @@ int trx2_set_map(trx2_ctx* ctx, int L, const char* seq, const float* dist, const
 int trx2_set_map_device(trx2_ctx* ctx, int L, const char* seq, const float* dist_dev, const float* omega_dev,
                         const float* theta_dev, const float* phi_dev, const trx2_params* prm);
 
+/* The other restraint builders of folding/folding.py:60-68 (-r) and the pair mask of mode 3.
+ * trx2_set_map_ex: idr[L][L] (or NULL) flags "disordered" pairs (npz['idr'] of the reference).  rst_kind 0 = gen_rst,
+ *   1 = gen_idp_rst (utils_ros.py:196-373: flagged pairs are normalised by their most probable bin).  With an idr mask set, runs
+ *   whose trx2_run.pair_filter is 1 use only the restraints of UNflagged pairs (add_idr_rst with 1 - idr, folding.py:173-179).
+ * trx2_set_map_af2: gen_rst_af2 (utils_ros.py:148-194): dist64[L][L][64] AlphaFold-style distogram, edges63[63] its bin edges;
+ *   C-alpha -- C-alpha restraints with 60 knots; distances only (the reference raises on --orient).
+ * trx2_override_table_rows: replaces the VALUES of n rows of one channel's table (y[n][K], as they would be printed; K = 35 or 60 /
+ *   28 / 28 / 16) and recomputes their spline; pairs (a[i], b[i]), a < b for dist / omega.  gen_gpcr_rst (utils_ros.py:484-654) =
+ *   gen_rst + its ling_sumlt edits of the flagged pairs, which the caller computes from the known structures
+ *   (trrosettax2-dynamics_amd/restraints.py). */
+int trx2_set_map_ex(trx2_ctx* ctx, int L, const char* seq, const float* dist, const float* omega, const float* theta,
+                    const float* phi, const trx2_params* prm, const unsigned char* idr, int rst_kind);
+int trx2_set_map_af2(trx2_ctx* ctx, int L, const char* seq, const float* dist64, const double* edges63, const trx2_params* prm);
+int trx2_override_table_rows(trx2_ctx* ctx, int channel, int n, const int* a, const int* b, const double* y);
+
 /* read the tables back (parity tests).  channel 0 dist, 1 omega, 2 theta, 3 phi.
- * y_y2: [L][L][K][2] float (value, second derivative), K = 35/28/28/16; knots: [K]; prob: [L][L];
+ * y_y2: [L][L][K][2] float (value, second derivative), K = 35/28/28/16 (60 for the distance channel of an af2 map); knots: [K];
+ * prob: [L][L];
  * gen, sel: [L][L] bit masks (TRX2_M_*).  Any output pointer may be NULL. */
 int trx2_get_tables(trx2_ctx* ctx, int channel, float* y_y2, float* knots, float* prob, unsigned char* gen,
                     unsigned char* sel);

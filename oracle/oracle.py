@@ -20,7 +20,7 @@ KD, KO, KP = 35, 28, 16
 class Run(C.Structure):
     """mirror of trx2_run (include/trx2_model.h)"""
     _fields_ = [("w", C.c_float * NW), ("max_iter", C.c_int), ("sep_lo", C.c_int), ("sep_hi", C.c_int),
-                ("precheck", C.c_int), ("skip_to", C.c_int), ("cartesian", C.c_int), ("pad0", C.c_int),
+                ("precheck", C.c_int), ("skip_to", C.c_int), ("cartesian", C.c_int), ("pair_filter", C.c_int),
                 ("pad1", C.c_int)]
 
 
@@ -61,6 +61,15 @@ def lib():
         L.orc_build_tables.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_double]
         L.orc_tables_free.argtypes = [vp]
         L.orc_tables_set_seq.argtypes = [vp, C.c_char_p]
+        L.orc_build_tables_ex.restype = vp
+        L.orc_build_tables_ex.argtypes = [C.c_int, vp, vp, vp, vp, vp, C.c_double, vp, C.c_int]
+        L.orc_build_tables_af2.restype = vp
+        L.orc_build_tables_af2.argtypes = [C.c_int, vp, vp, vp, C.c_double]
+        L.orc_tables_override_rows.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+        L.orc_tables_filter_pairs.argtypes = [vp, vp, C.c_int]
+        L.orc_tables_set_idr.argtypes = [vp, vp]
+        L.orc_tables_kd.restype = C.c_int
+        L.orc_tables_kd.argtypes = [vp]
         L.orc_place_h.argtypes = [vp, vp, vp, vp]
         L.orc_hbond_term.restype = C.c_double
         L.orc_hbond_term.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
@@ -112,12 +121,23 @@ def params_vec(p=None):
 class Tables:
     """orc_build_tables: gen_rst + add_rst selection, dense."""
 
-    def __init__(self, dist, omega=None, theta=None, phi=None, params=None, pcut=0.05, seq=None):
+    def __init__(self, dist, omega=None, theta=None, phi=None, params=None, pcut=0.05, seq=None, idr=None, kind="no-idp", af2_bins=None):
+        """kind: "no-idp" gen_rst, "idp" gen_idp_rst (needs idr[L,L]), "af2" gen_rst_af2 (dist[L,L,64] + af2_bins[63])"""
         self.L = int(dist.shape[0])
         arrs = [np.ascontiguousarray(a, dtype=np.float32) if a is not None else None for a in (dist, omega, theta, phi)]
         self._keep = arrs
         self.use_orient = all(a is not None for a in arrs)
-        self.h = lib().orc_build_tables(self.L, *[_p(a) for a in arrs], _p(params_vec(params)), float(pcut))
+        if kind == "af2":
+            edges = np.ascontiguousarray(af2_bins, np.float64)
+            assert arrs[0].shape == (self.L, self.L, 64) and edges.shape == (63,) and not self.use_orient
+            self.h = lib().orc_build_tables_af2(self.L, _p(arrs[0]), _p(edges), _p(params_vec(params)), float(pcut))
+        else:
+            fl = np.ascontiguousarray(idr, np.uint8) if idr is not None else None
+            self.h = lib().orc_build_tables_ex(self.L, *[_p(a) for a in arrs], _p(params_vec(params)), float(pcut), _p(fl),
+                                               {"no-idp": 0, "idp": 1}[kind])
+            if fl is not None:   # runs with pair_filter = 1 (mode 3, first stage) see the unflagged pairs only
+                lib().orc_tables_set_idr(self.h, _p(fl))
+        self.kd = lib().orc_tables_kd(self.h)
         if seq is not None:   # prolines donate no backbone hydrogen bond
             if len(seq) != self.L:
                 raise ValueError("sequence length does not match the map")
@@ -134,15 +154,25 @@ class Tables:
         return np.ctypeslib.as_array(ptr, shape=shape).copy()
 
     def knots(self):
-        return dict(dist=self._arr(8, (KD,)), omega=self._arr(9, (KO,)), theta=self._arr(10, (KO,)), phi=self._arr(11, (KP,)))
+        return dict(dist=self._arr(8, (self.kd,)), omega=self._arr(9, (KO,)), theta=self._arr(10, (KO,)), phi=self._arr(11, (KP,)))
 
     def y(self, ch):
-        k = {"dist": (0, KD), "omega": (2, KO), "theta": (4, KO), "phi": (6, KP)}[ch]
+        k = {"dist": (0, self.kd), "omega": (2, KO), "theta": (4, KO), "phi": (6, KP)}[ch]
         return self._arr(k[0], (self.L, self.L, k[1]))
 
     def y2(self, ch):
-        k = {"dist": (1, KD), "omega": (3, KO), "theta": (5, KO), "phi": (7, KP)}[ch]
+        k = {"dist": (1, self.kd), "omega": (3, KO), "theta": (5, KO), "phi": (7, KP)}[ch]
         return self._arr(k[0], (self.L, self.L, k[1]))
+
+    def override_rows(self, ch, a, b, y):
+        """replace table rows (gen_gpcr_rst's edits): y[n, K] as printed; second derivatives are recomputed"""
+        i = ["dist", "omega", "theta", "phi"].index(ch)
+        a = np.ascontiguousarray(a, np.int32); b = np.ascontiguousarray(b, np.int32); y = np.ascontiguousarray(y, np.float64)
+        lib().orc_tables_override_rows(self.h, i, len(a), _p(a), _p(b), _p(y))
+
+    def filter_pairs(self, flag, keep):
+        """add_idr_rst: keep the selected restraints only where flag[a,b] == keep"""
+        lib().orc_tables_filter_pairs(self.h, _p(np.ascontiguousarray(flag, np.uint8)), int(bool(keep)))
 
     def prob(self, ch):
         i = ["dist", "omega", "theta", "phi"].index(ch)
@@ -242,7 +272,7 @@ def make_runs(runs):
             arr[i].w[k] = float(r["w"][k])
         arr[i].max_iter = int(r["max_iter"]); arr[i].sep_lo = int(r["sep_lo"]); arr[i].sep_hi = int(r["sep_hi"])
         arr[i].precheck = int(r.get("precheck", 0)); arr[i].skip_to = int(r.get("skip_to", 0))
-        arr[i].cartesian = int(r.get("cartesian", 0))
+        arr[i].cartesian = int(r.get("cartesian", 0)); arr[i].pair_filter = int(r.get("pair_filter", 0))
     return arr
 
 

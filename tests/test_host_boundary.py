@@ -81,8 +81,13 @@ def test_option_string_parsing():
     a = FO.parse_options("-m 0 --no-orient -pd 0.15 --no-fastrelax")
     assert (a.mode, a.use_orient, a.pcut, a.fastrelax) == (0, False, 0.15, False)
     assert FO._unquote('"/a b/c.npz"') == "/a b/c.npz" and FO._unquote("x.npz") == "x.npz"
-    with pytest.raises(NotImplementedError):
-        FO.parse_options("-r idp")
+    a = FO.parse_options("-r idp -m 3 --orient")                     # the other builders and mode 3
+    assert (a.rst, a.mode) == ("idp", 3)
+    with pytest.raises(RuntimeError):                                 # utils_ros.py:149-150: gen_rst_af2 refuses --orient
+        FO.parse_options("-r af2 --orient")
+    assert FO.parse_options("-r af2 --no-orient").rst == "af2"
+    with pytest.raises(ValueError):                                   # folding.py:66-67: -r gpcr loads args.KNOWN
+        FO.parse_options("-r gpcr --orient")
 
 
 def test_output_layout_matches_committed_example(tmp_path):

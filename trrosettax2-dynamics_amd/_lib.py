@@ -26,7 +26,7 @@ class Params(C.Structure):
 class Run(C.Structure):
     """trx2_run (include/trx2_model.h)"""
     _fields_ = [("w", C.c_float * NW), ("max_iter", C.c_int), ("sep_lo", C.c_int), ("sep_hi", C.c_int),
-                ("precheck", C.c_int), ("skip_to", C.c_int), ("cartesian", C.c_int), ("pad0", C.c_int), ("pad1", C.c_int)]
+                ("precheck", C.c_int), ("skip_to", C.c_int), ("cartesian", C.c_int), ("pair_filter", C.c_int), ("pad1", C.c_int)]
 
 
 DEFAULT_PARAMS = dict(ebase=-0.5, erep=(10.0, 3.0, 0.5), drep=(0.0, 2.0, 3.5), meff=1e-4, dcut=19.5, alpha=1.57,
@@ -50,6 +50,7 @@ def make_runs(runs):
             arr[i].w[k] = float(r["w"][k])
         arr[i].max_iter, arr[i].sep_lo, arr[i].sep_hi = int(r["max_iter"]), int(r["sep_lo"]), int(r["sep_hi"])
         arr[i].precheck, arr[i].skip_to, arr[i].cartesian = int(r.get("precheck", 0)), int(r.get("skip_to", 0)), int(r.get("cartesian", 0))
+        arr[i].pair_filter = int(r.get("pair_filter", 0))
     return arr
 
 
@@ -75,6 +76,9 @@ def load():
     L.trx2_last_error.restype = C.c_char_p
     L.trx2_set_map.argtypes = [vp, C.c_int, C.c_char_p, vp, vp, vp, vp, C.POINTER(Params)]
     L.trx2_set_map_device.argtypes = [vp, C.c_int, C.c_char_p, vp, vp, vp, vp, C.POINTER(Params)]
+    L.trx2_set_map_ex.argtypes = [vp, C.c_int, C.c_char_p, vp, vp, vp, vp, C.POINTER(Params), vp, C.c_int]
+    L.trx2_set_map_af2.argtypes = [vp, C.c_int, C.c_char_p, vp, vp, C.POINTER(Params)]
+    L.trx2_override_table_rows.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.trx2_get_tables.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.trx2_eval_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]
     L.trx2_fold_batch.argtypes = [vp, C.c_int, vp, C.c_int, C.c_uint64, C.c_uint32, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
@@ -108,6 +112,7 @@ class Context:
             raise RuntimeError(f"trx2_ctx_create(device={device}) failed with code {rc}: no usable GPU (no CPU fallback)")
         self._h = h
         self.L = 0
+        self.kd = 35
         self.use_orient = False
         self.lanes = 1
         if lanes != 1:
@@ -128,15 +133,38 @@ class Context:
         if rc != 0:
             raise RuntimeError(f"{what}: {self._l.trx2_last_error(self._h).decode()}")
 
-    def set_map(self, dist, omega=None, theta=None, phi=None, seq=None, **params):
+    def set_map(self, dist, omega=None, theta=None, phi=None, seq=None, idr=None, kind="no-idp", **params):
+        """kind: "no-idp" (gen_rst) or "idp" (gen_idp_rst, needs idr[L,L]); an idr mask also enables runs with pair_filter=1 (mode 3)"""
         arrs = [np.ascontiguousarray(a, np.float32) if a is not None else None for a in (dist, omega, theta, phi)]
         L = int(arrs[0].shape[0])
         for a, nb in zip(arrs, (37, 25, 25, 13)):
             if a is not None and a.shape != (L, L, nb):
                 raise ValueError(f"expected shape {(L, L, nb)}, got {a.shape}")
         s = (seq or "A" * L).encode()
-        self._chk(self._l.trx2_set_map(self._h, L, s, *[_p(a) for a in arrs], C.byref(make_params(**params))), "trx2_set_map")
-        self.L, self.use_orient = L, all(a is not None for a in arrs)
+        if idr is None and kind == "no-idp":
+            self._chk(self._l.trx2_set_map(self._h, L, s, *[_p(a) for a in arrs], C.byref(make_params(**params))), "trx2_set_map")
+        else:
+            fl = np.ascontiguousarray(idr, np.uint8) if idr is not None else None
+            if fl is not None and fl.shape != (L, L):
+                raise ValueError(f"idr mask must have shape {(L, L)}")
+            self._chk(self._l.trx2_set_map_ex(self._h, L, s, *[_p(a) for a in arrs], C.byref(make_params(**params)), _p(fl),
+                                              {"no-idp": 0, "idp": 1}[kind]), "trx2_set_map_ex")
+        self.L, self.use_orient, self.kd = L, all(a is not None for a in arrs), 35
+
+    def set_map_af2(self, dist64, edges63, seq=None, **params):
+        """gen_rst_af2: AlphaFold-style distogram dist64[L,L,64] with its 63 bin edges -> C-alpha restraints (60 knots)"""
+        d = np.ascontiguousarray(dist64, np.float32); e = np.ascontiguousarray(edges63, np.float64)
+        L = int(d.shape[0])
+        if d.shape != (L, L, 64) or e.shape != (63,):
+            raise ValueError("need dist64[L,L,64] and 63 bin edges")
+        self._chk(self._l.trx2_set_map_af2(self._h, L, (seq or "A" * L).encode(), _p(d), _p(e), C.byref(make_params(**params))), "trx2_set_map_af2")
+        self.L, self.use_orient, self.kd = L, False, 60
+
+    def override_rows(self, ch, a, b, y):
+        """replace table rows (gen_gpcr_rst's edits): y[n, K] as printed; the device recomputes their splines"""
+        i = ("dist", "omega", "theta", "phi").index(ch)
+        a = np.ascontiguousarray(a, np.int32); b = np.ascontiguousarray(b, np.int32); y = np.ascontiguousarray(y, np.float64)
+        self._chk(self._l.trx2_override_table_rows(self._h, i, len(a), _p(a), _p(b), _p(y)), "trx2_override_table_rows")
 
     def set_map_device(self, L, dist_ptr, omega_ptr=0, theta_ptr=0, phi_ptr=0, seq=None, **params):
         """Same as set_map with DEVICE pointers (float32, row-major [L][L][37/25/25/13]) -- the in-memory hand-off from the
@@ -153,7 +181,8 @@ class Context:
     def get_tables(self, ch):
         i = ("dist", "omega", "theta", "phi").index(ch)
         L = self.L
-        yy = np.zeros((L, L, K[i], 2), np.float32); kn = np.zeros(K[i], np.float32); pr = np.zeros((L, L), np.float32)
+        Kc = getattr(self, "kd", 35) if i == 0 else K[i]
+        yy = np.zeros((L, L, Kc, 2), np.float32); kn = np.zeros(Kc, np.float32); pr = np.zeros((L, L), np.float32)
         gen = np.zeros((L, L), np.uint8); sel = np.zeros((L, L), np.uint8)
         self._chk(self._l.trx2_get_tables(self._h, i, _p(yy), _p(kn), _p(pr), _p(gen), _p(sel)), "trx2_get_tables")
         return dict(y=yy[..., 0], y2=yy[..., 1], knots=kn, prob=pr, gen=gen, sel=sel)

@@ -12,11 +12,14 @@
 
 struct PairArgs {
   int L, B, nsplit, Bpad;
+  int kd;       // knots of the distance spline: TRX2_KD, or TRX2_KD_AF2 for gen_rst_af2 tables
+  int dist_ca;  // 1: the distance restraint acts on C-alpha (gen_rst_af2), 0: on C-beta
   const float4* xyzT;  // [ngrp][L][5][BW] float4 : residue record N CA C O CB (+pad) | H, hasH ; decoy-minor
   const float2 *Td, *To, *Tt, *Tp;
   const unsigned char* mask;  // [L][L] packed: low nibble = selected bits of (a,b), high nibble = those of (b,a)
-  const float* knots;         // [107] float
-  const float* wcur;          // [B][8] : w_ap w_dih w_ang w_vdw sep_lo sep_hi active w_hb
+  const unsigned char* mask_odr;  // the same without the pairs flagged disordered (mode 3, first stage), or NULL
+  const float* knots;         // [kd + 72] float
+  const float* wcur;          // [B][8] : w_ap w_dih w_ang w_vdw sep_lo sep_hi active (2: ordered pairs only) w_hb
   float* FA;                  // [nsplit][B][L][24] per (slab, decoy, residue a): gradient on N CA C O CB H, then the raw energies
                               // dist omega theta phi vdw hb (PR_REC; the step kernel sums the slabs: sum_pair_records)
   int* seq_ctr;               // evaluation counter in device memory: bumped here, read by the step kernel that follows
@@ -102,9 +105,10 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   const int decc = min(dec, A.B - 1);
 
   STAMP_DECL
-  __shared__ float s_kn[TRX2_KTOT], s_ikn[TRX2_KTOT];
+  __shared__ float s_kn[TRX2_KTOT_MAX], s_ikn[TRX2_KTOT_MAX];
   __shared__ float s_red[PAIR_WAVES * 64 * RED_STRIDE];  // [wave][decoy][24 (+1 pad: bank-conflict-free)]
   __shared__ unsigned char s_mask[1024];  // packed masks of this workgroup's residues b (chunk <= L <= 1024)
+  __shared__ unsigned char s_mask_o[1024];  // ... without the disordered pairs (only when the map has an idr mask)
   // One evaluation = one sequence number.  Kept in device memory (not a kernel argument) so that a chunk of
   // (pair, step) launches is a STATIC graph that can be replayed.  The step kernel of this evaluation starts after this
   // kernel has finished (same stream), so every one of its workgroups reads the same, final value.
@@ -115,25 +119,32 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   const float4 w0 = wp[0], w1 = wp[1];
   const float4* xa = A.xyzT + ((size_t)(grp * L + a) * 5) * BW + d;
   const float4 q0 = xa[0], q1 = xa[BW], q2 = xa[2 * BW], q3 = xa[3 * BW], q4 = xa[4 * BW];
-  for (int i = threadIdx.x; i < TRX2_KTOT; i += PAIR_THREADS) {
+  const int kd = A.kd, ktot = kd + 2 * KO + KP;
+  for (int i = threadIdx.x; i < ktot; i += PAIR_THREADS) {
     s_kn[i] = A.knots[i];
-    s_ikn[i] = i + 1 < TRX2_KTOT ? 1.0f / (A.knots[i + 1] - A.knots[i]) : 0.0f;  // entries straddling two tables are never read
+    s_ikn[i] = i + 1 < ktot ? 1.0f / (A.knots[i + 1] - A.knots[i]) : 0.0f;  // entries straddling two tables are never read
   }
   {
     const int chunk0 = (L + A.nsplit - 1) / A.nsplit, lo0 = split * chunk0, hi0 = min(L, lo0 + chunk0);
-    for (int i = lo0 + threadIdx.x; i < hi0; i += PAIR_THREADS) s_mask[i - lo0] = A.mask[(size_t)a * L + i];
+    for (int i = lo0 + threadIdx.x; i < hi0; i += PAIR_THREADS) {
+      s_mask[i - lo0] = A.mask[(size_t)a * L + i];
+      if (A.mask_odr) s_mask_o[i - lo0] = A.mask_odr[(size_t)a * L + i];
+    }
   }
   __syncthreads();
   const float* knd = s_kn;
-  const float* kno = s_kn + KD;
-  const float* knt = s_kn + KD + KO;
-  const float* knp = s_kn + KD + 2 * KO;
-  const float *iknd = s_ikn, *ikno = s_ikn + KD, *iknt = s_ikn + KD + KO, *iknp = s_ikn + KD + 2 * KO;
+  const float* kno = s_kn + kd;
+  const float* knt = s_kn + kd + KO;
+  const float* knp = s_kn + kd + 2 * KO;
+  const float *iknd = s_ikn, *ikno = s_ikn + kd, *iknt = s_ikn + kd + KO, *iknp = s_ikn + kd + 2 * KO;
   const float inv_o = 1.0f / (kno[1] - kno[0]), inv_p = 1.0f / (knp[1] - knp[0]);
+  // distance knots: three unevenly spaced repulsive ones, then a uniform grid (0 / 2 / 3.5 / 4.25 + 0.5 k; AF2: 0 / 2.325 / 3.575 / 3.875 + 0.3125 k)
+  const float kd1 = knd[1], kd2 = knd[2], kd3 = knd[3], inv_d = 1.0f / (knd[4] - knd[3]);
 
   const float w_ap = w0.x, w_dih = w0.y, w_ang = w0.z, w_vdw = w0.w, w_hb = w1.w;
   const int sep_lo = (int)w1.x, sep_hi = (int)w1.y;
   const bool active = live && w1.z != 0.0f;
+  const bool odr_only = w1.z == 2.0f && A.mask_odr != nullptr;
 
   // residue a
   const f3 Na = mk3(q0.x, q0.y, q0.z), CAa = mk3(q0.w, q1.x, q1.y), Ca = mk3(q1.z, q1.w, q2.x),
@@ -166,7 +177,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
     const int sep = abs(a - bc);
     unsigned m_ab = 0, m_ba = 0;
     if (valid && sep >= sep_lo && sep < sep_hi) {
-      const unsigned mm = s_mask[bc - b_lo];
+      const unsigned mm = odr_only ? s_mask_o[bc - b_lo] : s_mask[bc - b_lo];
       m_ab = mm & 15u;
       m_ba = mm >> 4;
     }
@@ -186,13 +197,14 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
     const bool first = a < bc;  // symmetric energies are counted from the lower row only
 
     if ((FAM & FAM_SYM) && (msym & TRX2_M_DIST)) {
-      f3 u = CBa - CBb;
+      f3 u = A.dist_ca ? CAa - CAb : CBa - CBb;
       float d2 = dot(u, u), id = rsqrtf(d2), dd = d2 * id;
-      int idx = dd < 2.0f ? 0 : (dd < 3.5f ? 1 : (dd < 4.25f ? 2 : 3 + (int)((dd - 4.25f) * 2.0f)));
+      int idx = dd < kd1 ? 0 : (dd < kd2 ? 1 : (dd < kd3 ? 2 : 3 + (int)((dd - kd3) * inv_d)));
       float ev, de;
-      spline_eval_dev(A.Td + isym * KD, knd, iknd, KD, idx, dd, ev, de);
+      spline_eval_dev(A.Td + isym * kd, knd, iknd, kd, idx, dd, ev, de);
       if (first) e_d += ev;
-      gCB = fma3(u, w_ap * de * id, gCB);
+      if (A.dist_ca) gCA = fma3(u, w_ap * de * id, gCA);
+      else gCB = fma3(u, w_ap * de * id, gCB);
     }
     STAMP(3)  // dist
     if ((FAM & FAM_SYM) && (msym & TRX2_M_OMEGA)) {

@@ -556,7 +556,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
     float* w = A.wcur + (size_t)dec * 8;
     w[0] = Rn.w[0]; w[1] = Rn.w[1]; w[2] = Rn.w[2]; w[3] = Rn.w[3];
     w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi;
-    w[6] = (phase == PH_DONE && A.mode == MODE_STEP) ? 0.0f : 1.0f;
+    w[6] = (phase == PH_DONE && A.mode == MODE_STEP) ? 0.0f : (Rn.pair_filter ? 2.0f : 1.0f);
     w[7] = Rn.w[7];
   }
   if (!need_nerf) return;
@@ -1128,7 +1128,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
     float* w = A.wcur + (size_t)dec * 8;
     w[0] = Rn.w[0]; w[1] = Rn.w[1]; w[2] = Rn.w[2]; w[3] = Rn.w[3];
-    w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi; w[6] = (phase == PH_DONE) ? 0.0f : 1.0f; w[7] = Rn.w[7];
+    w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi; w[6] = (phase == PH_DONE) ? 0.0f : (Rn.pair_filter ? 2.0f : 1.0f); w[7] = Rn.w[7];
   }
   if (tid < LBM) A.rho[(size_t)dec * LBM + tid] = s_rho[tid];
 }

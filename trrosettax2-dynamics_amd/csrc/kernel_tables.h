@@ -14,6 +14,10 @@ struct BuildArgs {
   float2 *Td, *To, *Tt, *Tp;
   float *pd, *po, *pt, *pp;
   unsigned char *gen, *sel;
+  // gen_idp_rst (utils_ros.py:196-373): on pairs flagged in idr the tables are normalised by the pair's most probable bin
+  const unsigned char* idr;  // [L][L] or NULL
+  int kind;                  // 0 gen_rst, 1 gen_idp_rst
+  const double* idr_bk;      // [32][32] (bins_k / bins_m)^ALPHA, host pow (see bkgr)
 };
 
 __device__ float np_sum_f32_dev(const float* a, int n) {  // numpy pairwise_sum for 8 <= n <= 128
@@ -29,7 +33,7 @@ __device__ float np_sum_f32_dev(const float* a, int n) {  // numpy pairwise_sum 
 
 // clamped cubic spline (end slopes 0) second derivatives, then store (y, y'') as float2
 __device__ __noinline__ void spline_store(int n, const double* x, const double* y, float2* out) {
-  double y2[KD], u[KD];
+  double y2[TRX2_KD_AF2], u[TRX2_KD_AF2];
   y2[0] = -0.5;
   u[0] = (3.0 / (x[1] - x[0])) * ((y[1] - y[0]) / (x[1] - x[0]));
   _Pragma("unroll 1") for (int i = 1; i < n - 1; i++) {
@@ -55,6 +59,7 @@ __global__ void k_build_tables(BuildArgs A) {
   unsigned char gen = 0, sel = 0;
   const float meff32 = (float)A.meff;
   double y[KD];
+  const bool flagged = A.kind == 1 && A.idr && A.idr[ab];
   {  // ---- dist (utils_ros.py:54-75)
     const float* row = A.dist + ab * TRX2_ND_BINS;
     float p = np_sum_f32_dev(row + 5, 32);
@@ -69,7 +74,16 @@ __global__ void k_build_tables(BuildArgs A) {
         if (k == 0) attr0 = at;
         y[3 + k] = round_dp(at, 1e3);
       }
-      double rep0 = attr0 > 0.0 ? attr0 : 0.0;
+      if (flagged) {  // utils_ros.py:251-252: background relative to the bin of the maximum, normalised by the maximum
+        int km = 0;
+        _Pragma("unroll 1") for (int k = 1; k < 32; k++) if (row[5 + k] > row[5 + km]) km = k;  // np.argmax: first maximum
+        _Pragma("unroll 1") for (int k = 0; k < 32; k++) {
+          float num = row[5 + k] + meff32;
+          double den = (double)row[5 + km] * A.idr_bk[km * 32 + k] + 1e-6;
+          y[3 + k] = round_dp(-log((double)num / den) + A.ebase, 1e3);
+        }
+      }
+      double rep0 = attr0 > 0.0 ? attr0 : 0.0;  // the repulsive knots keep the last-bin normalisation (:255)
       _Pragma("unroll 1") for (int k = 0; k < 3; k++) y[k] = round_dp(rep0 + A.erep[k], 1e3);
       spline_store(KD, A.knots, y, A.Td + ab * KD);
       gen |= TRX2_M_DIST;
@@ -85,6 +99,11 @@ __global__ void k_build_tables(BuildArgs A) {
       if (!ok) continue;
       float v[TRX2_NO_BINS];
       float den = row[24] + meff32;
+      if (flagged) {  // utils_ros.py:285,312
+        float mx = row[0];
+        _Pragma("unroll 1") for (int k = 1; k < TRX2_NO_BINS; k++) if (row[k] > mx) mx = row[k];
+        den = mx + meff32;
+      }
       _Pragma("unroll 1") for (int k = 0; k < TRX2_NO_BINS; k++) v[k] = -(float)log((double)((row[k] + meff32) / den));
       double sc = ch == 0 ? 1e5 : 1e3;
       y[0] = round_dp(v[23], sc);
@@ -104,6 +123,11 @@ __global__ void k_build_tables(BuildArgs A) {
       if ((double)p > TRX2_GEN_PCUT && a != b) {
         float v[TRX2_NP_BINS];
         float den = row[12] + meff32;
+        if (flagged) {  // utils_ros.py:348
+          float mx = row[0];
+          _Pragma("unroll 1") for (int k = 1; k < TRX2_NP_BINS; k++) if (row[k] > mx) mx = row[k];
+          den = mx + meff32;
+        }
         _Pragma("unroll 1") for (int k = 0; k < TRX2_NP_BINS; k++) v[k] = -(float)log((double)((row[k] + meff32) / den));
         y[0] = round_dp(v[2], 1e3);
         y[1] = round_dp(v[1], 1e3);
@@ -120,12 +144,66 @@ __global__ void k_build_tables(BuildArgs A) {
   A.sel[ab] = sel;
 }
 
+// gen_rst_af2 (utils_ros.py:148-194): AlphaFold-style distogram dist[L][L][64]; 60 knots (A.knots: 3 repulsive + the bin edges
+// 5..61), generation threshold 0.0025, the LAST bin's background on every bin (:172), normalised by bin 62; restraint on C-alpha
+struct BuildAf2Args {
+  int L;
+  const float* dist;
+  double ebase, erep[3], meff, pcut, bk_last;
+  const double* knots;  // [60]
+  float2* Td;           // [L][L][60]
+  float* pd;
+  unsigned char *gen, *sel;
+};
+__global__ void k_build_tables_af2(BuildAf2Args A) {
+  const int L = A.L;
+  size_t ab = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ab >= (size_t)L * L) return;
+  const int a = (int)(ab / L), b = (int)(ab % L);
+  const float* row = A.dist + ab * 64;
+  constexpr int NA = TRX2_KD_AF2 - 3;
+  const float p = np_sum_f32_dev(row + 6, NA);
+  A.pd[ab] = p;
+  unsigned char gen = 0, sel = 0;
+  if ((double)p > 0.0025 && b > a) {
+    double y[TRX2_KD_AF2], attr0 = 0;
+    const float meff32 = (float)A.meff;
+    _Pragma("unroll 1") for (int k = 0; k < NA; k++) {
+      float num = row[6 + k] + meff32;
+      double den = (double)row[62] * A.bk_last + 1e-6;
+      double at = -log((double)num / den) + A.ebase;
+      if (k == 0) attr0 = at;
+      y[3 + k] = round_dp(at, 1e3);
+    }
+    const double rep0 = attr0 > 0.0 ? attr0 : 0.0;
+    _Pragma("unroll 1") for (int k = 0; k < 3; k++) y[k] = round_dp(rep0 + A.erep[k], 1e3);
+    spline_store(TRX2_KD_AF2, A.knots, y, A.Td + ab * TRX2_KD_AF2);
+    gen = TRX2_M_DIST;
+    if ((double)p >= A.pcut) sel = TRX2_M_DIST;
+  }
+  A.gen[ab] = gen;
+  A.sel[ab] = sel;
+}
+
+// replace the values of table rows (gen_gpcr_rst's edits of the idr pairs): one thread per row, second derivatives recomputed
+__global__ void k_override_rows(int n, int K, int L, const int* a, const int* b, const double* y, const double* knots, float2* T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double yy[TRX2_KD_AF2];
+  _Pragma("unroll 1") for (int k = 0; k < K; k++) yy[k] = y[(size_t)i * K + k];
+  spline_store(K, knots, yy, T + ((size_t)a[i] * L + b[i]) * K);
+}
+
 // mask2[a][b] = sel[a][b] | sel[b][a] << 4 : both directions of an ordered pair in ONE row-contiguous byte.  k_pair used
 // to fetch sel[a][b] and sel[b][a] (a column access: a fresh cache line per visit) before it could even issue its
 // coordinate loads -- ~950 of ~3250 cycles per visit (s_memtime stamps, profiles/README.md).
-__global__ void k_pack_masks(int L, const unsigned char* sel, unsigned char* mask2) {
+// mask_odr: the same with the restraints of the pairs flagged in idr removed (add_idr_rst with the complement mask, mode 3's
+// first stage, folding.py:173-179), or NULL when the map has no idr mask.
+__global__ void k_pack_masks(int L, const unsigned char* sel, const unsigned char* idr, unsigned char* mask2, unsigned char* mask_odr) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)L * L) return;
   const int a = (int)(i / L), b = (int)(i % L);
-  mask2[i] = (unsigned char)((sel[i] & 15) | ((sel[(size_t)b * L + a] & 15) << 4));
+  const size_t j = (size_t)b * L + a;
+  mask2[i] = (unsigned char)((sel[i] & 15) | ((sel[j] & 15) << 4));
+  if (mask_odr) mask_odr[i] = (unsigned char)((idr[i] ? 0 : (sel[i] & 15)) | ((idr[j] ? 0 : (sel[j] & 15)) << 4));
 }

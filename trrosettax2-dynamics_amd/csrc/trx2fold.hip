@@ -72,9 +72,15 @@ struct trx2_ctx {
   float2 *Td = nullptr, *To = nullptr, *Tt = nullptr, *Tp = nullptr;
   float *pd = nullptr, *po = nullptr, *pt = nullptr, *pp = nullptr;
   unsigned char *gen = nullptr, *sel = nullptr, *mask2 = nullptr, *hasH = nullptr;
+  // restraint variants: idr = pair flags of gen_idp_rst / mode 3 (NULL: none); mask_odr = packed masks without
+  // the flagged pairs; rst_kind 0 gen_rst, 1 gen_idp_rst, 2 gen_rst_af2 (kd = 60 knots, distance on C-alpha, 64-bin map)
+  unsigned char *idr = nullptr, *mask_odr = nullptr;
+  double* idr_bk = nullptr;
+  int rst_kind = 0, kd = KD, dist_ca = 0;
+  double knots_af2_last = 0;
   float* knots_f = nullptr;
   double* knots_d = nullptr;
-  double knots_h[TRX2_KTOT];
+  double knots_h[TRX2_KTOT_MAX];
   // batch
   int Bcap = 0, Lcap = 0, BW = 64, Bpad = 0, nsplit = 1, nsplit_cap = 0;
   int* st_i = nullptr; double* st_d = nullptr; float* rho = nullptr;
@@ -192,9 +198,10 @@ static void free_map(trx2_ctx* c) {
     if (c->child->stream) (void)hipStreamSynchronize(c->child->stream);
     trx2_ctx* k = c->child;
     k->Td = k->To = k->Tt = k->Tp = nullptr; k->pd = k->po = k->pt = k->pp = nullptr;
-    k->gen = k->sel = k->mask2 = k->hasH = nullptr; k->knots_f = nullptr; k->knots_d = nullptr; k->L = 0; k->alloc_epoch++;
+    k->gen = k->sel = k->mask2 = k->hasH = k->idr = k->mask_odr = nullptr; k->knots_f = nullptr; k->knots_d = nullptr; k->L = 0; k->alloc_epoch++;
   }
   void* p[] = {c->Td, c->To, c->Tt, c->Tp, c->pd, c->po, c->pt, c->pp, c->gen, c->sel, c->mask2, c->hasH, c->knots_f, c->knots_d,
+               c->idr, c->mask_odr, c->idr_bk,
                c->cur[0], c->cur[1], c->cur[2], c->cur[3], c->alt[0], c->alt[1], c->alt[2], c->alt[3], c->tmp_cur, c->tmp_alt};
   for (void* q : p)
     if (q && !c->borrows_map) (void)hipFree(q);
@@ -202,8 +209,9 @@ static void free_map(trx2_ctx* c) {
   c->tmp_cur = c->tmp_alt = nullptr; c->has_tmp = false;
   c->Td = c->To = c->Tt = c->Tp = nullptr;
   c->pd = c->po = c->pt = c->pp = nullptr;
-  c->gen = c->sel = c->mask2 = c->hasH = nullptr;
+  c->gen = c->sel = c->mask2 = c->hasH = c->idr = c->mask_odr = nullptr; c->idr_bk = nullptr;
   c->knots_f = nullptr; c->knots_d = nullptr;
+  c->rst_kind = 0; c->kd = KD; c->dist_ca = 0;
   c->L = 0;
 }
 static void free_batch(trx2_ctx* c) {
@@ -252,6 +260,7 @@ static void lend_map(trx2_ctx* c) {
   k->L = c->L; k->use_orient = c->use_orient; k->seq = c->seq;
   k->Td = c->Td; k->To = c->To; k->Tt = c->Tt; k->Tp = c->Tp; k->pd = c->pd; k->po = c->po; k->pt = c->pt; k->pp = c->pp;
   k->gen = c->gen; k->sel = c->sel; k->mask2 = c->mask2; k->hasH = c->hasH; k->knots_f = c->knots_f; k->knots_d = c->knots_d;
+  k->idr = c->idr; k->mask_odr = c->mask_odr; k->rst_kind = c->rst_kind; k->kd = c->kd; k->dist_ca = c->dist_ca;
   memcpy(k->knots_h, c->knots_h, sizeof c->knots_h);
   k->alloc_epoch++;
 }
@@ -295,6 +304,21 @@ static int build_tables(trx2_ctx* ctx) {
   const int L = ctx->L;
   const size_t LL = (size_t)L * L;
   const trx2_params* prm = &ctx->prm;
+  if (ctx->rst_kind == 2) {  // gen_rst_af2: the 64-bin map in cur[0]
+    HIPCHK(hipMemsetAsync(ctx->Td, 0, LL * TRX2_KD_AF2 * sizeof(float2), ctx->stream));
+    BuildAf2Args A;
+    A.L = L; A.dist = ctx->cur[0];
+    A.ebase = prm->ebase; for (int k = 0; k < 3; k++) A.erep[k] = prm->erep[k];
+    A.meff = prm->meff; A.pcut = prm->pcut;
+    A.bk_last = std::pow(ctx->knots_af2_last / prm->dcut, prm->alpha);
+    A.knots = ctx->knots_d; A.Td = ctx->Td; A.pd = ctx->pd; A.gen = ctx->gen; A.sel = ctx->sel;
+    hipLaunchKernelGGL(k_build_tables_af2, dim3((unsigned)((LL + 127) / 128)), dim3(128), 0, ctx->stream, A);
+    hipLaunchKernelGGL(k_pack_masks, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, ctx->stream, L, ctx->sel, (const unsigned char*)nullptr,
+                       ctx->mask2, (unsigned char*)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return 0;
+  }
   HIPCHK(hipMemsetAsync(ctx->Td, 0, LL * KD * sizeof(float2), ctx->stream));
   if (ctx->use_orient) {
     HIPCHK(hipMemsetAsync(ctx->To, 0, LL * KO * sizeof(float2), ctx->stream));
@@ -310,47 +334,73 @@ static int build_tables(trx2_ctx* ctx) {
   A.knots = ctx->knots_d;
   A.Td = ctx->Td; A.To = ctx->To; A.Tt = ctx->Tt; A.Tp = ctx->Tp;
   A.pd = ctx->pd; A.po = ctx->po; A.pt = ctx->pt; A.pp = ctx->pp; A.gen = ctx->gen; A.sel = ctx->sel;
+  A.idr = ctx->idr; A.kind = ctx->rst_kind; A.idr_bk = ctx->idr_bk;
   hipLaunchKernelGGL(k_build_tables, dim3((unsigned)((LL + 127) / 128)), dim3(128), 0, ctx->stream, A);
-  hipLaunchKernelGGL(k_pack_masks, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, ctx->stream, L, ctx->sel, ctx->mask2);
+  hipLaunchKernelGGL(k_pack_masks, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, ctx->stream, L, ctx->sel, (const unsigned char*)ctx->idr,
+                     ctx->mask2, ctx->mask_odr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
 }
 
 static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist, const float* omega, const float* theta,
-                        const float* phi, const trx2_params* prm, bool device_ptrs) {
+                        const float* phi, const trx2_params* prm, bool device_ptrs, const unsigned char* idr = nullptr, int rst_kind = 0,
+                        const double* af2_edges = nullptr) {
   if (!ctx) return 1;
   if (L < 4 || L > 1024 || !dist || !prm) { ctx->err = "trx2_set_map: need 4 <= L <= 1024, dist and params"; return 1; }
   const bool orient = omega && theta && phi;
   if (!orient && (omega || theta || phi)) { ctx->err = "trx2_set_map: omega/theta/phi must be all given or all NULL"; return 1; }
+  if (rst_kind < 0 || rst_kind > 2 || (rst_kind == 1 && !idr) || (rst_kind == 2 && (orient || !af2_edges || idr))) {
+    ctx->err = "trx2_set_map: restraint kind 1 (idp) needs the idr mask; kind 2 (af2) takes a 64-bin distance map with its 63 edges and no angles";
+    return 1;
+  }
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   free_map(ctx);
   ctx->alloc_epoch++;
   const size_t LL = (size_t)L * L;
   ctx->L = L; ctx->use_orient = orient; ctx->seq = seq ? std::string(seq, strnlen(seq, L)) : std::string();
+  ctx->rst_kind = rst_kind; ctx->kd = rst_kind == 2 ? TRX2_KD_AF2 : KD; ctx->dist_ca = rst_kind == 2;
+  const int KDr = ctx->kd, KT = KDr + 2 * KO + KP;
   // knot positions after the reference's "%.3f" / "%.5f" text round trip (utils_ros.py:70,92,111,135)
   double* kn = ctx->knots_h;
-  for (int k = 0; k < 3; k++) kn[k] = round_txt(prm->drep[k], 3);
-  for (int k = 0; k < 32; k++) kn[3 + k] = round_txt(4.25 + prm->dstep * k, 3);
+  if (rst_kind == 2) {  // utils_ros.py:174-181: DREP = 0 / 2.325 / 3.575, then the bin edges 5 .. 61
+    const double drep_af2[3] = {0.0, 2.325, 3.575};
+    for (int k = 0; k < 3; k++) kn[k] = round_txt(drep_af2[k], 3);
+    for (int k = 0; k < TRX2_KD_AF2 - 3; k++) kn[3 + k] = round_txt(af2_edges[5 + k], 3);
+    ctx->knots_af2_last = af2_edges[5 + TRX2_KD_AF2 - 4];
+  } else {
+    for (int k = 0; k < 3; k++) kn[k] = round_txt(prm->drep[k], 3);
+    for (int k = 0; k < 32; k++) kn[3 + k] = round_txt(4.25 + prm->dstep * k, 3);
+  }
   const double astep = prm->astep_deg * M_PI / 180.0;
   {
     double start = -M_PI - 1.5 * astep, stop = M_PI + 1.5 * astep, step = (stop - start) / (KO - 1);
     for (int k = 0; k < KO; k++) {
       double v = (k == KO - 1) ? stop : start + k * step;
-      kn[KD + k] = round_txt(v, 5);
-      kn[KD + KO + k] = round_txt(v, 3);
+      kn[KDr + k] = round_txt(v, 5);
+      kn[KDr + KO + k] = round_txt(v, 3);
     }
     start = -1.5 * astep; stop = M_PI + 1.5 * astep; step = (stop - start) / (KP - 1);
-    for (int k = 0; k < KP; k++) kn[KD + 2 * KO + k] = round_txt((k == KP - 1) ? stop : start + k * step, 3);
+    for (int k = 0; k < KP; k++) kn[KDr + 2 * KO + k] = round_txt((k == KP - 1) ? stop : start + k * step, 3);
   }
-  float knf[TRX2_KTOT];
-  for (int k = 0; k < TRX2_KTOT; k++) knf[k] = (float)kn[k];
-  HIPCHK(hipMalloc((void**)&ctx->knots_d, sizeof(double) * TRX2_KTOT));
-  HIPCHK(hipMalloc((void**)&ctx->knots_f, sizeof(float) * TRX2_KTOT));
-  HIPCHK(hipMemcpyAsync(ctx->knots_d, kn, sizeof(double) * TRX2_KTOT, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->knots_f, knf, sizeof knf, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMalloc((void**)&ctx->Td, LL * KD * sizeof(float2)));
+  float knf[TRX2_KTOT_MAX];
+  for (int k = 0; k < KT; k++) knf[k] = (float)kn[k];
+  HIPCHK(hipMalloc((void**)&ctx->knots_d, sizeof(double) * TRX2_KTOT_MAX));
+  HIPCHK(hipMalloc((void**)&ctx->knots_f, sizeof(float) * TRX2_KTOT_MAX));
+  HIPCHK(hipMemcpyAsync(ctx->knots_d, kn, sizeof(double) * KT, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->knots_f, knf, sizeof(float) * KT, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMalloc((void**)&ctx->Td, LL * KDr * sizeof(float2)));
+  if (idr) {  // pair flags: table variant (kind 1) and / or the ordered-pairs stage of mode 3
+    HIPCHK(hipMalloc((void**)&ctx->idr, LL));
+    HIPCHK(hipMalloc((void**)&ctx->mask_odr, LL));
+    HIPCHK(hipMemcpyAsync(ctx->idr, idr, LL, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<double> bk(32 * 32);
+    for (int m = 0; m < 32; m++)
+      for (int k = 0; k < 32; k++) bk[m * 32 + k] = std::pow((4.25 + prm->dstep * k) / (4.25 + prm->dstep * m), prm->alpha);
+    HIPCHK(hipMalloc((void**)&ctx->idr_bk, sizeof(double) * 32 * 32));
+    HIPCHK(hipMemcpy(ctx->idr_bk, bk.data(), sizeof(double) * 32 * 32, hipMemcpyHostToDevice));
+  }
   HIPCHK(hipMalloc((void**)&ctx->pd, LL * 4));
   HIPCHK(hipMalloc((void**)&ctx->gen, LL));
   HIPCHK(hipMalloc((void**)&ctx->sel, LL));
@@ -370,7 +420,7 @@ static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist
     HIPCHK(hipMalloc((void**)&ctx->pp, LL * 4));
   }
   const float* src[4] = {dist, omega, theta, phi};
-  const int nb[4] = {TRX2_ND_BINS, TRX2_NO_BINS, TRX2_NO_BINS, TRX2_NP_BINS};
+  const int nb[4] = {rst_kind == 2 ? 64 : TRX2_ND_BINS, TRX2_NO_BINS, TRX2_NO_BINS, TRX2_NP_BINS};
   for (int c = 0; c < 4; c++) {  // the distograms stay resident: the feedback step re-weights them in place
     if (!src[c]) continue;
     HIPCHK(hipMalloc((void**)&ctx->cur[c], LL * nb[c] * 4));
@@ -390,6 +440,39 @@ extern "C" int trx2_set_map_device(trx2_ctx* ctx, int L, const char* seq, const 
                                    const float* theta, const float* phi, const trx2_params* prm) {
   return set_map_impl(ctx, L, seq, dist, omega, theta, phi, prm, true);
 }
+extern "C" int trx2_set_map_ex(trx2_ctx* ctx, int L, const char* seq, const float* dist, const float* omega, const float* theta,
+                               const float* phi, const trx2_params* prm, const unsigned char* idr, int rst_kind) {
+  if (rst_kind == 2) { if (ctx) ctx->err = "trx2_set_map_ex: use trx2_set_map_af2 for AlphaFold-style maps"; return 1; }
+  return set_map_impl(ctx, L, seq, dist, omega, theta, phi, prm, false, idr, rst_kind);
+}
+extern "C" int trx2_set_map_af2(trx2_ctx* ctx, int L, const char* seq, const float* dist64, const double* edges63, const trx2_params* prm) {
+  return set_map_impl(ctx, L, seq, dist64, nullptr, nullptr, nullptr, prm, false, nullptr, 2, edges63);
+}
+// replace the values of n table rows (gen_gpcr_rst's edits of the flagged pairs, utils_ros.py:551,579,601,627)
+extern "C" int trx2_override_table_rows(trx2_ctx* ctx, int channel, int n, const int* a, const int* b, const double* y) {
+  if (!ctx || !ctx->L) return 1;
+  if (channel < 0 || channel > 3 || (channel > 0 && !ctx->use_orient) || n < 0 || (n && (!a || !b || !y))) { ctx->err = "trx2_override_table_rows: bad arguments"; return 1; }
+  if (!n) return 0;
+  const int L = ctx->L;
+  for (int i = 0; i < n; i++)
+    if (a[i] < 0 || a[i] >= L || b[i] < 0 || b[i] >= L || a[i] == b[i] || (channel < 2 && a[i] > b[i])) {
+      ctx->err = "trx2_override_table_rows: pair out of range (dist / omega rows live at a < b)"; return 1;
+    }
+  HIPCHK(hipSetDevice(ctx->device));
+  const int K = channel == 0 ? ctx->kd : channel == 3 ? KP : KO;
+  const int off = channel == 0 ? 0 : channel == 1 ? ctx->kd : channel == 2 ? ctx->kd + KO : ctx->kd + 2 * KO;
+  float2* T = channel == 0 ? ctx->Td : channel == 1 ? ctx->To : channel == 2 ? ctx->Tt : ctx->Tp;
+  int *da = nullptr, *db = nullptr; double* dy = nullptr;
+  HIPCHK(hipMalloc((void**)&da, sizeof(int) * n)); HIPCHK(hipMalloc((void**)&db, sizeof(int) * n)); HIPCHK(hipMalloc((void**)&dy, sizeof(double) * (size_t)n * K));
+  HIPCHK(hipMemcpy(da, a, sizeof(int) * n, hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(db, b, sizeof(int) * n, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dy, y, sizeof(double) * (size_t)n * K, hipMemcpyHostToDevice));
+  if (ctx->child && ctx->child->stream) HIPCHK(hipStreamSynchronize(ctx->child->stream));
+  hipLaunchKernelGGL(k_override_rows, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, K, L, da, db, dy, ctx->knots_d + off, T);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  (void)hipFree(da); (void)hipFree(db); (void)hipFree(dy);
+  return 0;
+}
 
 extern "C" int trx2_get_tables(trx2_ctx* ctx, int channel, float* y_y2, float* knots, float* prob, unsigned char* gen,
                                unsigned char* sel) {
@@ -397,8 +480,8 @@ extern "C" int trx2_get_tables(trx2_ctx* ctx, int channel, float* y_y2, float* k
   if (channel < 0 || channel > 3 || (channel > 0 && !ctx->use_orient)) { ctx->err = "trx2_get_tables: bad channel"; return 1; }
   HIPCHK(hipSetDevice(ctx->device));
   const size_t LL = (size_t)ctx->L * ctx->L;
-  const int K[4] = {KD, KO, KO, KP};
-  const int off[4] = {0, KD, KD + KO, KD + 2 * KO};
+  const int K[4] = {ctx->kd, KO, KO, KP};
+  const int off[4] = {0, ctx->kd, ctx->kd + KO, ctx->kd + 2 * KO};
   const float2* T[4] = {ctx->Td, ctx->To, ctx->Tt, ctx->Tp};
   const float* P[4] = {ctx->pd, ctx->po, ctx->pt, ctx->pp};
   if (y_y2) HIPCHK(hipMemcpy(y_y2, T[channel], LL * K[channel] * sizeof(float2), hipMemcpyDeviceToHost));
@@ -482,6 +565,7 @@ static PairArgs pair_args(trx2_ctx* c, int B) {
   P.L = c->L; P.B = B; P.nsplit = c->nsplit; P.Bpad = c->Bpad;
   P.xyzT = c->xyzT; P.Td = c->Td; P.To = c->To; P.Tt = c->Tt; P.Tp = c->Tp;
   P.mask = c->mask2; P.knots = c->knots_f; P.wcur = c->wcur; P.FA = c->FA; P.seq_ctr = c->seq_ctr;
+  P.kd = c->kd; P.dist_ca = c->dist_ca; P.mask_odr = c->mask_odr;
   return P;
 }
 static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_evals) {
@@ -798,6 +882,7 @@ extern "C" int trx2_feedback_step(trx2_ctx* ctx, const char* seq, const float* x
   if (!ctx) return 1;
   const int L = ctx->L;
   if (!L || !ctx->cur[0] || ctx->borrows_map) { ctx->err = "trx2_feedback_step: set a map first"; return 1; }
+  if (ctx->rst_kind == 2) { ctx->err = "trx2_feedback_step: not defined for AlphaFold-style maps (the reference's feedback works on its own 37-bin maps)"; return 1; }
   if (!fb_bins_args_ok(L, seq, xyz, d_edges, nd, a_edges, na, p_edges, np_) || !w9) { ctx->err = "trx2_feedback_step: bad arguments"; return 1; }
   if (angle && !ctx->use_orient) { ctx->err = "trx2_feedback_step: angle channels requested but the map has none"; return 1; }
   HIPCHK(hipSetDevice(ctx->device));

@@ -44,10 +44,10 @@ def parse_options(options):
     ap.add_argument("-KNOWN", type=str, required=False)
     ap.set_defaults(use_orient=True, fastrelax=True)
     args, unknown = ap.parse_known_args(shlex.split(options) if isinstance(options, str) else list(options))
-    if args.rst != "no-idp":
-        raise NotImplementedError(f"-r {args.rst}: only the no-idp restraint builder (the one run_inference.py uses) is implemented")
-    if args.mode == 3:
-        raise NotImplementedError("-m 3 needs the npz 'idr' mask and is not reachable from run_inference.py")
+    if args.rst == "af2" and args.use_orient:
+        raise RuntimeError("AF2 Not support ")           # utils_ros.py:149-150: gen_rst_af2 refuses --orient
+    if args.rst == "gpcr" and not args.KNOWN:
+        raise ValueError("-r gpcr needs -KNOWN (npz with the 6-D geometry of the known structures, folding.py:66-67)")
     return args
 
 
@@ -65,6 +65,27 @@ def get_context(device=0, lanes=1):
     return _CTX[key]
 
 
+def set_restraints(ctx, npz, seq, args, ang):
+    """the `-r` switch of folding/folding.py:60-68 + the idr mask mode 3 needs (folding.py:174)"""
+    need_idr = args.rst in ("idp", "gpcr") or args.mode == 3
+    if need_idr and "idr" not in npz:
+        raise KeyError(f"-r {args.rst} / -m {args.mode} needs an 'idr' pair mask in the npz (folding.py:174, utils_ros.py:198)")
+    idr = np.asarray(npz["idr"]) if need_idr else None
+    if args.rst == "af2":
+        ctx.set_map_af2(npz["dist"], npz["bins"], seq=seq, pcut=args.pcut)
+    elif args.rst == "idp":
+        ctx.set_map(npz["dist"], *ang, seq=seq, idr=idr, kind="idp", pcut=args.pcut)
+    else:
+        ctx.set_map(npz["dist"], *ang, seq=seq, idr=idr, pcut=args.pcut)
+        if args.rst == "gpcr":       # gen_rst tables + the edits of the flagged pairs from the known structures
+            from . import restraints
+            from ._lib import DEFAULT_PARAMS as P
+            prm = dict(MEFF=P["meff"], EBASE=P["ebase"], EREP=list(P["erep"]), DREP=list(P["drep"]), DCUT=P["dcut"], ALPHA=P["alpha"],
+                       DSTEP=P["dstep"], ASTEP=P["astep_deg"])
+            for ch, (a, b, y) in restraints.gpcr_rows(npz, np.load(args.KNOWN), prm, use_orient=args.use_orient).items():
+                ctx.override_rows(ch, a, b, y)
+
+
 def fold_arrays(npz, seq, n_decoys, options="", device=0, seed=None, decoy0=0, lanes=2):
     """fold n_decoys of one distogram -> dict(xyz[B,L,5,3], status, e_terms, ...); raises on any failed decoy.
     lanes=2 (default): 32 or more decoys are folded as two halves on two streams (+24..32 % decoys/s, include/trx2fold.h);
@@ -75,7 +96,7 @@ def fold_arrays(npz, seq, n_decoys, options="", device=0, seed=None, decoy0=0, l
         raise ValueError(f"sequence length {L} does not match the distogram {npz['dist'].shape}")
     ctx = get_context(device, lanes)
     ang = [npz[k] for k in ("omega", "theta", "phi")] if args.use_orient else []
-    ctx.set_map(npz["dist"], *ang, seq=seq, pcut=args.pcut)
+    set_restraints(ctx, npz, seq, args, ang)
     if seed is None:
         with _SEED_LOCK:  # chains are folded from concurrent host threads
             seed = _SEED[0]

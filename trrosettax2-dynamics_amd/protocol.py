@@ -26,24 +26,25 @@ N_REPEAT = 3         # folding.py:104
 N_DECLASH = 5        # utils_ros.py:700
 
 
-def _run(w, max_iter, sep_lo, sep_hi, precheck=0, skip_to=0, cartesian=0):
+def _run(w, max_iter, sep_lo, sep_hi, precheck=0, skip_to=0, cartesian=0, pair_filter=0):
     return dict(w=list(w), max_iter=max_iter, sep_lo=sep_lo, sep_hi=sep_hi, precheck=precheck, skip_to=skip_to,
-                cartesian=cartesian)
+                cartesian=cartesian, pair_filter=pair_filter)
 
 
-def _declash(runs, w, max_iter, sep_lo, sep_hi):
+def _declash(runs, w, max_iter, sep_lo, sep_hi, pair_filter=0):
     """remove_clash(sf_vdw, mover, pose): every round is guarded by the rama+vdw < 10 test."""
     end = len(runs) + N_DECLASH
     for _ in range(N_DECLASH):
-        runs.append(_run(w, max_iter, sep_lo, sep_hi, precheck=1, skip_to=end))
+        runs.append(_run(w, max_iter, sep_lo, sep_hi, precheck=1, skip_to=end, pair_filter=pair_filter))
 
 
 CART_MAX_L = 512  # the Cartesian step kernel handles one residue per thread, up to 512 threads (csrc/kernel_step.h, cart_body)
 
 
 def build_runs(L, mode=2, cartesian_stage=None):
-    """Run list for `-m mode` (folding/utils_ros/arguments.py:12).  Mode 3 needs the npz 'idr' mask and is
-    not reachable from run_inference.py: not built.
+    """Run list for `-m mode` (folding/utils_ros/arguments.py:12).  Mode 3 (folding.py:173-186) first loads the restraints of
+    the ORDERED pairs only (add_idr_rst with 1 - idr: runs with pair_filter = 1), then all of them; it needs a map set with its
+    idr mask (Context.set_map(idr=...)).
 
     cartesian_stage: run min_mover_cart (folding.py:100-102,170) in Cartesian space, as the reference does.  None = yes for
     chains the Cartesian kernel supports (L <= 512); longer chains run that stage in torsion space with sf_cart's
@@ -59,13 +60,16 @@ def build_runs(L, mode=2, cartesian_stage=None):
         stages = [(3, 24), (3, L)]               # folding.py:152,159
     elif mode == 2:
         stages = [(1, L)]                        # folding.py:168
+    elif mode == 3:
+        stages = [(1, L, 1), (1, L, 0)]          # folding.py:177,183: add_idr_rst has no separation window; restraints accumulate
     else:
-        raise ValueError("mode 3 (idr mask) is not supported")
-    for lo, hi in stages:
+        raise ValueError(f"unknown mode {mode}")
+    for st in stages:
+        lo, hi, flt = st if len(st) == 3 else (st[0], st[1], 0)
         for _ in range(N_REPEAT):                # repeat_mover.apply
-            runs.append(_run(SF, MAX_ITER, lo, hi))
+            runs.append(_run(SF, MAX_ITER, lo, hi, pair_filter=flt))
         # min_mover_cart.apply: Cartesian-space L-BFGS on sf_cart
         w_cart = SF_CART if cartesian_stage else SF_CART[:6] + [0.0, SF_CART[7]]  # no bonded term in torsion space
-        runs.append(_run(w_cart, MAX_ITER, lo, hi, cartesian=1 if cartesian_stage else 0))
-        _declash(runs, SF1, MAX_ITER, lo, hi)    # remove_clash(sf_vdw, min_mover1, pose)
+        runs.append(_run(w_cart, MAX_ITER, lo, hi, cartesian=1 if cartesian_stage else 0, pair_filter=flt))
+        _declash(runs, SF1, MAX_ITER, lo, hi, pair_filter=flt)    # remove_clash(sf_vdw, min_mover1, pose)
     return runs
