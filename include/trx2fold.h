@@ -136,6 +136,20 @@ int trx2_get_map(trx2_ctx* ctx, int channel, float* out);
  * seqs = n * L one-letter codes (glycines get the virtual C-beta), xyz[n][L][5][3] as read from the PDB files, out[n][n]. */
 int trx2_glocon_matrix(trx2_ctx* ctx, int n, int L, const char* seqs, const float* xyz, double dmax, double* out);
 
+/* Reliability score of n decoys, the quantity the reference ranks its initial decoys by (calculate_reliability_score,
+ * utils_trX2dy/utils.py:352-372; run_inference.py:60-73): xyz[n][L][5][3] as read from the decoys' PDB files ->
+ * counts[n][2] = (residues with a phi/psi pair as Biopython's PPBuilder reports them, those among them with phi <= 0).  The score
+ * is counts[.][1] / counts[.][0] (0 when there is none). */
+int trx2_reliability_scores(trx2_ctx* ctx, int n, int L, const float* xyz, int* counts);
+
+/* Batched optimal superposition: C-alpha RMSD and TM-score of every pair between two sets of structures with the
+ * same L ALIGNED residues -- what the reference obtains by running its prebuilt `TMscore` binary once per pair
+ * (utils_trX2dy/utils.py:514-541 for clustering, evaluate_utils.py:33-100 for evaluation).  xa[n][L][3], xb[m][L][3] C-alpha
+ * coordinates as read from the PDB files; xb NULL = xa against itself (symmetric n x n).  l_norm: the TM-score normalisation
+ * length (<= 0: L).  rmsd[n][m], tm[n][m]; either may be NULL.  RMSD by Horn's quaternion form of the Kabsch problem; TM-score by
+ * the TM-score program's seeded iterative search, one wave per (pair, seed fragment), in float64. */
+int trx2_superpose_matrix(trx2_ctx* ctx, int n, int m, int L, const float* xa, const float* xb, double l_norm, double* rmsd, double* tm);
+
 /* measurement helper (bench.py roofline leg): replays the pair-energy kernel n_rep times on the ctx stream
  * for the coordinates of the last eval/fold batch and returns the average launch duration in milliseconds
  * measured with hipEvents on that stream, plus the number of selected term-evaluations per launch. */

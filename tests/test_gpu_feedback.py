@@ -129,3 +129,63 @@ def test_device_glocon_matrix_equals_host(golden_dir, seq, tmp_path):
     assert np.allclose(np.diag(dev), 0) and np.array_equal(dev, dev.T)
     out = CL.save_cluster_result(str(d), n_clusters=2, n_files=2, mode="glocon", device=0)
     assert sorted(len(v) for v in out.values()) == [4, 4]
+
+
+def test_device_superposition_matrices_equal_host(golden_dir, seq, tmp_path):
+    """trx2_superpose_matrix against evaluate.rmsd_common / evaluate.tm_score (the numpy statements of the TM-score program's
+    numbers, pinned by the reference's committed summary.txt): all pairs of the eight example decoys, a rectangular batch against
+    the natives with another normalisation length, and a long chain (four residues per lane)."""
+    EV = importlib.import_module("trrosettax2-dynamics_amd.evaluate")
+    CL = importlib.import_module("trrosettax2-dynamics_amd.cluster")
+    ref = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    names = ("conf_1_1", "conf_1_2", "conf_1_3", "conf_1_4", "conf_2_1", "conf_2_2", "conf_2_3", "conf_2_4")
+    ca = np.stack([ref[n][:, 1] for n in names]).astype(np.float32)
+    ctx = T.Context(0)
+    try:
+        rm, tm = ctx.superpose_matrix(ca)
+        for i in range(8):
+            for j in range(i):
+                x, y = ca[i].astype(np.float64), ca[j].astype(np.float64)
+                assert abs(rm[i, j] - EV.rmsd_common(x, y)) < 1e-9 and abs(tm[i, j] - EV.tm_score(x, y)) < 1e-9, (i, j)
+        assert np.array_equal(rm, rm.T) and np.array_equal(tm, tm.T) and np.allclose(np.diag(rm), 0, atol=1e-6) and np.allclose(np.diag(tm), 1.0)
+        # natives x models on their common residues, normalised by the model's length (evaluate.compare)
+        nat = np.nan_to_num(ref["apo"][:, 1])
+        okr = np.ones(len(nat), bool)
+        xa = nat[okr][None].astype(np.float32)
+        xb = ca[:, okr]
+        rm2, tm2 = ctx.superpose_matrix(xa, xb, l_norm=90)
+        for j in range(8):
+            assert abs(tm2[0, j] - EV.tm_score(xa[0].astype(np.float64), xb[j].astype(np.float64), l_norm=90)) < 1e-9
+            assert abs(rm2[0, j] - EV.rmsd_common(xa[0].astype(np.float64), xb[j].astype(np.float64))) < 1e-9
+        # a long chain: 200 residues = four per lane
+        S = importlib.import_module("trrosettax2-dynamics_amd.synth")
+        rng = np.random.default_rng(3)
+        base = S.nerf_backbone(S.make_map(200, seed=200, n_moves=50)["tors"])[1]
+        pts = np.stack([base + rng.normal(size=base.shape) * s for s in (0.3, 1.0, 3.0)]).astype(np.float32)
+        rm3, tm3 = ctx.superpose_matrix(pts)
+        assert abs(tm3[0, 2] - EV.tm_score(pts[0].astype(np.float64), pts[2].astype(np.float64))) < 1e-9
+        assert abs(rm3[1, 2] - EV.rmsd_common(pts[1].astype(np.float64), pts[2].astype(np.float64))) < 1e-9
+        # reliability scores of a batch (the reference ranks its initial decoys by them) against the per-file host function
+        xyz = np.stack([P.as_read_from_pdb(seq, np.nan_to_num(ref[n].astype(np.float32)))[0] for n in names])
+        sc = ctx.reliability_scores(xyz)
+        for k, n in enumerate(names):
+            path, _ = pdb_rounded(ref[n], seq, tmp_path, f"{n}.pdb")
+            assert sc[k] == FB.calculate_reliability_score(path), (n, sc[k])
+        assert sc[4] == pytest.approx(81 / 88) and sc[0] == pytest.approx(83 / 88)      # SURVEY.md section 4
+    finally:
+        ctx.close()
+    # cluster.py -m tmscore / -m rmsd on the device, and evaluate.py --device reproducing the reference's summary.txt
+    d = tmp_path / "pdb"; d.mkdir()
+    nat_d = tmp_path / "nat"; nat_d.mkdir()
+    for n in names:
+        P.write_pdb(str(d / f"{n}.pdb"), seq, np.nan_to_num(ref[n].astype(np.float32)))
+    for n in ("apo", "holo"):
+        P.write_pdb(str(nat_d / f"{n}.pdb"), seq, np.nan_to_num(ref[n].astype(np.float32)))
+    tm_d, rm_d, files = CL.get_tmscore_and_rmsd_matrix(str(d), device=0)
+    tm_h, rm_h, _ = CL.get_tmscore_and_rmsd_matrix(str(d))
+    assert np.abs(tm_d - tm_h).max() < 1e-9 and np.abs(rm_d - rm_h).max() < 1e-9
+    out = CL.save_cluster_result(str(d), n_clusters=2, n_files=2, mode="tmscore", device=0)
+    assert sorted(len(v) for v in out.values()) == [4, 4]
+    host = EV.run_score(str(nat_d), str(d))
+    dev = EV.run_score(str(nat_d), str(d), device=0, save_summary=True, save_dir=str(tmp_path / "sum"))
+    assert host == dev

@@ -186,8 +186,11 @@ def test_glocon_matrix_is_bit_identical_to_reference(golden_dir, tmp_path, seq):
     assert abs(r[0, 1] - 0.62) < 0.01 and abs(r[4, 5] - 0.86) < 0.01          # conf_1_1/1_2, conf_2_1/2_2
     out = CL.save_cluster_result(str(d), n_clusters=2, n_files=1, mode="glocon")
     assert sorted(len(v) for v in out.values()) == [4, 4] and len(os.listdir(d / "clusters_result")) == 2   # the two models separate
-    with pytest.raises(NotImplementedError):
-        CL.save_cluster_result(str(d), mode="tmscore")
+    # mode tmscore (utils.py:524-541): TM-score matrix of all pairs, zero diagonal; the two models of the example separate on it too.
+    # (host path here: 28 pairs of the pure-numpy search; the device path is tested in test_gpu_feedback.py)
+    tm, rm, files = CL.get_tmscore_and_rmsd_matrix(str(d))
+    assert files == g["files"] and np.allclose(np.diag(tm), 0) and np.array_equal(tm, tm.T) and np.allclose(rm, r)
+    assert tm[0, 1] > 0.9 and tm[4, 5] > 0.9 and tm[0, 4] < 0.9            # same-map initials agree, the two maps differ (2.1-2.5 A)
 
 
 def test_evaluation_reproduces_the_reference_summary(golden_dir, tmp_path, seq):

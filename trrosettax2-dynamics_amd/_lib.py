@@ -86,6 +86,8 @@ def load():
     L.trx2_feedback_step.argtypes = [vp, C.c_char_p, vp, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_double, vp, C.c_int, C.POINTER(C.c_float)]
     L.trx2_get_map.argtypes = [vp, C.c_int, vp]
     L.trx2_glocon_matrix.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, vp, C.c_double, vp]
+    L.trx2_reliability_scores.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+    L.trx2_superpose_matrix.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_double, vp, vp]
     L.trx2_feedback_process.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
     L.trx2_time_pair_kernel.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, dp, dp]
     L.trx2_last_fold_stats.argtypes = [vp, dp, ip]
@@ -317,6 +319,34 @@ class Context:
         if self._l.trx2_ctx_info(self._h, int(key), C.byref(v)) != 0:
             raise RuntimeError(f"trx2_ctx_info: unknown key {key}")
         return v.value
+
+    def reliability_scores(self, xyz):
+        """calculate_reliability_score (utils_trX2dy/utils.py:352-372) of n decoys at once: xyz[n,L,5,3] as read from their PDB files
+        (pdbio.as_read_from_pdb gives that without the files) -> float scores [n]"""
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        n, L = xyz.shape[0], xyz.shape[1]
+        if xyz.shape != (n, L, 5, 3):
+            raise ValueError("need xyz[n,L,5,3]")
+        c = np.zeros((n, 2), np.int32)
+        self._chk(self._l.trx2_reliability_scores(self._h, n, L, _p(xyz), _p(c)), "trx2_reliability_scores")
+        return np.array([int(b) / int(a) if a else 0 for a, b in c])
+
+    def superpose_matrix(self, xa, xb=None, l_norm=None, rmsd=True, tm=True):
+        """C-alpha RMSD and TM-score of every pair: xa[n,L,3] against xb[m,L,3] (None: xa against itself) -> (rmsd[n,m], tm[n,m]),
+        the same numbers as evaluate.rmsd_common / evaluate.tm_score (trx2_superpose_matrix)"""
+        xa = np.ascontiguousarray(xa, np.float32)
+        n, L = xa.shape[0], xa.shape[1]
+        if xb is not None:
+            xb = np.ascontiguousarray(xb, np.float32)
+            if xb.shape[1:] != (L, 3):
+                raise ValueError("both sets need the same number of aligned residues")
+        m = n if xb is None else xb.shape[0]
+        if xa.shape != (n, L, 3) or not np.isfinite(xa).all() or (xb is not None and not np.isfinite(xb).all()):
+            raise ValueError("need finite C-alpha coordinates [n,L,3]")
+        r = np.zeros((n, m)) if rmsd else None
+        t = np.zeros((n, m)) if tm else None
+        self._chk(self._l.trx2_superpose_matrix(self._h, n, m, L, _p(xa), _p(xb), float(l_norm or 0), _p(r), _p(t)), "trx2_superpose_matrix")
+        return r, t
 
     def time_pair_kernel(self, B, w, sep_lo=1, sep_hi=None, n_rep=50):
         w = np.ascontiguousarray(w, np.float32)

@@ -3,8 +3,10 @@
 Mirrors /root/reference/utils_trX2dy/utils.py:514-616 (get_glocon_matrix, kmeans_clustering, save_cluster_result) and
 /root/reference/cluster.py.  SURVEY.md 8f4.  Differences, deliberate:
   D  files are taken in sorted order (the reference uses os.listdir order, so its matrix rows depend on the file system)
-  D  mode "rmsd" uses this package's Kabsch C-alpha RMSD; mode "tmscore" is rejected: both call the prebuilt ./bin/TMscore
-     ELF in the reference (utils.py:514-541), which has no source in the tree
+  D  modes "rmsd" and "tmscore": the reference runs its prebuilt ./bin/TMscore ELF once per pair of files (utils.py:514-541; no
+     source in the tree) and parses "RMSD of the common residues" and "TM-score".  Here both matrices come from this package's
+     superposition (evaluate.rmsd_common / evaluate.tm_score: the TM-score program's seeded search), computed for all pairs at
+     once on the GPU when device is given (trx2_superpose_matrix; tested equal to the host functions to 1e-9)
   D  selected files are copied with shutil instead of `os.system("cp ...")`
 The GloCon matrix is O(n^2 L^2) numpy passes on the host; device=<gpu index> computes it with trx2_glocon_matrix, summing in
 numpy's pairwise order (bitwise the same matrix in the tests).
@@ -53,18 +55,56 @@ def get_glocon_matrix(pdb_dir, device=None):
     return m + m.T, pdb_files
 
 
-def get_rmsd_matrix(pdb_dir):
-    """C-alpha RMSD after optimal superposition for every pair (stands in for TMscore's "RMSD of the common residues")"""
+def _ca_stack(pdb_dir):
     pdb_files = _pdb_files(pdb_dir)
-    ca = [read_backbone(os.path.join(pdb_dir, f))[0][:, 1].astype(np.float64) for f in pdb_files]
+    ca = [read_backbone(os.path.join(pdb_dir, f))[0][:, 1] for f in pdb_files]
+    if len({len(c) for c in ca}) != 1 or not all(np.isfinite(c).all() for c in ca):
+        raise ValueError("the superposition matrices need structures of one length with every C-alpha present")
+    return np.stack(ca), pdb_files
+
+
+def get_tmscore_and_rmsd_matrix(pdb_dir, device=None):
+    """-> (tmscore[n,n], rmsd[n,n], pdb_files): utils.py:524-541 without the TMscore subprocess per pair.  C-alpha RMSD after
+    optimal superposition and TM-score normalised by the chain length, for every pair; zero diagonal as in the reference."""
+    ca, pdb_files = _ca_stack(pdb_dir)
+    n = len(ca)
+    if device is not None:
+        from ._lib import Context
+        ctx = Context(int(device))
+        try:
+            rm, tm = ctx.superpose_matrix(ca)
+        finally:
+            ctx.close()
+    else:
+        from .evaluate import rmsd_common, tm_score
+        rm, tm = np.zeros((n, n)), np.zeros((n, n))
+        for i in range(n):
+            for j in range(i):
+                x, y = ca[i].astype(np.float64), ca[j].astype(np.float64)
+                rm[i, j] = rm[j, i] = rmsd_common(x, y)
+                tm[i, j] = tm[j, i] = tm_score(x, y)
+    rm[np.diag_indices(n)] = 0.0
+    tm[np.diag_indices(n)] = 0.0           # the reference never runs a file against itself: its diagonals stay 0
+    return tm, rm, pdb_files
+
+
+def get_rmsd_matrix(pdb_dir, device=None):
+    """C-alpha RMSD after optimal superposition for every pair (TMscore's "RMSD of the common residues")"""
+    _, rm, pdb_files = get_tmscore_and_rmsd_matrix(pdb_dir, device=device) if device is not None else (None, *_host_rmsd(pdb_dir))
+    return rm, pdb_files
+
+
+def _host_rmsd(pdb_dir):
+    ca, pdb_files = _ca_stack(pdb_dir)
+    ca = ca.astype(np.float64)
     n = len(ca)
     m = np.zeros((n, n))
     for i in range(n):
         for j in range(i):
             a, b = ca[i] - ca[i].mean(0), ca[j] - ca[j].mean(0)
-            u, s, vt = np.linalg.svd(a.T @ b)
-            s[-1] *= np.sign(np.linalg.det(u @ vt))
-            m[i][j] = np.sqrt(max(0.0, (np.sum(a * a) + np.sum(b * b) - 2.0 * s.sum()) / len(a)))
+            u, s_, vt = np.linalg.svd(a.T @ b)
+            s_[-1] *= np.sign(np.linalg.det(u @ vt))
+            m[i][j] = np.sqrt(max(0.0, (np.sum(a * a) + np.sum(b * b) - 2.0 * s_.sum()) / len(a)))
     return m + m.T, pdb_files
 
 
@@ -83,9 +123,9 @@ def save_cluster_result(pdb_dir, n_clusters=10, n_files=5, output_dir=None, mode
     if mode == "glocon":
         matrix, pdb_files = get_glocon_matrix(pdb_dir, device=device)
     elif mode == "rmsd":
-        matrix, pdb_files = get_rmsd_matrix(pdb_dir)
+        matrix, pdb_files = get_rmsd_matrix(pdb_dir, device=device)
     elif mode == "tmscore":
-        raise NotImplementedError("mode tmscore needs the reference's prebuilt ./bin/TMscore binary; use glocon or rmsd")
+        matrix, _, pdb_files = get_tmscore_and_rmsd_matrix(pdb_dir, device=device)
     else:
         raise ValueError(f"unknown mode {mode!r}")
     if output_dir is None:
@@ -109,7 +149,7 @@ def main(argv=None):
     ap.add_argument("-o", "--output_dir", default=None, help="where the kept models go (<pdb_dir>/clusters_result if omitted)")
     ap.add_argument("--n_clusters", type=int, default=10, help="KMeans k")
     ap.add_argument("--n_files", type=int, default=5, help="models kept from every cluster")
-    ap.add_argument("--device", type=int, default=None, help="compute the GloCon matrix on this GPU (extension; numpy if omitted)")
+    ap.add_argument("--device", type=int, default=None, help="compute the matrix on this GPU (extension; numpy if omitted)")
     a = ap.parse_args(argv)
     target = a.output_dir if a.output_dir else os.path.join(a.pdb_dir, "clusters_result")
     res = save_cluster_result(a.pdb_dir, n_clusters=a.n_clusters, n_files=a.n_files, output_dir=target, mode=a.mode, device=a.device)

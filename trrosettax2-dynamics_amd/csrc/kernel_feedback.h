@@ -55,6 +55,24 @@ __device__ __forceinline__ v3d fb_cbeta(const FbBinsArgs& A, int i) {
   const bool use = !A.gly[i] && isfinite(real.x) && isfinite(real.y) && isfinite(real.z);
   return use ? real : virt;
 }
+// Reliability score of n decoys (calculate_reliability_score, utils_trX2dy/utils.py:352-372 over Biopython's PPBuilder phi/psi,
+// :337-349): residues bonded on both sides (C-N peptide distance < 1.8 A) whose phi lies in [-180, 0] -- the reference compares
+// RADIANS with those degrees, so the test is phi <= 0 (quirk R10) and the psi test is always true.  One thread per (decoy,
+// residue); counts[2 d] = residues with both angles, counts[2 d + 1] = those with phi <= 0.  Same float64 arithmetic as above.
+__global__ void k_reliability(int n, int L, const float* xyz /* [n][L][5][3] as read from the PDB files */, int* counts) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * L) return;
+  const int d = t / L, i = t % L;
+  if (i < 1 || i > L - 2) return;
+  const float* p = xyz + (size_t)d * L * 15;
+  auto at = [&](int r, int k) { const float* q = p + (size_t)r * 15 + k * 3; return v3d{(double)q[0], (double)q[1], (double)q[2]}; };
+  const v3d Cp = at(i - 1, 2), N = at(i, 0), CA = at(i, 1), C = at(i, 2), Nn = at(i + 1, 0);
+  if (!(fb_norm(fb_sub(Cp, N)) < 1.8) || !(fb_norm(fb_sub(C, Nn)) < 1.8)) return;
+  const double phi = fb_dihedral(Cp, N, CA, C);
+  atomicAdd(counts + 2 * d, 1);
+  if (-180.0 <= phi && phi <= 0.0) atomicAdd(counts + 2 * d + 1, 1);
+}
+
 __device__ __forceinline__ int fb_count(const double* edges, int n, double x) {  // (edges < x).sum()
   int c = 0;
   for (int k = 0; k < n; k++) c += edges[k] < x;

@@ -58,6 +58,7 @@ __constant__ float c_cb_ideal[4];
 #include "kernel_pair.h"
 #include "kernel_step.h"
 #include "kernel_feedback.h"
+#include "kernel_superpose.h"
 
 // =================================================================================================
 // host side
@@ -980,6 +981,83 @@ extern "C" int trx2_glocon_matrix(trx2_ctx* ctx, int n, int L, const char* seqs,
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpyAsync(out, A.out, (size_t)n * n * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// reliability scores of n decoys (the reference ranks its initial decoys by them, run_inference.py:60-73)
+extern "C" int trx2_reliability_scores(trx2_ctx* ctx, int n, int L, const float* xyz, int* counts) {
+  if (!ctx) return 1;
+  if (n < 1 || L < 1 || L > 4096 || !xyz || !counts || (long)n * L > (1L << 28)) { ctx->err = "trx2_reliability_scores: need xyz[n][L][5][3] and counts[n][2]"; return 1; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t nx = (size_t)n * L * 15 * 4, nc = (size_t)n * 2 * 4;
+  if (fb_reserve(ctx, al256(nx) + al256(nc))) return 1;
+  char* base = (char*)ctx->fb_buf;
+  HIPCHK(hipMemcpyAsync(base, xyz, nx, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(base + al256(nx), 0, nc, ctx->stream));
+  hipLaunchKernelGGL(k_reliability, dim3((unsigned)(((size_t)n * L + 255) / 256)), dim3(256), 0, ctx->stream, n, L, (const float*)base, (int*)(base + al256(nx)));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(counts, base + al256(nx), nc, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// C-alpha RMSD and TM-score of every pair between two sets of aligned structures
+extern "C" int trx2_superpose_matrix(trx2_ctx* ctx, int n, int m, int L, const float* xa, const float* xb, double l_norm, double* rmsd,
+                                     double* tm) {
+  if (!ctx) return 1;
+  if (n < 1 || m < 0 || L < 3 || L > 1024 || !xa || (!rmsd && !tm) || (long)n * (xb ? m : n) > (1L << 24)) {
+    ctx->err = "trx2_superpose_matrix: need n x m structures of 3 <= L <= 1024 aligned residues (xa[n][L][3], xb[m][L][3] or NULL) and an output";
+    return 1;
+  }
+  const bool sym = xb == nullptr;
+  if (sym) m = n;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (l_norm <= 0) l_norm = L;
+  // seed fragments of the TM-score program's search (evaluate.tm_score): lengths L, L/2, .. (at most six, >= 4), then 4
+  std::vector<int2> seeds;
+  {
+    std::vector<int> lens;
+    for (int f = L; f >= 4 && lens.size() < 6; f /= 2) lens.push_back(f);
+    if (!lens.empty() && lens.back() > 4) lens.push_back(4);
+    for (int lf : lens)
+      for (int st = 0; st + lf <= L; st++) seeds.push_back(int2{st, lf});
+  }
+  SupArgs A;
+  A.n = n; A.m = m; A.L = L; A.nseed = (int)seeds.size(); A.symmetric = sym;
+  A.lnorm = l_norm;
+  double d0 = l_norm > 21 ? 1.24 * std::pow(l_norm - 15.0, 1.0 / 3.0) - 1.8 : 0.5;
+  if (d0 < 0.5) d0 = 0.5;
+  A.d0 = d0; A.d0_search = d0 < 4.5 ? 4.5 : (d0 > 8.0 ? 8.0 : d0);
+  const size_t na = (size_t)n * L * 3 * 4, nb = (size_t)m * L * 3 * 4, nm = (size_t)n * m * 8, ns = seeds.size() * sizeof(int2);
+  const size_t o_b = al256(na), o_r = o_b + (sym ? 0 : al256(nb)), o_t = o_r + al256(nm), o_s = o_t + al256(nm);
+  if (fb_reserve(ctx, o_s + al256(ns + 16))) return 1;
+  char* base = (char*)ctx->fb_buf;
+  HIPCHK(hipMemcpyAsync(base, xa, na, hipMemcpyHostToDevice, ctx->stream));
+  if (!sym) HIPCHK(hipMemcpyAsync(base + o_b, xb, nb, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(base + o_r, 0, 2 * al256(nm), ctx->stream));
+  if (!seeds.empty()) HIPCHK(hipMemcpyAsync(base + o_s, seeds.data(), ns, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // `seeds` is read by the copy above
+  A.xa = (const float*)base; A.xb = sym ? A.xa : (const float*)(base + o_b);
+  A.rmsd = (double*)(base + o_r); A.tm_bits = (unsigned long long*)(base + o_t); A.seeds = (const int2*)(base + o_s);
+  const long pairs = (long)n * m;
+  if (rmsd) hipLaunchKernelGGL(k_sup_rmsd, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, ctx->stream, A);
+  if (tm && A.nseed) {
+    const dim3 grid((unsigned)((A.nseed + 3) / 4), (unsigned)pairs);
+    if (L <= 128) hipLaunchKernelGGL((k_sup_tm<2>), grid, dim3(256), 0, ctx->stream, A);
+    else if (L <= 256) hipLaunchKernelGGL((k_sup_tm<4>), grid, dim3(256), 0, ctx->stream, A);
+    else if (L <= 512) hipLaunchKernelGGL((k_sup_tm<8>), grid, dim3(256), 0, ctx->stream, A);
+    else hipLaunchKernelGGL((k_sup_tm<16>), grid, dim3(256), 0, ctx->stream, A);
+  }
+  HIPCHK(hipGetLastError());
+  if (rmsd) HIPCHK(hipMemcpyAsync(rmsd, A.rmsd, nm, hipMemcpyDeviceToHost, ctx->stream));
+  if (tm) HIPCHK(hipMemcpyAsync(tm, A.tm_bits, nm, hipMemcpyDeviceToHost, ctx->stream));  // bit patterns of doubles
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (sym)
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < i; j++) {
+        if (rmsd) rmsd[(size_t)i * n + j] = rmsd[(size_t)j * n + i];
+        if (tm) tm[(size_t)i * n + j] = tm[(size_t)j * n + i];
+      }
   return 0;
 }
 

@@ -7,8 +7,11 @@ present in both files (matched by residue number), and the TM-score by the publi
 (Zhang & Skolnick 2004): seeds = every fragment of length L, L/2, L/4, .. 4 of the aligned residues; from each seed the
 superposition is refined on the pairs closer than a cutoff until the set stops changing; the best
 sum 1 / (1 + (d_i / d0)^2) / L_norm wins, d0 = 1.24 (L_norm - 15)^(1/3) - 1.8, L_norm = length of the second structure.
-Pinned by the reference's committed example summary (tests): apo 3.018 A / 0.6661, holo 3.931 A / 0.6269.
-Not mirrored: `--align` (TM-score's -seq sequence alignment) -> NotImplementedError.
+Pinned by the reference's committed example summary (tests): apo 3.018 A / 0.6661, holo 3.931 A / 0.6269 -- the four printed
+decimals of two proteins; the TM-score program's exact heuristics (its extra seeds from secondary structure, its d0 schedule)
+are not in the tree, so other inputs may differ from the binary in the 3rd-4th decimal.  `device=` computes all pairs of a
+native at once on the GPU (trx2_superpose_matrix: the same search, one wave per pair and seed; equal to tm_score() to 1e-9),
+instead of ~50 k numpy SVDs per pair.  Not mirrored: `--align` (TM-score's -seq sequence alignment) -> NotImplementedError.
 """
 import argparse
 import os
@@ -92,7 +95,31 @@ def compare(native_pdb, pred_pdb):
     return rmsd_common(x, y), tm_score(x, y, l_norm=len(b))
 
 
-def run_score(native_pdb_dir, pred_pdb_dir, align=False, save_summary=False, save_dir=None):
+def compare_many(native_pdb, pred_pdbs, device):
+    """compare(native, p) for every p on the GPU: the models are grouped by (residues shared with the native, own length), each
+    group is one trx2_superpose_matrix call"""
+    from ._lib import Context
+    a = read_ca(native_pdb)
+    groups, out = {}, [None] * len(pred_pdbs)
+    for k, p in enumerate(pred_pdbs):
+        b = read_ca(p)
+        common = tuple(sorted(set(a) & set(b)))
+        if len(common) < 3:
+            raise ValueError(f"{native_pdb} and {p} share fewer than three residues")
+        groups.setdefault((common, len(b)), []).append((k, np.array([b[r] for r in common], np.float32)))
+    ctx = Context(int(device))
+    try:
+        for (common, lb), items in groups.items():
+            x = np.array([[a[r] for r in common]], np.float32)
+            rm, tm = ctx.superpose_matrix(x, np.stack([y for _, y in items]), l_norm=lb)
+            for (k, _), r, t in zip(items, rm[0], tm[0]):
+                out[k] = (float(r), float(t))
+    finally:
+        ctx.close()
+    return out
+
+
+def run_score(native_pdb_dir, pred_pdb_dir, align=False, save_summary=False, save_dir=None, device=None):
     """evaluate_utils.py:33-100: -> (min_rmsd, max_tmscore, mean_rmsd, mean_tmscore); summary.txt in the reference's format
     (values rounded to the three / four decimals the TM-score program prints)"""
     if align:
@@ -100,8 +127,11 @@ def run_score(native_pdb_dir, pred_pdb_dir, align=False, save_summary=False, sav
     lines, rmsds, tms = [], [], []
     for native in sorted(f for f in os.listdir(native_pdb_dir) if f.endswith(".pdb")):
         best_r, best_t = None, None
-        for pred in sorted(f for f in os.listdir(pred_pdb_dir) if f.endswith(".pdb")) if os.path.exists(pred_pdb_dir) else []:
-            r, t = compare(os.path.join(native_pdb_dir, native), os.path.join(pred_pdb_dir, pred))
+        preds = sorted(f for f in os.listdir(pred_pdb_dir) if f.endswith(".pdb")) if os.path.exists(pred_pdb_dir) else []
+        pairs = compare_many(os.path.join(native_pdb_dir, native), [os.path.join(pred_pdb_dir, p) for p in preds], device) \
+            if device is not None and preds else None
+        for k, pred in enumerate(preds):
+            r, t = pairs[k] if pairs else compare(os.path.join(native_pdb_dir, native), os.path.join(pred_pdb_dir, pred))
             r, t = round(r, 3), round(t, 4)
             if best_r is None or r < best_r[0]:
                 best_r = (r, pred[:-4])
@@ -131,11 +161,12 @@ def main(argv=None):
     ap.add_argument("-p", "--pred_dir", required=True, help="folder of model .pdb files")
     ap.add_argument("-o", "--output", default=None, help="summary file (*.txt) or folder; the model folder if omitted")
     ap.add_argument("--align", action="store_true", help="TM-score's -seq alignment: not implemented, raises")
+    ap.add_argument("--device", type=int, default=None, help="superpose on this GPU (extension; numpy if omitted)")
     a = ap.parse_args(argv)
     folder, name = a.pred_dir, "summary.txt"
     if a.output:
         folder, name = (os.path.dirname(a.output) or os.getcwd(), os.path.basename(a.output)) if a.output.endswith(".txt") else (a.output, name)
-    stats = run_score(a.native_dir, a.pred_dir, align=a.align, save_summary=True, save_dir=folder)
+    stats = run_score(a.native_dir, a.pred_dir, align=a.align, save_summary=True, save_dir=folder, device=a.device)
     if name != "summary.txt":
         shutil.move(os.path.join(folder, "summary.txt"), os.path.join(folder, name))
     print("Evaluation Summary:")

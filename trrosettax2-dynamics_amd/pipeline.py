@@ -60,11 +60,15 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     r_init = fold_arrays_to_pdb(init, seq, pred_pdb_dir, [f"initial{i}.pdb" for i in range(N)], tta_opt, device=device, seed=seed, lanes=lanes)
     print("Done generating initial structures")
     best_score, best_pdb, best_i = -np.inf, None, 0
+    if device_feedback:
+        # the decoys as the reference would read them back from their PDB files (bit-exact "%8.3f" round trip, no file parse),
+        # scored in one device call (trx2_reliability_scores); tested equal to the per-file host function
+        scores = get_context(device, lanes).reliability_scores(np.stack([as_read_from_pdb(seq, r_init["xyz"][i])[0] for i in range(N)]))
+    else:
+        scores = [calculate_reliability_score(os.path.join(pred_pdb_dir, f"initial{i}.pdb")) for i in range(N)]
     for i in range(N):                                   # strict '>' : the first maximum wins (run_inference.py:67)
-        pdb = os.path.join(pred_pdb_dir, f"initial{i}.pdb")
-        score = calculate_reliability_score(pdb)
-        if score > best_score:
-            best_score, best_pdb, best_i = score, pdb, i
+        if scores[i] > best_score:
+            best_score, best_pdb, best_i = scores[i], os.path.join(pred_pdb_dir, f"initial{i}.pdb"), i
 
     pattern = os.path.join(processed_npz_dir, pdb_name + "{}.npz")
     if resident:
