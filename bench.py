@@ -4,8 +4,12 @@
 Contract:  python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank per GPU)
 prints ONE JSON line on rank 0.
 
-A "step" = one call of the hot path over one batch: fold B decoys of one distogram through the full staged protocol
-(folding/folding.py:118-171 mode 2), timed from tables-resident-in-HBM to the last coordinates on the host.
+A "step" = one pass of the hot path over one batch: B decoys of one distogram folded through the full staged protocol
+(folding/folding.py:118-171 mode 2), timed from tables-resident-in-HBM to the last coordinates on the host.  The K steps of a
+run are ONE queue of K x B decoys on B decoy slots: a slot whose decoy has finished takes the next decoy on the device
+(trx2_ctx_set_pool), as the reference's process pool starts the next `folding.py` child when a worker frees up
+(utils_trX2dy/utils.py:501-503); every decoy of every step is folded inside the timed region.  `per_call` is the same work as K
+separate calls of B decoys, each ending with its slowest decoy (what round 1 reported as `value`).
 Workload at N=1 = BASELINE.json configs[1]: L=150 single target, init_num=64, dist-only restraints (synthetic map,
 SURVEY.md 8d -- the reference ships data for L=90 only).  Other configs: --config 3 (all channels, two models),
 --config 4 (L=400, B=32), --config 5 (eight targets L=100..400, 32 decoys each, assigned to ranks longest-first: strong
@@ -147,7 +151,7 @@ def step_roofline(ctx, B, L, fold_times):
             "binding_limit": "latency of ~25 dependent phases on one workgroup per decoy (DESIGN.md section 4), not bandwidth"}
 
 
-def sampled_fold(ctx, B, runs, seed, decoy0):
+def sampled_fold(ctx, B, runs, seed, decoy0):  # B decoys through the context's slot pool
     """one extra, UNTIMED fold with every 8th evaluation bracketed by HIP events -> (pair ms, step ms, samples)"""
     ctx.set_profiling(8)
     try:
@@ -259,11 +263,11 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
         c_.set_map(m_["dist"], *([m_["omega"], m_["theta"], m_["phi"]] if cfg["orient"] else []), seq=m_["seq"])
     ctx = ctxs[0]
 
-    def step(i):
+    def step(i, n_steps=1):
         # distinct decoys for every step, rank and chain (timed steps use indices 0.., warm-up steps 900..); the chains of a
         # step are independent (run_inference.py:310-318) and run concurrently, one context = one stream each
         def one(c):
-            return ctxs[c].fold_batch(B, runs, seed=150 + c, decoy0=((rank * 1000 + i) * B))
+            return ctxs[c].fold_batch(n_steps * B, runs, seed=150 + c, decoy0=((rank * 1000 + i) * B))
         if n_chains == 1:
             return [one(0)]
         with ThreadPoolExecutor(max_workers=n_chains) as ex:
@@ -275,11 +279,13 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
             dist.barrier()
             torch.cuda.synchronize()
 
+    for c_ in ctxs:
+        c_.set_pool(B)           # B decoy slots; the K steps' decoys are their queue
     for i in range(warmup):
         step(900 + i)
     sync()
     t0 = time.perf_counter()
-    res = [r for i in range(steps) for r in step(i)]  # fold_batch returns with the coordinates on the host
+    res = step(0, steps)         # fold_batch returns with the coordinates of every decoy on the host
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -291,9 +297,24 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
     ok = all(np.all(r["status"] == 0) and np.all(np.isfinite(r["xyz"])) for r in res)
     evals = np.concatenate([r["n_evals"] for r in res])
     launches = sum(r["launches"] for r in res)
+    per_call = None
+    if full and rank == 0 and world == 1:
+        # the same decoys as K separate calls of B (one slot per decoy: every call ends with its slowest decoy)
+        for c_ in ctxs:
+            c_.set_pool(0)
+        t1 = time.perf_counter()
+        rs = [r for i in range(steps) for r in step(i)]
+        e1 = time.perf_counter() - t1
+        per_call = {"value": steps * B * n_chains / e1, "unit": "decoys/sec", "ms_per_step": 1e3 * e1 / steps,
+                    "pair_launches_per_step": sum(r["launches"] for r in rs) / steps / n_chains,
+                    "slot_efficiency": float(np.concatenate([r["n_evals"] for r in rs]).sum()) / (sum(r["launches"] for r in rs) * B),
+                    "all_decoys_converged": bool(all(np.all(r["status"] == 0) for r in rs)),
+                    "note": "K separate trx2_fold_batch calls of B decoys, one slot per decoy (round 1's `value`)"}
+        for c_ in ctxs:
+            c_.set_pool(B)
     out = None
     if rank == 0:
-        ft = sampled_fold(ctx, B, runs, 150, 901 * B)  # untimed; live per-kernel averages over a whole fold
+        ft = sampled_fold(ctx, 2 * B, runs, 150, 901 * B)  # untimed; live per-kernel averages over a whole (pooled) fold
         out = {
             "metric": "decoys/sec", "value": world * steps * B * n_chains / elapsed, "unit": "decoys/sec",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
@@ -303,24 +324,27 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
             "roofline": pair_roofline(ctx, T, B, L, config, ft),
             "roofline_step": step_roofline(ctx, B, L, ft),
             "all_decoys_converged": bool(ok), "evals_per_decoy": {"min": int(evals.min()), "median": float(np.median(evals)), "max": int(evals.max())},
-            "fold_quality": fold_quality(synth, m, res[::n_chains]),
+            "fold_quality": fold_quality(synth, m, res[:1]),
             "pair_launches_per_step": launches / steps / n_chains,
-            "slot_efficiency": float(evals.sum()) / (launches * B),  # sum of evaluations over decoys / (launches x decoy slots)
+            "slot_efficiency": float(evals.sum()) / (launches * B),  # sum of evaluations over decoys / (launch pairs x decoy slots)
+            "slots": B,
         }
+        if per_call:
+            out["per_call"] = per_call
         if full and world == 1 and n_chains == 1:
             # The same job with the library's two lanes (trx2_ctx_set_lanes: two half-batches on two streams, one half's step
             # kernel overlapping the other's pair kernel).  Reported beside `value`, which stays the single-stream figure so
             # that the per-kernel roofline above and the committed kernel trace describe the launches that were timed.
-            c2 = T.Context(local_rank, lanes=2)
+            c2 = T.Context(local_rank, lanes=2, pool=(B + 1) // 2)
             c2.set_map(m["dist"], *([m["omega"], m["theta"], m["phi"]] if cfg["orient"] else []), seq=m["seq"])
             c2.fold_batch(B, runs, seed=150, decoy0=900 * B)
             t1 = time.perf_counter()
-            r2 = [c2.fold_batch(B, runs, seed=150, decoy0=i * B) for i in range(steps)]
+            r2 = c2.fold_batch(steps * B, runs, seed=150, decoy0=0)
             e2 = time.perf_counter() - t1
             c2.close()
             out["two_lanes"] = {"value": steps * B / e2, "unit": "decoys/sec", "ms_per_step": 1e3 * e2 / steps,
-                                "all_decoys_converged": bool(all(np.all(r["status"] == 0) for r in r2)),
-                                "note": f"same job, Context(lanes=2): halves of {(B + 1) // 2} and {B // 2} decoys on two streams"}
+                                "all_decoys_converged": bool(np.all(r2["status"] == 0)),
+                                "note": f"same job, Context(lanes=2): two queues of {steps * B // 2} decoys on {(B + 1) // 2} slots each, two streams"}
     for c_ in ctxs:
         c_.close()
     return out, m, runs

@@ -54,6 +54,16 @@ void trx2_ctx_destroy(trx2_ctx* ctx);
  * two halves as separate batches.  lanes = 1 (default) restores one stream.  More than three streams folding at once in a
  * process need GPU_MAX_HW_QUEUES=8 (HIP runtime). */
 int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes);
+/* Slot pool.  trx2_fold_batch folds its B decoys on min(B, slots) decoy slots; every launch pair serves the slots, and a slot
+ * whose decoy has finished takes the next decoy of the batch on the device (no host round trip).  A batch ends with its slowest
+ * decoy: with one slot per decoy (slots = 0, the default) a quarter to a third of all launches serve a shrinking set of live
+ * decoys; with fewer slots than decoys the slots stay busy until the queue is empty.  The reference's counterpart is its
+ * process pool (ThreadPoolExecutor over `python folding.py` children, utils_trX2dy/utils.py:501-503), which also starts the next
+ * decoy when a worker frees up.  A decoy is identified by (seed, decoy0 + index) and its results do not depend on the slot that
+ * folded it, on `slots`, or on the order of completion.  trx2_last_fold_slot_efficiency: sum of evaluations over the decoys of
+ * the last fold / (launch pairs x slots). */
+int trx2_ctx_set_pool(trx2_ctx* ctx, int slots);
+int trx2_last_fold_slot_efficiency(trx2_ctx* ctx, double* eff);
 const char* trx2_last_error(const trx2_ctx* ctx);
 
 /* replaces np.load(NPZ) + gen_rst + add_rst selection (folding/folding.py:56-63; utils_ros.py:6-146,706-723).

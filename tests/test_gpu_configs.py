@@ -276,3 +276,48 @@ def test_device_feedback_matches_reference_digests(golden_dir, tmp_path, seq, ta
             assert np.array_equal(a[g["sample_i"], g["sample_j"]], g[f"{ch}_sample"]), ch
     finally:
         ctx.close()
+
+
+# ---- slot pool: a batch folded on fewer slots than decoys (trx2_ctx_set_pool) ---------------------------------------------
+def test_slot_pool_refills_on_the_device_and_keeps_decoy_identity(golden_dir, seq):
+    """24 decoys on 8 slots: a slot whose decoy has reported takes the next decoy of the queue on the device.  A decoy is
+    (seed, decoy0 + index) whatever slot folds it and whenever: the pooled fold must equal, bit for bit, the three separate
+    8-decoy folds (same group width and slab split, so the same arithmetic), and the slots must stay busy."""
+    m = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
+    runs = T.protocol.build_runs(90, 2)
+    ctx = T.Context(0)
+    try:
+        ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+        parts = [ctx.fold_batch(8, runs, seed=77, decoy0=8 * k) for k in range(3)]
+        ctx.set_pool(8)
+        r = ctx.fold_batch(24, runs, seed=77)
+        for key in ("xyz", "tors", "e_terms", "f", "status", "n_evals", "n_iters"):
+            assert np.array_equal(r[key], np.concatenate([p[key] for p in parts])), key
+        eff_parts = np.mean([p["slot_efficiency"] for p in parts])
+        print(f"\nslot efficiency: 24 decoys on 8 slots {r['slot_efficiency']:.3f} ({r['launches']} launch pairs), three separate 8-decoy batches "
+              f"{eff_parts:.3f} ({sum(p['launches'] for p in parts)} launch pairs)")
+        assert r["slot_efficiency"] > eff_parts + 0.05 and r["launches"] < sum(p["launches"] for p in parts)
+        # start torsions given by the caller travel with the decoy id too
+        t0 = np.stack([O.random_torsions(90, 5, d) for d in range(20)]).astype(np.float32)
+        ctx.set_pool(0)
+        a = ctx.fold_batch(20, runs, tors0=t0, max_evals=60)
+        ctx.set_pool(4)
+        b = ctx.fold_batch(20, runs, tors0=t0, max_evals=60)
+        ref4 = [ctx.fold_batch(4, runs, tors0=t0[4 * k:4 * k + 4], max_evals=60) for k in range(5)]   # pool 4 >= 4 decoys: no refill
+        assert np.array_equal(b["xyz"], np.concatenate([q["xyz"] for q in ref4])) and np.all(b["n_evals"] == 60) and np.all(a["n_evals"] == 60)
+        assert np.all(b["status"] == 2)                                     # TRX2_MAXEVAL: the budget ended every fold
+        # the device draw of a refilled slot is the decoy's own (seed, index)
+        ctx.set_pool(16)
+        c = ctx.fold_batch(100, runs, seed=123, decoy0=7, max_evals=1)
+        want = np.stack([O.random_torsions(90, 123, 7 + i) for i in range(100)]).astype(np.float32)
+        assert np.array_equal(c["tors"], want)
+        # two lanes + pool: each lane folds its half on its own slots
+        c2 = T.Context(0, lanes=2, pool=8)
+        try:
+            c2.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+            r2 = c2.fold_batch(48, runs, seed=77)
+            assert np.array_equal(r2["xyz"][:24], r["xyz"]) and np.all(r2["status"] == 0)
+        finally:
+            c2.close()
+    finally:
+        ctx.close()

@@ -91,6 +91,8 @@ def load():
     L.trx2_feedback_process.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
     L.trx2_time_pair_kernel.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, dp, dp]
     L.trx2_last_fold_stats.argtypes = [vp, dp, ip]
+    L.trx2_ctx_set_pool.argtypes = [vp, C.c_int]
+    L.trx2_last_fold_slot_efficiency.argtypes = [vp, dp]
     L.trx2_ctx_set_profiling.argtypes = [vp, C.c_int]
     L.trx2_last_fold_kernel_times.argtypes = [vp, dp, dp, ip]
     L.trx2_ctx_info.argtypes = [vp, C.c_int, dp]
@@ -106,7 +108,7 @@ class Context:
     """One GPU stream + one distogram.  Mirrors what one folding.py process holds (folding/folding.py:48-63).
     lanes=2: batches of 32 or more decoys are folded as two halves on two streams (trx2_ctx_set_lanes, include/trx2fold.h)."""
 
-    def __init__(self, device=0, lanes=1):
+    def __init__(self, device=0, lanes=1, pool=0):
         self._l = load()
         h = C.c_void_p()
         rc = self._l.trx2_ctx_create(int(device), C.byref(h))
@@ -117,12 +119,20 @@ class Context:
         self.kd = 35
         self.use_orient = False
         self.lanes = 1
+        self.pool = 0
         if lanes != 1:
             self.set_lanes(lanes)
+        if pool:
+            self.set_pool(pool)
 
     def set_lanes(self, lanes):
         self._chk(self._l.trx2_ctx_set_lanes(self._h, int(lanes)), "trx2_ctx_set_lanes")
         self.lanes = int(lanes)
+
+    def set_pool(self, slots):
+        """fold batches on `slots` decoy slots that refill from the batch's queue on the device (trx2_ctx_set_pool); 0 = one per decoy"""
+        self._chk(self._l.trx2_ctx_set_pool(self._h, int(slots)), "trx2_ctx_set_pool")
+        self.pool = int(slots)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -213,9 +223,11 @@ class Context:
         st = np.zeros(B, np.int32); ne = np.zeros(B, np.int32); ni = np.zeros(B, np.int32)
         self._chk(self._l.trx2_fold_batch(self._h, B, arr, len(runs), int(seed), int(decoy0), _p(t0), int(max_evals), _p(tors),
                                           _p(xyz), _p(e), _p(f), _p(st), _p(ne), _p(ni)), "trx2_fold_batch")
-        sec, nl = C.c_double(), C.c_int()
+        sec, nl, eff = C.c_double(), C.c_int(), C.c_double()
         self._l.trx2_last_fold_stats(self._h, C.byref(sec), C.byref(nl))
-        return dict(tors=tors, xyz=xyz, e_terms=e, f=f, status=st, n_evals=ne, n_iters=ni, seconds=sec.value, launches=nl.value)
+        self._l.trx2_last_fold_slot_efficiency(self._h, C.byref(eff))
+        return dict(tors=tors, xyz=xyz, e_terms=e, f=f, status=st, n_evals=ne, n_iters=ni, seconds=sec.value, launches=nl.value,
+                    slot_efficiency=eff.value)
 
     # ---- feedback step on the device; mirrors feedback.py, which is bit-identical to the reference
     _D_EDGES = np.arange(2, 20.5, 0.5)

@@ -4,7 +4,10 @@
 // =================================================================================================
 // K1/K5/K6: per-decoy chain kernel
 // =================================================================================================
-enum { PH_START = 0, PH_LS = 1, PH_DONE = 2 };
+// PH_REPORT: the decoy's protocol is over; its slot waits for ONE more evaluation, at the accepted point under the last run's
+// weights, which is the decoy's report (folding.py prints the final score the same way); then the slot takes the next decoy of
+// the queue or retires (PH_DONE).
+enum { PH_START = 0, PH_LS = 1, PH_DONE = 2, PH_REPORT = 3 };
 enum { MODE_INIT = 0, MODE_STEP = 1, MODE_FINISH = 2 };
 // integer state slots
 // SI_RUN and SI_SEQ share one aligned 8-byte word: in the fused step launch the two workgroups of a decoy read its state
@@ -28,7 +31,7 @@ struct ChainArgs {
   float4* P;               // [B][L][5] trial coordinates, decoy-major: N CA C O CB (15 floats + pad) | backbone H, hasH
   float4* xyzT;            // [ngrp][L][5][BW] decoy-minor copy for the pair kernel (its lanes are decoys)
   int BW;
-  const float4* geom;      // [B][L][3] internal geometry per residue (ResGeom)
+  float4* geom;            // [B][L][3] internal geometry per residue (ResGeom)
   float* wcur;             // [B][8]
   const float* FA;         // [nsplit][B][L][24] pair-kernel records: gradient on the six atoms + the pair energies
   int nsplit;
@@ -36,7 +39,18 @@ struct ChainArgs {
   double* e_last;          // [B][NTERMS] raw terms of the last evaluation
   double* f_last;          // [B]
   float* grad_out;         // [B][L][3] (MODE_FINISH)
-  int* done_count;
+  int* done_count;         // slots retired
+  // ---- the slot pool: B slots fold n_total decoys; a slot whose decoy has reported takes the next one of the queue
+  int* slot_id;            // [B] decoy (0 .. n_total-1) in the slot
+  int* next_id;            // queue head
+  int n_total;
+  unsigned long long seed; unsigned decoy0;   // identity of decoy i: (seed, decoy0 + i), whatever slot folds it
+  const float* tors0_all;  // [n_total][L][3] start torsions, or NULL: the reference's random start table
+  float4* out_xyz;         // [n_total][L][4] final coordinates (N CA C O CB)
+  float4* out_X;           // [n_total][L] final torsions
+  double* out_e;           // [n_total][NTERMS] raw terms of the report
+  double* out_f;           // [n_total]
+  int* out_stat;           // [n_total][4] status, evaluations, accepted iterations, slot
 };
 
 // Sum of the pair kernel's records of residue r of decoy dec over the b-range slabs (24 floats: gradient on N CA C O CB H,
@@ -149,6 +163,24 @@ extern __shared__ float4 s_hist[];
 __device__ __forceinline__ void lds_dma16(const float4* src /* per lane */, float4* dst_wave /* wave-uniform: lane i lands at dst + i */) {
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst_wave, 16, 0, 0);
 }
+// random start torsions: set_random_dihedral (utils_ros.py:656-696) with explicit (seed, decoy, residue) hashing
+__device__ __forceinline__ uint64_t splitmix64_dev(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ float4 start_torsions(int L, uint64_t seed, uint32_t decoy, int r, const float* tors0 /* [L][3] of this decoy or NULL */) {
+  if (tors0) return make_float4(tors0[(size_t)r * 3], tors0[(size_t)r * 3 + 1], tors0[(size_t)r * 3 + 2], 0);
+  if (r >= L - 1) return make_float4(180.0f * TRX2_DEG_F, 180.0f * TRX2_DEG_F, TRX2_PI_F, 0);  // the last residue keeps the extended pose (:658)
+  const double cum[6] = TRX2_RAND_CUM_INIT;
+  const uint64_t hsh = splitmix64_dev(seed ^ splitmix64_dev(((uint64_t)decoy << 32) | (uint32_t)r));
+  const double u = (double)(hsh >> 11) * (1.0 / 9007199254740992.0);
+  int k = 0;
+  while (!(u <= cum[k])) k++;
+  return make_float4(c_rama[k * 3], c_rama[k * 3 + 1], TRX2_PI_F, 0);
+}
+
 // NT threads step one decoy, RPT residues per thread (RPT * NT >= L).  NT = 256 is what runs.  One wave (NT = 64, RPT = 3 at
 // L = 150) makes every reduction and scan barrier-free but was SLOWER on MI355X (73.7 vs 61.2 us per evaluation,
 // profiles/README.md): the step is bound by the per-thread chain of dependent arithmetic and loads, which RPT multiplies,
@@ -180,7 +212,9 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
   if (A.mode == MODE_STEP && phase == PH_DONE) return;
   const int seq = (A.mode == MODE_STEP) ? *A.seq_ctr : -1;
-  if (A.mode == MODE_STEP && (s_i[SI_SEQ] == seq || A.runs[min(run, A.nruns - 1)].cartesian)) return;  // the Cartesian role's turn
+  // the Cartesian role's turn -- except for the report, which is a torsion-space evaluation whatever the last run was
+  if (A.mode == MODE_STEP && (s_i[SI_SEQ] == seq || (phase != PH_REPORT && A.runs[min(run, A.nruns - 1)].cartesian))) return;
+  bool fresh_geom = false;  // a refilled slot starts from ideal bond geometry: use it without reading it back
 
   const size_t vb = (size_t)dec * L;  // base of this decoy's [L] vectors
   float4 xt[RPT], gt[RPT];
@@ -326,6 +360,59 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
                        (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[7] * esum[8];
     if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
     if (tid == 0) A.f_last[dec] = f_t;
+
+    if (A.mode == MODE_STEP && phase == PH_REPORT) {
+      // ---- this evaluation was the decoy's report: results out by decoy id, then the slot takes the next decoy or retires
+      const int id = A.slot_id[dec];
+#pragma unroll
+      for (int k = 0; k < RPT; k++) {
+        const int r = k * NT + tid;
+        if (r < L) {
+          A.out_X[(size_t)id * L + r] = xt[k];
+          const float4* xp = A.P + (vb + r) * 5;
+          float4* xo = A.out_xyz + ((size_t)id * L + r) * 4;
+          xo[0] = xp[0]; xo[1] = xp[1]; xo[2] = xp[2]; xo[3] = xp[3];
+        }
+      }
+      if (tid < TRX2_NTERMS) A.out_e[(size_t)id * TRX2_NTERMS + tid] = esum[tid];
+      __shared__ int s_new;
+      if (tid == 0) {
+        A.out_f[id] = f_t;
+        int* st = A.out_stat + (size_t)id * 4;
+        st[0] = s_i[SI_STATUS]; st[1] = s_i[SI_NEVALS]; st[2] = s_i[SI_NITERS]; st[3] = dec;
+        s_new = atomicAdd(A.next_id, 1);
+      }
+      bsync<NW>();
+      const int nid = s_new;
+      if (nid >= A.n_total) {  // queue empty: the slot retires
+        if (tid == 0) {
+          gi[SI_PHASE] = PH_DONE;
+          *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)(unsigned)run;
+          A.wcur[(size_t)dec * 8 + 6] = 0.0f;
+          atomicAdd(A.done_count, 1);
+        }
+        return;
+      }
+      const ResGeom gid = ideal_geom();
+#pragma unroll
+      for (int k = 0; k < RPT; k++) {
+        const int r = k * NT + tid;
+        if (r < L) {
+          xt[k] = start_torsions(L, A.seed, A.decoy0 + (unsigned)nid, r, A.tors0_all ? A.tors0_all + (size_t)nid * L * 3 : nullptr);
+          A.X[vb + r] = xt[k]; A.XT[vb + r] = xt[k];
+          A.geom[(vb + r) * 3] = gid.g0; A.geom[(vb + r) * 3 + 1] = gid.g1; A.geom[(vb + r) * 3 + 2] = gid.g2;
+        } else xt[k] = make_float4(0, 0, 0, 0);
+      }
+      run = 0; phase = PH_START; fresh_geom = true; need_nerf = true;
+      if (tid == 0) {
+        A.slot_id[dec] = nid;
+        gi[SI_PHASE] = PH_START; gi[SI_ITER] = 0; gi[SI_NLS] = 0; gi[SI_HL] = 0; gi[SI_HH] = 0; gi[SI_NH] = 0; gi[SI_STATUS] = 0;
+        gi[SI_NEVALS] = 0; gi[SI_NITERS] = 0;
+        *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32);  // run 0, stepped in this launch
+        for (int q = 0; q < SD_N; q++) gd_[q] = 0.0;
+      }
+      goto next_pair;
+    }
 
     if (A.mode == MODE_FINISH) {
       if (A.grad_out)
@@ -525,6 +612,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         xt[k] = make_float4(fmaf(al, dv[k].x, x[k].x), fmaf(al, dv[k].y, x[k].y), fmaf(al, dv[k].z, x[k].z), 0);
     }
     if (phase != PH_DONE && n_evals >= A.max_evals) { status = TRX2_MAXEVAL; phase = PH_DONE; }
+    if (phase == PH_DONE) {  // over (protocol finished, budget spent, or diverged): next comes the report at the accepted point
+      phase = PH_REPORT; run = A.nruns - 1;
+#pragma unroll
+      for (int k = 0; k < RPT; k++) xt[k] = x[k];
+      need_nerf = true;
+    }
     // ---- store state
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
@@ -538,7 +631,6 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
       gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
       gd_[SD_GAMMA] = gamma_h;
-      if (phase == PH_DONE) atomicAdd(A.done_count, 1);
     }
     if (tid < LBM) A.rho[(size_t)dec * LBM + tid] = s_rho[tid];
   } else {
@@ -550,6 +642,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   }
 
   CSTAMP(9)  // trial point, state stores
+next_pair:
   // ------------------------------------------------------------------ weights for the next pair launch
   if (tid == 0) {
     const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
@@ -568,9 +661,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   for (int k = 0; k < RPT; k++) s_phi[k * NT + tid] = xt[k].x;
   bsync<NW>();
   const float4* gq = A.geom + vb * 3;
+  const ResGeom g_ideal = ideal_geom();
   Xf carry;  // F_0: N at the origin, CA on +x, C in the xy plane (same start as the oracle)
   {
-    const float4 q0 = gq[0];
+    const float4 q0 = fresh_geom ? g_ideal.g0 : gq[0];
     float sa, ca;
     fast_sincosf(q0.w, &sa, &ca);
     carry = xf_from_atoms(mk3(0, 0, 0), mk3(q0.x, 0, 0), mk3(q0.x - q0.y * ca, q0.y * sa, 0));
@@ -582,10 +676,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
     ResGeom gr = ideal_geom();
     f3 lN = mk3(0, 0, 0), lCA = lN, lC = lN, lCB = lN, lNn = lN, lCAn = lN;
     if (r < L) {
-      gr.g0 = gq[r * 3]; gr.g1 = gq[r * 3 + 1]; gr.g2 = gq[r * 3 + 2];
+      if (!fresh_geom) { gr.g0 = gq[r * 3]; gr.g1 = gq[r * 3 + 1]; gr.g2 = gq[r * 3 + 2]; }
       local_atoms(gr, lN, lCA, lC, lCB);
       if (r + 1 < L) {
-        const float4 n0 = gq[(r + 1) * 3];  // next residue: |N-CA|, |CA-C|, angle N-CA-C
+        const float4 n0 = fresh_geom ? g_ideal.g0 : gq[(r + 1) * 3];  // next residue: |N-CA|, |CA-C|, angle N-CA-C
         float spsi, cpsi, so, co, sp, cp, s1, c1, s2, c2, s3, c3;
         fast_sincosf(xt[k].y, &spsi, &cpsi);
         fast_sincosf(xt[k].z, &so, &co);
@@ -747,7 +841,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   __syncthreads();
   int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
   const int seq = *A.seq_ctr;
-  if (phase == PH_DONE || s_i[SI_SEQ] == seq) return;
+  if (phase == PH_DONE || phase == PH_REPORT || s_i[SI_SEQ] == seq) return;  // the report is the torsion role's
   const trx2_run R = A.runs[min(run, A.nruns - 1)];
   if (!R.cartesian) return;
   const size_t vb = (size_t)dec * L;
@@ -1049,6 +1143,12 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
       xt[q] = make_float4(fmaf(al, dv[q].x, x[q].x), fmaf(al, dv[q].y, x[q].y), fmaf(al, dv[q].z, x[q].z), fmaf(al, dv[q].w, x[q].w));
   }
   if (phase != PH_DONE && n_evals >= A.max_evals) { status = TRX2_MAXEVAL; phase = PH_DONE; }
+  const bool over = phase == PH_DONE;  // protocol finished here, budget spent, or diverged: the report (torsion role) comes next
+  if (over) {
+    phase = PH_REPORT; run = A.nruns - 1;
+#pragma unroll
+    for (int q = 0; q < 4; q++) xt[q] = x[q];  // at the accepted point
+  }
   // ---- store state and the coordinates for the next pair launch
   if (act) {
 #pragma unroll
@@ -1083,7 +1183,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   CSTAMP(26)  // direction test, trial point, state + coordinate stores
   // ---- leaving Cartesian space (run finished, or the decoy stops here on its evaluation budget / divergence): torsions +
   //      relaxed internal geometry of the ACCEPTED point, for the torsion-space runs after it and for the final report
-  if (next_run || phase == PH_DONE) {
+  if (next_run || over) {
     __syncthreads();
     if (act)
 #pragma unroll
@@ -1124,11 +1224,10 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
     gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
     gd_[SD_GAMMA] = gamma_h;
-    if (phase == PH_DONE) atomicAdd(A.done_count, 1);
     const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
     float* w = A.wcur + (size_t)dec * 8;
     w[0] = Rn.w[0]; w[1] = Rn.w[1]; w[2] = Rn.w[2]; w[3] = Rn.w[3];
-    w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi; w[6] = (phase == PH_DONE) ? 0.0f : (Rn.pair_filter ? 2.0f : 1.0f); w[7] = Rn.w[7];
+    w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi; w[6] = Rn.pair_filter ? 2.0f : 1.0f; w[7] = Rn.w[7];
   }
   if (tid < LBM) A.rho[(size_t)dec * LBM + tid] = s_rho[tid];
 }
@@ -1147,31 +1246,11 @@ __global__ __launch_bounds__(NT) void k_step(ChainArgs A, CartArgs C) {
   } else cart_body<NT>(C, (int)blockIdx.x - A.B);
 }
 
-// random start torsions: set_random_dihedral (utils_ros.py:656-696) with explicit (seed, decoy, residue) hashing
-__device__ __forceinline__ uint64_t splitmix64_dev(uint64_t x) {
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  return x ^ (x >> 31);
-}
 __global__ void k_init_torsions(int L, int B, uint64_t seed, uint32_t decoy0, const float* tors0, float4* X, float4* XT, float4* geom) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L * B) return;
   const int dec = i / L, r = i % L;
-  float4 v;
-  if (tors0) v = make_float4(tors0[(size_t)i * 3], tors0[(size_t)i * 3 + 1], tors0[(size_t)i * 3 + 2], 0);
-  else {
-    float ph = 180.0f, ps = 180.0f;
-    if (r < L - 1) {
-      const double cum[6] = TRX2_RAND_CUM_INIT;
-      uint64_t hsh = splitmix64_dev(seed ^ splitmix64_dev(((uint64_t)(decoy0 + dec) << 32) | (uint32_t)r));
-      double u = (double)(hsh >> 11) * (1.0 / 9007199254740992.0);
-      int k = 0;
-      while (!(u <= cum[k])) k++;
-      v = make_float4(c_rama[k * 3], c_rama[k * 3 + 1], TRX2_PI_F, 0);
-    } else
-      v = make_float4(ph * TRX2_DEG_F, ps * TRX2_DEG_F, TRX2_PI_F, 0);
-  }
+  const float4 v = start_torsions(L, seed, decoy0 + dec, r, tors0 ? tors0 + (size_t)dec * L * 3 : nullptr);
   X[i] = v;
   XT[i] = v;
   const ResGeom gi = ideal_geom();  // pose_from_sequence: ideal bond geometry (folding.py:109)

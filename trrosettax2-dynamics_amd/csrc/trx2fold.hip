@@ -100,7 +100,13 @@ struct trx2_ctx {
   long alloc_epoch = 0;
   trx2_run* runs = nullptr;
   int* h_done = nullptr;  // pinned
-  double last_seconds = 0; int last_launches = 0;
+  double last_seconds = 0; int last_launches = 0; double last_slot_eff = 0;
+  // slot pool (trx2_ctx_set_pool): a fold of N decoys runs on min(N, pool) slots; a slot whose decoy has reported takes the next
+  // one of the queue on the device.  0 = one slot per decoy.
+  int pool = 0;
+  int *slot_id = nullptr, *next_id = nullptr, *out_stat = nullptr;
+  float4 *out_xyz = nullptr, *out_X = nullptr; double *out_e = nullptr, *out_f = nullptr; float* tors0_all = nullptr;
+  size_t out_cap = 0, out_L = 0;  // decoys x residues the output arrays hold
   // trx2_ctx_set_profiling: every prof_every-th evaluation of a fold is bracketed by HIP events on the stream (pair | step)
   int prof_every = 0;
   std::vector<hipEvent_t> prof_ev;
@@ -226,10 +232,12 @@ static void free_batch(trx2_ctx* c) {
   c->e_last = c->f_last = nullptr; c->grad = nullptr; c->tors0 = nullptr; c->done_count = nullptr; c->seq_ctr = nullptr; c->runs = nullptr;
   c->Bcap = c->Lcap = 0;
   c->alloc_epoch++;
-  void* q[] = {c->CX, c->CG, c->CD, c->CS, c->CY};
+  void* q[] = {c->CX, c->CG, c->CD, c->CS, c->CY, c->slot_id, c->next_id, c->out_stat, c->out_xyz, c->out_X, c->out_e, c->out_f, c->tors0_all};
   for (void* v : q)
     if (v) (void)hipFree(v);
   c->CX = c->CG = c->CD = c->CS = c->CY = nullptr;
+  c->slot_id = c->next_id = c->out_stat = nullptr; c->out_xyz = c->out_X = nullptr; c->out_e = c->out_f = nullptr; c->tors0_all = nullptr;
+  c->out_cap = c->out_L = 0;
   c->cart_B = c->cart_L = 0;
 }
 static int ensure_cart(trx2_ctx* ctx, int B) {
@@ -273,6 +281,7 @@ extern "C" int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes) {
     trx2_ctx* k = nullptr;
     if (trx2_ctx_create(ctx->device, &k) != 0) { ctx->err = "trx2_ctx_set_lanes: cannot create the second lane"; return 1; }
     k->borrows_map = true;
+    k->pool = ctx->pool;
     ctx->child = k;
     if (ctx->L) { HIPCHK(hipStreamSynchronize(ctx->stream)); lend_map(ctx); }
   } else if (lanes == 1 && ctx->child) {
@@ -579,6 +588,8 @@ static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_eva
   A.wcur = c->wcur; A.FA = c->FA; A.nsplit = c->nsplit; A.hasH = c->hasH;
   A.e_last = c->e_last; A.f_last = c->f_last;
   A.grad_out = c->grad; A.done_count = c->done_count;
+  A.slot_id = c->slot_id; A.next_id = c->next_id; A.n_total = 0; A.seed = 0; A.decoy0 = 0; A.tors0_all = nullptr;
+  A.out_xyz = c->out_xyz; A.out_X = c->out_X; A.out_e = c->out_e; A.out_f = c->out_f; A.out_stat = c->out_stat;
   return A;
 }
 static void launch_pair(trx2_ctx* c, int B) {
@@ -604,8 +615,11 @@ static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals) {
   A.e_last = c->e_last; A.f_last = c->f_last; A.done_count = c->done_count;
   return A;
 }
+static void launch_chain_args(trx2_ctx* c, int B, const ChainArgs& A);
 static void launch_chain(trx2_ctx* c, int B, int mode, int nruns, int max_evals) {
-  ChainArgs A = chain_args(c, B, mode, nruns, max_evals);
+  launch_chain_args(c, B, chain_args(c, B, mode, nruns, max_evals));
+}
+static void launch_chain_args(trx2_ctx* c, int B, const ChainArgs& A) {
   const dim3 grid(B);
   const int L = c->L;
   // chains of up to 128 residues (the reference's example has 90) run the step on two waves: every workgroup reduction and
@@ -658,58 +672,104 @@ extern "C" int trx2_eval_batch(trx2_ctx* ctx, int B, const float* tors, const fl
   return 0;
 }
 
-static int fold_impl(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint64_t seed, uint32_t decoy0,
+static int ensure_outputs(trx2_ctx* ctx, size_t N, bool with_tors0) {
+  const size_t L = (size_t)(ctx->L > ctx->Lcap ? ctx->L : ctx->Lcap);  // sized like the batch buffers: a later, longer map that fits them fits these
+  if (N > ctx->out_cap || L > ctx->out_L || !ctx->slot_id) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    void* q[] = {ctx->slot_id, ctx->next_id, ctx->out_stat, ctx->out_xyz, ctx->out_X, ctx->out_e, ctx->out_f, ctx->tors0_all};
+    for (void* v : q)
+      if (v) (void)hipFree(v);
+    ctx->tors0_all = nullptr;
+    const size_t cap = N > (size_t)ctx->Bcap ? N : (size_t)ctx->Bcap;
+    HIPCHK(hipMalloc((void**)&ctx->slot_id, sizeof(int) * cap));
+    HIPCHK(hipMalloc((void**)&ctx->next_id, sizeof(int)));
+    HIPCHK(hipMalloc((void**)&ctx->out_stat, sizeof(int) * cap * 4));
+    HIPCHK(hipMalloc((void**)&ctx->out_xyz, sizeof(float4) * cap * L * 4));
+    HIPCHK(hipMalloc((void**)&ctx->out_X, sizeof(float4) * cap * L));
+    HIPCHK(hipMalloc((void**)&ctx->out_e, sizeof(double) * cap * TRX2_NTERMS));
+    HIPCHK(hipMalloc((void**)&ctx->out_f, sizeof(double) * cap));
+    ctx->out_cap = cap; ctx->out_L = L;
+    ctx->alloc_epoch++;
+  }
+  if (with_tors0 && !ctx->tors0_all) {
+    HIPCHK(hipMalloc((void**)&ctx->tors0_all, sizeof(float) * ctx->out_cap * L * 3));
+    ctx->alloc_epoch++;
+  }
+  return 0;
+}
+
+// Folds N decoys on P = min(N, pool) slots.  Every evaluation is one pair-kernel launch over the P slots and one step-kernel
+// launch; a decoy that is over reports (one evaluation at its accepted point under the last run's weights), its slot then takes
+// the next decoy of the queue ON THE DEVICE (kernel_step.h) -- the host only replays chunks of launches and polls the number of
+// retired slots.  A decoy's identity is (seed, decoy0 + index): results do not depend on the slot that folded it.
+static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint64_t seed, uint32_t decoy0,
                      const float* tors0, int max_evals, float* tors_out, float* xyz_out, double* e_terms,
                      double* f_final, int* status, int* n_evals, int* n_iters) {
   if (!ctx) return 1;
   if (!ctx->L) { ctx->err = "trx2_fold_batch: no map set"; return 1; }
-  if (B < 1 || !runs || nruns < 1 || nruns > TRX2_MAX_RUNS) { ctx->err = "trx2_fold_batch: bad arguments"; return 1; }
-  bool has_cart = false;
-  for (int i = 0; i < nruns; i++) has_cart |= runs[i].cartesian != 0;
+  if (N < 1 || !runs || nruns < 1 || nruns > TRX2_MAX_RUNS) { ctx->err = "trx2_fold_batch: bad arguments"; return 1; }
+  bool has_cart = false, has_filter = false;
+  for (int i = 0; i < nruns; i++) { has_cart |= runs[i].cartesian != 0; has_filter |= runs[i].pair_filter != 0; }
   if (has_cart && ctx->L > 2 * CHAIN_THREADS) { ctx->err = "trx2_fold_batch: Cartesian-space runs support chains of up to 512 residues"; return 1; }
+  if (has_filter && !ctx->mask_odr) { ctx->err = "trx2_fold_batch: a run filters by the idr mask, but the map was set without one (trx2_set_map_ex)"; return 1; }
   if (max_evals <= 0) max_evals = 1 << 30;
   HIPCHK(hipSetDevice(ctx->device));
+  const int B = (ctx->pool > 0 && ctx->pool < N) ? ctx->pool : N;   // slots
   if (ensure_batch(ctx, B)) return 1;
   if (has_cart && ensure_cart(ctx, B)) return 1;
+  if (ensure_outputs(ctx, (size_t)N, tors0 != nullptr)) return 1;
   const int L = ctx->L;
-  const size_t BL = (size_t)B * L;
+  const size_t BL = (size_t)B * L, NL = (size_t)N * L;
   auto t0 = std::chrono::steady_clock::now();
   HIPCHK(hipMemcpyAsync(ctx->runs, runs, sizeof(trx2_run) * nruns, hipMemcpyHostToDevice, ctx->stream));
-  if (tors0) HIPCHK(hipMemcpyAsync(ctx->tors0, tors0, sizeof(float) * BL * 3, hipMemcpyHostToDevice, ctx->stream));
+  if (tors0) HIPCHK(hipMemcpyAsync(ctx->tors0_all, tors0, sizeof(float) * NL * 3, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->st_i, 0, sizeof(int) * B * SI_N, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->st_d, 0, sizeof(double) * B * SD_N, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->done_count, 0, sizeof(int), ctx->stream));
+  {
+    std::vector<int> ids((size_t)B);
+    for (int i = 0; i < B; i++) ids[i] = i;
+    HIPCHK(hipMemcpyAsync(ctx->slot_id, ids.data(), sizeof(int) * B, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->next_id, &B, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));  // ids / B leave scope
+  }
   hipLaunchKernelGGL(k_init_torsions, dim3((unsigned)((BL + 255) / 256)), dim3(256), 0, ctx->stream, L, B, seed, decoy0,
-                     tors0 ? ctx->tors0 : (const float*)nullptr, ctx->X, ctx->XT, ctx->geom);
+                     tors0 ? ctx->tors0_all : (const float*)nullptr, ctx->X, ctx->XT, ctx->geom);
   launch_chain(ctx, B, MODE_INIT, nruns, max_evals);
   int launches = 0;
   const int chunk = 64;
-  // hard cap on launches: every decoy stops by itself at max_evals; the extra margin covers skipped runs
-  const long cap = (long)max_evals + 64;
+  // hard cap on launches: a decoy stops by itself at max_evals (+ its report, + skipped runs); a slot folds ceil(N / B) of them
+  const long rounds = (N + B - 1) / B;
+  long cap = ((long)max_evals + 96) * rounds;
+  if (cap > 200000000L || cap < 0) cap = 200000000L;
   HIPCHK(hipMemsetAsync(ctx->seq_ctr, 0, sizeof(int), ctx->stream));
   const int pe = ctx->prof_every;
   int prof_used = 0;
   ctx->prof_pair_ms = ctx->prof_step_ms = 0; ctx->prof_n = 0;
   if (pe > 0 && ctx->prof_ev.empty()) {
-    ctx->prof_ev.resize(3 * (size_t)(chunk / 1));
+    ctx->prof_ev.resize(3 * (size_t)chunk);
     for (auto& e : ctx->prof_ev) HIPCHK(hipEventCreate(&e));
   }
+  auto pool_args = [&](ChainArgs& ca) {
+    ca.n_total = N; ca.seed = seed; ca.decoy0 = decoy0; ca.tors0_all = tors0 ? ctx->tors0_all : nullptr;
+  };
   auto enqueue_chunk = [&]() {
     for (int i = 0; i < chunk; i++) {
       const bool samp = pe > 0 && (i % pe) == 0 && (size_t)(3 * prof_used + 2) < ctx->prof_ev.size();
       if (samp) (void)hipEventRecord(ctx->prof_ev[3 * prof_used], ctx->stream);
       launch_pair(ctx, B);  // bumps the device-side evaluation counter
       if (samp) (void)hipEventRecord(ctx->prof_ev[3 * prof_used + 1], ctx->stream);
+      ChainArgs ca = chain_args(ctx, B, MODE_STEP, nruns, max_evals);
+      pool_args(ca);
       if (has_cart) {
         // fused launch: workgroups of 256 (512 for 256 < L <= 512) threads, one residue per thread in the Cartesian role
-        const ChainArgs ca = chain_args(ctx, B, MODE_STEP, nruns, max_evals);
         const CartArgs cc = cart_args(ctx, B, nruns, max_evals);
         const dim3 g2(2 * B), b1(CHAIN_THREADS), b2(2 * CHAIN_THREADS);
         if (L <= 128) hipLaunchKernelGGL((k_step<1, 128, 128>), g2, dim3(128), HIST_LDS_BYTES(128), ctx->stream, ca, cc);
         else if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS>), g2, b1, HIST_LDS_BYTES(CHAIN_THREADS), ctx->stream, ca, cc);
         else hipLaunchKernelGGL((k_step<2, CHAIN_THREADS, 2 * CHAIN_THREADS>), g2, b2, 0, ctx->stream, ca, cc);
       } else
-        launch_chain(ctx, B, MODE_STEP, nruns, max_evals);
+        launch_chain_args(ctx, B, ca);
       if (samp) { (void)hipEventRecord(ctx->prof_ev[3 * prof_used + 2], ctx->stream); prof_used++; }
     }
   };
@@ -719,7 +779,7 @@ static int fold_impl(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint
   // TRX2_GRAPH=1 opts in.
   static const bool no_graph = getenv("TRX2_GRAPH") == nullptr;
   if (!no_graph) {
-    const long key[8] = {B, nruns, max_evals, has_cart ? 1 : 0, L, ctx->nsplit, ctx->BW, ctx->alloc_epoch};
+    const long key[8] = {B, nruns, max_evals, has_cart ? 1 : 0, (long)L * 4096 + N, (long)(seed ^ ((uint64_t)decoy0 << 40) ^ (tors0 ? 1 : 0)), (long)ctx->nsplit * 128 + ctx->BW, ctx->alloc_epoch};
     if (!ctx->gexec || memcmp(key, ctx->g_key, sizeof key) != 0) {
       if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
       hipGraph_t graph = nullptr;
@@ -748,35 +808,29 @@ static int fold_impl(trx2_ctx* ctx, int B, const trx2_run* runs, int nruns, uint
     prof_used = 0;
     if (*ctx->h_done >= B || launches >= cap) break;
   }
-  // final report: energies of the accepted point X under the last run's weights
-  HIPCHK(hipMemcpyAsync(ctx->XT, ctx->X, sizeof(float4) * BL, hipMemcpyDeviceToDevice, ctx->stream));
-  {
-    std::vector<int> sti((size_t)B * SI_N);
-    HIPCHK(hipMemcpyAsync(sti.data(), ctx->st_i, sizeof(int) * B * SI_N, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < B; i++) {
-      if (status) status[i] = sti[(size_t)i * SI_N + SI_PHASE] == PH_DONE ? sti[(size_t)i * SI_N + SI_STATUS] : TRX2_MAXEVAL;
-      if (n_evals) n_evals[i] = sti[(size_t)i * SI_N + SI_NEVALS];
-      if (n_iters) n_iters[i] = sti[(size_t)i * SI_N + SI_NITERS];
-      sti[(size_t)i * SI_N + SI_RUN] = nruns - 1;
-    }
-    HIPCHK(hipMemcpyAsync(ctx->st_i, sti.data(), sizeof(int) * B * SI_N, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-  }
-  launch_chain(ctx, B, MODE_INIT, nruns, max_evals);
-  launch_pair(ctx, B);
-  launch_chain(ctx, B, MODE_FINISH, nruns, max_evals);
-  HIPCHK(hipGetLastError());
+  const bool all_retired = *ctx->h_done >= B;
+  // results by decoy id
   std::vector<float> tmpx, tmpt;
-  if (xyz_out) { tmpx.resize(BL * 20); HIPCHK(hipMemcpyAsync(tmpx.data(), ctx->P, sizeof(float) * BL * 20, hipMemcpyDeviceToHost, ctx->stream)); }
-  if (tors_out) { tmpt.resize(BL * 4); HIPCHK(hipMemcpyAsync(tmpt.data(), ctx->X, sizeof(float4) * BL, hipMemcpyDeviceToHost, ctx->stream)); }
-  if (e_terms) HIPCHK(hipMemcpyAsync(e_terms, ctx->e_last, sizeof(double) * B * TRX2_NTERMS, hipMemcpyDeviceToHost, ctx->stream));
-  if (f_final) HIPCHK(hipMemcpyAsync(f_final, ctx->f_last, sizeof(double) * B, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<int> st((size_t)N * 4);
+  if (xyz_out) { tmpx.resize(NL * 16); HIPCHK(hipMemcpyAsync(tmpx.data(), ctx->out_xyz, sizeof(float) * NL * 16, hipMemcpyDeviceToHost, ctx->stream)); }
+  if (tors_out) { tmpt.resize(NL * 4); HIPCHK(hipMemcpyAsync(tmpt.data(), ctx->out_X, sizeof(float4) * NL, hipMemcpyDeviceToHost, ctx->stream)); }
+  if (e_terms) HIPCHK(hipMemcpyAsync(e_terms, ctx->out_e, sizeof(double) * N * TRX2_NTERMS, hipMemcpyDeviceToHost, ctx->stream));
+  if (f_final) HIPCHK(hipMemcpyAsync(f_final, ctx->out_f, sizeof(double) * N, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipMemcpyAsync(st.data(), ctx->out_stat, sizeof(int) * N * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  if (xyz_out) for (size_t i = 0; i < BL; i++) memcpy(xyz_out + i * 15, tmpx.data() + i * 20, 15 * sizeof(float));
-  if (tors_out) for (size_t i = 0; i < BL; i++) memcpy(tors_out + i * 3, tmpt.data() + i * 4, 3 * sizeof(float));
+  if (!all_retired) { ctx->err = "trx2_fold_batch: launch cap reached before every decoy had reported"; return 1; }
+  if (xyz_out) for (size_t i = 0; i < NL; i++) memcpy(xyz_out + i * 15, tmpx.data() + i * 16, 15 * sizeof(float));
+  if (tors_out) for (size_t i = 0; i < NL; i++) memcpy(tors_out + i * 3, tmpt.data() + i * 4, 3 * sizeof(float));
+  double evals = 0;
+  for (int i = 0; i < N; i++) {
+    if (status) status[i] = st[(size_t)i * 4];
+    if (n_evals) n_evals[i] = st[(size_t)i * 4 + 1];
+    if (n_iters) n_iters[i] = st[(size_t)i * 4 + 2];
+    evals += st[(size_t)i * 4 + 1];
+  }
   ctx->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   ctx->last_launches = launches;
+  ctx->last_slot_eff = evals / ((double)launches * B);
   return 0;
 }
 
@@ -1103,6 +1157,18 @@ extern "C" int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int s
   return 0;
 }
 
+extern "C" int trx2_ctx_set_pool(trx2_ctx* ctx, int slots) {
+  if (!ctx) return 1;
+  if (slots < 0 || slots > 4096) { ctx->err = "trx2_ctx_set_pool: 0 (one slot per decoy) .. 4096 slots"; return 1; }
+  ctx->pool = slots;
+  if (ctx->child) ctx->child->pool = slots;
+  return 0;
+}
+extern "C" int trx2_last_fold_slot_efficiency(trx2_ctx* ctx, double* eff) {
+  if (!ctx || !eff) return 1;
+  *eff = ctx->last_slot_eff;
+  return 0;
+}
 extern "C" int trx2_ctx_set_profiling(trx2_ctx* ctx, int every) {
   if (!ctx) return 1;
   if (every < 0 || every > 64) { ctx->err = "trx2_ctx_set_profiling: every in 0..64"; return 1; }
