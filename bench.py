@@ -6,10 +6,13 @@ prints ONE JSON line on rank 0.
 
 A "step" = one pass of the hot path over one batch: B decoys of one distogram folded through the full staged protocol
 (folding/folding.py:118-171 mode 2), timed from tables-resident-in-HBM to the last coordinates on the host.  The K steps of a
-run are ONE queue of K x B decoys on B decoy slots: a slot whose decoy has finished takes the next decoy on the device
-(trx2_ctx_set_pool), as the reference's process pool starts the next `folding.py` child when a worker frees up
-(utils_trX2dy/utils.py:501-503); every decoy of every step is folded inside the timed region.  `per_call` is the same work as K
-separate calls of B decoys, each ending with its slowest decoy (what round 1 reported as `value`).
+run are ONE queue of K x B decoys on B decoy slots (never more than B = init_num decoys in flight): a slot whose decoy has
+finished takes the next decoy on the device (trx2_ctx_set_pool), as the reference's process pool starts the next `folding.py`
+child when a worker frees up (utils_trX2dy/utils.py:501-503); every decoy of every step is folded inside the timed region.  With
+one chain the B slots are two lanes of B/2 on two streams (trx2_ctx_set_lanes, the library's default for batches), so that one
+lane's step kernel overlaps the other's pair kernel.  Beside `value`: `single_stream` (the same queue on one stream of B slots),
+`per_call` (K separate calls of B decoys, one slot per decoy, each call ending with its slowest decoy: round 1's `value`) and
+`wide_pool` (two lanes of B slots: 2 B decoys in flight).
 Workload at N=1 = BASELINE.json configs[1]: L=150 single target, init_num=64, dist-only restraints (synthetic map,
 SURVEY.md 8d -- the reference ships data for L=90 only).  Other configs: --config 3 (all channels, two models),
 --config 4 (L=400, B=32), --config 5 (eight targets L=100..400, 32 decoys each, assigned to ranks longest-first: strong
@@ -258,7 +261,9 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
     ms_ = [synth.make_map(L, seed=L + c) for c in range(n_chains)]
     m = ms_[0]
     runs = T.protocol.build_runs(L, 2)
-    ctxs = [T.Context(local_rank) for _ in range(n_chains)]
+    lanes = 2 if n_chains == 1 else 1          # two chains already occupy two streams
+    slots = (B + 1) // 2 if lanes == 2 else B   # per lane: B decoys in flight per chain either way
+    ctxs = [T.Context(local_rank, lanes=lanes) for _ in range(n_chains)]
     for c_, m_ in zip(ctxs, ms_):
         c_.set_map(m_["dist"], *([m_["omega"], m_["theta"], m_["phi"]] if cfg["orient"] else []), seq=m_["seq"])
     ctx = ctxs[0]
@@ -280,7 +285,7 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
             torch.cuda.synchronize()
 
     for c_ in ctxs:
-        c_.set_pool(B)           # B decoy slots; the K steps' decoys are their queue
+        c_.set_pool(slots)       # B decoy slots per chain; the K steps' decoys are their queue
     for i in range(warmup):
         step(900 + i)
     sync()
@@ -296,55 +301,49 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
 
     ok = all(np.all(r["status"] == 0) and np.all(np.isfinite(r["xyz"])) for r in res)
     evals = np.concatenate([r["n_evals"] for r in res])
-    launches = sum(r["launches"] for r in res)
-    per_call = None
+    launches = sum(r["launches"] for r in res)   # per lane: both lanes of a context make about the same number
+    per_call = single = wide = None
     if full and rank == 0 and world == 1:
-        # the same decoys as K separate calls of B (one slot per decoy: every call ends with its slowest decoy)
+        def leg(lanes_, pool_, calls):
+            for c_ in ctxs:
+                c_.set_lanes(lanes_); c_.set_pool(pool_)
+            step(900, 1)
+            t1 = time.perf_counter()
+            rs = [r for i in range(steps) for r in step(i)] if calls else step(0, steps)
+            e1 = time.perf_counter() - t1
+            nl = sum(r["launches"] for r in rs) / n_chains
+            return {"value": steps * B * n_chains / e1, "unit": "decoys/sec", "ms_per_step": 1e3 * e1 / steps, "pair_launches_per_step": nl / steps,
+                    "all_decoys_converged": bool(all(np.all(r["status"] == 0) for r in rs))}
+        # the same decoys as K separate calls of B on one stream (one slot per decoy: every call ends with its slowest decoy)
+        per_call = leg(1, 0, True)
+        per_call["note"] = "K separate trx2_fold_batch calls of B decoys, one stream, one slot per decoy (round 1's `value`)"
+        if lanes == 2:
+            single = leg(1, B, False)
+            single["note"] = f"the same queue on ONE stream of {B} slots"
+            wide = leg(2, B, False)
+            wide["note"] = f"two lanes of {B} slots each: {2 * B} decoys in flight"
         for c_ in ctxs:
-            c_.set_pool(0)
-        t1 = time.perf_counter()
-        rs = [r for i in range(steps) for r in step(i)]
-        e1 = time.perf_counter() - t1
-        per_call = {"value": steps * B * n_chains / e1, "unit": "decoys/sec", "ms_per_step": 1e3 * e1 / steps,
-                    "pair_launches_per_step": sum(r["launches"] for r in rs) / steps / n_chains,
-                    "slot_efficiency": float(np.concatenate([r["n_evals"] for r in rs]).sum()) / (sum(r["launches"] for r in rs) * B),
-                    "all_decoys_converged": bool(all(np.all(r["status"] == 0) for r in rs)),
-                    "note": "K separate trx2_fold_batch calls of B decoys, one slot per decoy (round 1's `value`)"}
-        for c_ in ctxs:
-            c_.set_pool(B)
+            c_.set_lanes(lanes); c_.set_pool(slots)
     out = None
     if rank == 0:
-        ft = sampled_fold(ctx, 2 * B, runs, 150, 901 * B)  # untimed; live per-kernel averages over a whole (pooled) fold
+        ft = sampled_fold(ctx, 2 * B, runs, 150, 901 * B)  # untimed; live per-kernel averages over a whole (pooled) fold: lane 0's launches
         out = {
             "metric": "decoys/sec", "value": world * steps * B * n_chains / elapsed, "unit": "decoys/sec",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "L": L, "decoys_per_step": B * n_chains, "protocol": "mode 2, full staged minimisation",
+                       "slots": f"{B} per chain" + (f" = 2 lanes x {slots} on two streams" if lanes == 2 else ""),
                        "parallelism": f"decoys sharded over {world} rank(s), no collective on the data path"},
-            "roofline": pair_roofline(ctx, T, B, L, config, ft),
-            "roofline_step": step_roofline(ctx, B, L, ft),
+            "roofline": pair_roofline(ctx, T, slots, L, config, ft),
+            "roofline_step": step_roofline(ctx, slots, L, ft),
             "all_decoys_converged": bool(ok), "evals_per_decoy": {"min": int(evals.min()), "median": float(np.median(evals)), "max": int(evals.max())},
             "fold_quality": fold_quality(synth, m, res[:1]),
             "pair_launches_per_step": launches / steps / n_chains,
-            "slot_efficiency": float(evals.sum()) / (launches * B),  # sum of evaluations over decoys / (launch pairs x decoy slots)
-            "slots": B,
+            "slot_efficiency": float(np.mean([r["slot_efficiency"] for r in res])),  # evaluations of the decoys / (launch pairs x slots), per lane
         }
-        if per_call:
-            out["per_call"] = per_call
-        if full and world == 1 and n_chains == 1:
-            # The same job with the library's two lanes (trx2_ctx_set_lanes: two half-batches on two streams, one half's step
-            # kernel overlapping the other's pair kernel).  Reported beside `value`, which stays the single-stream figure so
-            # that the per-kernel roofline above and the committed kernel trace describe the launches that were timed.
-            c2 = T.Context(local_rank, lanes=2, pool=(B + 1) // 2)
-            c2.set_map(m["dist"], *([m["omega"], m["theta"], m["phi"]] if cfg["orient"] else []), seq=m["seq"])
-            c2.fold_batch(B, runs, seed=150, decoy0=900 * B)
-            t1 = time.perf_counter()
-            r2 = c2.fold_batch(steps * B, runs, seed=150, decoy0=0)
-            e2 = time.perf_counter() - t1
-            c2.close()
-            out["two_lanes"] = {"value": steps * B / e2, "unit": "decoys/sec", "ms_per_step": 1e3 * e2 / steps,
-                                "all_decoys_converged": bool(np.all(r2["status"] == 0)),
-                                "note": f"same job, Context(lanes=2): two queues of {steps * B // 2} decoys on {(B + 1) // 2} slots each, two streams"}
+        for k_, v_ in (("single_stream", single), ("wide_pool", wide), ("per_call", per_call)):
+            if v_:
+                out[k_] = v_
     for c_ in ctxs:
         c_.close()
     return out, m, runs

@@ -11,9 +11,9 @@ for grp in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/pass$i -- python3 $R/tools/pmc_pair.py $R $CFG $N > $OUT/pass$i.log 2>&1
+  timeout -k 10 240 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/c${CFG}_pass$i -- python3 $R/tools/pmc_pair.py $R $CFG $N > $OUT/c${CFG}_pass$i.log 2>&1
   rc=$?; echo "pass $i ($grp) rc=$rc"
   if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then exit $rc; fi
-  f=$(ls $OUT/pass$i/*/*counter_collection.csv 2>/dev/null | head -1)
-  if [ -n "$f" ]; then python3 $R/tools/pmc_report.py $f $N $OUT/c${CFG}_pass$i.csv | tee $OUT/c${CFG}_pass$i.json; echo; fi
+  f=$(ls $OUT/c${CFG}_pass$i/*/*counter_collection.csv 2>/dev/null | head -1)
+  if [ -n "$f" ]; then python3 $R/tools/pmc_report.py $f $N $OUT/c${CFG}_pass$i.csv | tee $OUT/c${CFG}_pass$i.json; echo; rm -rf $OUT/c${CFG}_pass$i; fi  # keep the summaries, drop the raw traces
 done
