@@ -23,7 +23,7 @@ for k, (nm, x) in enumerate(zip(names, v)):
     per = x / (nd if k in (5, 6, 7) else n)
     print(f"   {nm:34s} {100*x/v.sum():5.1f} %   {per:8.0f} ticks per {'new-direction step' if k in (5,6,7) else 'step'}")
 v = np.array(out[16:27], float); n, nd = out[28], out[29]
-names = ["state load + role test", "coordinates -> LDS, slab sums", "rama/omega: angles, dE/dangle", "rama/omega: gradients on atoms", "bonded term",
+names = ["state load + role test", "coordinates -> LDS, slab sums", "backbone H, rama/omega", "bonded term, hand-over", "neighbours' parts, assembly",
          "energy reduction + X,G,D loads", "Armijo / (s,y) pair", "two-loop: first loop", "two-loop: gamma", "two-loop: second loop", "direction, trial, stores"]
 if n:
     print(f"Cartesian role: decoy 0, {n} steps, {nd} with a new direction; ticks per step: total {v.sum()/n:.0f}")

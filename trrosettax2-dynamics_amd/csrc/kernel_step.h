@@ -160,6 +160,7 @@ __device__ unsigned long long g_cstamp[32];
 // the recursion starts a phase later) and every round reads the thread's own slot from LDS.
 extern __shared__ float4 s_hist[];
 #define HIST_LDS_BYTES(NT) (LBM * 2 * (NT) * 16)
+#define CART_HIST_BYTES(L) ((size_t)(L) * 128)  // one stored pair of the Cartesian role in LDS: [s | y][4][L] float4
 __device__ __forceinline__ void lds_dma16(const float4* src /* per lane */, float4* dst_wave /* wave-uniform: lane i lands at dst + i */) {
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst_wave, 16, 0, 0);
 }
@@ -355,10 +356,21 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       car1 = car1 + mk3(tot[3], tot[4], tot[5]);
     }
     CSTAMP(2)  // suffix scan + torsion gradient
-    block_sum_n<9, NW>(esum, s_buf, flip);
-    const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] +
-                       (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[7] * esum[8];
-    if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
+    // The nine terms are needed by the report, by the INIT / FINISH passes and by the guard of a pre-checked run; a plain
+    // minimiser step needs their weighted total only: ONE f64 workgroup sum instead of nine.
+    const bool all_terms = A.mode != MODE_STEP || phase == PH_REPORT || (phase == PH_START && R.precheck);
+    double f_t;
+    if (all_terms) {
+      block_sum_n<9, NW>(esum, s_buf, flip);
+      f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] +
+            (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[7] * esum[8];
+      if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
+    } else {
+      double ft1[1] = {(double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] +
+                       (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[7] * esum[8]};
+      block_sum_n<1, NW>(ft1, s_buf, flip);
+      f_t = ft1[0];
+    }
     if (tid == 0) A.f_last[dec] = f_t;
 
     if (A.mode == MODE_STEP && phase == PH_REPORT) {
@@ -773,7 +785,8 @@ struct CartArgs {
   const trx2_run* runs;
   int* st_i; double* st_d; float* rho;
   float4 *CX, *CG, *CD;      // [B][L][4] accepted point, its gradient, direction
-  float4 *CS, *CY;           // [B][LBM][L][4]
+  float4 *CS, *CY;           // [B][LBM][4][L]: stored pairs, component-major so that a wave reads 1 KB in one piece
+  int hist_lds;              // stored pairs the launch has dynamic LDS for in this role (CART_HIST_BYTES each); 0: none
   float4* P;                 // [B][L][5]: the first 4 float4 of a record = trial coordinates = trial DOF vector (in/out), 5th = H
   float4* xyzT; int BW;      // decoy-minor copy for the pair kernel
   float4 *X, *XT, *geom;     // torsions and internal geometry, written when the run ends
@@ -826,8 +839,8 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   __shared__ double s_d[SD_N];
   __shared__ float s_rho[LBM];
   __shared__ float s_xyz[NT * 16];
-  __shared__ float s_dt[NT * 3];
-  __shared__ float s_gp[NT * 3];  // gradient a residue's backbone H sends to C of the residue before it
+  __shared__ float s_dt[NT * 6];  // gradient a residue's psi, omega and link terms put on N and CA of the residue after it
+  __shared__ float s_gp[NT * 3];  // gradient a residue's phi and backbone H put on C of the residue before it
   int* gi = A.st_i + (size_t)dec * SI_N;
   double* gd_ = A.st_d + (size_t)dec * SD_N;
   KSTAMP_DECL
@@ -845,6 +858,23 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   const trx2_run R = A.runs[min(run, A.nruns - 1)];
   if (!R.cartesian) return;
   const size_t vb = (size_t)dec * L;
+  // The stored pairs, newest first, requested into LDS now and read by the two-loop a phase later (as the torsion role does):
+  // slot t = the t-th newest pair, [s | y][4 components][L] float4.  The rows are exactly L long -- lanes beyond the chain
+  // are switched off, LDS-DMA writes only for active lanes -- so that 7 pairs of a 150-residue chain fit beside the
+  // kernel's static LDS; what does not fit (long chains) is read from global memory in the recursion.
+  const int hl0 = s_i[SI_HL], hh0 = s_i[SI_HH];
+  const int nl = (NT <= 256) ? min(hl0, A.hist_lds) : 0;
+  if (NT <= 256 && act) {
+    const int wave = tid >> 6;
+    for (int kk = 0; kk < nl; kk++) {
+      const int j = (hh0 - 1 - kk + LBM) % LBM;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        lds_dma16(A.CS + (((size_t)dec * LBM + j) * 4 + q) * L + r, s_hist + (size_t)((kk * 2 + 0) * 4 + q) * L + wave * 64);
+        lds_dma16(A.CY + (((size_t)dec * LBM + j) * 4 + q) * L + r, s_hist + (size_t)((kk * 2 + 1) * 4 + q) * L + wave * 64);
+      }
+    }
+  }
   CSTAMP(16)  // state load, role test
   CCOUNT(28)
 
@@ -868,15 +898,17 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   __syncthreads();
   CSTAMP(17)  // coordinates -> LDS, slab sums
   f3 aN = mk3(0, 0, 0), aCA = aN, aC = aN, aO = aN, aCB = aN;  // gradient of the local terms on this residue's atoms
-  float dphi = 0, dpsi = 0, dom = 0;
   Res5 Me = unpack5(s_xyz + (act ? r : 0) * 16), Pv = Me, Nx = Me;
   if (act && r > 0) Pv = unpack5(s_xyz + (r - 1) * 16);
   if (act && r + 1 < L) Nx = unpack5(s_xyz + (r + 1) * 16);
-  // The pair kernel's gradient on the backbone H goes to the three atoms H is built from (transpose of the Jacobian of
-  // place_h; oracle: hb_spread_h): N and CA of this residue, C of the previous one (handed over through LDS).
-  f3 hN = mk3(0, 0, 0), hCA = hN;
+  // Every term that spans the peptide bond is evaluated ONCE, by the residue on its N-terminal side (phi: by its own residue),
+  // and the part of its gradient that lands on the neighbour's atoms is handed over through LDS: three floats to C of the
+  // residue before (phi; the backbone H), six to N and CA of the residue after (psi, omega, the link terms).  Both owners
+  // evaluated such a term before -- up to six more dihedral gradients and a second set of link terms per thread.
   if (act) {
-    f3 gp1 = mk3(0, 0, 0);
+    f3 toC = mk3(0, 0, 0), toN = toC, toCA = toC;
+    // The pair kernel's gradient on the backbone H goes to the three atoms H is built from (transpose of the Jacobian of
+    // place_h; oracle: hb_spread_h): N and CA of this residue, C of the previous one.
     if (R.w[7] != 0.0f && r > 0) {
       const f3 d1 = Me.N - Pv.C, d2 = Me.N - Me.CA;
       const float il1 = rsqrtf(dot(d1, d1)), il2 = rsqrtf(dot(d2, d2));
@@ -885,15 +917,13 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
       const f3 uh = u * ilu;
       const f3 gp = (gH - uh * dot(uh, gH)) * ((float)TRX2_HB_B_NH * ilu);
       const f3 g1 = (gp - e1 * dot(e1, gp)) * il1, g2 = (gp - e2 * dot(e2, gp)) * il2;
-      hN = gH + g1 + g2; hCA = g2 * -1.0f; gp1 = g1 * -1.0f;
+      aN = gH + g1 + g2; aCA = g2 * -1.0f; toC = g1 * -1.0f;
     }
-    s_gp[r * 3] = gp1.x; s_gp[r * 3 + 1] = gp1.y; s_gp[r * 3 + 2] = gp1.z;
-  }
-  if (act) {
-    // rama (residues 2..L-1) and omega_bb (1..L-1): derivatives with respect to the torsion angles
+    // rama (residues 2..L-1) and omega_bb (1..L-1)
     f3 t1, t2, t3, t4;
     if (r >= 1 && r < L - 1) {
-      const float ph = dihedral_grad(Pv.C, Me.N, Me.CA, Me.C, t1, t2, t3, t4), ps = dihedral_grad(Me.N, Me.CA, Me.C, Nx.N, t1, t2, t3, t4);
+      f3 p1, p2, p3, p4;
+      const float ph = dihedral_grad(Pv.C, Me.N, Me.CA, Me.C, p1, p2, p3, p4), ps = dihedral_grad(Me.N, Me.CA, Me.C, Nx.N, t1, t2, t3, t4);
       float sph, cph, sps, cps, sm = 0, a1 = 0, a2 = 0;
       fast_sincosf(ph, &sph, &cph); fast_sincosf(ps, &sps, &cps);
 #pragma unroll
@@ -905,33 +935,18 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
       }
       const float inv = 1.0f / (sm + (float)TRX2_RAMA_FLOOR);
       esum[5] += -(double)logf((sm + (float)TRX2_RAMA_FLOOR) * (1.0f / (float)TRX2_RAMA_PREF));
-      dphi = -R.w[4] * a1 * inv; dpsi = -R.w[4] * a2 * inv;
+      const float dphi = -R.w[4] * a1 * inv, dpsi = -R.w[4] * a2 * inv;
+      toC = fma3(p1, dphi, toC); aN = fma3(p2, dphi, aN); aCA = fma3(p3, dphi, aCA); aC = fma3(p4, dphi, aC);
+      aN = fma3(t1, dpsi, aN); aCA = fma3(t2, dpsi, aCA); aC = fma3(t3, dpsi, aC); toN = fma3(t4, dpsi, toN);
     }
     if (r < L - 1) {
-      float dw = wrap_pi_f(dihedral_grad(Me.CA, Me.C, Nx.N, Nx.CA, t1, t2, t3, t4) - TRX2_PI_F) * (1.0f / TRX2_DEG_F);
+      const float dw = wrap_pi_f(dihedral_grad(Me.CA, Me.C, Nx.N, Nx.CA, t1, t2, t3, t4) - TRX2_PI_F) * (1.0f / TRX2_DEG_F);
       esum[6] += (double)((float)TRX2_OMEGA_K * dw * dw);
-      dom = R.w[5] * 2.0f * (float)TRX2_OMEGA_K * dw * (1.0f / TRX2_DEG_F);
+      const float dom = R.w[5] * 2.0f * (float)TRX2_OMEGA_K * dw * (1.0f / TRX2_DEG_F);
+      aCA = fma3(t1, dom, aCA); aC = fma3(t2, dom, aC); toN = fma3(t3, dom, toN); toCA = fma3(t4, dom, toCA);
     }
-    s_dt[r * 3] = dphi; s_dt[r * 3 + 1] = dpsi; s_dt[r * 3 + 2] = dom;
-  }
-  __syncthreads();
-  CSTAMP(18)  // rama / omega: angles and dE/dangle
-  if (act) {
-    f3 d1, d2, d3, d4;
-    if (dphi != 0.0f) { dihedral_grad(Pv.C, Me.N, Me.CA, Me.C, d1, d2, d3, d4); aN = fma3(d2, dphi, aN); aCA = fma3(d3, dphi, aCA); aC = fma3(d4, dphi, aC); }
-    if (dpsi != 0.0f) { dihedral_grad(Me.N, Me.CA, Me.C, Nx.N, d1, d2, d3, d4); aN = fma3(d1, dpsi, aN); aCA = fma3(d2, dpsi, aCA); aC = fma3(d3, dpsi, aC); }
-    if (dom != 0.0f) { dihedral_grad(Me.CA, Me.C, Nx.N, Nx.CA, d1, d2, d3, d4); aCA = fma3(d1, dom, aCA); aC = fma3(d2, dom, aC); }
-    if (r + 1 < L) {  // phi of the next residue moves C of this one
-      const float c = s_dt[(r + 1) * 3];
-      if (c != 0.0f) { Res5 N2 = Nx; dihedral_grad(Me.C, N2.N, N2.CA, N2.C, d1, d2, d3, d4); aC = fma3(d1, c, aC); }
-    }
-    if (r > 0) {      // psi and omega of the previous residue move N (and CA) of this one
-      const float c1 = s_dt[(r - 1) * 3 + 1], c2 = s_dt[(r - 1) * 3 + 2];
-      if (c1 != 0.0f) { dihedral_grad(Pv.N, Pv.CA, Pv.C, Me.N, d1, d2, d3, d4); aN = fma3(d4, c1, aN); }
-      if (c2 != 0.0f) { dihedral_grad(Pv.CA, Pv.C, Me.N, Me.CA, d1, d2, d3, d4); aN = fma3(d3, c2, aN); aCA = fma3(d4, c2, aCA); }
-    }
+    CSTAMP(18)  // backbone H, rama / omega
     // bonded term: ideal CB geometry from the ideal local frame
-    CSTAMP(19)  // rama / omega gradients on atoms (up to 6 dihedral gradients)
     const float wcb = R.w[6];
     if (wcb != 0.0f) {
       const float d_cacb = c_cb_ideal[0], a_ncacb = c_cb_ideal[1], a_ccacb = c_cb_ideal[2], t_cb = c_cb_ideal[3];
@@ -946,23 +961,38 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
       eb += hangle(Me.N, Me.CA, Me.CB, a_ncacb, KA, a, b, c); bN += a; bCA += b; bCB += c;
       eb += hangle(Me.C, Me.CA, Me.CB, a_ccacb, KA, a, b, c); bC += a; bCA += b; bCB += c;
       eb += hdih(Me.N, Me.C, Me.CA, Me.CB, t_cb, KI, a, b, c, d); bN += a; bC += b; bCA += c; bCB += d;
-      if (r + 1 < L) { LinkGrad G = link_terms(Me, Nx); eb += G.e; bCA += G.CA; bC += G.C; bO += G.O; }
-      if (r > 0) { LinkGrad G = link_terms(Pv, Me); bN += G.Nn; bCA += G.CAn; }
+      if (r + 1 < L) {
+        const LinkGrad G = link_terms(Me, Nx);
+        eb += G.e; bCA += G.CA; bC += G.C; bO += G.O;
+        toN = fma3(G.Nn, wcb, toN); toCA = fma3(G.CAn, wcb, toCA);
+      }
       esum[7] += (double)eb;
       aN = fma3(bN, wcb, aN); aCA = fma3(bCA, wcb, aCA); aC = fma3(bC, wcb, aC); aO = fma3(bO, wcb, aO); aCB = fma3(bCB, wcb, aCB);
     }
-    aN += hN; aCA += hCA;
-    if (r + 1 < L) aC += mk3(s_gp[(r + 1) * 3], s_gp[(r + 1) * 3 + 1], s_gp[(r + 1) * 3 + 2]);  // from the next residue's H
+    s_gp[r * 3] = toC.x; s_gp[r * 3 + 1] = toC.y; s_gp[r * 3 + 2] = toC.z;
+    s_dt[r * 6] = toN.x; s_dt[r * 6 + 1] = toN.y; s_dt[r * 6 + 2] = toN.z;
+    s_dt[r * 6 + 3] = toCA.x; s_dt[r * 6 + 4] = toCA.y; s_dt[r * 6 + 5] = toCA.z;
+  }
+  __syncthreads();
+  CSTAMP(19)  // bonded term, hand-over
+  if (act) {
+    if (r + 1 < L) aC += mk3(s_gp[(r + 1) * 3], s_gp[(r + 1) * 3 + 1], s_gp[(r + 1) * 3 + 2]);
+    if (r > 0) {
+      aN += mk3(s_dt[(r - 1) * 6], s_dt[(r - 1) * 6 + 1], s_dt[(r - 1) * 6 + 2]);
+      aCA += mk3(s_dt[(r - 1) * 6 + 3], s_dt[(r - 1) * 6 + 4], s_dt[(r - 1) * 6 + 5]);
+    }
     gt[0].x += aN.x; gt[0].y += aN.y; gt[0].z += aN.z; gt[0].w += aCA.x;
     gt[1].x += aCA.y; gt[1].y += aCA.z; gt[1].z += aC.x; gt[1].w += aC.y;
     gt[2].x += aC.z; gt[2].y += aO.x; gt[2].z += aO.y; gt[2].w += aO.z;
     gt[3].x += aCB.x; gt[3].y += aCB.y; gt[3].z += aCB.z;
   }
-  CSTAMP(20)  // bonded term
-  block_sum_n<9, NW>(esum, s_buf, flip);
-  const double f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] + (double)R.w[3] * esum[4] +
-                     (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[6] * esum[7] + (double)R.w[7] * esum[8];
-  if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
+  CSTAMP(20)  // neighbours' parts, gradient assembled
+  // the minimiser needs the weighted total only (the terms are reported by the torsion role's report evaluation): ONE f64
+  // workgroup sum instead of nine
+  double ft1[1] = {(double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] + (double)R.w[3] * esum[4] +
+                   (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[6] * esum[7] + (double)R.w[7] * esum[8]};
+  block_sum_n<1, NW>(ft1, s_buf, flip);
+  const double f_t = ft1[0];
   if (tid == 0) A.f_last[dec] = f_t;
 
   // ------------------------------------------------------------------ minimiser state machine (as k_chain, 4 float4 per residue)
@@ -978,6 +1008,10 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     if (act) { x[q] = A.CX[(vb + r) * 4 + q]; g[q] = A.CG[(vb + r) * 4 + q]; dv[q] = A.CD[(vb + r) * 4 + q]; }
   }
   bool next_run = false, new_dir = false, steepest = false, new_trial = false;
+  float4 sv[4], yv[4];  // the pair of the step just accepted: the newest pair of the recursion, taken from registers
+  bool stored = false;
+#pragma unroll
+  for (int q = 0; q < 4; q++) sv[q] = yv[q] = make_float4(0, 0, 0, 0);
   const bool finite_t = isfinite(f_t);
   CSTAMP(21)  // energy reduction, loads of X, G, D
   if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
@@ -993,7 +1027,6 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     const bool accept = finite_t && f_t <= fref + (double)TRX2_LS_C1 * alpha * gdir;
     if (accept) {
       double v3[3] = {0, 0, 0};
-      float4 sv[4], yv[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         sv[q] = make_float4(xt[q].x - x[q].x, xt[q].y - x[q].y, xt[q].z - x[q].z, xt[q].w - x[q].w);
@@ -1005,9 +1038,10 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
         if (act)
 #pragma unroll
           for (int q = 0; q < 4; q++) {
-            A.CS[(((size_t)dec * LBM + hh) * L + r) * 4 + q] = sv[q];
-            A.CY[(((size_t)dec * LBM + hh) * L + r) * 4 + q] = yv[q];
+            A.CS[(((size_t)dec * LBM + hh) * 4 + q) * L + r] = sv[q];
+            A.CY[(((size_t)dec * LBM + hh) * 4 + q) * L + r] = yv[q];
           }
+        stored = true;
         __syncthreads();
         if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
         gamma_h = v3[0] / v3[2];
@@ -1048,9 +1082,9 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     const int rc = min(r, L - 1);
     auto pair_at = [&](int kk) { return (hh - 1 - kk + LBM) % LBM; };
     auto load_pair = [&](int kk, float4 (&s_)[4], float4 (&y_)[4]) {
-      const size_t o = (((size_t)dec * LBM + pair_at(kk)) * L + rc) * 4;
+      const size_t o = ((size_t)dec * LBM + pair_at(kk)) * 4 * L + rc;
 #pragma unroll
-      for (int q = 0; q < 4; q++) { s_[q] = A.CS[o + q]; y_[q] = A.CY[o + q]; }
+      for (int q = 0; q < 4; q++) { s_[q] = A.CS[o + (size_t)q * L]; y_[q] = A.CY[o + (size_t)q * L]; }
     };
     auto round1 = [&](int kk, const float4 (&s_)[4], const float4 (&y_)[4]) {
       const int j = pair_at(kk);
@@ -1074,41 +1108,101 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
 #pragma unroll
       for (int q = 0; q < 4; q++) { qv[q].x += c * s_[q].x; qv[q].y += c * s_[q].y; qv[q].z += c * s_[q].z; qv[q].w += c * s_[q].w; }
     };
-    // Three rotating buffers, loops advancing in groups of three so that the buffer of pair kk (kk % 3) is a compile-time
-    // choice: two pairs are always in flight.  With 64 decoys the histories (460 KB each at L=150) do not stay in L2 and a
-    // round is shorter than one memory round trip, so one pair ahead was not enough (profiles/README.md).
-    float4 sb[3][4], yb[3][4];
-    if (hl > 0) load_pair(0, sb[0], yb[0]);
-    if (hl > 1) load_pair(1, sb[1], yb[1]);
-#pragma unroll 1
-    for (int k0 = 0; k0 < hl; k0 += 3)
+    // Where the pairs come from, newest (kk = 0) to oldest.  NT <= 256: the pair stored a moment ago is still in registers;
+    // the pairs staged at the top of the step follow (slot t held the t-th newest pair then, so it is pair t + 1 now); what
+    // the launch had no LDS for comes from global memory -- the first two of those are requested before the first loop
+    // starts and kept for the second, which begins with them.  At L = 150 nothing is read from global memory here: the
+    // recursion read the 150 KB history through three rotating register buffers before, ~1400 cycles per dependent round
+    // against ~700 in the torsion role (profiles/README.md).
+    if constexpr (NT <= 256) {
+      const int sh = stored ? 1 : 0, kg0 = nl + sh;  // first pair that is neither in registers nor staged
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged pairs have landed (long ago)
+      float4 e0s[4], e0y[4], e1s[4], e1y[4];
+      if (kg0 < hl) load_pair(kg0, e0s, e0y);
+      if (kg0 + 1 < hl) load_pair(kg0 + 1, e1s, e1y);
+      auto staged = [&](int t, float4 (&s_)[4], float4 (&y_)[4]) {
 #pragma unroll
-      for (int u = 0; u < 3; u++) {
-        const int kk = k0 + u;
-        if (kk < hl) {
-          if (kk + 2 < hl) load_pair(kk + 2, sb[(u + 2) % 3], yb[(u + 2) % 3]);
-          round1(kk, sb[u], yb[u]);
+        for (int q = 0; q < 4; q++) { s_[q] = s_hist[(size_t)((t * 2 + 0) * 4 + q) * L + rc]; y_[q] = s_hist[(size_t)((t * 2 + 1) * 4 + q) * L + rc]; }
+      };
+      // the staged pairs alternate between two named buffers, the next one requested from LDS before the current round's
+      // reduction (no register copy: a copy would wait for the read just issued)
+      const int ns = min(kg0, hl) - sh;  // staged pairs in use: kk = sh .. sh + ns - 1 is slot kk - sh
+      float4 as[4], ay[4], bs[4], by[4];
+      if (sh) round1(0, sv, yv);
+      if (ns > 0) staged(0, as, ay);
+#pragma unroll 1
+      for (int t = 0; t < ns; t += 2) {
+        if (t + 1 < ns) staged(t + 1, bs, by);
+        round1(t + sh, as, ay);
+        if (t + 1 < ns) {
+          if (t + 2 < ns) staged(t + 2, as, ay);
+          round1(t + 1 + sh, bs, by);
         }
       }
-    CSTAMP(23)  // two-loop: first loop
-    if (hl > 0) {
-      const float gam = (float)gamma_h;
+      if (kg0 < hl) round1(kg0, e0s, e0y);
+      if (kg0 + 1 < hl) round1(kg0 + 1, e1s, e1y);
+#pragma unroll 1
+      for (int kk = kg0 + 2; kk < hl; kk++) { float4 s_[4], y_[4]; load_pair(kk, s_, y_); round1(kk, s_, y_); }
+      CSTAMP(23)  // two-loop: first loop
+      if (hl > 0) {
+        const float gam = (float)gamma_h;
 #pragma unroll
-      for (int q = 0; q < 4; q++) { qv[q].x *= gam; qv[q].y *= gam; qv[q].z *= gam; qv[q].w *= gam; }
+        for (int q = 0; q < 4; q++) { qv[q].x *= gam; qv[q].y *= gam; qv[q].z *= gam; qv[q].w *= gam; }
+      }
+      __syncthreads();
+      CSTAMP(24)  // two-loop: gamma
+#pragma unroll 1
+      for (int kk = hl - 1; kk >= kg0 + 2; kk--) { float4 s_[4], y_[4]; load_pair(kk, s_, y_); round2(kk, s_, y_); }
+      if (kg0 + 1 < hl) round2(kg0 + 1, e1s, e1y);
+      if (kg0 < hl) round2(kg0, e0s, e0y);
+      if (ns > 0) staged(ns - 1, as, ay);
+#pragma unroll 1
+      for (int t = ns - 1; t >= 0; t -= 2) {
+        if (t >= 1) staged(t - 1, bs, by);
+        round2(t + sh, as, ay);
+        if (t >= 1) {
+          if (t >= 2) staged(t - 2, as, ay);
+          round2(t - 1 + sh, bs, by);
+        }
+      }
+      if (sh) round2(0, sv, yv);
+    } else {
+      // Three rotating buffers, loops advancing in groups of three so that the buffer of pair kk (kk % 3) is a compile-time
+      // choice: two pairs are always in flight.  With 64 decoys the histories (460 KB each at L=150) do not stay in L2 and a
+      // round is shorter than one memory round trip, so one pair ahead was not enough (profiles/README.md).
+      float4 sb[3][4], yb[3][4];
+      if (hl > 0) load_pair(0, sb[0], yb[0]);
+      if (hl > 1) load_pair(1, sb[1], yb[1]);
+#pragma unroll 1
+      for (int k0 = 0; k0 < hl; k0 += 3)
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+          const int kk = k0 + u;
+          if (kk < hl) {
+            if (kk + 2 < hl) load_pair(kk + 2, sb[(u + 2) % 3], yb[(u + 2) % 3]);
+            round1(kk, sb[u], yb[u]);
+          }
+        }
+      CSTAMP(23)  // two-loop: first loop
+      if (hl > 0) {
+        const float gam = (float)gamma_h;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { qv[q].x *= gam; qv[q].y *= gam; qv[q].z *= gam; qv[q].w *= gam; }
+      }
+      __syncthreads();
+      CSTAMP(24)  // two-loop: gamma
+      // backwards: the three oldest pairs are still in their buffers; a buffer is refilled (pair kk - 3) as soon as it is done
+#pragma unroll 1
+      for (int k0 = (hl - 1) / 3 * 3; k0 >= 0; k0 -= 3)
+#pragma unroll
+        for (int u = 2; u >= 0; u--) {
+          const int kk = k0 + u;
+          if (kk < hl) {
+            round2(kk, sb[u], yb[u]);
+            if (kk >= 3) load_pair(kk - 3, sb[u], yb[u]);
+          }
+        }
     }
-    __syncthreads();
-    CSTAMP(24)  // two-loop: gamma
-    // backwards: the three oldest pairs are still in their buffers; a buffer is refilled (pair kk - 3) as soon as it is done
-#pragma unroll 1
-    for (int k0 = (hl - 1) / 3 * 3; k0 >= 0; k0 -= 3)
-#pragma unroll
-      for (int u = 2; u >= 0; u--) {
-        const int kk = k0 + u;
-        if (kk < hl) {
-          round2(kk, sb[u], yb[u]);
-          if (kk >= 3) load_pair(kk - 3, sb[u], yb[u]);
-        }
-      }
     CSTAMP(25)  // two-loop: second loop
     double v2[2] = {0, 0};
 #pragma unroll
@@ -1230,6 +1324,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi; w[6] = Rn.pair_filter ? 2.0f : 1.0f; w[7] = Rn.w[7];
   }
   if (tid < LBM) A.rho[(size_t)dec * LBM + tid] = s_rho[tid];
+  if (NT <= 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA of this workgroup outlives it
 }
 
 // ---- launchable forms.  k_chain: INIT / FINISH passes and protocols without a Cartesian run.  k_step: one launch of 2B

@@ -13,6 +13,7 @@
 // included below the shared macros and constant tables; this file holds those and the host side (context, C ABI).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -109,6 +110,7 @@ struct trx2_ctx {
   size_t out_cap = 0, out_L = 0;  // decoys x residues the output arrays hold
   // trx2_ctx_set_profiling: every prof_every-th evaluation of a fold is bracketed by HIP events on the stream (pair | step)
   int prof_every = 0;
+  int step_dyn_max[2] = {0, 0};  // dynamic LDS the fused step kernels may ask for (L <= 128 | L <= 256): 160 KB - their static LDS
   std::vector<hipEvent_t> prof_ev;
   double prof_pair_ms = 0, prof_step_ms = 0; int prof_n = 0;
   // second lane (trx2_ctx_set_lanes): a context of its own stream and batch buffers that BORROWS this one's tables, so that
@@ -162,13 +164,33 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
     rm[k * 3 + 2] = (float)rama[k][2];
     rsc[k * 4] = (float)sin(ph); rsc[k * 4 + 1] = (float)cos(ph); rsc[k * 4 + 2] = (float)sin(ps); rsc[k * 4 + 3] = (float)cos(ps);
   }
-  // the step kernels of short chains stage the L-BFGS history in dynamic LDS (HIST_LDS_BYTES: 64 KB with 8 pairs and 256 threads)
-  if (hipFuncSetAttribute((const void*)k_chain<1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(128)) != hipSuccess ||
-      hipFuncSetAttribute((const void*)k_step<1, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(128)) != hipSuccess ||
-      hipFuncSetAttribute((const void*)k_chain<1, CHAIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(CHAIN_THREADS)) != hipSuccess ||
-      hipFuncSetAttribute((const void*)k_step<1, CHAIN_THREADS, CHAIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, HIST_LDS_BYTES(CHAIN_THREADS)) != hipSuccess) {
-    delete ctx;
-    return 4;
+  // The step kernels of short chains stage the L-BFGS history in dynamic LDS: the torsion role all of it (HIST_LDS_BYTES: 64 KB
+  // with 8 pairs and 256 threads), the Cartesian role as many pairs (CART_HIST_BYTES(L) each) as fit beside the kernel's static
+  // LDS in the 160 KB of a gfx950 workgroup.
+  {
+    int lds_max = 0;
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || lds_max <= 0) lds_max = 65536;
+    if (lds_max > 160 * 1024) lds_max = 160 * 1024;
+    const void* fstep[2] = {(const void*)k_step<1, 128, 128>, (const void*)k_step<1, CHAIN_THREADS, CHAIN_THREADS>};
+    const int hist[2] = {HIST_LDS_BYTES(128), HIST_LDS_BYTES(CHAIN_THREADS)};
+    bool ok = hipFuncSetAttribute((const void*)k_chain<1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, hist[0]) == hipSuccess &&
+              hipFuncSetAttribute((const void*)k_chain<1, CHAIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, hist[1]) == hipSuccess;
+    for (int k = 0; k < 2 && ok; k++) {
+      hipFuncAttributes fa;
+      ok = hipFuncGetAttributes(&fa, fstep[k]) == hipSuccess;
+      if (!ok) break;
+      // ... less what one workgroup of the pair kernel needs (~28 KB): with two lanes the other lane's pair kernel runs beside
+      // this one, and a step workgroup that fills a CU's LDS keeps it off that CU (measured: profiles/README.md)
+      static const int reserve = getenv("TRX2_STEP_LDS_RESERVE") ? atoi(getenv("TRX2_STEP_LDS_RESERVE")) : 32 * 1024;
+      int dyn = lds_max - (int)fa.sharedSizeBytes - reserve;
+      if (dyn < hist[k]) dyn = hist[k];
+      ctx->step_dyn_max[k] = dyn;
+      ok = hipFuncSetAttribute(fstep[k], hipFuncAttributeMaxDynamicSharedMemorySize, dyn) == hipSuccess;
+    }
+    if (!ok) {
+      delete ctx;
+      return 4;
+    }
   }
   float cb[4];
   {  // local frame of local_atoms(): CA at the origin, C on +x, N in the xy plane; CB = CA + ka (b x c) + kb b + kc c
@@ -613,6 +635,7 @@ static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals) {
   A.P = c->P; A.xyzT = c->xyzT; A.BW = c->BW; A.X = c->X; A.XT = c->XT; A.geom = c->geom; A.wcur = c->wcur;
   A.FA = c->FA; A.nsplit = c->nsplit; A.hasH = c->hasH;
   A.e_last = c->e_last; A.f_last = c->f_last; A.done_count = c->done_count;
+  A.hist_lds = 0;
   return A;
 }
 static void launch_chain_args(trx2_ctx* c, int B, const ChainArgs& A);
@@ -763,10 +786,17 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
       pool_args(ca);
       if (has_cart) {
         // fused launch: workgroups of 256 (512 for 256 < L <= 512) threads, one residue per thread in the Cartesian role
-        const CartArgs cc = cart_args(ctx, B, nruns, max_evals);
+        CartArgs cc = cart_args(ctx, B, nruns, max_evals);
         const dim3 g2(2 * B), b1(CHAIN_THREADS), b2(2 * CHAIN_THREADS);
-        if (L <= 128) hipLaunchKernelGGL((k_step<1, 128, 128>), g2, dim3(128), HIST_LDS_BYTES(128), ctx->stream, ca, cc);
-        else if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS>), g2, b1, HIST_LDS_BYTES(CHAIN_THREADS), ctx->stream, ca, cc);
+        // dynamic LDS of the launch: the larger of the two roles' staged histories
+        const int k = L <= 128 ? 0 : 1;
+        size_t dyn = k == 0 ? HIST_LDS_BYTES(128) : HIST_LDS_BYTES(CHAIN_THREADS);
+        if (L <= CHAIN_THREADS) {
+          cc.hist_lds = (int)std::min<size_t>(LBM, (size_t)ctx->step_dyn_max[k] / CART_HIST_BYTES(L));
+          dyn = std::max(dyn, cc.hist_lds * CART_HIST_BYTES(L));
+        }
+        if (L <= 128) hipLaunchKernelGGL((k_step<1, 128, 128>), g2, dim3(128), dyn, ctx->stream, ca, cc);
+        else if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS>), g2, b1, dyn, ctx->stream, ca, cc);
         else hipLaunchKernelGGL((k_step<2, CHAIN_THREADS, 2 * CHAIN_THREADS>), g2, b2, 0, ctx->stream, ca, cc);
       } else
         launch_chain_args(ctx, B, ca);
