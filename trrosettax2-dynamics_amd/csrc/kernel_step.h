@@ -202,6 +202,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   int* gi = A.st_i + (size_t)dec * SI_N;
   double* gd_ = A.st_d + (size_t)dec * SD_N;
   CSTAMP_DECL
+  // Everything the role test needs is requested at once: the decoy's state, the evaluation counter and the protocol table
+  // (into LDS: which run applies is known only when the state has arrived, and reading the run from global memory then was a
+  // second dependent round trip, the counter a third).
+  __shared__ int s_runs[TRX2_MAX_RUNS * (sizeof(trx2_run) / 4)];
+  const int seq = (A.mode == MODE_STEP) ? *A.seq_ctr : -1;
+  for (int i = tid; i < A.nruns * (int)(sizeof(trx2_run) / 4); i += NT) s_runs[i] = reinterpret_cast<const int*>(A.runs)[i];
   if (tid < SI_N && tid >= 2) s_i[tid] = gi[tid];
   if (tid == 0) {  // (run, seq) in ONE 8-byte load
     const unsigned long long rs = *reinterpret_cast<const volatile unsigned long long*>(gi);
@@ -210,12 +216,16 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   if (tid < SD_N) s_d[tid] = gd_[tid];
   if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
   bsync<NW>();
+  const trx2_run* runs_l = reinterpret_cast<const trx2_run*>(s_runs);
   int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
   if (A.mode == MODE_STEP && phase == PH_DONE) return;
-  const int seq = (A.mode == MODE_STEP) ? *A.seq_ctr : -1;
   // the Cartesian role's turn -- except for the report, which is a torsion-space evaluation whatever the last run was
-  if (A.mode == MODE_STEP && (s_i[SI_SEQ] == seq || (phase != PH_REPORT && A.runs[min(run, A.nruns - 1)].cartesian))) return;
+  if (A.mode == MODE_STEP && (s_i[SI_SEQ] == seq || (phase != PH_REPORT && runs_l[min(run, A.nruns - 1)].cartesian))) return;
   bool fresh_geom = false;  // a refilled slot starts from ideal bond geometry: use it without reading it back
+  // internal geometry of residues 0, r and r + 1 for the NeRF pass, requested when the two-loop recursion starts (its ~5000
+  // cycles cover the round trip; the recursion itself reads LDS only)
+  float4 gpre[5];
+  bool gpre_ok = false;
 
   const size_t vb = (size_t)dec * L;  // base of this decoy's [L] vectors
   float4 xt[RPT], gt[RPT];
@@ -235,7 +245,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
 
   if (A.mode != MODE_INIT) {
     // ------------------------------------------------------------------ consume the evaluation at XT
-    const trx2_run R = A.runs[min(run, A.nruns - 1)];
+    const trx2_run R = runs_l[min(run, A.nruns - 1)];
     // accepted point, its gradient and the direction: needed only by the state machine below, loaded here so that their
     // latency overlaps the slab loads and the gradient assembly
     float4 x[RPT], g[RPT], dv[RPT];
@@ -357,14 +367,20 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
     }
     CSTAMP(2)  // suffix scan + torsion gradient
     // The nine terms are needed by the report, by the INIT / FINISH passes and by the guard of a pre-checked run; a plain
-    // minimiser step needs their weighted total only: ONE f64 workgroup sum instead of nine.
-    const bool all_terms = A.mode != MODE_STEP || phase == PH_REPORT || (phase == PH_START && R.precheck);
+    // minimiser step needs their weighted total only: ONE f64 workgroup sum instead of nine.  One residue per thread only:
+    // with RPT = 2 inside the fused kernel (k_step<2, 256, 512>, L = 400) the one-sum build never accepted a step
+    // (tools/debug_l400.py: 0 iterations in 60 evaluations) while the same source is right in k_chain<2, 256>, with RPT = 1,
+    // and in the fused kernel as soon as esum[] lives in scratch memory -- register-allocation dependent, not understood;
+    // tests/test_gpu_configs.py (configuration 4) guards it.
+    const bool all_terms = RPT > 1 || A.mode != MODE_STEP || phase == PH_REPORT || (phase == PH_START && R.precheck);
     double f_t;
     if (all_terms) {
       block_sum_n<9, NW>(esum, s_buf, flip);
       f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] +
             (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[7] * esum[8];
-      if (tid < TRX2_NTERMS) A.e_last[(size_t)dec * TRX2_NTERMS + tid] = esum[tid];
+      if (tid == 0)  // one lane, constant indices: indexing the register array with the thread id moved it to scratch memory
+#pragma unroll
+        for (int k = 0; k < TRX2_NTERMS; k++) A.e_last[(size_t)dec * TRX2_NTERMS + k] = esum[k];
     } else {
       double ft1[1] = {(double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] +
                        (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[7] * esum[8]};
@@ -386,7 +402,9 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
           xo[0] = xp[0]; xo[1] = xp[1]; xo[2] = xp[2]; xo[3] = xp[3];
         }
       }
-      if (tid < TRX2_NTERMS) A.out_e[(size_t)id * TRX2_NTERMS + tid] = esum[tid];
+      if (tid == 0)
+#pragma unroll
+        for (int k = 0; k < TRX2_NTERMS; k++) A.out_e[(size_t)id * TRX2_NTERMS + k] = esum[k];
       __shared__ int s_new;
       if (tid == 0) {
         A.out_f[id] = f_t;
@@ -530,7 +548,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         float4 q[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; k++) q[k] = g[k];
-        if (HIST_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged history has landed (long ago)
+        if (HIST_LDS) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged history has landed (long ago)
+          const float4* gq0 = A.geom + vb * 3;
+          const int rq = min(tid, L - 1), rn = min(tid + 1, L - 1);
+          gpre[0] = gq0[0]; gpre[1] = gq0[rq * 3]; gpre[2] = gq0[rq * 3 + 1]; gpre[3] = gq0[rq * 3 + 2]; gpre[4] = gq0[rn * 3];
+          gpre_ok = true;
+        }
         auto load_pair = [&](int j, float4 (&s_)[RPT], float4 (&y_)[RPT]) {
           if (HIST_LDS) {
             const float4 z = make_float4(0, 0, 0, 0), sv = s_hist[(j * 2 + 0) * NT + tid], yv = s_hist[(j * 2 + 1) * NT + tid];
@@ -657,7 +681,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
 next_pair:
   // ------------------------------------------------------------------ weights for the next pair launch
   if (tid == 0) {
-    const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
+    const trx2_run Rn = runs_l[min(run, A.nruns - 1)];
     float* w = A.wcur + (size_t)dec * 8;
     w[0] = Rn.w[0]; w[1] = Rn.w[1]; w[2] = Rn.w[2]; w[3] = Rn.w[3];
     w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi;
@@ -676,7 +700,7 @@ next_pair:
   const ResGeom g_ideal = ideal_geom();
   Xf carry;  // F_0: N at the origin, CA on +x, C in the xy plane (same start as the oracle)
   {
-    const float4 q0 = fresh_geom ? g_ideal.g0 : gq[0];
+    const float4 q0 = fresh_geom ? g_ideal.g0 : (RPT == 1 && gpre_ok) ? gpre[0] : gq[0];
     float sa, ca;
     fast_sincosf(q0.w, &sa, &ca);
     carry = xf_from_atoms(mk3(0, 0, 0), mk3(q0.x, 0, 0), mk3(q0.x - q0.y * ca, q0.y * sa, 0));
@@ -688,10 +712,11 @@ next_pair:
     ResGeom gr = ideal_geom();
     f3 lN = mk3(0, 0, 0), lCA = lN, lC = lN, lCB = lN, lNn = lN, lCAn = lN;
     if (r < L) {
-      if (!fresh_geom) { gr.g0 = gq[r * 3]; gr.g1 = gq[r * 3 + 1]; gr.g2 = gq[r * 3 + 2]; }
+      if (RPT == 1 && gpre_ok && !fresh_geom) { gr.g0 = gpre[1]; gr.g1 = gpre[2]; gr.g2 = gpre[3]; }
+      else if (!fresh_geom) { gr.g0 = gq[r * 3]; gr.g1 = gq[r * 3 + 1]; gr.g2 = gq[r * 3 + 2]; }
       local_atoms(gr, lN, lCA, lC, lCB);
       if (r + 1 < L) {
-        const float4 n0 = fresh_geom ? g_ideal.g0 : gq[(r + 1) * 3];  // next residue: |N-CA|, |CA-C|, angle N-CA-C
+        const float4 n0 = fresh_geom ? g_ideal.g0 : (RPT == 1 && gpre_ok) ? gpre[4] : gq[(r + 1) * 3];  // next residue: |N-CA|, |CA-C|, angle N-CA-C
         float spsi, cpsi, so, co, sp, cp, s1, c1, s2, c2, s3, c3;
         fast_sincosf(xt[k].y, &spsi, &cpsi);
         fast_sincosf(xt[k].z, &so, &co);
@@ -844,6 +869,9 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   int* gi = A.st_i + (size_t)dec * SI_N;
   double* gd_ = A.st_d + (size_t)dec * SD_N;
   KSTAMP_DECL
+  __shared__ int s_runs[TRX2_MAX_RUNS * (sizeof(trx2_run) / 4)];  // as in the torsion role: state, counter and protocol table at once
+  const int seq = *A.seq_ctr;
+  for (int i = tid; i < A.nruns * (int)(sizeof(trx2_run) / 4); i += NT) s_runs[i] = reinterpret_cast<const int*>(A.runs)[i];
   if (tid < SI_N && tid >= 2) s_i[tid] = gi[tid];
   if (tid == 0) {  // (run, seq) in ONE 8-byte load
     const unsigned long long rs = *reinterpret_cast<const volatile unsigned long long*>(gi);
@@ -852,10 +880,10 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   if (tid < SD_N) s_d[tid] = gd_[tid];
   if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
   __syncthreads();
+  const trx2_run* runs_l = reinterpret_cast<const trx2_run*>(s_runs);
   int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
-  const int seq = *A.seq_ctr;
   if (phase == PH_DONE || phase == PH_REPORT || s_i[SI_SEQ] == seq) return;  // the report is the torsion role's
-  const trx2_run R = A.runs[min(run, A.nruns - 1)];
+  const trx2_run R = runs_l[min(run, A.nruns - 1)];
   if (!R.cartesian) return;
   const size_t vb = (size_t)dec * L;
   // The stored pairs, newest first, requested into LDS now and read by the two-loop a phase later (as the torsion role does):
@@ -1318,7 +1346,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
     *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
     gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
     gd_[SD_GAMMA] = gamma_h;
-    const trx2_run Rn = A.runs[min(run, A.nruns - 1)];
+    const trx2_run Rn = runs_l[min(run, A.nruns - 1)];
     float* w = A.wcur + (size_t)dec * 8;
     w[0] = Rn.w[0]; w[1] = Rn.w[1]; w[2] = Rn.w[2]; w[3] = Rn.w[3];
     w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi; w[6] = Rn.pair_filter ? 2.0f : 1.0f; w[7] = Rn.w[7];
