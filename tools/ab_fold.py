@@ -18,6 +18,6 @@ for name, lanes, pool in (("2x32", 2, 32), ("1x64", 1, 64), ("2x64", 2, 64)):
     for i in range(R):
         t0 = time.perf_counter(); r = ctx.fold_batch(K * B, runs, seed=150, decoy0=0); v.append(K * B / (time.perf_counter() - t0))
         assert np.all(r["status"] == 0)
-    out.append(f"{name}: best {max(v):6.1f} median {np.median(v):6.1f}")
+    out.append(f"{name}: best {max(v):6.1f} median {np.median(v):6.1f} ({r['launches']} launches, {r['n_evals'].mean():.0f} evals/decoy, {r['n_iters'].mean():.0f} iters)")
 print(" | ".join(out), "decoys/s")
 ctx.close()

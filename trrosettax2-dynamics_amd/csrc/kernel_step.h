@@ -26,6 +26,7 @@ struct ChainArgs {
   int* st_i;       // [B][SI_N]
   double* st_d;    // [B][SD_N]
   float* rho;      // [B][LBM]
+  double* gram;    // [B][GR_N] scalars of the Gram form of the recursion (chains of one residue per thread)
   float4 *X, *G, *D, *XT;  // [B][L] (phi, psi, omega, -)
   float4 *S, *Y;           // [B][LBM][L]
   float4* P;               // [B][L][5] trial coordinates, decoy-major: N CA C O CB (15 floats + pad) | backbone H, hasH
@@ -164,6 +165,121 @@ extern __shared__ float4 s_hist[];
 __device__ __forceinline__ void lds_dma16(const float4* src /* per lane */, float4* dst_wave /* wave-uniform: lane i lands at dst + i */) {
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst_wave, 16, 0, 0);
 }
+// ---- The two-loop recursion from Gram matrices ("vector-free" L-BFGS, Chen et al. 2014), chains of one residue per thread.
+// The recursion is 2 x LBM DEPENDENT rounds of { dot with a stored vector, workgroup sum, axpy }: ~400 ns each, 6.5 us of an
+// 18 us step (launch-length histogram of single-decoy folds, profiles/README.md) however cheap the sum itself is made.  But
+// every dot product in it is a combination of the scalars s_i.y_j, y_i.y_j, s_i.g and y_i.g:
+//   s_k . q      = s_k.g - sum_{m newer than k} alpha_m s_k.y_m                         (first loop)
+//   y_k . r      = gamma (y_k.g - sum_m alpha_m y_k.y_m) + sum_{m older than k} c_m s_m.y_k      (second loop, c = alpha - beta)
+//   direction    = -(gamma g - gamma sum_m alpha_m y_m + sum_m c_m s_m),  g.d from the same scalars.
+// So the decoy keeps those scalars (GR_N doubles, pairs in AGE order, 0 = newest); an accepted step costs ONE fused
+// workgroup reduction of the GV_N products that involve the new pair and the new gradient, a shift of the matrices, the
+// recurrences in registers (every thread, ~250 f64 operations, no barrier) and one pass over the stored vectors.  s_i.g and
+// y_i.g follow the gradient by g_new = g_old + y_new (a stored pair lives LBM steps: at most LBM - 1 such updates).
+#define GR_SY 0                         /* [LBM][LBM] s_i . y_j */
+#define GR_YY (LBM * LBM)               /* [LBM][LBM] y_i . y_j */
+#define GR_SG (2 * LBM * LBM)           /* [LBM] s_i . g        */
+#define GR_YG (2 * LBM * LBM + LBM)     /* [LBM] y_i . g        */
+#define GR_N (2 * LBM * LBM + 2 * LBM)
+// products of one accepted step (s, y = the new pair, g = the new gradient, k = the stored pairs by age BEFORE the step)
+enum { GV_A = 0 /* s_k.y [LBM] */, GV_B = LBM /* y_k.y [LBM] */, GV_C = 2 * LBM /* s.y_k [LBM-1] */, GV_SY = 3 * LBM - 1, GV_SS, GV_YY, GV_SG /* s.g */,
+       GV_YG /* y.g */, GV_GG /* g.g */, GV_N };
+static_assert(LBM == 8, "the Gram recursion below is written for 8 stored pairs (thread <-> matrix entry maps, 128 + 16 threads)");
+template <int NT>
+struct GramLds {
+  double gram[GR_N];
+  double out[GV_N + 1];
+  float part[GV_N * (NT / 16)];
+};
+// Workgroup sums of GV_N per-thread products: f32 butterfly inside each row of 16 lanes (one DPP-fused add per stage), the
+// NT / 16 row sums of a value added in f64 in a fixed order by one thread.  (One f64 DPP sum per value, as block_sum_n does
+// it, is ~150 cycles each: 4000 cycles for this set.)
+template <int NT>
+__device__ __forceinline__ void gram_reduce(float (&pv)[GV_N], GramLds<NT>& gl) {
+  constexpr int ROWS = NT / 16;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < GV_N; k++) {
+    float v = pv[k];
+    v += dpp_move<0xB1>(v); v += dpp_move<0x4E>(v); v += dpp_move<0x141>(v); v += dpp_move<0x140>(v);
+    pv[k] = v;
+  }
+  if ((tid & 15) == 0)
+#pragma unroll
+    for (int k = 0; k < GV_N; k++) gl.part[k * ROWS + (tid >> 4)] = pv[k];
+  __syncthreads();
+  if (tid < GV_N) {
+    double a = 0;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) a += (double)gl.part[tid * ROWS + r];
+    gl.out[tid] = a;
+  }
+  __syncthreads();
+}
+// After gram_reduce: the decoy's scalars follow the step.  `stored`: the pair (s, y) becomes pair 0, every older pair moves
+// one place (the oldest drops out); otherwise only the gradient changed.  old0 = this thread's matrix entry before the step
+// (entry tid of gram[], tid < 2 LBM^2), old1 = entry 2 LBM^2 + tid (tid < 2 LBM).  Ends with a barrier.
+template <int NT>
+__device__ __forceinline__ void gram_advance(GramLds<NT>& gl, bool stored, double old0, double old1) {
+  const int tid = threadIdx.x;
+  const double* o = gl.out;
+  if (stored) {
+    if (tid < 2 * LBM * LBM) {
+      const int i = (tid >> 3) & 7, j = tid & 7;
+      if (i < LBM - 1 && j < LBM - 1) gl.gram[tid + LBM + 1] = old0;  // [i][j] -> [i+1][j+1]
+    }
+    if (tid < LBM) gl.gram[GR_SY + tid] = tid == 0 ? o[GV_SY] : o[GV_C + tid - 1];                       // s_0 . y_j
+    else if (tid < 2 * LBM) { if (tid > LBM) gl.gram[GR_SY + (tid - LBM) * LBM] = o[GV_A + tid - LBM - 1]; }  // s_i . y_0
+    else if (tid < 3 * LBM) gl.gram[GR_YY + tid - 2 * LBM] = tid == 2 * LBM ? o[GV_YY] : o[GV_B + tid - 2 * LBM - 1];
+    else if (tid < 4 * LBM) { if (tid > 3 * LBM) gl.gram[GR_YY + (tid - 3 * LBM) * LBM] = o[GV_B + tid - 3 * LBM - 1]; }
+    if (tid < LBM - 1) gl.gram[GR_SG + tid + 1] = old1 + o[GV_A + tid];
+    else if (tid >= LBM && tid < 2 * LBM - 1) gl.gram[GR_YG + tid - LBM + 1] = old1 + o[GV_B + tid - LBM];
+    if (tid == 2 * LBM - 1) { gl.gram[GR_SG] = o[GV_SG]; gl.gram[GR_YG] = o[GV_YG]; }
+  } else {
+    if (tid < LBM) gl.gram[GR_SG + tid] = old1 + o[GV_A + tid];
+    else if (tid < 2 * LBM) gl.gram[GR_YG + tid - LBM] = old1 + o[GV_B + tid - LBM];
+  }
+  __syncthreads();
+}
+// The recurrences: n stored pairs (age order), gamma, g.g -> alpha_m (times gamma, sign folded: coefficient of y_m) and c_m
+// (coefficient of s_m) of r = gamma g + sum cy_m y_m + sum cs_m s_m, and g.r.  Entries of pairs >= n are never multiplied
+// by anything but zero (and are kept finite: zeroed whenever the history restarts).
+__device__ __forceinline__ void gram_recursion(const double* G, int n, double gam, double gg, float (&cy)[LBM], float (&cs)[LBM], double& g_r) {
+  double al[LBM], c[LBM], t[LBM], rho[LBM];
+#pragma unroll
+  for (int k = 0; k < LBM; k++) {
+    const double d = G[GR_SY + k * (LBM + 1)];
+    double r = __builtin_amdgcn_rcp(d);  // 1 / s_k.y_k: hardware estimate + two Newton steps (a division is ~30 instructions)
+    r = fma(fma(-d, r, 1.0), r, r); r = fma(fma(-d, r, 1.0), r, r);
+    rho[k] = k < n ? r : 0.0;
+    double a = G[GR_SG + k];
+#pragma unroll
+    for (int m = 0; m < k; m++) a -= al[m] * G[GR_SY + k * LBM + m];
+    al[k] = k < n ? rho[k] * a : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < LBM; k++) t[k] = G[GR_YG + k];
+#pragma unroll
+  for (int k = 0; k < LBM; k++) {  // y_k.y_m is symmetric: one read serves (k, m) and (m, k)
+    t[k] -= al[k] * G[GR_YY + k * (LBM + 1)];
+#pragma unroll
+    for (int m = k + 1; m < LBM; m++) { const double v = G[GR_YY + k * LBM + m]; t[k] -= al[m] * v; t[m] -= al[k] * v; }
+  }
+#pragma unroll
+  for (int k = LBM - 1; k >= 0; k--) {
+    double yr = gam * t[k];
+#pragma unroll
+    for (int m = k + 1; m < LBM; m++) yr += c[m] * G[GR_SY + m * LBM + k];
+    c[k] = k < n ? al[k] - rho[k] * yr : 0.0;
+  }
+  double a = gam * gg;
+#pragma unroll
+  for (int m = 0; m < LBM; m++) {
+    a += c[m] * G[GR_SG + m] - gam * al[m] * G[GR_YG + m];
+    cy[m] = (float)(-gam * al[m]); cs[m] = (float)c[m];
+  }
+  g_r = a;
+}
 // random start torsions: set_random_dihedral (utils_ros.py:656-696) with explicit (seed, decoy, residue) hashing
 __device__ __forceinline__ uint64_t splitmix64_dev(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -186,8 +302,11 @@ __device__ __forceinline__ float4 start_torsions(int L, uint64_t seed, uint32_t 
 // L = 150) makes every reduction and scan barrier-free but was SLOWER on MI355X (73.7 vs 61.2 us per evaluation,
 // profiles/README.md): the step is bound by the per-thread chain of dependent arithmetic and loads, which RPT multiplies,
 // not by its ~25 barriers.
+// LDS both roles of a step kernel use, declared once per kernel: the protocol table and the Gram scalars (GN = the workgroup
+// width of the one-residue-per-thread instantiations, 16 = a stub where the recursion keeps its two-loop form)
+#define STEP_RUNS_INTS (TRX2_MAX_RUNS * (int)(sizeof(trx2_run) / 4))
 template <int RPT, int NT>
-__device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
+__device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, int* s_runs, GramLds<(RPT == 1) ? NT : 16>& s_gl) {
   constexpr int NW = NT / 64;
   const int L = A.L, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ double s_buf[2 * NW * SBUF_K];
@@ -205,7 +324,6 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   // Everything the role test needs is requested at once: the decoy's state, the evaluation counter and the protocol table
   // (into LDS: which run applies is known only when the state has arrived, and reading the run from global memory then was a
   // second dependent round trip, the counter a third).
-  __shared__ int s_runs[TRX2_MAX_RUNS * (sizeof(trx2_run) / 4)];
   const int seq = (A.mode == MODE_STEP) ? *A.seq_ctr : -1;
   for (int i = tid; i < A.nruns * (int)(sizeof(trx2_run) / 4); i += NT) s_runs[i] = reinterpret_cast<const int*>(A.runs)[i];
   if (tid < SI_N && tid >= 2) s_i[tid] = gi[tid];
@@ -215,6 +333,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   }
   if (tid < SD_N) s_d[tid] = gd_[tid];
   if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
+  constexpr bool HIST_LDS = (RPT == 1);  // one residue per thread: history staged in LDS, recursion in its Gram form
+  double gr_old0 = 0, gr_old1 = 0;  // this thread's entries of the decoy's Gram scalars as the step finds them
+  if (HIST_LDS && A.mode == MODE_STEP) {
+    if (tid < 2 * LBM * LBM) { gr_old0 = A.gram[(size_t)dec * GR_N + tid]; s_gl.gram[tid] = gr_old0; }
+    if (tid < 2 * LBM) { gr_old1 = A.gram[(size_t)dec * GR_N + 2 * LBM * LBM + tid]; s_gl.gram[2 * LBM * LBM + tid] = gr_old1; }
+  }
+  bool gram_dirty = false;
   bsync<NW>();
   const trx2_run* runs_l = reinterpret_cast<const trx2_run*>(s_runs);
   int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
@@ -230,7 +355,6 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
   const size_t vb = (size_t)dec * L;  // base of this decoy's [L] vectors
   float4 xt[RPT], gt[RPT];
   bool need_nerf = true;
-  constexpr bool HIST_LDS = (RPT == 1);
   if (HIST_LDS && A.mode == MODE_STEP) {
     // the hl stored pairs, newest first; lanes beyond L copy the last residue (no branch around the load), never used
     const int hl0 = s_i[SI_HL], hh0 = s_i[SI_HH], rc = min(tid, L - 1);
@@ -490,10 +614,37 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
         for (int k = 0; k < RPT; k++) {
           s[k] = make_float4(xt[k].x - x[k].x, xt[k].y - x[k].y, xt[k].z - x[k].z, 0);
           y[k] = make_float4(gt[k].x - g[k].x, gt[k].y - g[k].y, gt[k].z - g[k].z, 0);
-          v3[0] += (double)dot3(s[k], y[k]); v3[1] += (double)dot3(s[k], s[k]); v3[2] += (double)dot3(y[k], y[k]);
         }
-        block_sum_n<3, NW>(v3, s_buf, flip);
-        if (v3[0] > 1e-12 * sqrt(v3[1] * v3[2])) {
+        if constexpr (HIST_LDS) {
+          // every product of the new pair and the new gradient with the stored pairs (age order), one fused reduction
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged history has landed (long ago)
+          float pv[GV_N];
+          {
+            // all 2 LBM reads issued together (a slot that holds no pair is read and discarded: one wait instead of LBM)
+            float4 so[LBM], yo[LBM];
+#pragma unroll
+            for (int k = 0; k < LBM; k++) {
+              const int j = (hh - 1 - k + LBM) % LBM;
+              so[k] = s_hist[(j * 2 + 0) * NT + tid]; yo[k] = s_hist[(j * 2 + 1) * NT + tid];
+            }
+#pragma unroll
+            for (int k = 0; k < LBM; k++) {
+              const bool on = k < hl && tid < L;
+              pv[GV_A + k] = on ? dot3(so[k], y[0]) : 0.0f; pv[GV_B + k] = on ? dot3(yo[k], y[0]) : 0.0f;
+              if (k < LBM - 1) pv[GV_C + k] = on ? dot3(s[0], yo[k]) : 0.0f;
+            }
+          }
+          pv[GV_SY] = dot3(s[0], y[0]); pv[GV_SS] = dot3(s[0], s[0]); pv[GV_YY] = dot3(y[0], y[0]);
+          pv[GV_SG] = dot3(s[0], gt[0]); pv[GV_YG] = dot3(y[0], gt[0]); pv[GV_GG] = dot3(gt[0], gt[0]);
+          gram_reduce<HIST_LDS ? NT : 16>(pv, s_gl);
+          v3[0] = s_gl.out[GV_SY]; v3[1] = s_gl.out[GV_SS]; v3[2] = s_gl.out[GV_YY];
+        } else {
+#pragma unroll
+          for (int k = 0; k < RPT; k++) { v3[0] += (double)dot3(s[k], y[k]); v3[1] += (double)dot3(s[k], s[k]); v3[2] += (double)dot3(y[k], y[k]); }
+          block_sum_n<3, NW>(v3, s_buf, flip);
+        }
+        const bool store = v3[0] > 1e-12 * sqrt(v3[1] * v3[2]);
+        if (store) {
 #pragma unroll
           for (int k = 0; k < RPT; k++) {
             const int r = k * NT + tid;
@@ -502,17 +653,21 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
               A.Y[((size_t)dec * LBM + hh) * L + r] = y[k];
             }
           }
-          if (HIST_LDS) {  // slot hh of the staged copy: its DMA (the oldest pair) must have landed before it is replaced
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (HIST_LDS) {  // slot hh of the staged copy (the oldest pair: its products are taken)
             s_hist[(hh * 2 + 0) * NT + tid] = s[0];
             s_hist[(hh * 2 + 1) * NT + tid] = y[0];
+          } else {
+            bsync<NW>();
+            if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
           }
-          bsync<NW>();
-          if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
           gamma_h = v3[0] / v3[2];
-          bsync<NW>();
+          if (!HIST_LDS) bsync<NW>();
           hh = (hh + 1) % LBM;
           if (hl < LBM) hl++;
+        }
+        if constexpr (HIST_LDS) {
+          gram_advance<HIST_LDS ? NT : 16>(s_gl, store, gr_old0, gr_old1);  // ends with a barrier: the LDS copy of the pair is visible too
+          gram_dirty = true;
         }
         const double fprev = f;
 #pragma unroll
@@ -544,17 +699,40 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       // LDS read of rho, the axpy), not by the loads or the barriers.
       double v2[2] = {0, 0};
       auto pair_at = [&](int kk) { return (hh - 1 - kk + LBM) % LBM; };
+      if constexpr (HIST_LDS) {
+        // internal geometry for the NeRF pass: requested here, used after the direction is built
+        const float4* gq0 = A.geom + vb * 3;
+        const int rq = min(tid, L - 1), rn = min(tid + 1, L - 1);
+        gpre[0] = gq0[0]; gpre[1] = gq0[rq * 3]; gpre[2] = gq0[rq * 3 + 1]; gpre[3] = gq0[rq * 3 + 2]; gpre[4] = gq0[rn * 3];
+        gpre_ok = true;
+        float cy[LBM], cs[LBM];
+        double g_r;
+        gram_recursion(s_gl.gram, hl, gamma_h, s_gl.out[GV_GG], cy, cs, g_r);
+        CSTAMP(5)  // recurrences on the Gram scalars
+        const float gam = (float)gamma_h;
+        float4 q = make_float4(gam * g[0].x, gam * g[0].y, gam * g[0].z, 0);
+        {
+          float4 sm[LBM], ym[LBM];
+#pragma unroll
+          for (int m = 0; m < LBM; m++) {
+            const int j = pair_at(m);
+            sm[m] = s_hist[(j * 2 + 0) * NT + tid]; ym[m] = s_hist[(j * 2 + 1) * NT + tid];
+          }
+#pragma unroll
+          for (int m = 0; m < LBM; m++) {
+            const float a = m < hl ? cs[m] : 0.0f, b = m < hl ? cy[m] : 0.0f;
+            const float4 z = make_float4(0, 0, 0, 0), s_ = m < hl ? sm[m] : z, y_ = m < hl ? ym[m] : z;  // an unused slot may hold anything
+            q.x = fmaf(b, y_.x, fmaf(a, s_.x, q.x)); q.y = fmaf(b, y_.y, fmaf(a, s_.y, q.y)); q.z = fmaf(b, y_.z, fmaf(a, s_.z, q.z));
+          }
+        }
+        dv[0] = tid < L ? make_float4(-q.x, -q.y, -q.z, 0) : make_float4(0, 0, 0, 0);
+        v2[0] = -g_r; v2[1] = s_gl.out[GV_GG];
+        CSTAMP(7)  // direction from the stored vectors
+      } else
       {
         float4 q[RPT];
 #pragma unroll
         for (int k = 0; k < RPT; k++) q[k] = g[k];
-        if (HIST_LDS) {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged history has landed (long ago)
-          const float4* gq0 = A.geom + vb * 3;
-          const int rq = min(tid, L - 1), rn = min(tid + 1, L - 1);
-          gpre[0] = gq0[0]; gpre[1] = gq0[rq * 3]; gpre[2] = gq0[rq * 3 + 1]; gpre[3] = gq0[rq * 3 + 2]; gpre[4] = gq0[rn * 3];
-          gpre_ok = true;
-        }
         auto load_pair = [&](int j, float4 (&s_)[RPT], float4 (&y_)[RPT]) {
           if (HIST_LDS) {
             const float4 z = make_float4(0, 0, 0, 0), sv = s_hist[(j * 2 + 0) * NT + tid], yv = s_hist[(j * 2 + 1) * NT + tid];
@@ -661,6 +839,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec) {
       if (r < L) { A.X[vb + r] = x[k]; A.G[vb + r] = g[k]; A.D[vb + r] = dv[k]; A.XT[vb + r] = xt[k]; }
     }
     bsync<NW>();
+    if (HIST_LDS && A.mode == MODE_STEP && (gram_dirty || hl == 0)) {
+      // the Gram scalars follow the history; a restarted history starts from zeros (entries of absent pairs are only ever
+      // multiplied by zero coefficients, so they must stay finite)
+      const bool z = hl == 0;
+      if (tid < 2 * LBM * LBM) A.gram[(size_t)dec * GR_N + tid] = z ? 0.0 : s_gl.gram[tid];
+      if (tid < 2 * LBM) A.gram[(size_t)dec * GR_N + 2 * LBM * LBM + tid] = z ? 0.0 : s_gl.gram[2 * LBM * LBM + tid];
+    }
     if (tid == 0) {
       gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
       gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
@@ -808,7 +993,7 @@ struct CartArgs {
   int L, B, nruns, max_evals;
   const int* seq_ctr;
   const trx2_run* runs;
-  int* st_i; double* st_d; float* rho;
+  int* st_i; double* st_d; float* rho; double* gram;
   float4 *CX, *CG, *CD;      // [B][L][4] accepted point, its gradient, direction
   float4 *CS, *CY;           // [B][LBM][4][L]: stored pairs, component-major so that a wave reads 1 KB in one piece
   int hist_lds;              // stored pairs the launch has dynamic LDS for in this role (CART_HIST_BYTES each); 0: none
@@ -853,7 +1038,7 @@ __device__ __forceinline__ LinkGrad link_terms(const Res5& P, const Res5& Q) {
 }
 
 template <int NT>
-__device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
+__device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int* s_runs, GramLds<(NT <= 256) ? NT : 16>& s_gl) {
   constexpr int NW = NT / 64;  // one residue per thread: NT = 256 for chains up to 256 residues, 512 up to 512
   const int L = A.L, tid = threadIdx.x, r = tid;
   const bool act = r < L;
@@ -869,7 +1054,6 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
   int* gi = A.st_i + (size_t)dec * SI_N;
   double* gd_ = A.st_d + (size_t)dec * SD_N;
   KSTAMP_DECL
-  __shared__ int s_runs[TRX2_MAX_RUNS * (sizeof(trx2_run) / 4)];  // as in the torsion role: state, counter and protocol table at once
   const int seq = *A.seq_ctr;
   for (int i = tid; i < A.nruns * (int)(sizeof(trx2_run) / 4); i += NT) s_runs[i] = reinterpret_cast<const int*>(A.runs)[i];
   if (tid < SI_N && tid >= 2) s_i[tid] = gi[tid];
@@ -1361,12 +1545,19 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec) {
 // run concurrently instead of as two half-empty launches back to back (k_cart alone was 22-27 % of GPU time).
 // The torsion role runs on TN threads, RPT residues each.
 template <int RPT, int TN>
-__global__ __launch_bounds__(TN) void k_chain(ChainArgs A) { chain_body<RPT, TN>(A, blockIdx.x); }
+__global__ __launch_bounds__(TN) void k_chain(ChainArgs A) {
+  __shared__ int s_runs[STEP_RUNS_INTS];
+  __shared__ GramLds<(RPT == 1) ? TN : 16> s_gl;
+  chain_body<RPT, TN>(A, blockIdx.x, s_runs, s_gl);
+}
 template <int RPT, int TN, int NT>
 __global__ __launch_bounds__(NT) void k_step(ChainArgs A, CartArgs C) {
+  static_assert(((RPT == 1) ? TN : 16) == ((NT <= 256) ? NT : 16), "the two roles share one GramLds");
+  __shared__ int s_runs[STEP_RUNS_INTS];
+  __shared__ GramLds<(RPT == 1) ? TN : 16> s_gl;
   if ((int)blockIdx.x < A.B) {
-    if (NT == TN || threadIdx.x < TN) chain_body<RPT, TN>(A, blockIdx.x);  // the other waves of the workgroup exit at once
-  } else cart_body<NT>(C, (int)blockIdx.x - A.B);
+    if (NT == TN || threadIdx.x < TN) chain_body<RPT, TN>(A, blockIdx.x, s_runs, s_gl);  // the other waves of the workgroup exit at once
+  } else cart_body<NT>(C, (int)blockIdx.x - A.B, s_runs, s_gl);
 }
 
 __global__ void k_init_torsions(int L, int B, uint64_t seed, uint32_t decoy0, const float* tors0, float4* X, float4* XT, float4* geom) {

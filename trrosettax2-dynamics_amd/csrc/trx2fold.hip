@@ -85,7 +85,7 @@ struct trx2_ctx {
   double knots_h[TRX2_KTOT_MAX];
   // batch
   int Bcap = 0, Lcap = 0, BW = 64, Bpad = 0, nsplit = 1, nsplit_cap = 0;
-  int* st_i = nullptr; double* st_d = nullptr; float* rho = nullptr;
+  int* st_i = nullptr; double* st_d = nullptr; float* rho = nullptr; double* gram = nullptr;
   float4 *X = nullptr, *G = nullptr, *D = nullptr, *XT = nullptr, *S = nullptr, *Y = nullptr;
   float4* P = nullptr; float4* xyzT = nullptr; float* wcur = nullptr; float4* geom = nullptr;
   float* FA = nullptr;
@@ -179,9 +179,9 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
       hipFuncAttributes fa;
       ok = hipFuncGetAttributes(&fa, fstep[k]) == hipSuccess;
       if (!ok) break;
-      // ... less what one workgroup of the pair kernel needs (~28 KB): with two lanes the other lane's pair kernel runs beside
+      // ... less what one workgroup of the pair kernel needs (28.0 KB): with two lanes the other lane's pair kernel runs beside
       // this one, and a step workgroup that fills a CU's LDS keeps it off that CU (measured: profiles/README.md)
-      static const int reserve = getenv("TRX2_STEP_LDS_RESERVE") ? atoi(getenv("TRX2_STEP_LDS_RESERVE")) : 32 * 1024;
+      static const int reserve = getenv("TRX2_STEP_LDS_RESERVE") ? atoi(getenv("TRX2_STEP_LDS_RESERVE")) : 30 * 1024;
       int dyn = lds_max - (int)fa.sharedSizeBytes - reserve;
       if (dyn < hist[k]) dyn = hist[k];
       ctx->step_dyn_max[k] = dyn;
@@ -244,11 +244,11 @@ static void free_map(trx2_ctx* c) {
   c->L = 0;
 }
 static void free_batch(trx2_ctx* c) {
-  void* p[] = {c->st_i, c->st_d, c->rho, c->X, c->G, c->D, c->XT, c->S, c->Y, c->P, c->xyzT, c->geom, c->wcur, c->FA,
+  void* p[] = {c->st_i, c->st_d, c->rho, c->gram, c->X, c->G, c->D, c->XT, c->S, c->Y, c->P, c->xyzT, c->geom, c->wcur, c->FA,
                c->e_last, c->f_last, c->grad, c->tors0, c->done_count, c->seq_ctr, c->runs};
   for (void* q : p)
     if (q) (void)hipFree(q);
-  c->st_i = nullptr; c->st_d = nullptr; c->rho = nullptr;
+  c->st_i = nullptr; c->st_d = nullptr; c->rho = nullptr; c->gram = nullptr;
   c->X = c->G = c->D = c->XT = c->S = c->Y = nullptr;
   c->P = nullptr; c->xyzT = nullptr; c->geom = nullptr; c->wcur = nullptr; c->FA = nullptr;
   c->e_last = c->f_last = nullptr; c->grad = nullptr; c->tors0 = nullptr; c->done_count = nullptr; c->seq_ctr = nullptr; c->runs = nullptr;
@@ -563,6 +563,8 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
   HIPCHK(hipMalloc((void**)&ctx->st_i, sizeof(int) * B * SI_N));
   HIPCHK(hipMalloc((void**)&ctx->st_d, sizeof(double) * B * SD_N));
   HIPCHK(hipMalloc((void**)&ctx->rho, sizeof(float) * B * LBM));
+  HIPCHK(hipMalloc((void**)&ctx->gram, sizeof(double) * B * GR_N));
+  HIPCHK(hipMemsetAsync(ctx->gram, 0, sizeof(double) * B * GR_N, ctx->stream));
   HIPCHK(hipMalloc((void**)&ctx->X, sizeof(float4) * BL));
   HIPCHK(hipMalloc((void**)&ctx->G, sizeof(float4) * BL));
   HIPCHK(hipMalloc((void**)&ctx->D, sizeof(float4) * BL));
@@ -604,7 +606,7 @@ static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_eva
   ChainArgs A;
   A.seq_ctr = c->seq_ctr;
   A.L = c->L; A.B = B; A.mode = mode; A.nruns = nruns;
-  A.max_evals = max_evals; A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho;
+  A.max_evals = max_evals; A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho; A.gram = c->gram;
   A.X = c->X; A.G = c->G; A.D = c->D; A.XT = c->XT; A.S = c->S; A.Y = c->Y; A.P = c->P; A.geom = c->geom;
   A.xyzT = c->xyzT; A.BW = c->BW;
   A.wcur = c->wcur; A.FA = c->FA; A.nsplit = c->nsplit; A.hasH = c->hasH;
@@ -630,7 +632,7 @@ static void launch_pair(trx2_ctx* c, int B) {
 static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals) {
   CartArgs A;
   A.L = c->L; A.B = B; A.nruns = nruns; A.max_evals = max_evals; A.seq_ctr = c->seq_ctr;
-  A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho;
+  A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho; A.gram = c->gram;
   A.CX = c->CX; A.CG = c->CG; A.CD = c->CD; A.CS = c->CS; A.CY = c->CY;
   A.P = c->P; A.xyzT = c->xyzT; A.BW = c->BW; A.X = c->X; A.XT = c->XT; A.geom = c->geom; A.wcur = c->wcur;
   A.FA = c->FA; A.nsplit = c->nsplit; A.hasH = c->hasH;
@@ -748,6 +750,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   if (tors0) HIPCHK(hipMemcpyAsync(ctx->tors0_all, tors0, sizeof(float) * NL * 3, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->st_i, 0, sizeof(int) * B * SI_N, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->st_d, 0, sizeof(double) * B * SD_N, ctx->stream));
+  HIPCHK(hipMemsetAsync(ctx->gram, 0, sizeof(double) * B * GR_N, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->done_count, 0, sizeof(int), ctx->stream));
   {
     std::vector<int> ids((size_t)B);
