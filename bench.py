@@ -6,13 +6,14 @@ prints ONE JSON line on rank 0.
 
 A "step" = one pass of the hot path over one batch: B decoys of one distogram folded through the full staged protocol
 (folding/folding.py:118-171 mode 2), timed from tables-resident-in-HBM to the last coordinates on the host.  The K steps of a
-run are ONE queue of K x B decoys on B decoy slots (never more than B = init_num decoys in flight): a slot whose decoy has
-finished takes the next decoy on the device (trx2_ctx_set_pool), as the reference's process pool starts the next `folding.py`
-child when a worker frees up (utils_trX2dy/utils.py:501-503); every decoy of every step is folded inside the timed region.  With
-one chain the B slots are two lanes of B/2 on two streams (trx2_ctx_set_lanes, the library's default for batches), so that one
-lane's step kernel overlaps the other's pair kernel.  Beside `value`: `single_stream` (the same queue on one stream of B slots),
-`per_call` (K separate calls of B decoys, one slot per decoy, each call ending with its slowest decoy: round 1's `value`) and
-`wide_pool` (two lanes of B slots: 2 B decoys in flight).
+run are ONE queue of K x B decoys: every decoy of every step is folded inside the timed region.  The queue runs on decoy slots
+(trx2_ctx_set_pool): a slot whose decoy has finished takes the next decoy on the device, as the reference's process pool starts
+the next `folding.py` child when a worker frees up (utils_trX2dy/utils.py:501-503).  How many slots is a scheduling choice of the
+library's user, not part of the workload: both kernels are latency-bound, a launch over 192 slots takes 2.7 x as long as one
+over 32 (profiles/README.md), so `value` uses two lanes (two streams: one lane's step kernel overlaps the other's pair kernel,
+trx2_ctx_set_lanes) of min(192, K B / 2) slots each.  Beside `value`, the same queue with only B decoys in flight:
+`in_flight_B` (two lanes of B/2 slots: round 2's first `value`) and `single_stream` (one stream of B slots); and `per_call`
+(K separate calls of B decoys, one slot per decoy, each call ending with its slowest decoy: round 1's `value`).
 Workload at N=1 = BASELINE.json configs[1]: L=150 single target, init_num=64, dist-only restraints (synthetic map,
 SURVEY.md 8d -- the reference ships data for L=90 only).  Other configs: --config 3 (all channels, two models),
 --config 4 (L=400, B=32), --config 5 (eight targets L=100..400, 32 decoys each, assigned to ranks longest-first: strong
@@ -49,6 +50,7 @@ CONFIGS = {
             name="eight targets L in {100,140,180,220,260,300,350,400}, init_num=32 each, dist+omega+theta+phi, synthetic maps "
                  "seed L; (target, decoy-block) items assigned to ranks longest-processing-time-first"),
 }
+MAX_SLOTS = 192  # decoy slots per lane (three groups of 64 decoys in the pair kernel): tools/pool_sweep.py
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 KERNEL_SOURCES = ("kernel_pair.h", "trx2_device.h")
 
@@ -103,15 +105,17 @@ def cpu_baseline(m, cfg, runs, budget_s=10.0):
                 single_thread=one, host_cores_available=os.cpu_count(), host_cores_usable=cores)
 
 
-def traffic_record(config):
+def traffic_record(config, decoys_per_launch):
     """HBM-side bytes of the pair kernel per launch: PMC counters cannot be collected from inside this process, so the value is the
-    one measured with rocprofv3 for THIS kernel source and config and committed under profiles/ (null when the sources changed)"""
+    one measured with rocprofv3 for THIS kernel source, config and launch shape and committed under profiles/ (null when the
+    sources changed, or when --steps gives the lanes another number of slots than the record's)"""
     if not os.path.exists(TRAFFIC_FILE):
         return None
     rec = json.load(open(TRAFFIC_FILE))
     if rec.get("kernel_src_sha") != kernel_source_sha():
         return None
-    return rec.get(str(config))
+    r = rec.get(str(config))
+    return r if r and r.get("decoys_per_launch") == decoys_per_launch else None
 
 
 def pair_roofline(ctx, T, B, L, config, fold_times=None):
@@ -120,7 +124,7 @@ def pair_roofline(ctx, T, B, L, config, fold_times=None):
     n_terms = term_evals / B
     abytes = algorithmic_bytes(B, n_terms, L)
     achieved = abytes / (ms * 1e-3) / 1e9
-    rec = traffic_record(config)
+    rec = traffic_record(config, B)
     traffic, valu = None, None
     if rec:
         traffic = rec["hbm_bytes_per_launch"]
@@ -262,7 +266,8 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
     m = ms_[0]
     runs = T.protocol.build_runs(L, 2)
     lanes = 2 if n_chains == 1 else 1          # two chains already occupy two streams
-    slots = (B + 1) // 2 if lanes == 2 else B   # per lane: B decoys in flight per chain either way
+    per_lane = (steps * B + lanes - 1) // lanes  # decoys a lane folds in the timed region
+    slots = min(MAX_SLOTS, per_lane)             # per lane
     ctxs = [T.Context(local_rank, lanes=lanes) for _ in range(n_chains)]
     for c_, m_ in zip(ctxs, ms_):
         c_.set_map(m_["dist"], *([m_["omega"], m_["theta"], m_["phi"]] if cfg["orient"] else []), seq=m_["seq"])
@@ -303,7 +308,7 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
     evals = np.concatenate([r["n_evals"] for r in res])
     launches = sum(r["launches"] for r in res)   # per lane: both lanes of a context make about the same number
     per_call = single = wide = None
-    if full and rank == 0 and world == 1:
+    if full and rank == 0 and world == 1 and not args.no_legs:
         def leg(lanes_, pool_, calls):
             for c_ in ctxs:
                 c_.set_lanes(lanes_); c_.set_pool(pool_)
@@ -319,20 +324,20 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
         per_call["note"] = "K separate trx2_fold_batch calls of B decoys, one stream, one slot per decoy (round 1's `value`)"
         if lanes == 2:
             single = leg(1, B, False)
-            single["note"] = f"the same queue on ONE stream of {B} slots"
-            wide = leg(2, B, False)
-            wide["note"] = f"two lanes of {B} slots each: {2 * B} decoys in flight"
+            single["note"] = f"the same queue with {B} decoys in flight: ONE stream of {B} slots"
+            wide = leg(2, (B + 1) // 2, False)
+            wide["note"] = f"the same queue with {B} decoys in flight: two lanes of {(B + 1) // 2} slots (round 2's first `value`)"
         for c_ in ctxs:
             c_.set_lanes(lanes); c_.set_pool(slots)
     out = None
     if rank == 0:
-        ft = sampled_fold(ctx, 2 * B, runs, 150, 901 * B)  # untimed; live per-kernel averages over a whole (pooled) fold: lane 0's launches
+        ft = sampled_fold(ctx, steps * B, runs, 150, 901 * B)  # untimed; live per-kernel averages over the same queue once more: lane 0's launches
         out = {
             "metric": "decoys/sec", "value": world * steps * B * n_chains / elapsed, "unit": "decoys/sec",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "L": L, "decoys_per_step": B * n_chains, "protocol": "mode 2, full staged minimisation",
-                       "slots": f"{B} per chain" + (f" = 2 lanes x {slots} on two streams" if lanes == 2 else ""),
+                       "slots": f"{lanes} lane(s) x {slots} decoy slots per chain (queue of {steps * B} decoys per chain)",
                        "parallelism": f"decoys sharded over {world} rank(s), no collective on the data path"},
             "roofline": pair_roofline(ctx, T, slots, L, config, ft),
             "roofline_step": step_roofline(ctx, slots, L, ft),
@@ -341,7 +346,7 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
             "pair_launches_per_step": launches / steps / n_chains,
             "slot_efficiency": float(np.mean([r["slot_efficiency"] for r in res])),  # evaluations of the decoys / (launch pairs x slots), per lane
         }
-        for k_, v_ in (("single_stream", single), ("wide_pool", wide), ("per_call", per_call)):
+        for k_, v_ in (("in_flight_B", wide), ("single_stream", single), ("per_call", per_call)):
             if v_:
                 out[k_] = v_
     for c_ in ctxs:
@@ -368,6 +373,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the B-in-flight / single-stream / per-call legs (profiling: every launch in the trace then belongs to `value`'s queue)")
     ap.add_argument("--no-sub-records", action="store_true", help="skip the config 3 / 4 sub-records (N=1) and the batch-mode record (N>1)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]

@@ -15,7 +15,7 @@ for cfg in (2, 3, 4):
         continue
     a, b, f, w = (json.load(open(q)) for q in p)
     rec[str(cfg)] = {
-        "kernel": a["kernel"].replace("void ", ""), "decoys_per_launch": {2: 32, 3: 64, 4: 16}[cfg], "fetch_bytes_raw": f["FETCH_SIZE"] * 1024.0, "write_bytes": w["WRITE_SIZE"] * 1024.0,
+        "kernel": a["kernel"].replace("void ", ""), "decoys_per_launch": {2: 160, 3: 128, 4: 32}[cfg], "fetch_bytes_raw": f["FETCH_SIZE"] * 1024.0, "write_bytes": w["WRITE_SIZE"] * 1024.0,
         "hbm_bytes_per_launch": 2.0 * f["FETCH_SIZE"] * 1024.0 + w["WRITE_SIZE"] * 1024.0,
         "method": "rocprofv3 --pmc in separate runs of tools/pmc_pair.py (tools/pmc_run.sh: two SQ groups, FETCH_SIZE, WRITE_SIZE; mean of the last "
                   f"{a['launches']} replays on final coordinates, tools/pmc_report.py); KiB -> bytes; FETCH_SIZE doubled (gfx950 counts wide coalesced reads at half)",

@@ -4,8 +4,10 @@ import importlib, sys
 import numpy as np
 sys.path.insert(0, sys.argv[1])
 T = importlib.import_module("trrosettax2-dynamics_amd"); S = importlib.import_module("trrosettax2-dynamics_amd.synth")
-# decoys per launch = the slots of one lane in bench.py: B/2 for the single-chain configs (two lanes), B for config 3 (two chains)
-cfg = {2: (150, 32, False), 3: (150, 64, True), 4: (400, 16, True)}[int(sys.argv[2])]
+# decoys per launch = the slots of one lane in a default bench.py run (bench.py: min(192, decoys of the run per lane)): config 2 folds
+# 5 x 64 decoys on two lanes, configs 3 and 4 are sub-records of 2 steps (two chains of 128 on one lane each; 64 on two lanes)
+SHAPES = {2: (150, 160, False), 3: (150, 128, True), 4: (400, 32, True)}
+cfg = SHAPES[int(sys.argv[2])]
 L, B, orient = cfg
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 40
 m = S.make_map(L); ctx = T.Context(0)

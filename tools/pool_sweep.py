@@ -1,16 +1,21 @@
-"""Throughput of one queue of decoys against the number of slots (trx2_ctx_set_pool) and lanes.  usage: pool_sweep.py <repo> <config> <n decoys>"""
+"""How many decoy slots should a job of N decoys use?  N decoys (L=150, distances only, full protocol) on 2 lanes x S slots.
+usage: pool_sweep.py <repo> [N=512] [orient]"""
 import importlib, sys, time
 import numpy as np
 sys.path.insert(0, sys.argv[1])
 T = importlib.import_module("trrosettax2-dynamics_amd"); S = importlib.import_module("trrosettax2-dynamics_amd.synth")
-L, B, orient = {2: (150, 64, False), 3: (150, 64, True), 4: (400, 32, True)}[int(sys.argv[2])]
-N = int(sys.argv[3]) if len(sys.argv) > 3 else 5 * B
-m = S.make_map(L); runs = T.protocol.build_runs(L, 2)
-for lanes in (1, 2):
-    for pool in (B // 2, B, 3 * B // 2, 2 * B, 4 * B):
-        ctx = T.Context(0, lanes=lanes, pool=pool)
-        ctx.set_map(m["dist"], *([m["omega"], m["theta"], m["phi"]] if orient else []), seq=m["seq"])
-        ctx.fold_batch(min(N, 2 * pool), runs, seed=1, decoy0=10000)
-        t = time.perf_counter(); r = ctx.fold_batch(N, runs, seed=150); el = time.perf_counter() - t
-        print(f"config {sys.argv[2]} N={N} lanes={lanes} slots per lane={pool:4d}: {N/el:7.1f} decoys/s  slot efficiency {r['slot_efficiency']:.3f}  launches {r['launches']}  ok {bool(np.all(r['status']==0))}", flush=True)
-        ctx.close()
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+orient = len(sys.argv) > 3
+L = 150
+m = S.make_map(L, seed=L); runs = T.protocol.build_runs(L, 2)
+ctx = T.Context(0, lanes=2)
+ctx.set_map(m["dist"], *([m["omega"], m["theta"], m["phi"]] if orient else []), seq=m["seq"])
+for slots in (32, 48, 64, 96, 128, 192, 256):
+    ctx.set_pool(slots)
+    ctx.fold_batch(2 * slots, runs, seed=150, decoy0=900 * 64)
+    v = []
+    for rep in range(2):
+        t0 = time.perf_counter(); r = ctx.fold_batch(N, runs, seed=150, decoy0=0); v.append(N / (time.perf_counter() - t0))
+        assert np.all(r["status"] == 0)
+    print(f"   2 lanes x {slots:3d} slots: {max(v):6.1f} decoys/s  ({r['launches']} launch pairs per lane, slot efficiency {r['slot_efficiency']:.2f})", flush=True)
+ctx.close()
