@@ -796,6 +796,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
         size_t dyn = k == 0 ? HIST_LDS_BYTES(128) : HIST_LDS_BYTES(CHAIN_THREADS);
         if (L <= CHAIN_THREADS) {
           cc.hist_lds = (int)std::min<size_t>(LBM, (size_t)ctx->step_dyn_max[k] / CART_HIST_BYTES(L));
+          if (const char* e = getenv("TRX2_CART_HIST_LDS")) cc.hist_lds = std::min(cc.hist_lds, std::max(0, atoi(e)));  // A/B and debugging only
           dyn = std::max(dyn, cc.hist_lds * CART_HIST_BYTES(L));
         }
         if (L <= 128) hipLaunchKernelGGL((k_step<1, 128, 128>), g2, dim3(128), dyn, ctx->stream, ca, cc);
