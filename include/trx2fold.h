@@ -63,6 +63,12 @@ int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes);
  * folded it, on `slots`, or on the order of completion.  trx2_last_fold_slot_efficiency: sum of evaluations over the decoys of
  * the last fold / (launch pairs x slots). */
 int trx2_ctx_set_pool(trx2_ctx* ctx, int slots);
+/* Tail of a fold.  Once the queue is empty the slots retire one by one, but a launch over several decoy groups (more than 64 slots)
+ * keeps its full length while every group still holds a live decoy.  mode 1 (default): whenever the live decoys fit into one group
+ * fewer, those of the last group are moved into retired slots on the device and the launches shrink by a group (with that shape's split of the pair kernel: results
+ * equal those of mode 0 up to the order in which a residue's gradient records are added).  mode 2: the same with the split kept
+ * (bitwise equal to mode 0; slower).  mode 0: off.  No counterpart in the reference (its decoys are separate processes). */
+int trx2_ctx_set_tail_compaction(trx2_ctx* ctx, int mode);
 int trx2_last_fold_slot_efficiency(trx2_ctx* ctx, double* eff);
 const char* trx2_last_error(const trx2_ctx* ctx);
 

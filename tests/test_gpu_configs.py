@@ -323,3 +323,33 @@ def test_slot_pool_refills_on_the_device_and_keeps_decoy_identity(golden_dir, se
             c2.close()
     finally:
         ctx.close()
+
+
+def test_tail_compaction_moves_the_survivors_and_changes_nothing(golden_dir, seq):
+    """100 decoys on 100 slots = two decoy groups of the pair kernel.  When no more than 64 are left alive they move into the first
+    group on the device (every piece of a slot's state: torsion and Cartesian vectors, both histories, Gram scalars, geometry,
+    both coordinate copies) and the launches shrink to one group.  With the pair kernel's split kept (mode 2) the fold must equal
+    the uncompacted one bit for bit -- which it can only do if nothing of a decoy's state was left behind; the default (mode 1,
+    one group's own split) differs by rounding only: same statuses, evaluation counts within the spread of a flipped
+    line-search decision, the same structures for most decoys."""
+    m = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
+    runs = T.protocol.build_runs(90, 2)
+    assert any(q["cartesian"] for q in runs)
+    ctx = T.Context(0)
+    try:
+        ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+        out = {}
+        for mode in (0, 2, 1):
+            ctx.set_tail_compaction(mode)
+            out[mode] = ctx.fold_batch(100, runs, seed=9)
+            assert np.all(out[mode]["status"] == 0)
+        for key in ("xyz", "tors", "e_terms", "f", "n_evals", "n_iters"):
+            assert np.array_equal(out[0][key], out[2][key]), key
+        assert out[2]["launches"] == out[0]["launches"] and out[2]["slot_efficiency"] > out[0]["slot_efficiency"] + 0.03
+        same = np.mean(np.sqrt(((out[1]["xyz"] - out[0]["xyz"]) ** 2).sum(-1)).max(axis=(1, 2)) < 0.5)
+        print(f"\ntail compaction: slot efficiency {out[0]['slot_efficiency']:.3f} -> {out[2]['slot_efficiency']:.3f} (split kept) / {out[1]['slot_efficiency']:.3f}; "
+              f"seconds {out[0]['seconds']:.3f} / {out[2]['seconds']:.3f} / {out[1]['seconds']:.3f}; decoys unchanged within 0.5 A with the new split: {same:.2f}")
+        assert abs(np.median(out[1]["n_evals"]) - np.median(out[0]["n_evals"])) <= 0.1 * np.median(out[0]["n_evals"])
+        assert same >= 0.5
+    finally:
+        ctx.close()

@@ -92,6 +92,7 @@ def load():
     L.trx2_time_pair_kernel.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, dp, dp]
     L.trx2_last_fold_stats.argtypes = [vp, dp, ip]
     L.trx2_ctx_set_pool.argtypes = [vp, C.c_int]
+    L.trx2_ctx_set_tail_compaction.argtypes = [vp, C.c_int]
     L.trx2_last_fold_slot_efficiency.argtypes = [vp, dp]
     L.trx2_ctx_set_profiling.argtypes = [vp, C.c_int]
     L.trx2_last_fold_kernel_times.argtypes = [vp, dp, dp, ip]
@@ -313,6 +314,11 @@ class Context:
         out = np.empty((n, n), np.float64)
         self._chk(self._l.trx2_glocon_matrix(self._h, n, L, "".join(seqs).encode(), _p(xyz), float(dmax), _p(out)), "trx2_glocon_matrix")
         return out
+
+    def set_tail_compaction(self, mode):
+        """0 off, 1 (default) the last <= 64 live decoys of a wider batch move into one decoy group, 2 the same with the pair kernel's
+        split kept (bitwise equal to 0): trx2_ctx_set_tail_compaction"""
+        self._chk(self._l.trx2_ctx_set_tail_compaction(self._h, int(mode)), "trx2_ctx_set_tail_compaction")
 
     def set_profiling(self, every):
         """every > 0: bracket every `every`-th evaluation of the following folds by HIP events (trx2_ctx_set_profiling)"""

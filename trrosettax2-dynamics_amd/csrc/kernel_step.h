@@ -1560,6 +1560,56 @@ __global__ __launch_bounds__(NT) void k_step(ChainArgs A, CartArgs C) {
   } else cart_body<NT>(C, (int)blockIdx.x - A.B, s_runs, s_gl);
 }
 
+// ---- Tail of a fold: once the queue is empty the slots retire one by one, but a pair-kernel wave costs the same while ANY of its
+// 64 decoys is alive, and a batch of several decoy groups keeps all of them partly alive almost to the end.  When no more than
+// one group's worth of decoys is left, the survivors are moved into group 0 and the launches shrink to one group.
+struct CompactArgs {
+  int B, Bc, L, BW;          // slots before / after (Bc = BW = one group)
+  int* plan;                 // [1 + 2 Bc]: count, then (from, to) pairs
+  int* st_i; double* st_d; float* rho; double* gram; float* wcur; int* slot_id; int* done_count;
+  float4 *X, *G, *D, *XT, *geom, *S, *Y, *P, *xyzT;
+  float4 *CX, *CG, *CD, *CS, *CY;   // NULL without a Cartesian run
+};
+__global__ void k_compact_plan(CompactArgs A) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int nf = 0, nm = 0, live = 0;
+  for (int s = 0; s < A.B; s++) live += A.st_i[(size_t)s * SI_N + SI_PHASE] != PH_DONE;
+  for (int s = A.Bc; s < A.B; s++)
+    if (A.st_i[(size_t)s * SI_N + SI_PHASE] != PH_DONE) {
+      while (nf < A.Bc - 1 && A.st_i[(size_t)nf * SI_N + SI_PHASE] != PH_DONE) nf++;  // live <= Bc: a retired slot below Bc exists for every survivor above
+      A.plan[1 + 2 * nm] = s; A.plan[2 + 2 * nm] = nf; nm++; nf++;
+    }
+  A.plan[0] = nm;
+  *A.done_count = A.Bc - live;
+}
+__device__ __forceinline__ void copy_f4(float4* dst, const float4* src, size_t n) {
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void k_compact_move(CompactArgs A) {
+  const int k = blockIdx.x;
+  if (k >= A.plan[0]) return;
+  const int s = A.plan[1 + 2 * k], d = A.plan[2 + 2 * k], L = A.L, tid = threadIdx.x;
+  const size_t so = (size_t)s * L, dn = (size_t)d * L;
+  if (tid < SI_N) A.st_i[(size_t)d * SI_N + tid] = A.st_i[(size_t)s * SI_N + tid];
+  if (tid < SD_N) A.st_d[(size_t)d * SD_N + tid] = A.st_d[(size_t)s * SD_N + tid];
+  if (tid < LBM) A.rho[(size_t)d * LBM + tid] = A.rho[(size_t)s * LBM + tid];
+  if (tid < GR_N) A.gram[(size_t)d * GR_N + tid] = A.gram[(size_t)s * GR_N + tid];
+  if (tid < 8) A.wcur[(size_t)d * 8 + tid] = A.wcur[(size_t)s * 8 + tid];
+  if (tid == 0) A.slot_id[d] = A.slot_id[s];
+  copy_f4(A.X + dn, A.X + so, L); copy_f4(A.G + dn, A.G + so, L); copy_f4(A.D + dn, A.D + so, L); copy_f4(A.XT + dn, A.XT + so, L);
+  copy_f4(A.geom + dn * 3, A.geom + so * 3, (size_t)L * 3);
+  copy_f4(A.S + dn * LBM, A.S + so * LBM, (size_t)L * LBM); copy_f4(A.Y + dn * LBM, A.Y + so * LBM, (size_t)L * LBM);
+  copy_f4(A.P + dn * 5, A.P + so * 5, (size_t)L * 5);
+  for (int i = tid; i < L * 5; i += blockDim.x)
+    A.xyzT[((size_t)(d / A.BW) * L * 5 + i) * A.BW + d % A.BW] = A.xyzT[((size_t)(s / A.BW) * L * 5 + i) * A.BW + s % A.BW];
+  if (A.CX) {
+    copy_f4(A.CX + dn * 4, A.CX + so * 4, (size_t)L * 4); copy_f4(A.CG + dn * 4, A.CG + so * 4, (size_t)L * 4); copy_f4(A.CD + dn * 4, A.CD + so * 4, (size_t)L * 4);
+    copy_f4(A.CS + dn * 4 * LBM, A.CS + so * 4 * LBM, (size_t)L * 4 * LBM); copy_f4(A.CY + dn * 4 * LBM, A.CY + so * 4 * LBM, (size_t)L * 4 * LBM);
+  }
+  __syncthreads();
+  if (tid == 0) { A.st_i[(size_t)s * SI_N + SI_PHASE] = PH_DONE; A.wcur[(size_t)s * 8 + 6] = 0.0f; }  // the vacated slot (never launched again)
+}
+
 __global__ void k_init_torsions(int L, int B, uint64_t seed, uint32_t decoy0, const float* tors0, float4* X, float4* XT, float4* geom) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L * B) return;

@@ -84,7 +84,11 @@ struct trx2_ctx {
   double* knots_d = nullptr;
   double knots_h[TRX2_KTOT_MAX];
   // batch
-  int Bcap = 0, Lcap = 0, BW = 64, Bpad = 0, nsplit = 1, nsplit_cap = 0;
+  int Bcap = 0, Lcap = 0, BW = 64, Bpad = 0, nsplit = 1;
+  size_t fa_cap = 0;     // pair-kernel records the FA buffer holds: (splits x slots) units of L records
+  std::vector<int> nsplit_g;  // [g]: split of a launch over g groups of 64 decoys (the shapes a fold shrinks through at its tail, fold_impl)
+  int* plan = nullptr;   // compaction plan (device)
+  int compact = 1;       // trx2_ctx_set_tail_compaction
   int* st_i = nullptr; double* st_d = nullptr; float* rho = nullptr; double* gram = nullptr;
   float4 *X = nullptr, *G = nullptr, *D = nullptr, *XT = nullptr, *S = nullptr, *Y = nullptr;
   float4* P = nullptr; float4* xyzT = nullptr; float* wcur = nullptr; float4* geom = nullptr;
@@ -245,13 +249,14 @@ static void free_map(trx2_ctx* c) {
 }
 static void free_batch(trx2_ctx* c) {
   void* p[] = {c->st_i, c->st_d, c->rho, c->gram, c->X, c->G, c->D, c->XT, c->S, c->Y, c->P, c->xyzT, c->geom, c->wcur, c->FA,
-               c->e_last, c->f_last, c->grad, c->tors0, c->done_count, c->seq_ctr, c->runs};
+               c->e_last, c->f_last, c->grad, c->tors0, c->done_count, c->seq_ctr, c->runs, c->plan};
   for (void* q : p)
     if (q) (void)hipFree(q);
   c->st_i = nullptr; c->st_d = nullptr; c->rho = nullptr; c->gram = nullptr;
   c->X = c->G = c->D = c->XT = c->S = c->Y = nullptr;
   c->P = nullptr; c->xyzT = nullptr; c->geom = nullptr; c->wcur = nullptr; c->FA = nullptr;
   c->e_last = c->f_last = nullptr; c->grad = nullptr; c->tors0 = nullptr; c->done_count = nullptr; c->seq_ctr = nullptr; c->runs = nullptr;
+  c->plan = nullptr; c->fa_cap = 0;
   c->Bcap = c->Lcap = 0;
   c->alloc_epoch++;
   void* q[] = {c->CX, c->CG, c->CD, c->CS, c->CY, c->slot_id, c->next_id, c->out_stat, c->out_xyz, c->out_X, c->out_e, c->out_f, c->tors0_all};
@@ -304,6 +309,7 @@ extern "C" int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes) {
     if (trx2_ctx_create(ctx->device, &k) != 0) { ctx->err = "trx2_ctx_set_lanes: cannot create the second lane"; return 1; }
     k->borrows_map = true;
     k->pool = ctx->pool;
+    k->compact = ctx->compact;
     ctx->child = k;
     if (ctx->L) { HIPCHK(hipStreamSynchronize(ctx->stream)); lend_map(ctx); }
   } else if (lanes == 1 && ctx->child) {
@@ -536,21 +542,27 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
   const int ngrp = (B + BW - 1) / BW;
   const int Bpad = ngrp * BW;
   // b-range splits: enough workgroups (>= ~2 per CU) while every wave keeps a few residues b
-  int nsplit = 1;
-  {
-    // k_pair holds 2 workgroups per CU (232 VGPRs): 512 resident slots.  EMPIRICAL rule from profiles/README.md
-    // (L=150, B=64, splits 2/3/4/6 timed on MI355X): with distances only, the largest split whose grid fits one
-    // round is fastest; with the angle channels on, 600 smaller workgroups win despite the partial second round.
-    // Every wave keeps at least two residues b.
-    const int PW = 64 / BW;
+  // k_pair holds 2 workgroups per CU (232 VGPRs): 512 resident slots.  EMPIRICAL rule from profiles/README.md
+  // (L=150, B=64, splits 2/3/4/6 timed on MI355X): with distances only, the largest split whose grid fits one
+  // round is fastest; with the angle channels on, 600 smaller workgroups win despite the partial second round.
+  // Every wave keeps at least two residues b.
+  auto split_rule = [&](int groups, int bw) {
+    int n_best = 1;
+    const int PW = 64 / bw;
     const long slots = ctx->use_orient ? 640 : 512;
     for (int n = 1; n <= 16; n++)
-      if ((long)L * n * ngrp <= slots && L / n >= PAIR_WAVES * PW * 2) nsplit = n;
-    if (const char* e = getenv("TRX2_NSPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) nsplit = v; }  // A/B timing only
-  }
+      if ((long)L * n * groups <= slots && L / n >= PAIR_WAVES * PW * 2) n_best = n;
+    if (const char* e = getenv("TRX2_NSPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) n_best = v; }  // A/B timing only
+    return n_best;
+  };
+  const int nsplit = split_rule(ngrp, BW);
+  // the tail compaction drops one group of 64 at a time: the record buffer must hold every shape on the way
+  std::vector<int> nsplit_g((size_t)ngrp + 1, nsplit);
+  size_t fa_units = (size_t)nsplit * B;
+  for (int g = 1; g < ngrp; g++) { nsplit_g[g] = split_rule(g, 64); fa_units = std::max(fa_units, (size_t)nsplit_g[g] * g * 64); }
   const bool layout_changed = BW != ctx->BW || Bpad != ctx->Bpad;
-  ctx->BW = BW; ctx->Bpad = Bpad; ctx->nsplit = nsplit;
-  if (B <= ctx->Bcap && L <= ctx->Lcap && nsplit <= ctx->nsplit_cap) {
+  ctx->BW = BW; ctx->Bpad = Bpad; ctx->nsplit = nsplit; ctx->nsplit_g = nsplit_g;
+  if (B <= ctx->Bcap && L <= ctx->Lcap && fa_units * L <= ctx->fa_cap) {
     if (layout_changed) {  // the pad lanes of a group layout must hold finite numbers
       HIPCHK(hipMemsetAsync(ctx->xyzT, 0, sizeof(float4) * (size_t)Bpad * L * 5, ctx->stream));
       ctx->alloc_epoch++;
@@ -577,7 +589,8 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
   const size_t xt_alloc = (size_t)((B + 63) / 64 * 64) * L * 5;
   HIPCHK(hipMalloc((void**)&ctx->xyzT, sizeof(float4) * xt_alloc));
   HIPCHK(hipMalloc((void**)&ctx->wcur, sizeof(float) * B * 8));
-  HIPCHK(hipMalloc((void**)&ctx->FA, sizeof(float) * (size_t)nsplit * B * L * PR_REC));
+  HIPCHK(hipMalloc((void**)&ctx->FA, sizeof(float) * fa_units * L * PR_REC));
+  HIPCHK(hipMalloc((void**)&ctx->plan, sizeof(int) * (1 + 2 * 64)));
   HIPCHK(hipMalloc((void**)&ctx->e_last, sizeof(double) * B * TRX2_NTERMS));
   HIPCHK(hipMalloc((void**)&ctx->f_last, sizeof(double) * B));
   HIPCHK(hipMalloc((void**)&ctx->grad, sizeof(float) * BL * 3));
@@ -589,7 +602,7 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
   HIPCHK(hipMemsetAsync(ctx->P, 0, sizeof(float4) * BL * 5, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->xyzT, 0, sizeof(float4) * xt_alloc, ctx->stream));
   HIPCHK(hipMemsetAsync(ctx->wcur, 0, sizeof(float) * B * 8, ctx->stream));
-  ctx->Bcap = B; ctx->Lcap = L; ctx->nsplit_cap = nsplit;
+  ctx->Bcap = B; ctx->Lcap = L; ctx->fa_cap = fa_units * L;
   ctx->alloc_epoch++;
   return 0;
 }
@@ -739,7 +752,8 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   if (has_filter && !ctx->mask_odr) { ctx->err = "trx2_fold_batch: a run filters by the idr mask, but the map was set without one (trx2_set_map_ex)"; return 1; }
   if (max_evals <= 0) max_evals = 1 << 30;
   HIPCHK(hipSetDevice(ctx->device));
-  const int B = (ctx->pool > 0 && ctx->pool < N) ? ctx->pool : N;   // slots
+  const int B0 = (ctx->pool > 0 && ctx->pool < N) ? ctx->pool : N;   // slots
+  int B = B0;   // shrinks to one decoy group at the tail of the fold (below)
   if (ensure_batch(ctx, B)) return 1;
   if (has_cart && ensure_cart(ctx, B)) return 1;
   if (ensure_outputs(ctx, (size_t)N, tors0 != nullptr)) return 1;
@@ -763,9 +777,11 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
                      tors0 ? ctx->tors0_all : (const float*)nullptr, ctx->X, ctx->XT, ctx->geom);
   launch_chain(ctx, B, MODE_INIT, nruns, max_evals);
   int launches = 0;
+  double slot_launches = 0;  // sum over launch pairs of the slots they served
   const int chunk = 64;
+  const int compact_mode = ctx->compact;
   // hard cap on launches: a decoy stops by itself at max_evals (+ its report, + skipped runs); a slot folds ceil(N / B) of them
-  const long rounds = (N + B - 1) / B;
+  const long rounds = (N + B0 - 1) / B0;
   long cap = ((long)max_evals + 96) * rounds;
   if (cap > 200000000L || cap < 0) cap = 200000000L;
   HIPCHK(hipMemsetAsync(ctx->seq_ctr, 0, sizeof(int), ctx->stream));
@@ -840,7 +856,27 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
       }
     }
     prof_used = 0;
+    slot_launches += (double)chunk * B;
     if (*ctx->h_done >= B || launches >= cap) break;
+    // Tail compaction.  The queue is empty once the first slot has retired; a pair-kernel wave costs the same while any of its
+    // 64 decoys is alive and the survivors are spread over all groups, so a three-group launch stays at full length almost to
+    // the end.  Whenever the survivors fit into one group fewer, those of the last group move into retired slots of the others
+    // (k_compact_*) and the launches shrink by a group, with that shape's split.  The decoys' arithmetic does not depend on the slot; the split (the order in which a
+    // residue's records are added) does, so results equal those without compaction up to rounding, not bitwise
+    // (trx2_ctx_set_tail_compaction: 0 off, 1 on, 2 on with the split kept -- bitwise equal to off: tests).
+    if (compact_mode && no_graph && ctx->BW == 64 && ctx->Bpad > 64 && *ctx->h_done > 0 && B - *ctx->h_done <= ctx->Bpad - 64) {
+      const int Bc = ctx->Bpad - 64;  // one group fewer (the survivors of the last group: at most 64 moves)
+      CompactArgs C;
+      C.B = B; C.Bc = Bc; C.L = L; C.BW = 64; C.plan = ctx->plan;
+      C.st_i = ctx->st_i; C.st_d = ctx->st_d; C.rho = ctx->rho; C.gram = ctx->gram; C.wcur = ctx->wcur; C.slot_id = ctx->slot_id; C.done_count = ctx->done_count;
+      C.X = ctx->X; C.G = ctx->G; C.D = ctx->D; C.XT = ctx->XT; C.geom = ctx->geom; C.S = ctx->S; C.Y = ctx->Y; C.P = ctx->P; C.xyzT = ctx->xyzT;
+      C.CX = has_cart ? ctx->CX : nullptr; C.CG = ctx->CG; C.CD = ctx->CD; C.CS = ctx->CS; C.CY = ctx->CY;
+      hipLaunchKernelGGL(k_compact_plan, dim3(1), dim3(64), 0, ctx->stream, C);
+      hipLaunchKernelGGL(k_compact_move, dim3(64), dim3(256), 0, ctx->stream, C);
+      HIPCHK(hipGetLastError());
+      B = Bc; ctx->Bpad = Bc;
+      if (compact_mode == 1) ctx->nsplit = ctx->nsplit_g[(size_t)Bc / 64];
+    }
   }
   const bool all_retired = *ctx->h_done >= B;
   // results by decoy id
@@ -864,7 +900,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   }
   ctx->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   ctx->last_launches = launches;
-  ctx->last_slot_eff = evals / ((double)launches * B);
+  ctx->last_slot_eff = evals / slot_launches;
   return 0;
 }
 
@@ -1188,6 +1224,14 @@ extern "C" int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int s
       }
     *term_evals = n * B;
   }
+  return 0;
+}
+
+extern "C" int trx2_ctx_set_tail_compaction(trx2_ctx* ctx, int mode) {
+  if (!ctx) return 1;
+  if (mode < 0 || mode > 2) { ctx->err = "trx2_ctx_set_tail_compaction: 0 (off), 1 (on) or 2 (on, pair-kernel split kept)"; return 1; }
+  ctx->compact = mode;
+  if (ctx->child) ctx->child->compact = mode;
   return 0;
 }
 
