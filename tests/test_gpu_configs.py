@@ -351,5 +351,11 @@ def test_tail_compaction_moves_the_survivors_and_changes_nothing(golden_dir, seq
               f"seconds {out[0]['seconds']:.3f} / {out[2]['seconds']:.3f} / {out[1]['seconds']:.3f}; decoys unchanged within 0.5 A with the new split: {same:.2f}")
         assert abs(np.median(out[1]["n_evals"]) - np.median(out[0]["n_evals"])) <= 0.1 * np.median(out[0]["n_evals"])
         assert same >= 0.5
+        # the fold leaves the full batch's launch shape behind: a pair-kernel replay of all 100 slots (what bench.py's roofline
+        # does) and an evaluation batch must find buffers and grid in agreement (they did not once: a GPU memory fault)
+        ms, terms = ctx.time_pair_kernel(100, np.array(T.protocol.SF, np.float32), 1, 90, n_rep=3)
+        assert 0 < ms < 10 and terms > 0
+        f, e, g, xyz = ctx.eval_batch(out[1]["tors"][:70], np.array(T.protocol.SF, np.float32))
+        assert np.all(np.isfinite(f)) and np.all(np.isfinite(xyz))
     finally:
         ctx.close()

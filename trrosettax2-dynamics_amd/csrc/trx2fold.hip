@@ -630,6 +630,14 @@ static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_eva
   return A;
 }
 static void launch_pair(trx2_ctx* c, int B) {
+  // never launch a shape the buffers were not sized for (operand shapes are checked on the host: a kernel that writes out of
+  // bounds can reset every GPU of the node)
+  if (B < 1 || B > c->Bpad || B > c->Bcap || c->Bpad % c->BW != 0 || (size_t)c->nsplit * B * c->L > c->fa_cap ||
+      (size_t)c->Bpad > (size_t)(c->Bcap + 63) / 64 * 64) {
+    c->err = "internal: pair-kernel launch shape does not fit the batch buffers";
+    fprintf(stderr, "trx2fold: %s (B=%d Bpad=%d Bcap=%d nsplit=%d)\n", c->err.c_str(), B, c->Bpad, c->Bcap, c->nsplit);
+    return;
+  }
   const PairArgs P = pair_args(c, B);
   const dim3 grid(c->L, c->nsplit, c->Bpad / c->BW), block(PAIR_THREADS);
   switch (c->BW) {
@@ -753,10 +761,15 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   if (max_evals <= 0) max_evals = 1 << 30;
   HIPCHK(hipSetDevice(ctx->device));
   const int B0 = (ctx->pool > 0 && ctx->pool < N) ? ctx->pool : N;   // slots
-  int B = B0;   // shrinks to one decoy group at the tail of the fold (below)
+  int B = B0;   // shrinks by a decoy group at a time at the tail of the fold (below)
   if (ensure_batch(ctx, B)) return 1;
   if (has_cart && ensure_cart(ctx, B)) return 1;
   if (ensure_outputs(ctx, (size_t)N, tors0 != nullptr)) return 1;
+  // The launch shape of the full batch comes back when the fold ends, however it ends: the buffers are laid out for it, and
+  // whoever launches on them next (the pair-kernel replays of trx2_time_pair_kernel, for one) sizes its grid and its record
+  // indices by these fields.  (A replay of B slots on the shape the tail compaction had left behind wrote records past the end
+  // of the buffer: a GPU memory fault, found under rocprofv3.)
+  struct ShapeGuard { trx2_ctx* c; int bpad, ns; ~ShapeGuard() { c->Bpad = bpad; c->nsplit = ns; } } shape_guard{ctx, ctx->Bpad, ctx->nsplit};
   const int L = ctx->L;
   const size_t BL = (size_t)B * L, NL = (size_t)N * L;
   auto t0 = std::chrono::steady_clock::now();
@@ -1188,7 +1201,10 @@ extern "C" int trx2_superpose_matrix(trx2_ctx* ctx, int n, int m, int L, const f
 extern "C" int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int sep_lo, int sep_hi, int n_rep,
                                      double* ms_avg, double* term_evals) {
   if (!ctx) return 1;
-  if (!ctx->L || !ctx->P || B > ctx->Bcap || B < 1 || n_rep < 1) { ctx->err = "trx2_time_pair_kernel: run an eval/fold batch of this size first"; return 1; }
+  if (!ctx->L || !ctx->P || B > ctx->Bcap || B > ctx->Bpad || B < 1 || n_rep < 1 || (size_t)ctx->nsplit * B * ctx->L > ctx->fa_cap) {
+    ctx->err = "trx2_time_pair_kernel: run an eval/fold batch of this size first";
+    return 1;
+  }
   HIPCHK(hipSetDevice(ctx->device));
   const int L = ctx->L;
   // weights / separation window for every decoy
