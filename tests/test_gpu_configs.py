@@ -288,6 +288,7 @@ def test_slot_pool_refills_on_the_device_and_keeps_decoy_identity(golden_dir, se
     ctx = T.Context(0)
     try:
         ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+        ctx.set_tail_compaction(0)   # bitwise comparisons below: the tail compaction narrows the waves when it likes (its own test)
         parts = [ctx.fold_batch(8, runs, seed=77, decoy0=8 * k) for k in range(3)]
         ctx.set_pool(8)
         r = ctx.fold_batch(24, runs, seed=77)
@@ -316,6 +317,7 @@ def test_slot_pool_refills_on_the_device_and_keeps_decoy_identity(golden_dir, se
         # two lanes + pool: each lane folds its half on its own slots
         c2 = T.Context(0, lanes=2, pool=8)
         try:
+            c2.set_tail_compaction(0)
             c2.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
             r2 = c2.fold_batch(48, runs, seed=77)
             assert np.array_equal(r2["xyz"][:24], r["xyz"]) and np.all(r2["status"] == 0)
@@ -351,8 +353,21 @@ def test_tail_compaction_moves_the_survivors_and_changes_nothing(golden_dir, seq
               f"seconds {out[0]['seconds']:.3f} / {out[2]['seconds']:.3f} / {out[1]['seconds']:.3f}; decoys unchanged within 0.5 A with the new split: {same:.2f}")
         assert abs(np.median(out[1]["n_evals"]) - np.median(out[0]["n_evals"])) <= 0.1 * np.median(out[0]["n_evals"])
         assert same >= 0.5
+        # below one group the group itself halves (64 -> 32 -> .. decoys per wave, coordinates laid out anew): a batch of 48
+        a, b = {}, {}
+        for mode, dst in ((0, a), (1, b)):
+            ctx.set_tail_compaction(mode)
+            dst.update(ctx.fold_batch(48, runs, seed=21))
+            assert np.all(dst["status"] == 0) and np.all(np.isfinite(dst["xyz"]))
+        same48 = np.mean(np.sqrt(((a["xyz"] - b["xyz"]) ** 2).sum(-1)).max(axis=(1, 2)) < 0.5)
+        print(f"48 decoys: slot efficiency {a['slot_efficiency']:.3f} -> {b['slot_efficiency']:.3f}, seconds {a['seconds']:.3f} -> {b['seconds']:.3f}, unchanged within 0.5 A: {same48:.2f}")
+        assert b["slot_efficiency"] > a["slot_efficiency"] + 0.05 and same48 >= 0.5
+        assert abs(np.median(b["n_evals"]) - np.median(a["n_evals"])) <= 0.1 * np.median(a["n_evals"])
         # the fold leaves the full batch's launch shape behind: a pair-kernel replay of all 100 slots (what bench.py's roofline
         # does) and an evaluation batch must find buffers and grid in agreement (they did not once: a GPU memory fault)
+        ms, terms = ctx.time_pair_kernel(48, np.array(T.protocol.SF, np.float32), 1, 90, n_rep=3)
+        assert 0 < ms < 10 and terms > 0
+        ctx.fold_batch(100, runs, seed=9)
         ms, terms = ctx.time_pair_kernel(100, np.array(T.protocol.SF, np.float32), 1, 90, n_rep=3)
         assert 0 < ms < 10 and terms > 0
         f, e, g, xyz = ctx.eval_batch(out[1]["tors"][:70], np.array(T.protocol.SF, np.float32))

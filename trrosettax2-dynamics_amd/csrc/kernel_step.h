@@ -1610,6 +1610,16 @@ __global__ __launch_bounds__(256) void k_compact_move(CompactArgs A) {
   if (tid == 0) { A.st_i[(size_t)s * SI_N + SI_PHASE] = PH_DONE; A.wcur[(size_t)s * 8 + 6] = 0.0f; }  // the vacated slot (never launched again)
 }
 
+// After a compaction below one group of 64: the decoy-minor coordinate copy in the narrower layout, from the decoy-major one
+// (both hold the current trial coordinates)
+__global__ void k_relayout(int B, int L, int BW, const float4* P, float4* xyzT) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)B * L * 5) return;
+  const int dec = (int)(i / ((size_t)L * 5));
+  const size_t rq = i % ((size_t)L * 5);
+  xyzT[((size_t)(dec / BW) * L * 5 + rq) * BW + dec % BW] = P[i];
+}
+
 __global__ void k_init_torsions(int L, int B, uint64_t seed, uint32_t decoy0, const float* tors0, float4* X, float4* XT, float4* geom) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L * B) return;

@@ -87,6 +87,7 @@ struct trx2_ctx {
   int Bcap = 0, Lcap = 0, BW = 64, Bpad = 0, nsplit = 1;
   size_t fa_cap = 0;     // pair-kernel records the FA buffer holds: (splits x slots) units of L records
   std::vector<int> nsplit_g;  // [g]: split of a launch over g groups of 64 decoys (the shapes a fold shrinks through at its tail, fold_impl)
+  int nsplit_w[7] = {1, 1, 1, 1, 1, 1, 1};  // [log2 w]: split of a one-group launch of w decoys per wave
   int* plan = nullptr;   // compaction plan (device)
   int compact = 1;       // trx2_ctx_set_tail_compaction
   int* st_i = nullptr; double* st_d = nullptr; float* rho = nullptr; double* gram = nullptr;
@@ -560,8 +561,14 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
   std::vector<int> nsplit_g((size_t)ngrp + 1, nsplit);
   size_t fa_units = (size_t)nsplit * B;
   for (int g = 1; g < ngrp; g++) { nsplit_g[g] = split_rule(g, 64); fa_units = std::max(fa_units, (size_t)nsplit_g[g] * g * 64); }
+  int nsplit_w[7];  // ... and then halves the last group: 32, 16, .. 1 decoys per wave
+  for (int k = 0; k < 7; k++) {
+    nsplit_w[k] = split_rule(1, 1 << k);
+    if ((1 << k) < BW || ngrp > 1) fa_units = std::max(fa_units, (size_t)nsplit_w[k] * (1 << k));
+  }
   const bool layout_changed = BW != ctx->BW || Bpad != ctx->Bpad;
   ctx->BW = BW; ctx->Bpad = Bpad; ctx->nsplit = nsplit; ctx->nsplit_g = nsplit_g;
+  memcpy(ctx->nsplit_w, nsplit_w, sizeof nsplit_w);
   if (B <= ctx->Bcap && L <= ctx->Lcap && fa_units * L <= ctx->fa_cap) {
     if (layout_changed) {  // the pad lanes of a group layout must hold finite numbers
       HIPCHK(hipMemsetAsync(ctx->xyzT, 0, sizeof(float4) * (size_t)Bpad * L * 5, ctx->stream));
@@ -769,7 +776,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   // whoever launches on them next (the pair-kernel replays of trx2_time_pair_kernel, for one) sizes its grid and its record
   // indices by these fields.  (A replay of B slots on the shape the tail compaction had left behind wrote records past the end
   // of the buffer: a GPU memory fault, found under rocprofv3.)
-  struct ShapeGuard { trx2_ctx* c; int bpad, ns; ~ShapeGuard() { c->Bpad = bpad; c->nsplit = ns; } } shape_guard{ctx, ctx->Bpad, ctx->nsplit};
+  struct ShapeGuard { trx2_ctx* c; int bpad, ns, bw; ~ShapeGuard() { c->Bpad = bpad; c->nsplit = ns; c->BW = bw; } } shape_guard{ctx, ctx->Bpad, ctx->nsplit, ctx->BW};
   const int L = ctx->L;
   const size_t BL = (size_t)B * L, NL = (size_t)N * L;
   auto t0 = std::chrono::steady_clock::now();
@@ -877,18 +884,32 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
     // (k_compact_*) and the launches shrink by a group, with that shape's split.  The decoys' arithmetic does not depend on the slot; the split (the order in which a
     // residue's records are added) does, so results equal those without compaction up to rounding, not bitwise
     // (trx2_ctx_set_tail_compaction: 0 off, 1 on, 2 on with the split kept -- bitwise equal to off: tests).
-    if (compact_mode && no_graph && ctx->BW == 64 && ctx->Bpad > 64 && *ctx->h_done > 0 && B - *ctx->h_done <= ctx->Bpad - 64) {
-      const int Bc = ctx->Bpad - 64;  // one group fewer (the survivors of the last group: at most 64 moves)
+    const int live = B - *ctx->h_done;
+    const bool drop_group = ctx->BW == 64 && ctx->Bpad > 64 && live <= ctx->Bpad - 64;
+    // ... and below one group the group itself halves (32, 16, .. decoys per wave: the decoy-minor coordinates are laid out anew
+    // from the decoy-major copy); the sub-lanes of a narrower wave split a decoy's partner residues differently, so this is
+    // mode 1 only
+    const bool halve = compact_mode == 1 && !drop_group && ctx->Bpad == ctx->BW && ctx->BW >= 2 && live <= ctx->BW / 2;
+    if (compact_mode && no_graph && *ctx->h_done > 0 && live > 0 && (drop_group || halve)) {
+      const int Bc = drop_group ? ctx->Bpad - 64 : ctx->BW / 2;  // at most 64 moves either way
       CompactArgs C;
-      C.B = B; C.Bc = Bc; C.L = L; C.BW = 64; C.plan = ctx->plan;
+      C.B = B; C.Bc = Bc; C.L = L; C.BW = ctx->BW; C.plan = ctx->plan;
       C.st_i = ctx->st_i; C.st_d = ctx->st_d; C.rho = ctx->rho; C.gram = ctx->gram; C.wcur = ctx->wcur; C.slot_id = ctx->slot_id; C.done_count = ctx->done_count;
       C.X = ctx->X; C.G = ctx->G; C.D = ctx->D; C.XT = ctx->XT; C.geom = ctx->geom; C.S = ctx->S; C.Y = ctx->Y; C.P = ctx->P; C.xyzT = ctx->xyzT;
       C.CX = has_cart ? ctx->CX : nullptr; C.CG = ctx->CG; C.CD = ctx->CD; C.CS = ctx->CS; C.CY = ctx->CY;
       hipLaunchKernelGGL(k_compact_plan, dim3(1), dim3(64), 0, ctx->stream, C);
       hipLaunchKernelGGL(k_compact_move, dim3(64), dim3(256), 0, ctx->stream, C);
-      HIPCHK(hipGetLastError());
       B = Bc; ctx->Bpad = Bc;
-      if (compact_mode == 1) ctx->nsplit = ctx->nsplit_g[(size_t)Bc / 64];
+      if (drop_group) {
+        if (compact_mode == 1) ctx->nsplit = ctx->nsplit_g[(size_t)Bc / 64];
+      } else {
+        ctx->BW = Bc;
+        int lg = 0;
+        while ((1 << lg) < Bc) lg++;
+        ctx->nsplit = ctx->nsplit_w[lg];
+        hipLaunchKernelGGL(k_relayout, dim3((unsigned)(((size_t)Bc * L * 5 + 255) / 256)), dim3(256), 0, ctx->stream, Bc, L, Bc, (const float4*)ctx->P, ctx->xyzT);
+      }
+      HIPCHK(hipGetLastError());
     }
   }
   const bool all_retired = *ctx->h_done >= B;
