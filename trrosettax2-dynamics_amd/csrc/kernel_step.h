@@ -1540,7 +1540,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
 }
 
 // ---- launchable forms.  k_chain: INIT / FINISH passes and protocols without a Cartesian run.  k_step: one launch of 2B
-// workgroups per evaluation -- workgroup d < B steps decoy d in torsion space, workgroup B + d steps it in Cartesian
+// workgroups per evaluation -- workgroup d < B steps decoy d in Cartesian space, workgroup B + d steps it in torsion
 // space; whichever does not match the decoy's current run exits at once.  The two roles touch disjoint decoys, so they
 // run concurrently instead of as two half-empty launches back to back (k_cart alone was 22-27 % of GPU time).
 // The torsion role runs on TN threads, RPT residues each.
@@ -1555,9 +1555,10 @@ __global__ __launch_bounds__(NT) void k_step(ChainArgs A, CartArgs C) {
   static_assert(((RPT == 1) ? TN : 16) == ((NT <= 256) ? NT : 16), "the two roles share one GramLds");
   __shared__ int s_runs[STEP_RUNS_INTS];
   __shared__ GramLds<(RPT == 1) ? TN : 16> s_gl;
-  if ((int)blockIdx.x < A.B) {
-    if (NT == TN || threadIdx.x < TN) chain_body<RPT, TN>(A, blockIdx.x, s_runs, s_gl);  // the other waves of the workgroup exit at once
-  } else cart_body<NT>(C, (int)blockIdx.x - A.B, s_runs, s_gl);
+  // the Cartesian role first: its workgroups are the slower ones, and the launch ends with the last of them
+  if ((int)blockIdx.x >= A.B) {
+    if (NT == TN || threadIdx.x < TN) chain_body<RPT, TN>(A, (int)blockIdx.x - A.B, s_runs, s_gl);  // the other waves of the workgroup exit at once
+  } else cart_body<NT>(C, (int)blockIdx.x, s_runs, s_gl);
 }
 
 // ---- Tail of a fold: once the queue is empty the slots retire one by one, but a pair-kernel wave costs the same while ANY of its
