@@ -51,9 +51,9 @@ __device__ __forceinline__ void spline_eval_dev(const float2* __restrict__ row, 
 // residue, O=C of the other.  Returns the raw energy (<= 0) and ADDS its gradient scaled by s to gN, gH, gO, gC.
 __device__ __forceinline__ float hbond_dev(f3 N, f3 H, f3 O, f3 C, float s, f3& gN, f3& gH, f3& gO, f3& gC) {
   const f3 u = H - N, v = O - H, w = O - C;
-  const float d2 = dot(v, v), id = rsqrtf(d2), d = d2 * id, x = (d - (float)TRX2_HB_D0) * (1.0f / (float)TRX2_HB_R);
+  const float d2 = dot(v, v), id = frsq(d2), d = d2 * id, x = (d - (float)TRX2_HB_D0) * (1.0f / (float)TRX2_HB_R);
   if (!(x > -1.0f && x < 1.0f)) return 0.0f;
-  const float ilu = rsqrtf(dot(u, u)), ilw = rsqrtf(dot(w, w));
+  const float ilu = frsq(dot(u, u)), ilw = frsq(dot(w, w));
   const f3 uh = u * ilu, vh = v * id, wh = w * ilw;
   const float ct = dot(uh, vh), cp = -dot(wh, vh);
   if (!(ct > 0.0f && cp > 0.0f)) return 0.0f;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
 
     if ((FAM & FAM_SYM) && (msym & TRX2_M_DIST)) {
       f3 u = A.dist_ca ? CAa - CAb : CBa - CBb;
-      float d2 = dot(u, u), id = rsqrtf(d2), dd = d2 * id;
+      float d2 = dot(u, u), id = frsq(d2), dd = d2 * id;
       int idx = dd < kd1 ? 0 : (dd < kd2 ? 1 : (dd < kd3 ? 2 : 3 + (int)((dd - kd3) * inv_d)));
       float ev, de;
       spline_eval_dev(A.Td + isym * kd, knd, iknd, kd, idx, dd, ev, de);

@@ -73,6 +73,10 @@ __device__ __forceinline__ f3 place_atom(f3 a, f3 b, f3 c, float len, float cang
 // hardware reciprocal (v_rcp_f32, 1 ulp) for the geometric factors below: an IEEE division is ~10 vector instructions and
 // the pair kernel, which is vector-ALU-bound (profiles/README.md), evaluates up to eight of them per residue-pair visit
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// 1/sqrt and sqrt straight from the hardware instruction (1 ulp): rsqrtf() / sqrtf() wrap it in a rescaling for denormal arguments
+// (five more instructions each), and squared interatomic distances are never denormal
+__device__ __forceinline__ float frsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
 // atan2 for the restraint angles: the library's is 43 vector instructions, this is ~23.  atan(a) = a P(a^2) on [0,1] (degree-7
 // fit, max error 1.4e-7 rad evaluated in float32 = 1-2 ulp at pi/4), octant fix-ups by selects.  atan2(0,0) = 0 as in libm.
@@ -116,7 +120,7 @@ __device__ __forceinline__ float dihedral_grad(f3 p1, f3 p2, f3 p3, f3 p4, f3& d
   f3 F = p1 - p2, G = p2 - p3, H = p4 - p3;
   f3 A = cross(F, G), B = cross(H, G);
   float G2 = dot(G, G);
-  float iGn = rsqrtf(G2), Gn = G2 * iGn;
+  float iGn = frsq(G2), Gn = G2 * iGn;
   float iA2 = frcp(fmaxf(dot(A, A), 1e-12f)), iB2 = frcp(fmaxf(dot(B, B), 1e-12f));
   float cosv = dot(A, B), sinv = dot(cross(B, A), G) * iGn;
   float ang = fast_atan2f(sinv, cosv);
@@ -132,11 +136,12 @@ __device__ __forceinline__ float dihedral_grad(f3 p1, f3 p2, f3 p3, f3 p4, f3& d
 // planar angle p1-p2-p3 in [0,pi] and gradient
 __device__ __forceinline__ float angle_grad(f3 p1, f3 p2, f3 p3, f3& d1, f3& d2, f3& d3) {
   f3 v = p1 - p2, w = p3 - p2;
-  float ivn = rsqrtf(dot(v, v)), iwn = rsqrtf(dot(w, w));
+  float ivn = frsq(dot(v, v)), iwn = frsq(dot(w, w));
   f3 vh = v * ivn, wh = w * iwn;
   float c = fminf(1.0f, fmaxf(-1.0f, dot(vh, wh)));
-  float ang = acosf(c);
-  float is = -frcp(fmaxf(sqrtf(1.0f - c * c), 1e-8f));
+  const float sn = fsqrt(1.0f - c * c);  // sin of the angle (>= 0): the angle is atan2(sin, cos) by the same polynomial as the dihedrals
+  float ang = fast_atan2f(sn, c);     // (acosf() is ~35 instructions)
+  float is = -frcp(fmaxf(sn, 1e-8f));
   d1 = (wh - vh * c) * (is * ivn);
   d3 = (vh - wh * c) * (is * iwn);
   d2 = (d1 + d3) * -1.0f;
