@@ -156,6 +156,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
 
   const int chunk = (L + A.nsplit - 1) / A.nsplit;
   const int b_lo = split * chunk, b_hi = min(L, b_lo + chunk);
+  const unsigned aL = (unsigned)a * (unsigned)L;
   STAMP(0)  // prologue: knots to LDS, barrier, weights, residue a
 
   // The loop runs in blocks of up to 32 visits.  Restraint terms are evaluated in the visit (the pair, hence the table, is
@@ -188,12 +189,14 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
     STAMP(1)  // masks (2 byte loads) + loop control
     if (!__any((int)(m_ab | m_ba | (unsigned)dovdw))) continue;
 
-    const float4* xb = A.xyzT + ((size_t)(grp * L + bc) * 5) * BW + d;
+    // index arithmetic in 24-bit multiplies (full rate; L <= 1024, a few decoy groups): the 64-bit multiply-adds size_t indexing
+    // compiles to are quarter-rate, and there were nine of them per visit
+    const float4* xb = A.xyzT + (__umul24((unsigned)(grp * L + bc), 5u * BW) + (unsigned)d);
     float4 r0 = xb[0], r1 = xb[BW], r3 = xb[3 * BW];
     const f3 Nb = mk3(r0.x, r0.y, r0.z), CAb = mk3(r0.w, r1.x, r1.y), CBb = mk3(r3.x, r3.y, r3.z);
     STAMP(2)  // coordinates of residue b (4 x 16 B per lane)
-    const size_t iab = (size_t)a * L + bc, iba = (size_t)bc * L + a;
-    const size_t isym = (a < bc) ? iab : iba;
+    const unsigned iab = aL + (unsigned)bc, iba = __umul24((unsigned)bc, (unsigned)L) + (unsigned)a;
+    const unsigned isym = (a < bc) ? iab : iba;
     const bool first = a < bc;  // symmetric energies are counted from the lower row only
 
     if ((FAM & FAM_SYM) && (msym & TRX2_M_DIST)) {
@@ -201,7 +204,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       float d2 = dot(u, u), id = frsq(d2), dd = d2 * id;
       int idx = dd < kd1 ? 0 : (dd < kd2 ? 1 : (dd < kd3 ? 2 : 3 + (int)((dd - kd3) * inv_d)));
       float ev, de;
-      spline_eval_dev(A.Td + isym * kd, knd, iknd, kd, idx, dd, ev, de);
+      spline_eval_dev(A.Td + __umul24(isym, (unsigned)kd), knd, iknd, kd, idx, dd, ev, de);
       if (first) e_d += ev;
       if (A.dist_ca) gCA = fma3(u, w_ap * de * id, gCA);
       else gCB = fma3(u, w_ap * de * id, gCB);
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       f3 d1, d2, d3, d4;
       float x = dihedral_grad(CAa, CBa, CBb, CAb, d1, d2, d3, d4);
       float ev, de;
-      spline_eval_dev(A.To + isym * KO, kno, ikno, KO, (int)((x - kno[0]) * inv_o), x, ev, de);
+      spline_eval_dev(A.To + __umul24(isym, (unsigned)KO), kno, ikno, KO, (int)((x - kno[0]) * inv_o), x, ev, de);
       if (first) e_o += ev;
       float s = w_dih * de;
       gCA = fma3(d1, s, gCA);
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       f3 d1, d2, d3, d4;
       float x = dihedral_grad(Na, CAa, CBa, CBb, d1, d2, d3, d4);
       float ev, de;
-      spline_eval_dev(A.Tt + iab * KO, knt, iknt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
+      spline_eval_dev(A.Tt + __umul24(iab, (unsigned)KO), knt, iknt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
       e_t += ev;
       float s = w_dih * de;
       gN = fma3(d1, s, gN);
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       f3 d1, d2, d3, d4;
       float x = dihedral_grad(Nb, CAb, CBb, CBa, d1, d2, d3, d4);
       float ev, de;
-      spline_eval_dev(A.Tt + iba * KO, knt, iknt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
+      spline_eval_dev(A.Tt + __umul24(iba, (unsigned)KO), knt, iknt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
       gCB = fma3(d4, w_dih * de, gCB);
     }
     STAMP(6)  // theta(b,a)
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       f3 d1, d2, d3;
       float x = angle_grad(CAa, CBa, CBb, d1, d2, d3);
       float ev, de;
-      spline_eval_dev(A.Tp + iab * KP, knp, iknp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
+      spline_eval_dev(A.Tp + __umul24(iab, (unsigned)KP), knp, iknp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
       e_p += ev;
       float s = w_ang * de;
       gCA = fma3(d1, s, gCA);
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       f3 d1, d2, d3;
       float x = angle_grad(CAb, CBb, CBa, d1, d2, d3);
       float ev, de;
-      spline_eval_dev(A.Tp + iba * KP, knp, iknp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
+      spline_eval_dev(A.Tp + __umul24(iba, (unsigned)KP), knp, iknp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
       gCB = fma3(d3, w_ang * de, gCB);
     }
     STAMP(8)  // phi(b,a)
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       const int v = __ffs((int)vmask) - 1;
       vmask &= vmask - 1;
       const int b = bb + v * VSTRIDE + h;
-      const float4* xb = A.xyzT + ((size_t)(grp * L + b) * 5) * BW + d;
+      const float4* xb = A.xyzT + (__umul24((unsigned)(grp * L + b), 5u * BW) + (unsigned)d);
       const float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW], r4 = xb[4 * BW];
       const f3 Nb = mk3(r0.x, r0.y, r0.z), Cb = mk3(r1.z, r1.w, r2.x), Ob = mk3(r2.y, r2.z, r2.w), Hb = mk3(r4.x, r4.y, r4.z);
       if (w_vdw != 0.0f) {
