@@ -47,6 +47,33 @@ __device__ __forceinline__ void spline_eval_dev(const float2* __restrict__ row, 
   de = inside ? dv : 0.0f;
 }
 
+// The same evaluation in three stages, so that the lookups of all the terms of a visit can travel together: seek (ONE round of
+// LDS reads: the guessed segment's ends and its neighbours' far ends), fetch (the segment's two knots: one 16-byte gather) and
+// value (arithmetic only).  Term by term, a visit with all channels on was six dependent LDS -> LDS -> gather chains in a row.
+struct SplSeg { int idx; float t, h, lo0, hi0; };
+__device__ __forceinline__ SplSeg spline_seek(const float* kn, int K, int guess, float x) {
+  const int idx = max(0, min(K - 2, guess));
+  const float k0 = kn[idx], k1 = kn[idx + 1], km = kn[max(idx - 1, 0)], kp = kn[min(idx + 2, K - 1)];
+  const bool dn = x < k0, up = !dn && x >= k1;
+  SplSeg g;
+  g.idx = dn ? max(0, idx - 1) : (up ? min(K - 2, idx + 1) : idx);
+  const float lo = dn ? km : (up && idx < K - 2 ? k1 : k0);
+  const float hi = dn ? (idx > 0 ? k0 : k1) : (up ? kp : k1);
+  g.t = x - lo; g.h = hi - lo;
+  g.lo0 = kn[0]; g.hi0 = kn[K - 1];
+  return g;
+}
+__device__ __forceinline__ void spline_value(const SplSeg& g, float2 k0, float2 k1, float x, float& e, float& de) {
+  const float h = g.h, ih = frcp(h), t = g.t;
+  const bool inside = (x > g.lo0) && (x < g.hi0);
+  const float c1 = fmaf(-h * (1.0f / 6.0f), fmaf(2.0f, k0.y, k1.y), (k1.x - k0.x) * ih);
+  const float c3 = (k1.y - k0.y) * (ih * (1.0f / 6.0f));
+  const float ev = fmaf(fmaf(fmaf(c3, t, 0.5f * k0.y), t, c1), t, k0.x);
+  const float dv = fmaf(fmaf(3.0f * c3, t, k0.y), t, c1);
+  e = inside ? ev : (x <= g.lo0 ? k0.x : k1.x);
+  de = inside ? dv : 0.0f;
+}
+
 // one donor -> acceptor candidate of a backbone hydrogen bond (trx2_model.h TRX2_HB_*; oracle: orc_hbond_term): N-H of one
 // residue, O=C of the other.  Returns the raw energy (<= 0) and ADDS its gradient scaled by s to gN, gH, gO, gC.
 __device__ __forceinline__ float hbond_dev(f3 N, f3 H, f3 O, f3 C, float s, f3& gN, f3& gH, f3& gO, f3& gC) {
@@ -205,75 +232,91 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
     // (dihedral_grad / angle_grad, which stay for the step kernels): the all-channel visit is ~25 % shorter.
     const f3 u = CBa - CBb;
     const float u2 = dot(u, u), iu = frsq(u2), du = u2 * iu;
-    if ((FAM & FAM_SYM) && (msym & TRX2_M_DIST)) {
-      f3 ud = u;
-      float id = iu, dd = du;
-      if (A.dist_ca) { ud = CAa - CAb; const float d2 = dot(ud, ud); id = frsq(d2); dd = d2 * id; }
-      int idx = dd < kd1 ? 0 : (dd < kd2 ? 1 : (dd < kd3 ? 2 : 3 + (int)((dd - kd3) * inv_d)));
-      float ev, de;
-      spline_eval_dev(A.Td + __umul24(isym, (unsigned)kd), knd, iknd, kd, idx, dd, ev, de);
-      if (first) e_d += ev;
-      if (A.dist_ca) gCA = fma3(ud, w_ap * de * id, gCA);
-      else gCB = fma3(ud, w_ap * de * id, gCB);
+    // ---- distance: seek + fetch now, value after the angular lookups have been sent off too
+    const bool on_d = (FAM & FAM_SYM) && (msym & TRX2_M_DIST);
+    f3 ud = u;
+    float idd = iu, dd = du;
+    if (A.dist_ca) { ud = CAa - CAb; const float d2 = dot(ud, ud); idd = frsq(d2); dd = d2 * idd; }
+    SplSeg sd;
+    float2 kd0 = make_float2(0, 0), kd1_ = kd0;
+    if (on_d) {
+      sd = spline_seek(knd, kd, dd < kd1 ? 0 : (dd < kd2 ? 1 : (dd < kd3 ? 2 : 3 + (int)((dd - kd3) * inv_d))), dd);
+      const float2* row = A.Td + __umul24(isym, (unsigned)kd) + sd.idx;
+      kd0 = row[0]; kd1_ = row[1];
     }
-    STAMP(3)  // dist
+    STAMP(3)  // dist: seek, fetch
     const unsigned m_om = (FAM & FAM_SYM) ? (msym & TRX2_M_OMEGA) : 0u;
     const unsigned m_tp_ab = (FAM & FAM_ASYM) ? (m_ab & (TRX2_M_THETA | TRX2_M_PHI)) : 0u, m_tp_ba = (FAM & FAM_ASYM) ? (m_ba & (TRX2_M_THETA | TRX2_M_PHI)) : 0u;
     if (m_om | m_tp_ab | m_tp_ba) {
+      // every angle of the pair (those whose channel is off get weight zero: the selections of a pair's channels go together,
+      // and straight-line code lets the five lookups share their round trips)
       const f3 va = CAa - CBa, vb = CAb - CBb;
       const float va2 = dot(va, va), vb2 = dot(vb, vb), iva = frsq(va2), ivb = frsq(vb2), vau = dot(va, u), vbu = dot(vb, u);
       const f3 Aa = cross(va, u), Bb = cross(vb, u);
       const float iAa2 = frcp(fmaxf(dot(Aa, Aa), 1e-12f)), iBb2 = frcp(fmaxf(dot(Bb, Bb), 1e-12f));
-      if (m_om) {  // dihedral CA_a - CB_a - CB_b - CA_b: F = va, G = u, H = vb
-        const float x = fast_atan2f(dot(cross(Bb, Aa), u) * iu, dot(Aa, Bb));
-        float ev, de;
-        spline_eval_dev(A.To + __umul24(isym, (unsigned)KO), kno, ikno, KO, (int)((x - kno[0]) * inv_o), x, ev, de);
-        if (first) e_o += ev;
-        const float s = w_dih * de, ga = du * iAa2, ca = vau * iAa2 * iu, cb = vbu * iBb2 * iu;
-        gCA = fma3(Aa, -ga * s, gCA);
-        gCB = fma3(Aa, (ga + ca) * s, fma3(Bb, -cb * s, gCB));
+      const f3 na = Na - CAa, Ta = cross(na, va), nb = Nb - CAb, Tb = cross(nb, vb);
+      const float iT2 = frcp(fmaxf(dot(Ta, Ta), 1e-12f));
+      const float x_o = fast_atan2f(dot(cross(Bb, Aa), u) * iu, dot(Aa, Bb));                  // CA_a - CB_a - CB_b - CA_b
+      const float x_t1 = fast_atan2f(dot(cross(Aa, Ta), va) * iva, dot(Ta, Aa));               // N_a - CA_a - CB_a - CB_b
+      const float x_t2 = fast_atan2f(-dot(cross(Bb, Tb), vb) * ivb, -dot(Tb, Bb));             // N_b - CA_b - CB_b - CB_a
+      const float c_p1 = fminf(1.0f, fmaxf(-1.0f, -vau * iva * iu)), s_p1 = fsqrt(1.0f - c_p1 * c_p1), x_p1 = fast_atan2f(s_p1, c_p1);  // CA_a - CB_a - CB_b
+      const float c_p2 = fminf(1.0f, fmaxf(-1.0f, vbu * ivb * iu)), s_p2 = fsqrt(1.0f - c_p2 * c_p2), x_p2 = fast_atan2f(s_p2, c_p2);   // CA_b - CB_b - CB_a
+      const SplSeg g_o = spline_seek(kno, KO, (int)((x_o - kno[0]) * inv_o), x_o), g_t1 = spline_seek(knt, KO, (int)((x_t1 - knt[0]) * inv_o), x_t1),
+                   g_t2 = spline_seek(knt, KO, (int)((x_t2 - knt[0]) * inv_o), x_t2), g_p1 = spline_seek(knp, KP, (int)((x_p1 - knp[0]) * inv_p), x_p1),
+                   g_p2 = spline_seek(knp, KP, (int)((x_p2 - knp[0]) * inv_p), x_p2);
+      const float2* r_o = A.To + __umul24(isym, (unsigned)KO) + g_o.idx;
+      const float2* r_t1 = A.Tt + __umul24(iab, (unsigned)KO) + g_t1.idx;
+      const float2* r_t2 = A.Tt + __umul24(iba, (unsigned)KO) + g_t2.idx;
+      const float2* r_p1 = A.Tp + __umul24(iab, (unsigned)KP) + g_p1.idx;
+      const float2* r_p2 = A.Tp + __umul24(iba, (unsigned)KP) + g_p2.idx;
+      const float2 o0 = r_o[0], o1 = r_o[1], t10 = r_t1[0], t11 = r_t1[1], t20 = r_t2[0], t21 = r_t2[1], p10 = r_p1[0], p11 = r_p1[1], p20 = r_p2[0], p21 = r_p2[1];
+      STAMP(4)  // angles, five seeks, five fetches
+      float ev, de;
+      {  // omega: F = va, G = u, H = vb
+        spline_value(g_o, o0, o1, x_o, ev, de);
+        const float on = m_om ? 1.0f : 0.0f;
+        if (first) e_o += on * ev;
+        const float sc = on * w_dih * de, ga = du * iAa2, ca = vau * iAa2 * iu, cb = vbu * iBb2 * iu;
+        gCA = fma3(Aa, -ga * sc, gCA);
+        gCB = fma3(Aa, (ga + ca) * sc, fma3(Bb, -cb * sc, gCB));
       }
-      STAMP(4)  // omega
-      if (m_tp_ab & TRX2_M_THETA) {  // dihedral N_a - CA_a - CB_a - CB_b: F = na, G = va, H = -u; second normal = va x u
-        const f3 na = Na - CAa, Ta = cross(na, va);
-        const float iT2 = frcp(fmaxf(dot(Ta, Ta), 1e-12f));
-        const float x = fast_atan2f(dot(cross(Aa, Ta), va) * iva, dot(Ta, Aa));
-        float ev, de;
-        spline_eval_dev(A.Tt + __umul24(iab, (unsigned)KO), knt, iknt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
-        e_t += ev;
-        const float s = w_dih * de, Gn = va2 * iva, ga = Gn * iT2, gb = Gn * iAa2, ca = dot(na, va) * iT2 * iva, cb = -vau * iAa2 * iva;
-        gN = fma3(Ta, -ga * s, gN);
-        gCA = fma3(Ta, (ga + ca) * s, fma3(Aa, -cb * s, gCA));
-        gCB = fma3(Aa, (cb - gb) * s, fma3(Ta, -ca * s, gCB));
+      {  // theta(a,b): F = na, G = va, H = -u; second normal = va x u
+        spline_value(g_t1, t10, t11, x_t1, ev, de);
+        const float on = (m_tp_ab & TRX2_M_THETA) ? 1.0f : 0.0f;
+        e_t += on * ev;
+        const float sc = on * w_dih * de, Gn = va2 * iva, ga = Gn * iT2, gb = Gn * iAa2, ca = dot(na, va) * iT2 * iva, cb = -vau * iAa2 * iva;
+        gN = fma3(Ta, -ga * sc, gN);
+        gCA = fma3(Ta, (ga + ca) * sc, fma3(Aa, -cb * sc, gCA));
+        gCB = fma3(Aa, (cb - gb) * sc, fma3(Ta, -ca * sc, gCB));
       }
-      STAMP(5)  // theta(a,b)
-      if (m_tp_ba & TRX2_M_THETA) {  // dihedral N_b - CA_b - CB_b - CB_a: F = nb, G = vb, H = u; second normal = -(vb x u); only CB_a's share
-        const f3 nb = Nb - CAb, Tb = cross(nb, vb);
-        const float x = fast_atan2f(-dot(cross(Bb, Tb), vb) * ivb, -dot(Tb, Bb));
-        float ev, de;
-        spline_eval_dev(A.Tt + __umul24(iba, (unsigned)KO), knt, iknt, KO, (int)((x - knt[0]) * inv_o), x, ev, de);
-        gCB = fma3(Bb, -(vb2 * ivb) * iBb2 * (w_dih * de), gCB);
+      {  // theta(b,a): F = nb, G = vb, H = u; second normal = -(vb x u); only CB_a's share
+        spline_value(g_t2, t20, t21, x_t2, ev, de);
+        const float on = (m_tp_ba & TRX2_M_THETA) ? 1.0f : 0.0f;
+        gCB = fma3(Bb, -(vb2 * ivb) * iBb2 * (on * w_dih * de), gCB);
       }
-      STAMP(6)  // theta(b,a)
-      if (m_tp_ab & TRX2_M_PHI) {  // angle CA_a - CB_a - CB_b: between va and -u
+      {  // phi(a,b): between va and -u
+        spline_value(g_p1, p10, p11, x_p1, ev, de);
+        const float on = (m_tp_ab & TRX2_M_PHI) ? 1.0f : 0.0f;
+        e_p += on * ev;
         const f3 vh = va * iva, wh = u * -iu;
-        const float c = fminf(1.0f, fmaxf(-1.0f, -vau * iva * iu)), sn = fsqrt(1.0f - c * c), x = fast_atan2f(sn, c);
-        float ev, de;
-        spline_eval_dev(A.Tp + __umul24(iab, (unsigned)KP), knp, iknp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
-        e_p += ev;
-        const float is = -frcp(fmaxf(sn, 1e-8f)) * (w_ang * de);
-        const f3 d1 = (wh - vh * c) * (is * iva), d3 = (vh - wh * c) * (is * iu);
+        const float is = -frcp(fmaxf(s_p1, 1e-8f)) * (on * w_ang * de);
+        const f3 d1 = (wh - vh * c_p1) * (is * iva), d3 = (vh - wh * c_p1) * (is * iu);
         gCA += d1;
         gCB += (d1 + d3) * -1.0f;
       }
-      STAMP(7)  // phi(a,b)
-      if (m_tp_ba & TRX2_M_PHI) {  // angle CA_b - CB_b - CB_a: between vb and u; only CB_a's share
+      {  // phi(b,a): between vb and u; only CB_a's share
+        spline_value(g_p2, p20, p21, x_p2, ev, de);
+        const float on = (m_tp_ba & TRX2_M_PHI) ? 1.0f : 0.0f;
         const f3 vh = vb * ivb, wh = u * iu;
-        const float c = fminf(1.0f, fmaxf(-1.0f, vbu * ivb * iu)), sn = fsqrt(1.0f - c * c), x = fast_atan2f(sn, c);
-        float ev, de;
-        spline_eval_dev(A.Tp + __umul24(iba, (unsigned)KP), knp, iknp, KP, (int)((x - knp[0]) * inv_p), x, ev, de);
-        gCB = fma3(vh - wh * c, -frcp(fmaxf(sn, 1e-8f)) * iu * (w_ang * de), gCB);
+        gCB = fma3(vh - wh * c_p2, -frcp(fmaxf(s_p2, 1e-8f)) * iu * (on * w_ang * de), gCB);
       }
+    }
+    if (on_d) {
+      float ev, de;
+      spline_value(sd, kd0, kd1_, dd, ev, de);
+      if (first) e_d += ev;
+      if (A.dist_ca) gCA = fma3(ud, w_ap * de * idd, gCA);
+      else gCB = fma3(ud, w_ap * de * idd, gCB);
     }
     STAMP(8)  // phi(b,a)
     if ((FAM & FAM_VDW) && dovdw) {
