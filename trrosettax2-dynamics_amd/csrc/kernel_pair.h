@@ -203,6 +203,11 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
     const bool valid = live && active && b < b_hi && b != a;
     const int bc = min(b, L - 1);
     const int sep = abs(a - bc);
+    // residue b's N, CA, CB: requested before the masks are looked at (the address needs only b), so that the two reads travel
+    // together; a visit that turns out to have nothing to do drops them.  Index arithmetic in 24-bit multiplies (full rate;
+    // L <= 1024, a few decoy groups) instead of the quarter-rate 64-bit multiply-adds of size_t indexing.
+    const float4* xb = A.xyzT + (__umul24((unsigned)(grp * L + bc), 5u * BW) + (unsigned)d);
+    float4 r0 = xb[0], r1 = xb[BW], r3 = xb[3 * BW];
     unsigned m_ab = 0, m_ba = 0;
     if (valid && sep >= sep_lo && sep < sep_hi) {
       const unsigned mm = odr_only ? s_mask_o[bc - b_lo] : s_mask[bc - b_lo];
@@ -216,10 +221,6 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
     STAMP(1)  // masks (2 byte loads) + loop control
     if (!__any((int)(m_ab | m_ba | (unsigned)dovdw))) continue;
 
-    // index arithmetic in 24-bit multiplies (full rate; L <= 1024, a few decoy groups): the 64-bit multiply-adds size_t indexing
-    // compiles to are quarter-rate, and there were nine of them per visit
-    const float4* xb = A.xyzT + (__umul24((unsigned)(grp * L + bc), 5u * BW) + (unsigned)d);
-    float4 r0 = xb[0], r1 = xb[BW], r3 = xb[3 * BW];
     const f3 Nb = mk3(r0.x, r0.y, r0.z), CAb = mk3(r0.w, r1.x, r1.y), CBb = mk3(r3.x, r3.y, r3.z);
     STAMP(2)  // coordinates of residue b (4 x 16 B per lane)
     const unsigned iab = aL + (unsigned)bc, iba = __umul24((unsigned)bc, (unsigned)L) + (unsigned)a;
