@@ -374,3 +374,25 @@ def test_tail_compaction_moves_the_survivors_and_changes_nothing(golden_dir, seq
         assert np.all(np.isfinite(f)) and np.all(np.isfinite(xyz))
     finally:
         ctx.close()
+
+
+def test_tail_compaction_with_slot_pool_and_two_lanes(golden_dir, seq):
+    """A queue longer than the slots, on two lanes: slots refill while the queue lasts, and only then do the groups empty and the
+    survivors move.  With the split kept (mode 2) every decoy must come out bit for bit as without compaction."""
+    m = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
+    runs = T.protocol.build_runs(90, 2)
+    ctx = T.Context(0, lanes=2, pool=96)
+    try:
+        ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+        out = {}
+        for mode in (0, 2, 1):
+            ctx.set_tail_compaction(mode)
+            out[mode] = ctx.fold_batch(260, runs, seed=33)
+            assert np.all(out[mode]["status"] == 0) and np.all(np.isfinite(out[mode]["xyz"]))
+        for key in ("xyz", "tors", "e_terms", "f", "n_evals", "n_iters"):
+            assert np.array_equal(out[0][key], out[2][key]), key
+        print(f"\n260 decoys, 2 lanes x 96 slots: seconds {out[0]['seconds']:.3f} (off) / {out[2]['seconds']:.3f} (split kept) / {out[1]['seconds']:.3f} (default); "
+              f"slot efficiency {out[0]['slot_efficiency']:.3f} / {out[2]['slot_efficiency']:.3f} / {out[1]['slot_efficiency']:.3f}")
+        assert out[1]["slot_efficiency"] > out[0]["slot_efficiency"]
+    finally:
+        ctx.close()
