@@ -553,6 +553,9 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
     const long slots = ctx->use_orient ? 640 : 512;
     for (int n = 1; n <= 16; n++)
       if ((long)L * n * groups <= slots && L / n >= PAIR_WAVES * PW * 2) n_best = n;
+    // ... but not fewer than ~450 workgroups when one more split would give them (L=400, 32 decoys: 400 -> 800 workgroups,
+    // 119 -> 133 decoys/s; two groups of 64 at L=150: 300 -> 600)
+    if ((long)L * n_best * groups < 450 && L / (n_best + 1) >= PAIR_WAVES * PW * 2) n_best++;
     if (const char* e = getenv("TRX2_NSPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) n_best = v; }  // A/B timing only
     return n_best;
   };
