@@ -56,6 +56,9 @@ def _unquote(p):
     return p[1:-1] if len(p) >= 2 and p[0] == p[-1] and p[0] in "\"'" else p
 
 
+SLOTS_PER_LANE = 192  # three decoy groups of the pair kernel (bench.py uses the same figure)
+
+
 def get_context(device=0, lanes=1):
     key = (device, threading.get_ident())
     if key not in _CTX:
@@ -101,6 +104,10 @@ def fold_arrays(npz, seq, n_decoys, options="", device=0, seed=None, decoy0=0, l
         with _SEED_LOCK:  # chains are folded from concurrent host threads
             seed = _SEED[0]
             _SEED[0] += 1
+    # decoy slots: every decoy in flight up to SLOTS_PER_LANE per lane, beyond that a queue that refills them on the device (a
+    # launch over more slots takes proportionally longer: profiles/README.md, "How many slots")
+    per_lane = (n_decoys + ctx.lanes - 1) // ctx.lanes if n_decoys >= 32 else n_decoys
+    ctx.set_pool(SLOTS_PER_LANE if per_lane > SLOTS_PER_LANE else 0)
     r = ctx.fold_batch(n_decoys, protocol.build_runs(L, args.mode), seed=seed, decoy0=decoy0)
     bad = np.nonzero((r["status"] != 0) | ~np.isfinite(r["xyz"]).all(axis=(1, 2, 3)))[0]
     if len(bad):
