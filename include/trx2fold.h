@@ -180,6 +180,7 @@ int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int sep_lo, int 
 #define TRX2_INFO_GROUP_WIDTH 0 /* decoys per wave of the pair kernel */
 #define TRX2_INFO_SLAB_BYTES 1  /* bytes of pair-kernel records the step kernel sums per residue (average over residues) */
 #define TRX2_INFO_PAIR_WGS 4    /* workgroups of one pair-kernel launch */
+#define TRX2_INFO_CART_STAGED 5 /* stored L-BFGS pairs the Cartesian role stages in LDS at the current chain length (0: none) */
 #define TRX2_INFO_LBFGS_M 2     /* stored correction pairs */
 #define TRX2_INFO_L 3
 int trx2_ctx_set_profiling(trx2_ctx* ctx, int every);

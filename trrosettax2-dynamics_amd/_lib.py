@@ -332,7 +332,7 @@ class Context:
 
     def info(self, key):
         """layout facts for the roofline arithmetic: 0 decoys per wave of the pair kernel, 1 bytes of pair-kernel records summed
-        per residue by the step kernel, 2 L-BFGS pairs, 3 L, 4 workgroups per pair-kernel launch"""
+        per residue by the step kernel, 2 L-BFGS pairs, 3 L, 4 workgroups per pair-kernel launch, 5 stored pairs the Cartesian role stages in LDS"""
         v = C.c_double()
         if self._l.trx2_ctx_info(self._h, int(key), C.byref(v)) != 0:
             raise RuntimeError(f"trx2_ctx_info: unknown key {key}")

@@ -1308,6 +1308,9 @@ extern "C" int trx2_ctx_info(const trx2_ctx* ctx, int key, double* value) {
     case TRX2_INFO_GROUP_WIDTH: *value = ctx->BW; return 0;
     case TRX2_INFO_SLAB_BYTES: *value = (double)ctx->nsplit * PR_REC * 4; return 0;
     case TRX2_INFO_PAIR_WGS: *value = (double)ctx->L * ctx->nsplit * (ctx->Bpad / ctx->BW); return 0;
+    case TRX2_INFO_CART_STAGED:
+      *value = (ctx->L >= 1 && ctx->L <= CHAIN_THREADS) ? (double)std::min<size_t>(LBM, (size_t)ctx->step_dyn_max[ctx->L <= 128 ? 0 : 1] / CART_HIST_BYTES(ctx->L)) : 0.0;
+      return 0;
     case TRX2_INFO_LBFGS_M: *value = LBM; return 0;
     case TRX2_INFO_L: *value = ctx->L; return 0;
     default: return 1;
