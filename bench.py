@@ -293,6 +293,12 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
         c_.set_pool(slots)       # B decoy slots per chain; the K steps' decoys are their queue
     for i in range(warmup):
         step(900 + i)
+    if warmup > 0 and steps > 1:
+        # the warm-up steps fold B decoys each; the timed queue runs on more slots: size the slot buffers for it now (one
+        # evaluation of as many decoys as there are slots -- an allocation, nothing the timed folds could reuse), so that the
+        # timed region holds folds and no hipMalloc
+        for c_ in ctxs:
+            c_.fold_batch(min(steps * B, lanes * slots), runs, seed=149, decoy0=10 ** 6, max_evals=1)
     sync()
     t0 = time.perf_counter()
     res = step(0, steps)         # fold_batch returns with the coordinates of every decoy on the host
