@@ -30,4 +30,5 @@ if n:
     for k, (nm, xx) in enumerate(zip(names, v)):
         per = xx / (nd if k in (7, 8, 9) else n)
         print(f"   {nm:34s} {100*xx/v.sum():5.1f} %   {per:8.0f} ticks per {'new-direction step' if k in (7,8,9) else 'step'}")
+print(f"staged Cartesian history entries that differ from their global copy (diagnostic counter 27): {out[27]}")
 ctx.close()

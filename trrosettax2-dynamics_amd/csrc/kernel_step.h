@@ -1329,6 +1329,21 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
     if constexpr (NT <= 256) {
       const int sh = stored ? 1 : 0, kg0 = nl + sh;  // first pair that is neither in registers nor staged
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged pairs have landed (long ago)
+#ifdef TRX2_STAMP
+      if (act) {  // diagnostic build: every staged entry against the global copy it was requested from (counter 27: must stay 0)
+        unsigned bad = 0;
+        for (int t = 0; t < nl; t++) {
+          const int j = (hh0 - 1 - t + LBM) % LBM;
+          if (stored && j == (hh + LBM - 1) % LBM) continue;  // the slot the new pair has just overwritten in global memory
+          for (int q = 0; q < 4; q++) {
+            const float4 a = s_hist[(size_t)((t * 2 + 0) * 4 + q) * L + r], b = A.CS[(((size_t)dec * LBM + j) * 4 + q) * L + r];
+            const float4 c = s_hist[(size_t)((t * 2 + 1) * 4 + q) * L + r], d = A.CY[(((size_t)dec * LBM + j) * 4 + q) * L + r];
+            bad += (a.x != b.x) + (a.y != b.y) + (a.z != b.z) + (a.w != b.w) + (c.x != d.x) + (c.y != d.y) + (c.z != d.z) + (c.w != d.w);
+          }
+        }
+        if (bad) atomicAdd(&g_cstamp[27], (unsigned long long)bad);
+      }
+#endif
       float4 e0s[4], e0y[4], e1s[4], e1y[4];
       if (kg0 < hl) load_pair(kg0, e0s, e0y);
       if (kg0 + 1 < hl) load_pair(kg0 + 1, e1s, e1y);
