@@ -136,7 +136,7 @@ def test_cartesian_history_staged_in_lds_tracks_oracle(ctx, L):
     B = 4
     m = S.make_map(L, seed=L, n_moves=150)
     ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=m["seq"])
-    assert int(ctx.info(5)) == {150: 5, 230: 3}[L]   # pairs staged in LDS: 160 KB - the kernel's static LDS - 30 KB left to the pair kernel
+    assert int(ctx.info(5)) == {150: 6, 230: 4}[L]   # pairs staged in LDS by a lane that folds alone: 160 KB - the kernel's static LDS (two lanes leave 58 KB to the other lane's pair kernel: 3 and 2)
     Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"])
     rng = np.random.default_rng(L)
     t0 = np.stack([m["tors"] + rng.normal(size=(L, 3)) * 0.08 for _ in range(B)]).astype(np.float32)

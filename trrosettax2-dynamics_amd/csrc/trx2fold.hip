@@ -116,6 +116,7 @@ struct trx2_ctx {
   // trx2_ctx_set_profiling: every prof_every-th evaluation of a fold is bracketed by HIP events on the stream (pair | step)
   int prof_every = 0;
   int step_dyn_max[2] = {0, 0};  // dynamic LDS the fused step kernels may ask for (L <= 128 | L <= 256): 160 KB - their static LDS
+  int step_dyn_floor[2] = {0, 0};  // ... and what the torsion role needs of it (its staged history)
   std::vector<hipEvent_t> prof_ev;
   double prof_pair_ms = 0, prof_step_ms = 0; int prof_n = 0;
   // second lane (trx2_ctx_set_lanes): a context of its own stream and batch buffers that BORROWS this one's tables, so that
@@ -184,12 +185,10 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
       hipFuncAttributes fa;
       ok = hipFuncGetAttributes(&fa, fstep[k]) == hipSuccess;
       if (!ok) break;
-      // ... less what one workgroup of the pair kernel needs (28.0 KB): with two lanes the other lane's pair kernel runs beside
-      // this one, and a step workgroup that fills a CU's LDS keeps it off that CU (measured: profiles/README.md)
-      static const int reserve = getenv("TRX2_STEP_LDS_RESERVE") ? atoi(getenv("TRX2_STEP_LDS_RESERVE")) : 30 * 1024;
-      int dyn = lds_max - (int)fa.sharedSizeBytes - reserve;
+      int dyn = lds_max - (int)fa.sharedSizeBytes;  // what a launch may ask for at most; how much it does ask for: step_dyn_budget()
       if (dyn < hist[k]) dyn = hist[k];
       ctx->step_dyn_max[k] = dyn;
+      ctx->step_dyn_floor[k] = hist[k];
       ok = hipFuncSetAttribute(fstep[k], hipFuncAttributeMaxDynamicSharedMemorySize, dyn) == hipSuccess;
     }
     if (!ok) {
@@ -758,6 +757,18 @@ static int ensure_outputs(trx2_ctx* ctx, size_t N, bool with_tors0) {
 // launch; a decoy that is over reports (one evaluation at its accepted point under the last run's weights), its slot then takes
 // the next decoy of the queue ON THE DEVICE (kernel_step.h) -- the host only replays chunks of launches and polls the number of
 // retired slots.  A decoy's identity is (seed, decoy0 + index): results do not depend on the slot that folded it.
+// Dynamic LDS the fused step launch uses for the Cartesian role's staged history.  A lane that folds alone takes all there is
+// (its own pair kernel never runs beside its step kernel).  With two lanes the other lane's pair kernel does, and a step workgroup
+// that fills a CU's LDS keeps it off that CU: two pair-kernel workgroups' worth (2 x 28.0 KB) stay free -- measured at 2 x 160
+// slots: no reserve 837, one workgroup's 865, two 900 decoys/s (all channels 789 -> 840 from one to two); one lane of 64 slots
+// loses 2 % with the reserve, hence the distinction (profiles/README.md).
+static int step_dyn_budget(const trx2_ctx* ctx, int k) {
+  static const int env = getenv("TRX2_STEP_LDS_RESERVE") ? atoi(getenv("TRX2_STEP_LDS_RESERVE")) : -1;  // A/B timing only
+  const bool two_lanes = ctx->child != nullptr || ctx->borrows_map;
+  const int reserve = env >= 0 ? env : (two_lanes ? 58 * 1024 : 0);
+  return std::max(ctx->step_dyn_floor[k], ctx->step_dyn_max[k] - reserve);
+}
+
 static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint64_t seed, uint32_t decoy0,
                      const float* tors0, int max_evals, float* tors_out, float* xyz_out, double* e_terms,
                      double* f_final, int* status, int* n_evals, int* n_iters) {
@@ -834,7 +845,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
         const int k = L <= 128 ? 0 : 1;
         size_t dyn = k == 0 ? HIST_LDS_BYTES(128) : HIST_LDS_BYTES(CHAIN_THREADS);
         if (L <= CHAIN_THREADS) {
-          cc.hist_lds = (int)std::min<size_t>(LBM, (size_t)ctx->step_dyn_max[k] / CART_HIST_BYTES(L));
+          cc.hist_lds = (int)std::min<size_t>(LBM, (size_t)step_dyn_budget(ctx, k) / CART_HIST_BYTES(L));
           if (const char* e = getenv("TRX2_CART_HIST_LDS")) cc.hist_lds = std::min(cc.hist_lds, std::max(0, atoi(e)));  // A/B and debugging only
           dyn = std::max(dyn, cc.hist_lds * CART_HIST_BYTES(L));
         }
@@ -1309,7 +1320,7 @@ extern "C" int trx2_ctx_info(const trx2_ctx* ctx, int key, double* value) {
     case TRX2_INFO_SLAB_BYTES: *value = (double)ctx->nsplit * PR_REC * 4; return 0;
     case TRX2_INFO_PAIR_WGS: *value = (double)ctx->L * ctx->nsplit * (ctx->Bpad / ctx->BW); return 0;
     case TRX2_INFO_CART_STAGED:
-      *value = (ctx->L >= 1 && ctx->L <= CHAIN_THREADS) ? (double)std::min<size_t>(LBM, (size_t)ctx->step_dyn_max[ctx->L <= 128 ? 0 : 1] / CART_HIST_BYTES(ctx->L)) : 0.0;
+      *value = (ctx->L >= 1 && ctx->L <= CHAIN_THREADS) ? (double)std::min<size_t>(LBM, (size_t)step_dyn_budget(ctx, ctx->L <= 128 ? 0 : 1) / CART_HIST_BYTES(ctx->L)) : 0.0;
       return 0;
     case TRX2_INFO_LBFGS_M: *value = LBM; return 0;
     case TRX2_INFO_L: *value = ctx->L; return 0;
