@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -149,6 +150,8 @@ static double round_txt(double v, int dp) {
   return strtod(buf, nullptr);
 }
 
+static std::atomic<int> g_live_contexts{0};  // contexts alive in this process (lanes are contexts too): step_dyn_budget
+
 extern "C" int trx2_abi_version(void) { return 1; }
 
 extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
@@ -221,6 +224,7 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
     delete ctx;
     return 4;
   }
+  g_live_contexts++;
   *out = ctx;
   return 0;
 }
@@ -322,6 +326,7 @@ extern "C" int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes) {
 
 extern "C" void trx2_ctx_destroy(trx2_ctx* ctx) {
   if (!ctx) return;
+  g_live_contexts--;
   (void)hipSetDevice(ctx->device);
   if (ctx->child) { trx2_ctx* k = ctx->child; ctx->child = nullptr; trx2_ctx_destroy(k); }
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -757,15 +762,16 @@ static int ensure_outputs(trx2_ctx* ctx, size_t N, bool with_tors0) {
 // launch; a decoy that is over reports (one evaluation at its accepted point under the last run's weights), its slot then takes
 // the next decoy of the queue ON THE DEVICE (kernel_step.h) -- the host only replays chunks of launches and polls the number of
 // retired slots.  A decoy's identity is (seed, decoy0 + index): results do not depend on the slot that folded it.
-// Dynamic LDS the fused step launch uses for the Cartesian role's staged history.  A lane that folds alone takes all there is
-// (its own pair kernel never runs beside its step kernel).  With two lanes the other lane's pair kernel does, and a step workgroup
+// Dynamic LDS the fused step launch uses for the Cartesian role's staged history.  A context that is alone in the process takes
+// all there is (its own pair kernel never runs beside its step kernel).  With a second lane or another chain's context the
+// other stream's pair kernel does, and a step workgroup
 // that fills a CU's LDS keeps it off that CU: two pair-kernel workgroups' worth (2 x 28.0 KB) stay free -- measured at 2 x 160
 // slots: no reserve 837, one workgroup's 865, two 900 decoys/s (all channels 789 -> 840 from one to two); one lane of 64 slots
 // loses 2 % with the reserve, hence the distinction (profiles/README.md).
 static int step_dyn_budget(const trx2_ctx* ctx, int k) {
   static const int env = getenv("TRX2_STEP_LDS_RESERVE") ? atoi(getenv("TRX2_STEP_LDS_RESERVE")) : -1;  // A/B timing only
-  const bool two_lanes = ctx->child != nullptr || ctx->borrows_map;
-  const int reserve = env >= 0 ? env : (two_lanes ? 58 * 1024 : 0);
+  const bool shared = g_live_contexts.load() > 1;  // a second lane (a context of its own) or another chain's context in this process
+  const int reserve = env >= 0 ? env : (shared ? 58 * 1024 : 0);
   return std::max(ctx->step_dyn_floor[k], ctx->step_dyn_max[k] - reserve);
 }
 
