@@ -1,25 +1,30 @@
 #!/usr/bin/env python
-"""bench.py -- decoys/sec of the MI355X-native fold, with kernel rooflines and a CPU baseline.
+"""bench.py -- decoys/sec of the MI355X-native fold, with kernel rooflines, a CPU baseline and the end-to-end job.
 
 Contract:  python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank per GPU)
 prints ONE JSON line on rank 0.
 
-A "step" = one pass of the hot path over one batch: B decoys of one distogram folded through the full staged protocol
-(folding/folding.py:118-171 mode 2), timed from tables-resident-in-HBM to the last coordinates on the host.  The K steps of a
-run are ONE queue of K x B decoys: every decoy of every step is folded inside the timed region.  The queue runs on decoy slots
-(trx2_ctx_set_pool): a slot whose decoy has finished takes the next decoy on the device, as the reference's process pool starts
-the next `folding.py` child when a worker frees up (utils_trX2dy/utils.py:501-503).  How many slots is a scheduling choice of the
-library's user, not part of the workload: both kernels are latency-bound, a launch over 192 slots takes 2.7 x as long as one
-over 32 (profiles/README.md), so `value` uses two lanes (two streams: one lane's step kernel overlaps the other's pair kernel,
-trx2_ctx_set_lanes) of min(192, K B / 2) slots each.  Beside `value`, the same queue with only B decoys in flight:
-`in_flight_B` (two lanes of B/2 slots: round 2's first `value`) and `single_stream` (one stream of B slots); and `per_call`
-(K separate calls of B decoys, one slot per decoy, each call ending with its slowest decoy: round 1's `value`).
-Workload at N=1 = BASELINE.json configs[1]: L=150 single target, init_num=64, dist-only restraints (synthetic map,
-SURVEY.md 8d -- the reference ships data for L=90 only).  Other configs: --config 3 (all channels, two models),
---config 4 (L=400, B=32), --config 5 (eight targets L=100..400, 32 decoys each, assigned to ranks longest-first: strong
-scaling).  N>1: every rank folds its own B decoys of the same target (independent units, no data-path collective): weak
-scaling; the same line then also carries the config-5 batch-mode record ("batch_mode", strong scaling), which is the
-north star's multi-GPU mode.  At N=1 the line carries compact sub-records for configs 3 and 4 ("sub_records").
+A "step" = one pass of the hot path over one batch AS BASELINE.json WRITES IT: ONE call of the drop-in boundary for init_num
+decoys of one distogram -- `trx2_fold_batch(B = init_num)` on a context with the library's defaults (what
+`folding_with_pred_npz(repeat=init_num)` makes: two lanes, one slot per decoy, default tail compaction) -- folded through the
+full staged protocol (folding/folding.py:118-171 mode 2), timed from tables-resident-in-HBM to the last coordinates on the
+host.  The K steps are K such calls, one after the other; every call ends with its slowest decoy, so `value` does not depend
+on K.  Workload at N=1 = BASELINE.json configs[1]: L=150 single target, init_num=64, dist-only restraints (synthetic map,
+SURVEY.md 8d -- the reference ships data for L=90 only).
+
+Named legs beside `value` (N=1 only; none of them is `value`):
+  pooled_queue   ONE call over a queue of 1280 decoys on 2 lanes x 192 decoy slots that refill on the device
+                 (trx2_ctx_set_pool): the throughput mode of a job that has that many independent decoys (round 2's headline)
+  in_flight_B    a queue of 320 decoys with init_num in flight: two lanes of init_num/2 slots
+  single_stream  the same queue on ONE stream of init_num slots
+  e2e            the job the reference actually runs: run_inference.py end to end (pipeline.run_single: init_num initial decoys
+                 per model, then the SEQUENTIAL chain of single-decoy folds + feedback until convergence or Nmax, both models,
+                 PDB files written), at init_num = 10 (BASELINE's metric) and 64, with the split initial / iteration phase
+Other configs: --config 3 (all channels, two models), --config 4 (L=400, B=32), --config 5 (eight targets L=100..400, 32 decoys
+each, assigned to ranks longest-first: strong scaling).  N>1: every rank folds its own calls of the same target (independent
+units, no data-path collective): weak scaling; the same line then also carries the config-5 batch-mode record ("batch_mode",
+strong scaling, with per-rank seconds and the plan), which is the north star's multi-GPU mode.  At N=1 the line carries compact
+sub-records for configs 3 and 4 ("sub_records").
 
 Nothing here reads /root/reference.  The oracle is imported ONLY for the cpu_baseline leg (rank 0, N=1).
 """
@@ -28,7 +33,9 @@ import hashlib
 import importlib
 import json
 import os
+import shutil
 import sys
+import tempfile
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -51,14 +58,16 @@ CONFIGS = {
                  "seed L; (target, decoy-block) items assigned to ranks longest-processing-time-first"),
 }
 MAX_SLOTS = 192  # decoy slots per lane (three groups of 64 decoys in the pair kernel): tools/pool_sweep.py
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
-KERNEL_SOURCES = ("kernel_pair.h", "trx2_device.h")
+POOLED_QUEUE = 1280  # decoys of the pooled_queue leg (fixed: the leg does not depend on --steps)
+LEG_QUEUE = 320      # decoys of the in_flight_B / single_stream legs
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+KERNEL_SOURCES = {"k_pair": ("kernel_pair.h", "trx2_device.h"), "k_step": ("kernel_step.h", "trx2_device.h")}
 
 
-def kernel_source_sha():
-    """identifies the pair-kernel build a committed PMC record belongs to (records must not go stale silently)"""
+def kernel_source_sha(kernel="k_pair"):
+    """identifies the kernel build a committed PMC record belongs to (records must not go stale silently)"""
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in KERNEL_SOURCES[kernel]:
         with open(os.path.join(ROOT, "trrosettax2-dynamics_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -99,32 +108,50 @@ def cpu_baseline(m, cfg, runs, budget_s=10.0):
     t0 = time.time()
     _, _, st, used = O.fold_batch(Tb, np.stack([O.random_torsions(L, 12345, 100 + d) for d in range(nb)]), runs, nthreads=cores)
     el2 = time.time() - t0
+    # BASELINE.md section 3 / SURVEY.md 8d: the PyRosetta leg is timed only where `import pyrosetta` succeeds; say which
+    try:
+        importlib.import_module("pyrosetta")
+        pyro, pyro_note = True, "pyrosetta is importable on this host, but no PyRosetta driver ships with this build: the port is the baseline"
+    except Exception as e:  # noqa: BLE001 -- ModuleNotFoundError on every host seen so far
+        pyro, pyro_note = False, f"PyRosetta unavailable ({type(e).__name__}); CPU baseline = the build's own C restatement (kind: port)"
+    host = os.cpu_count() or used
     return dict(value=nb / el2, unit="decoys/sec", cores=used, kind="port",
                 sample=f"{nb} decoys of the same map and protocol, oracle/trx2_oracle.c (gcc -O3 -march=native -fopenmp), "
                        f"OpenMP over decoys on {used} threads, {el2:.1f} s",
-                single_thread=one, host_cores_available=os.cpu_count(), host_cores_usable=cores)
+                single_thread=one, host_cores_available=host, host_cores_usable=cores,
+                all_core_extrapolation={"value": nb / el2 * host / max(used, 1), "unit": "decoys/sec", "cores": host,
+                                        "note": "NOT measured: the usable-core figure scaled linearly to every core the host reports "
+                                                "(decoys are independent; an upper bound for this port)"},
+                pyrosetta_available=pyro, pyrosetta_note=pyro_note)
 
 
-def traffic_record(config, decoys_per_launch):
-    """HBM-side bytes of the pair kernel per launch: PMC counters cannot be collected from inside this process, so the value is the
-    one measured with rocprofv3 for THIS kernel source, config and launch shape and committed under profiles/ (null when the
-    sources changed, or when --steps gives the lanes another number of slots than the record's)"""
+def traffic_record(config, decoys_per_launch, kernel="k_pair"):
+    """HBM-side bytes of a kernel per launch: PMC counters cannot be collected from inside this process, so the value is the one
+    measured with rocprofv3 for THIS kernel source, config and launch shape and committed under profiles/ (tools/pmc_run.sh;
+    null when the sources changed since, or when no record exists for the shape this run launches)"""
     if not os.path.exists(TRAFFIC_FILE):
         return None
     rec = json.load(open(TRAFFIC_FILE))
-    if rec.get("kernel_src_sha") != kernel_source_sha():
+    if rec.get("kernel_src_sha", {}).get(kernel) != kernel_source_sha(kernel):
         return None
-    r = rec.get(str(config))
-    return r if r and r.get("decoys_per_launch") == decoys_per_launch else None
+    for r in rec.get("records", []):
+        if r["config"] == config and r["kernel_family"] == kernel and r["decoys_per_launch"] == decoys_per_launch:
+            return r
+    return None
 
 
-def pair_roofline(ctx, T, B, L, config, fold_times=None):
+def pair_roofline(ctx, T, tors, L, config, fold_times=None):
+    """k_pair on the FINAL coordinates of the timed decoys at the launch shape of the timed calls: one evaluation batch of their
+    final torsions lays the coordinates out for exactly that many slots (full layout, nothing left over from a compacted fold:
+    ADVICE r2), then 200 replays bracketed by HIP events on the kernel's own stream (trx2_time_pair_kernel)."""
     w = np.array(T.protocol.SF, np.float32)
+    B = tors.shape[0]
+    ctx.eval_batch(tors, w)
     ms, term_evals = ctx.time_pair_kernel(B, w, 1, L, n_rep=200)
     n_terms = term_evals / B
     abytes = algorithmic_bytes(B, n_terms, L)
     achieved = abytes / (ms * 1e-3) / 1e9
-    rec = traffic_record(config, B)
+    rec = traffic_record(config, B, "k_pair")
     traffic, valu = None, None
     if rec:
         traffic = rec["hbm_bytes_per_launch"]
@@ -135,8 +162,8 @@ def pair_roofline(ctx, T, B, L, config, fold_times=None):
         valu = {"insts_per_launch": rec["valu_insts_per_launch"], "busy_cycles_per_simd": cyc, "busy_frac": cyc / (ms * 1e-3 * CLOCK_HZ),
                 "clock_hz_assumed": CLOCK_HZ, "wave_time_waiting_frac": rec["wait_any_quad_cycles"] / rec["wave_quad_cycles"]}
     bw = int(ctx.info(0))
-    out = {"bound": "hbm", "kernel": f"k_pair<{bw}> ({int(ctx.info(4))} workgroups)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": (rec or {}).get("method"),
+    out = {"bound": "hbm", "kernel": f"k_pair<{bw}> ({int(ctx.info(4))} workgroups, {B} decoys per launch)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+           "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": (rec or {}).get("method"),
            "avg_launch_ms": ms, "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": n_terms, "valu": valu,
            "binding_limit": "vector-ALU issue + dependent-load latency, not HBM bandwidth (DESIGN.md section 5)"}
     if fold_times and fold_times[2]:
@@ -144,7 +171,7 @@ def pair_roofline(ctx, T, B, L, config, fold_times=None):
     return out
 
 
-def step_roofline(ctx, B, L, fold_times):
+def step_roofline(ctx, B, L, config, fold_times):
     """second roofline record: the fused step kernel, live average over a whole (untimed, event-sampled) fold"""
     if not fold_times or not fold_times[2]:
         return None
@@ -152,20 +179,59 @@ def step_roofline(ctx, B, L, fold_times):
     ms = fold_times[1]
     abytes = step_algorithmic_bytes(B, L, rec_bytes, m)
     ach = abytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "k_step (torsion + Cartesian roles, one workgroup per decoy and role)", "achieved": ach,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": ms,
+    rec = traffic_record(config, B, "k_step")
+    return {"bound": "hbm", "kernel": f"k_step (torsion + Cartesian roles, one workgroup per decoy and role, {B} decoys per launch)", "achieved": ach,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": rec["hbm_bytes_per_launch"] if rec else None,
+            "traffic_source": (rec or {}).get("method"), "avg_launch_ms": ms,
             "algorithmic_bytes_per_launch": abytes, "samples": fold_times[2],
             "binding_limit": "latency of ~25 dependent phases on one workgroup per decoy (DESIGN.md section 4), not bandwidth"}
 
 
-def sampled_fold(ctx, B, runs, seed, decoy0):  # B decoys through the context's slot pool
-    """one extra, UNTIMED fold with every 8th evaluation bracketed by HIP events -> (pair ms, step ms, samples)"""
+def sampled_fold(ctx, B, runs, seed, decoy0):
+    """one extra, UNTIMED call of the same shape with every 8th evaluation bracketed by HIP events -> (pair ms, step ms, samples)"""
     ctx.set_profiling(8)
     try:
         ctx.fold_batch(B, runs, seed=seed, decoy0=decoy0)
         return ctx.last_fold_kernel_times()
     finally:
         ctx.set_profiling(0)
+
+
+def e2e_leg(pipe_mod, synth, L, init_num, seed=7):
+    """The job the reference runs (run_inference.py:16-143,280-337; VERDICT r2 missing 2): both models of one target end to end --
+    init_num initial decoys per model as one batch, the best one fed back, then ONE decoy per iteration (fold + feedback on the
+    resident distograms) until the cumulative array moves by < 0.01 or Nmax = 300 (the CLI default) -- every decoy written as a
+    PDB file, final renaming included.  Synthetic pair of maps (seeds L and L + 1).  decoys/sec = files written / wall."""
+    work = tempfile.mkdtemp(prefix="trx2_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        name = "t"
+        fasta = os.path.join(work, name + ".fasta")
+        maps = [synth.make_map(L, seed=L + c) for c in range(2)]
+        with open(fasta, "w") as f:
+            f.write(f">{name}\n{maps[0]['seq']}\n")
+        paths = []
+        for tag, m in zip(("NMR", "Xray"), maps):
+            q = os.path.join(work, f"{name}_{tag}.npz")
+            np.savez(q, dist=m["dist"], omega=m["omega"], theta=m["theta"], phi=m["phi"])
+            paths.append(q)
+        phases = {}
+        t0 = time.perf_counter()
+        n_out = pipe_mod.run_single(name, fasta, os.path.join(work, "out"), init_num=init_num, Nmax=300, angle=True, mult_two_models=True,
+                                    npz_nmr=paths[0], npz_xray=paths[1], device=0, seed=seed, phase_times=phases)
+        wall = time.perf_counter() - t0
+        n_files = len([f for f in os.listdir(os.path.join(work, "out", name, "pred_pdb")) if f.endswith(".pdb")])
+        it = {k: v for k, v in phases.items()}
+        n_iter = sum(v["iterations"] for v in it.values())
+        t_init = max(v["initial_s"] for v in it.values())           # the two chains run concurrently
+        t_iter = max(v["iteration_s"] for v in it.values())
+        return {"workload": f"run_inference end to end: L={L}, init_num={init_num} per model, two models (synthetic maps seed {L}, {L + 1}), all channels, "
+                            "Nmax=300, PDB files written", "value": n_out / wall, "unit": "decoys/sec", "decoys_written": n_out, "pdb_files": n_files,
+                "wall_s": wall, "initial_phase_s": t_init, "iteration_phase_s": t_iter, "iterations": {k: v["iterations"] for k, v in it.items()},
+                "ms_per_iteration": 1e3 * sum(v["iteration_s"] for v in it.values()) / max(n_iter, 1),
+                "ms_per_iteration_fold": 1e3 * sum(v["iteration_fold_s"] for v in it.values()) / max(n_iter, 1),
+                "note": "chains (models) run concurrently on two streams; within a chain the iterations are sequential single-decoy folds"}
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def fold_quality(synth, m, results):
@@ -223,6 +289,7 @@ def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, wit
     sync()
     t0 = time.perf_counter()
     res = [r for i in range(args.steps) for r in step(i)]
+    t_work = time.perf_counter() - t0   # this rank's own folds, before it waits for the others
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -231,7 +298,8 @@ def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, wit
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ok = all(np.all(r["status"] == 0) and np.all(np.isfinite(r["xyz"])) for r in res)
-    stats = sched.gather_stats(dict(decoys=sum(it.n for it in mine) * args.steps, seconds=elapsed, failed=0 if ok else 1), dist)
+    stats = sched.gather_stats(dict(decoys=sum(it.n for it in mine) * args.steps, seconds=t_work, failed=0 if ok else 1,
+                                    items=[(i.target, i.decoy0, i.n) for i in mine]), dist)
     out = None
     if rank == 0:
         total = len(cfg["targets"]) * B
@@ -244,6 +312,9 @@ def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, wit
                                       "no collective on the data path",
                        "items_rank0": [(i.target, i.decoy0, i.n) for i in mine]},
             "all_decoys_converged": bool(all(p["failed"] == 0 for p in stats)),
+            # the longest-first plan and every rank's own seconds (before the closing barrier): the 8-GPU claim can be read off
+            # this one record
+            "per_rank": [{"rank": k, "decoys": p["decoys"], "seconds": p["seconds"], "items": p["items"]} for k, p in enumerate(stats)],
         }
         if mine:
             it = mine[0]  # rank 0's heaviest item: its pair kernel on the coordinates of the last batch
@@ -259,25 +330,25 @@ def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, wit
 
 
 def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, forced, steps, warmup, full):
-    """one target (configs 2, 3, 4): B decoys per chain and step on every rank.  full: roofline records, two-lane leg"""
+    """one target (configs 2, 3, 4): every step is ONE call of B decoys per chain on every rank.  full: legs"""
     L, B = cfg["L"], cfg["B"]
     n_chains = cfg.get("chains", 1)
     ms_ = [synth.make_map(L, seed=L + c) for c in range(n_chains)]
     m = ms_[0]
     runs = T.protocol.build_runs(L, 2)
-    lanes = 2 if n_chains == 1 else 1          # two chains already occupy two streams
-    per_lane = (steps * B + lanes - 1) // lanes  # decoys a lane folds in the timed region
-    slots = min(MAX_SLOTS, per_lane)             # per lane
+    # the library's defaults for a call of B decoys (fold.fold_arrays): two lanes, unless two chains already occupy two streams
+    # (pipeline.run_single); one slot per decoy; default tail compaction
+    lanes = 2 if n_chains == 1 else 1
     ctxs = [T.Context(local_rank, lanes=lanes) for _ in range(n_chains)]
     for c_, m_ in zip(ctxs, ms_):
         c_.set_map(m_["dist"], *([m_["omega"], m_["theta"], m_["phi"]] if cfg["orient"] else []), seq=m_["seq"])
     ctx = ctxs[0]
 
-    def step(i, n_steps=1):
+    def step(i, n=B):
         # distinct decoys for every step, rank and chain (timed steps use indices 0.., warm-up steps 900..); the chains of a
         # step are independent (run_inference.py:310-318) and run concurrently, one context = one stream each
         def one(c):
-            return ctxs[c].fold_batch(n_steps * B, runs, seed=150 + c, decoy0=((rank * 1000 + i) * B))
+            return ctxs[c].fold_batch(n, runs, seed=150 + c, decoy0=((rank * 1000 + i) * B))
         if n_chains == 1:
             return [one(0)]
         with ThreadPoolExecutor(max_workers=n_chains) as ex:
@@ -289,75 +360,82 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
             dist.barrier()
             torch.cuda.synchronize()
 
-    for c_ in ctxs:
-        c_.set_pool(slots)       # B decoy slots per chain; the K steps' decoys are their queue
     for i in range(warmup):
         step(900 + i)
-    if warmup > 0 and steps > 1:
-        # the warm-up steps fold B decoys each; the timed queue runs on more slots: size the slot buffers for it now (one
-        # evaluation of as many decoys as there are slots -- an allocation, nothing the timed folds could reuse), so that the
-        # timed region holds folds and no hipMalloc
-        for c_ in ctxs:
-            c_.fold_batch(min(steps * B, lanes * slots), runs, seed=149, decoy0=10 ** 6, max_evals=1)
     sync()
     t0 = time.perf_counter()
-    res = step(0, steps)         # fold_batch returns with the coordinates of every decoy on the host
+    res = [step(i) for i in range(steps)]   # K separate calls; each returns with the coordinates of its decoys on the host
     sync()
-    elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed = time.perf_counter() - t0
+    per_rank = None
     if dist is not None:
         import torch
         tt = torch.tensor([elapsed], device="cpu" if forced is not None else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    ok = all(np.all(r["status"] == 0) and np.all(np.isfinite(r["xyz"])) for r in res)
-    evals = np.concatenate([r["n_evals"] for r in res])
-    launches = sum(r["launches"] for r in res)   # per lane: both lanes of a context make about the same number
-    per_call = single = wide = None
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(gathered, tt)
+        per_rank = [float(g.item()) for g in gathered]
+        elapsed = max(per_rank)
+    flat = [r for st in res for r in st]
+    ok = all(np.all(r["status"] == 0) and np.all(np.isfinite(r["xyz"])) for r in flat)
+    evals = np.concatenate([r["n_evals"] for r in flat])
+    launches = sum(r["launches"] for r in flat)   # per lane: both lanes of a context make about the same number
+    legs = {}
     if full and rank == 0 and world == 1 and not args.no_legs:
-        def leg(lanes_, pool_, calls):
+        def leg(lanes_, pool_, n_queue, note):
             for c_ in ctxs:
                 c_.set_lanes(lanes_); c_.set_pool(pool_)
-            step(900, 1)
+            # slot buffers sized before the clock starts (one evaluation of as many decoys as there are slots: an allocation, nothing
+            # the timed fold could reuse)
+            for c_ in ctxs:
+                c_.fold_batch(min(n_queue, lanes_ * pool_ if pool_ else n_queue), runs, seed=149, decoy0=10 ** 6, max_evals=1)
             t1 = time.perf_counter()
-            rs = [r for i in range(steps) for r in step(i)] if calls else step(0, steps)
+            rs = step(700, n_queue)
             e1 = time.perf_counter() - t1
-            nl = sum(r["launches"] for r in rs) / n_chains
-            return {"value": steps * B * n_chains / e1, "unit": "decoys/sec", "ms_per_step": 1e3 * e1 / steps, "pair_launches_per_step": nl / steps,
-                    "all_decoys_converged": bool(all(np.all(r["status"] == 0) for r in rs))}
-        # the same decoys as K separate calls of B on one stream (one slot per decoy: every call ends with its slowest decoy)
-        per_call = leg(1, 0, True)
-        per_call["note"] = "K separate trx2_fold_batch calls of B decoys, one stream, one slot per decoy (round 1's `value`)"
+            return {"value": n_queue * n_chains / e1, "unit": "decoys/sec", "seconds": e1, "workload": note,
+                    "pair_launches": sum(r["launches"] for r in rs) / n_chains, "slot_efficiency": float(np.mean([r["slot_efficiency"] for r in rs])),
+                    "all_decoys_converged": bool(all(np.all(r["status"] == 0) for r in rs))}, rs
         if lanes == 2:
-            single = leg(1, B, False)
-            single["note"] = f"the same queue with {B} decoys in flight: ONE stream of {B} slots"
-            wide = leg(2, (B + 1) // 2, False)
-            wide["note"] = f"the same queue with {B} decoys in flight: two lanes of {(B + 1) // 2} slots (round 2's first `value`)"
+            legs["pooled_queue"], rs_pool = leg(2, MAX_SLOTS, POOLED_QUEUE, f"ONE call over a queue of {POOLED_QUEUE} decoys of the same map on 2 lanes x {MAX_SLOTS} "
+                                                f"decoy slots that refill on the device (round 2's headline mode)")
+            # kernel records at the pooled shape: 192 decoys per launch on lane 0
+            ctx.set_lanes(1); ctx.set_pool(MAX_SLOTS)
+            ftp = sampled_fold(ctx, 2 * MAX_SLOTS, runs, 150, 902 * B)
+            legs["pooled_queue"]["roofline"] = compact_roofline(pair_roofline(ctx, T, rs_pool[0]["tors"][:MAX_SLOTS], L, config, ftp))
+            legs["pooled_queue"]["roofline_step"] = compact_roofline(step_roofline(ctx, MAX_SLOTS, L, config, ftp))
+            legs["in_flight_B"], _ = leg(2, (B + 1) // 2, LEG_QUEUE, f"a queue of {LEG_QUEUE} decoys with {B} in flight: two lanes of {(B + 1) // 2} slots")
+            legs["single_stream"], _ = leg(1, B, LEG_QUEUE, f"a queue of {LEG_QUEUE} decoys with {B} in flight: ONE stream of {B} slots")
         for c_ in ctxs:
-            c_.set_lanes(lanes); c_.set_pool(slots)
+            c_.set_lanes(lanes); c_.set_pool(0)
     out = None
     if rank == 0:
-        ft = sampled_fold(ctx, steps * B, runs, 150, 901 * B)  # untimed; live per-kernel averages over the same queue once more: lane 0's launches
+        # live per-kernel averages over one more (untimed) call of the same shape: lane 0's launches
+        b_lane = (B + 1) // 2 if (lanes == 2 and B >= 32) else B     # decoys per launch on lane 0 (trx2_fold_batch's split)
+        ft = sampled_fold(ctx, B, runs, 150, 901 * B)
         out = {
             "metric": "decoys/sec", "value": world * steps * B * n_chains / elapsed, "unit": "decoys/sec",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "L": L, "decoys_per_step": B * n_chains, "protocol": "mode 2, full staged minimisation",
-                       "slots": f"{lanes} lane(s) x {slots} decoy slots per chain (queue of {steps * B} decoys per chain)",
-                       "parallelism": f"decoys sharded over {world} rank(s), no collective on the data path"},
-            "roofline": pair_roofline(ctx, T, slots, L, config, ft),
-            "roofline_step": step_roofline(ctx, slots, L, ft),
+                       "call": f"one trx2_fold_batch of {B} decoys per chain and step, library defaults: {lanes} lane(s) "
+                               f"({b_lane} decoys per launch), one slot per decoy, default tail compaction",
+                       "parallelism": f"calls sharded over {world} rank(s), no collective on the data path"},
+            "roofline": pair_roofline(ctx, T, flat[-n_chains]["tors"][:b_lane], L, config, ft),
+            "roofline_step": step_roofline(ctx, b_lane, L, config, ft),
             "all_decoys_converged": bool(ok), "evals_per_decoy": {"min": int(evals.min()), "median": float(np.median(evals)), "max": int(evals.max())},
-            "fold_quality": fold_quality(synth, m, res[:1]),
+            "fold_quality": fold_quality(synth, m, [r for r in flat[::n_chains]]),
             "pair_launches_per_step": launches / steps / n_chains,
-            "slot_efficiency": float(np.mean([r["slot_efficiency"] for r in res])),  # evaluations of the decoys / (launch pairs x slots), per lane
+            "slot_efficiency": float(np.mean([r["slot_efficiency"] for r in flat])),  # evaluations of the decoys / (launch pairs x slots), per lane
         }
-        for k_, v_ in (("in_flight_B", wide), ("single_stream", single), ("per_call", per_call)):
-            if v_:
-                out[k_] = v_
+        if per_rank is not None:
+            out["per_rank_seconds"] = per_rank
+        out.update(legs)
     for c_ in ctxs:
         c_.close()
     return out, m, runs
+
+
+def compact_roofline(r):
+    return {q: r[q] for q in ("kernel", "achieved", "frac", "unit", "avg_launch_ms", "avg_launch_ms_over_fold", "algorithmic_bytes_per_launch", "traffic") if q in r} if r else None
 
 
 def compact(rec):
@@ -365,10 +443,10 @@ def compact(rec):
     keys = ("value", "unit", "steps", "ms_per_step", "all_decoys_converged", "evals_per_decoy", "pair_launches_per_step", "slot_efficiency", "fold_quality")
     out = {k: rec[k] for k in keys if k in rec}
     out["workload"] = rec["config"]["workload"]
+    out["call"] = rec["config"]["call"]
     for k in ("roofline", "roofline_step"):
-        r = rec.get(k)
-        if r:
-            out[k] = {q: r[q] for q in ("kernel", "achieved", "frac", "unit", "avg_launch_ms", "algorithmic_bytes_per_launch", "traffic") if q in r}
+        if rec.get(k):
+            out[k] = compact_roofline(rec[k])
     return out
 
 
@@ -379,8 +457,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-legs", action="store_true", help="skip the B-in-flight / single-stream / per-call legs (profiling: every launch in the trace then belongs to `value`'s queue)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the pooled-queue / B-in-flight / single-stream legs (profiling: every launch in the trace then belongs to `value`'s calls)")
     ap.add_argument("--no-sub-records", action="store_true", help="skip the config 3 / 4 sub-records (N=1) and the batch-mode record (N>1)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run_inference leg (N=1, config 2)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -412,6 +491,12 @@ def main():
         out, m, runs = single_target(args, cfg, args.config, T, synth, rank, local_rank, world, dist, forced, args.steps, args.warmup, True)
         if rank == 0 and with_cpu:
             out["cpu_baseline"] = cpu_baseline(m, cfg, runs)
+        if args.config == 2 and world == 1 and rank == 0 and not args.no_e2e and not args.no_legs:
+            pipe_mod = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):     # the pipeline prints the reference's progress lines
+                out["e2e"] = {f"init_num_{n}": e2e_leg(pipe_mod, synth, cfg["L"], n) for n in (10, 64)}
         if args.config == 2 and not args.no_sub_records:
             if world == 1:
                 # the other single-GPU configs of BASELINE.json, shorter legs of the same measurement
@@ -425,7 +510,7 @@ def main():
                 a5 = argparse.Namespace(steps=1, warmup=0)
                 bm = multi_target(a5, CONFIGS[5], T, synth, rank, local_rank, world, dist, forced, False)
                 if rank == 0:
-                    out["batch_mode"] = {k: bm[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "all_decoys_converged")}
+                    out["batch_mode"] = {k: bm[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "all_decoys_converged", "per_rank")}
                     out["batch_mode"]["workload"] = bm["config"]["workload"]
                     out["batch_mode"]["parallelism"] = bm["config"]["parallelism"]
     if dist is not None:

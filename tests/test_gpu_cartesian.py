@@ -66,15 +66,21 @@ def test_cartesian_run_tracks_oracle_over_a_short_horizon(ctx, golden_dir, seq):
     assert dmax <= 1.5 * omax + 0.02, (dmax, omax)
 
 
-@pytest.mark.parametrize("tag,refs,med_max", [("Xray", ("conf_1_1", "conf_1_2"), 0.9), ("NMR", ("conf_2_1", "conf_2_2"), 1.15)])
-def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med_max):
-    """Mode-2 protocol with the Cartesian run on (the default for L <= 256).  Oracle scan (tools/model_scan.py, 24 decoys): median RMSD to the reference
-    decoys 0.64 A on the X-ray map (torsion-only: 0.96), CA-C bond sd 0.007-0.008 A, N-CA-C sd 2.6-2.8 deg, 1-4 of 24 decoys
-    with a peptide twisted > 60 deg (torsion-only: 9 of 24)."""
+@pytest.mark.parametrize("tag,refs,med_max,trap_max", [("Xray", ("conf_1_1", "conf_1_2"), 0.60, 0.11), ("NMR", ("conf_2_1", "conf_2_2"), 0.90, 0.08)])
+def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med_max, trap_max):
+    """Mode-2 protocol with the Cartesian run on (the default for L <= 512): OUTCOME parity with the reference's PyRosetta decoys
+    (the energy model itself is unpinned, DESIGN.md section 2, so this is the only anchor it has).
+    Thresholds = measured + margin, not slack.  Measured on 1024 decoys per map
+    (profiles/r02_outcome_parity_n1024.txt): median RMSD to the closer initial reference decoy X-ray 0.48 A (quartiles 0.39-0.89),
+    NMR 0.76 A (0.63-0.90); decoys > 3 A away 6.2 % / 3.6 %, nearly all of them the mirror-image topology (6.0 % / 3.3 %).
+    With 256 decoys the median's sampling error is ~0.04 A (X-ray: the density around the median is low) and the trapped
+    count's standard deviation 3.9 / 3.0 decoys: asserted are median <= 0.60 / 0.90 A and trapped <= 11 % / 8 % (a regression
+    of 0.15 A or a doubling of the trapped starts fails), and that the far decoys ARE mirror images (>= 70 % within 3.5 A of
+    the mirrored reference)."""
     m = np.load(os.path.join(golden_dir, f"seq_{tag}.npz"))
     ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
     dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
-    B = 64  # mirror trapping is decided by the random start (1-8 % of starts, DESIGN.md section 2): a rate needs a full batch
+    B = 256  # mirror trapping is decided by the random start (3-6 % of starts, DESIGN.md section 2): a rate needs a large batch
     runs = P.build_runs(90, 2)
     assert any(q["cartesian"] for q in runs)
     r = ctx.fold_batch(B, runs, seed=4242)
@@ -86,9 +92,16 @@ def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med
     twisted = int((dw.max(1) > 60).sum())
     print("\ncart protocol, " + tag + " map, %d decoys: median RMSD %.2f (good only %.2f), >3 A: %d, twisted>60: %d, CA-C sd %.3f, N-CA-C sd %.1f, evals median %d, %.3f s"
           % (B, np.median(best), np.median(best[best < 3]), int((best > 3).sum()), twisted, bond_sd, ang_sd, np.median(r["n_evals"]), r["seconds"]))
-    assert np.median(best) < med_max, np.sort(best)
+    far = np.nonzero(best > 3.0)[0]
+    mir = np.array([min(kabsch_rmsd(r["xyz"][i, :, 1] * np.array([1.0, 1.0, -1.0]), dec[k][:, 1]) for k in refs) for i in far])
+    n_mirror = int((mir < 3.5).sum())
+    print("   <= 0.5 A: %.0f %%, <= 1 A: %.0f %%; > 3 A: %d of %d, of which mirror images (mirrored RMSD < 3.5 A): %d"
+          % (100 * (best <= 0.5).mean(), 100 * (best <= 1.0).mean(), len(far), B, n_mirror))
+    assert np.median(best) <= med_max, np.sort(best)[::16]
+    assert len(far) <= trap_max * B, (len(far), B)
+    assert n_mirror >= 0.7 * len(far) - 1, (n_mirror, len(far))
     assert bond_sd < 0.02 and 1.5 < ang_sd < 4.5
-    assert twisted <= 0.25 * B and (best > 3).sum() <= 0.2 * B
+    assert twisted <= 0.25 * B
 
 
 def test_cartesian_run_on_a_chain_longer_than_256(ctx):

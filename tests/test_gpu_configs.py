@@ -396,3 +396,74 @@ def test_tail_compaction_with_slot_pool_and_two_lanes(golden_dir, seq):
         assert out[1]["slot_efficiency"] > out[0]["slot_efficiency"]
     finally:
         ctx.close()
+
+
+# ---- the shape bench.py's `pooled_queue` leg times: L=150, two lanes x 192 slots, a queue of 1280 decoys -------------------------
+def test_bench_pooled_shape_two_lanes_192_slots():
+    """the benched shape was never compared with the oracle.  Config-size parity tests run one lane, <= 64 slots,
+    one decoy group; the pooled queue runs 2 lanes x 192 slots (three decoy groups per launch, that shape's split of the pair kernel,
+    slot refill, tail compaction).  Here, at L=150 with distances only (BASELINE config 2's map):
+      (a) one evaluation of 192 and of 384 decoys (three / six groups) against the oracle on EVERY decoy; and the shape of
+          bench.py's `value` (one call of 64 decoys on two lanes) against two 32-decoy calls, bit for bit;
+      (b) the pooled fold of 1280 decoys with the pair kernel's split kept (compaction mode 2) against separate 64-decoy calls,
+          one slot per decoy, no compaction, the same split: bit for bit, every decoy, every output;
+      (c) the default compaction (mode 1: each shape's own split, wave narrowing below one group) against (b) decoy by decoy:
+          it differs by the summation order of a residue's gradient records from the moment a group is dropped, i.e. by
+          rounding that a ~2000-evaluation minimisation amplifies; what is asserted is what was measured to hold (printed)."""
+    L = 150
+    m = S.make_map(L, seed=L)
+    Tb = oracle_tables(m, False)
+    runs = T.protocol.build_runs(L, 2)
+    N = 1280
+    ctx = T.Context(0, lanes=2, pool=192)
+    ref = T.Context(0)
+    old = os.environ.get("TRX2_NSPLIT")
+    try:
+        ctx.set_map(m["dist"], seq=m["seq"])
+        ref.set_map(m["dist"], seq=m["seq"])
+        for B in (192, 384):
+            w = check_eval_every_decoy(ctx, Tb, mixed_starts(m, B, 40 + B), SF, 2e-3)
+            print(f"\n   eval of {B} decoys at the pooled shape ({int(ctx.info(4))} pair-kernel workgroups, {int(ctx.info(0))} decoys per wave): worst xyz {w['xyz']:.1e} A, term {w['term']:.1e}, gradient {w['grad']:.1e}")
+        # bench.py's `value` shape: ONE call of 64 decoys on a two-lane context = lane 0 folds decoys 0..31, lane 1 decoys 32..63, each
+        # as its own batch of 32 (32 decoys per wave): bit for bit the two 32-decoy calls of a one-lane context, default compaction
+        two = T.Context(0, lanes=2)
+        try:
+            two.set_map(m["dist"], seq=m["seq"])
+            r64 = two.fold_batch(64, runs, seed=150)
+        finally:
+            two.close()
+        halves = [ref.fold_batch(32, runs, seed=150, decoy0=32 * k) for k in range(2)]
+        for key in ("xyz", "tors", "e_terms", "f", "status", "n_evals", "n_iters"):
+            assert np.array_equal(r64[key], np.concatenate([h[key] for h in halves])), key
+        assert np.all(r64["status"] == 0)
+        out = {}
+        for mode in (2, 1):
+            ctx.set_tail_compaction(mode)
+            out[mode] = ctx.fold_batch(N, runs, seed=150)
+            assert np.all(out[mode]["status"] == 0) and np.all(np.isfinite(out[mode]["xyz"]))
+        # three groups of 64 at L=150 without angles launch with ONE slab (ensure_batch's rule); a lone group would take three:
+        # the reference calls are pinned to the pooled shape's split so that the arithmetic is the same
+        os.environ["TRX2_NSPLIT"] = "1"
+        ref.set_tail_compaction(0)
+        parts = [ref.fold_batch(64, runs, seed=150, decoy0=64 * k) for k in range(N // 64)]
+        for key in ("xyz", "tors", "e_terms", "f", "status", "n_evals", "n_iters"):
+            assert np.array_equal(out[2][key], np.concatenate([p[key] for p in parts])), key
+        a, b = out[2], out[1]
+        dx = np.sqrt(((a["xyz"][:, :, 1] - b["xyz"][:, :, 1]) ** 2).sum(-1)).max(axis=1)       # same frame: both start from the same pose
+        from oracle.kabsch import kabsch_rmsd
+        rms = np.array([kabsch_rmsd(a["xyz"][i, :, 1], b["xyz"][i, :, 1]) for i in range(N)])
+        de = np.abs(a["f"] - b["f"]) / np.abs(a["f"])
+        same_bits = float(np.mean([np.array_equal(a["xyz"][i], b["xyz"][i]) for i in range(N)]))
+        close = float(np.mean((rms < 0.5) & (de < 0.01)))
+        print(f"   pooled fold, default compaction vs split kept: {same_bits:.3f} of the decoys bit-identical (they finished before the first group was dropped), "
+              f"{close:.3f} within 0.5 A C-alpha RMSD and 1 % of the final energy; seconds {a['seconds']:.3f} (split kept) / {b['seconds']:.3f} (default); "
+              f"slot efficiency {a['slot_efficiency']:.3f} / {b['slot_efficiency']:.3f}; evaluations median {np.median(a['n_evals']):.0f} / {np.median(b['n_evals']):.0f}")
+        assert close >= 0.90, (close, same_bits)
+        assert abs(np.median(b["n_evals"]) - np.median(a["n_evals"])) <= 0.03 * np.median(a["n_evals"])
+        assert abs(np.median(b["f"]) - np.median(a["f"])) <= 2e-3 * abs(np.median(a["f"]))
+    finally:
+        if old is None:
+            os.environ.pop("TRX2_NSPLIT", None)
+        else:
+            os.environ["TRX2_NSPLIT"] = old
+        ctx.close(); ref.close()

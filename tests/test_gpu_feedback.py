@@ -189,3 +189,37 @@ def test_device_superposition_matrices_equal_host(golden_dir, seq, tmp_path):
     host = EV.run_score(str(nat_d), str(d))
     dev = EV.run_score(str(nat_d), str(d), device=0, save_summary=True, save_dir=str(tmp_path / "sum"))
     assert host == dev
+
+
+def test_superposition_of_more_than_256_structures_and_nonfinite_input(golden_dir):
+    """(pair) used to sit on gridDim.y, so 257 structures against themselves exceeded its 65 535 blocks; now the
+    upper triangle is enumerated on gridDim.x.  300 noisy copies of a reference decoy (L = 40 residues of it: 45 150 pairs):
+    sampled entries against the host functions, symmetry, diagonal; and non-finite coordinates are refused at the C ABI
+    (the TM-score search's cutoff-widening loop never ended on a NaN)."""
+    EV = importlib.import_module("trrosettax2-dynamics_amd.evaluate")
+    ref = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    base = ref["conf_1_1"][:40, 1].astype(np.float64)
+    rng = np.random.default_rng(11)
+    n = 300
+    pts = (base[None] + rng.normal(size=(n, 40, 3)) * rng.uniform(0.1, 2.0, size=(n, 1, 1))).astype(np.float32)
+    ctx = T.Context(0)
+    try:
+        rm, tm = ctx.superpose_matrix(pts)
+        assert rm.shape == (n, n) and np.array_equal(rm, rm.T) and np.array_equal(tm, tm.T)
+        assert np.allclose(np.diag(rm), 0, atol=1e-6) and np.allclose(np.diag(tm), 1.0)
+        for i, j in [(0, 1), (0, 299), (255, 256), (256, 257), (299, 298), (128, 290), (7, 7)] + [tuple(rng.integers(0, n, 2)) for _ in range(12)]:
+            x, y = pts[i].astype(np.float64), pts[j].astype(np.float64)
+            assert abs(rm[i, j] - EV.rmsd_common(x, y)) < 1e-9 and abs(tm[i, j] - EV.tm_score(x, y)) < 1e-9, (i, j)
+        # rectangular, more than 65 535 pairs: 300 x 260
+        rm2, tm2 = ctx.superpose_matrix(pts, pts[:260])
+        assert np.abs(rm2 - rm[:, :260]).max() < 1e-12 and np.abs(tm2 - tm[:, :260]).max() < 1e-12
+        bad = pts[:3].copy()
+        bad[1, 5, 2] = np.nan
+        L = ctx._l
+        import ctypes as C
+        out = np.zeros((3, 3))
+        rc = L.trx2_superpose_matrix(ctx._h, 3, 3, 40, bad.ctypes.data_as(C.c_void_p), None, C.c_double(0), out.ctypes.data_as(C.c_void_p),
+                                     out.ctypes.data_as(C.c_void_p))
+        assert rc != 0 and b"non-finite" in L.trx2_last_error(ctx._h)
+    finally:
+        ctx.close()

@@ -102,11 +102,14 @@ def test_eval_is_bitwise_reproducible(ctx, maps, seq):
 def test_fold_reaches_reference_decoys(ctx, maps, seq, golden_dir):
     """TORSION-SPACE protocol (the Cartesian run replaced by its torsion-space stand-in; full protocol: test_gpu_cartesian.py).
     Outcome parity: fold the committed NMR map and compare with the reference's PyRosetta decoys
-    conf_2_1 / conf_2_2 (NMR/initial0,1).  Their own mutual RMSD is 0.86 A; criterion median <= 0.5 + 0.86 A."""
+    conf_2_1 / conf_2_2 (NMR/initial0,1).  Their own mutual RMSD is 0.86 A (SURVEY.md 8c's criterion: median <= 0.5 + 0.86 A).
+    Asserted is measured + margin instead: 0.92 A median over 1024 decoys of this torsion-only protocol
+    (quartiles 0.78-1.09, profiles/r02_outcome_parity_n1024.txt); with 128 decoys the median's sampling error is ~0.04 A:
+    <= 1.05 A."""
     m = maps["NMR"]
     ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
     dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
-    B = 16
+    B = 128
     r = ctx.fold_batch(B, T.protocol.build_runs(90, 2, cartesian_stage=False), seed=2024)  # torsion space only: the exact
     assert np.all(r["status"] == 0), r["status"]                                             # ideal-geometry invariants below
     assert np.all(np.isfinite(r["xyz"])) and np.all(np.isfinite(r["f"]))
@@ -140,8 +143,8 @@ def test_fold_reaches_reference_decoys(ctx, maps, seq, golden_dir):
     # topology (RMSD ~12 A, mirror ~3 A) for roughly 1 start in 6-20 -- report it, and bound it loosely.
     n_gross = int((best > 3.0).sum())
     print(" decoys with RMSD > 3 A (mirror-trapped / misfolded):", n_gross, "of", B)
-    assert n_gross <= B // 4, np.sort(best)
-    assert np.median(best) <= 0.5 + 0.86, np.sort(best)
+    assert n_gross <= 0.09 * B, np.sort(best)          # measured 3.6 % of 1024 (sd of the count at B=128: 2.1 decoys)
+    assert np.median(best) <= 1.05, np.sort(best)[::8]
     # depth of optimisation: restraint energies of the reference decoys under the same tables are
     # dist -19679/-19689, theta -28121/-28288
     assert np.median(r["e_terms"][:, 0]) < -19000 and np.median(r["e_terms"][:, 2]) < -27000, r["e_terms"][:, :4].mean(0)

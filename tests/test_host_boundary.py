@@ -216,3 +216,19 @@ def test_evaluation_reproduces_the_reference_summary(golden_dir, tmp_path, seq):
     assert EV.tm_score(x, x) == pytest.approx(1.0) and EV.rmsd_common(x, x[::-1].copy()[::-1]) == pytest.approx(0.0, abs=1e-9)
     with pytest.raises(NotImplementedError):
         EV.run_score(str(nat), str(pred), align=True)
+
+
+def test_one_failed_decoy_does_not_discard_the_batch(golden_dir, tmp_path, seq):
+    """the decoys that folded are written, the failed one gets no file, and the call still raises
+    (the reference passes silently, utils.py:498; SURVEY.md 8b: raise, never a partial PDB)."""
+    xyz = np.load(os.path.join(golden_dir, "ref_decoys.npz"))["conf_2_1"].copy()
+    xyz[np.isnan(xyz[:, 4, 0]), 4] = 0.0
+    r = dict(xyz=np.stack([xyz, xyz, xyz]).astype(np.float32), status=np.array([0, 1, 0], np.int32), n_evals=np.array([10, 20, 30], np.int32))
+    r["xyz"][1, 3, 1, 0] = np.nan
+    names = ["a0.pdb", "a1.pdb", "a2.pdb"]
+    with pytest.raises(FO.FoldError, match=r"decoys \[1\]") as ei:
+        FO._write_decoys(r, seq, str(tmp_path), names, seed=7)
+    assert ei.value.bad == [1] and ei.value.result is r and isinstance(ei.value, RuntimeError)
+    assert sorted(os.listdir(tmp_path)) == ["a0.pdb", "a2.pdb"]
+    got, s = P.read_backbone(str(tmp_path / "a2.pdb"))
+    assert s == seq and np.allclose(got[:, 1], xyz[:, 1], atol=6e-4)

@@ -75,6 +75,9 @@ __device__ __forceinline__ f3 place_h(f3 Cp, f3 N, f3 CA) {
   return N + u * ((float)TRX2_HB_B_NH * rsqrtf(dot(u, u)));
 }
 
+#ifdef TRX2_SELFCHECK
+__device__ unsigned long long g_selfcheck[4];  // torsion role: checks, mismatches; Cartesian role: checks, mismatches
+#endif
 // workgroup barrier of an NW-wave role.  One wave: its LDS operations execute in program order, so only the compiler has
 // to be kept from reordering them.
 template <int NW>
@@ -496,7 +499,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
     // (tools/debug_l400.py: 0 iterations in 60 evaluations) while the same source is right in k_chain<2, 256>, with RPT = 1,
     // and in the fused kernel as soon as esum[] lives in scratch memory -- register-allocation dependent, not understood;
     // tests/test_gpu_configs.py (configuration 4) guards it.
-    const bool all_terms = RPT > 1 || A.mode != MODE_STEP || phase == PH_REPORT || (phase == PH_START && R.precheck);
+#ifndef TRX2_ONESUM_RPT2
+#define TRX2_ONESUM_RPT2 0
+#endif
+    const bool all_terms = (RPT > 1 && !TRX2_ONESUM_RPT2) || A.mode != MODE_STEP || phase == PH_REPORT || (phase == PH_START && R.precheck);
     double f_t;
     if (all_terms) {
       block_sum_n<9, NW>(esum, s_buf, flip);
@@ -512,6 +518,23 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
       f_t = ft1[0];
     }
     if (tid == 0) A.f_last[dec] = f_t;
+#ifdef TRX2_SELFCHECK
+    // Checking build only (libtrx2fold_check.so, never the shipped library): wherever a step took the ONE-sum path, the
+    // nine terms are reduced as well and their weighted total compared with it.  g_selfcheck[0] counts the checks, [1] the
+    // mismatches (relative 1e-9: both are float64 sums of the same per-thread values in another order).
+    if (!all_terms) {
+      double chk[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) chk[k] = esum[k];
+      block_sum_n<9, NW>(chk, s_buf, flip);
+      const double f9 = (double)R.w[0] * chk[0] + (double)R.w[1] * (chk[1] + chk[2]) + (double)R.w[2] * chk[3] + (double)R.w[3] * chk[4] +
+                        (double)R.w[4] * chk[5] + (double)R.w[5] * chk[6] + (double)R.w[7] * chk[8];
+      if (tid == 0) {
+        atomicAdd(&g_selfcheck[0], 1ull);
+        if (!(fabs(f9 - f_t) <= 1e-9 * fabs(f9) + 1e-9)) atomicAdd(&g_selfcheck[1], 1ull);
+      }
+    }
+#endif
 
     if (A.mode == MODE_STEP && phase == PH_REPORT) {
       // ---- this evaluation was the decoy's report: results out by decoy id, then the slot takes the next decoy or retires
@@ -1206,6 +1229,20 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
   block_sum_n<1, NW>(ft1, s_buf, flip);
   const double f_t = ft1[0];
   if (tid == 0) A.f_last[dec] = f_t;
+#ifdef TRX2_SELFCHECK
+  {  // checking build only: the Cartesian role's one sum against the nine terms reduced one by one (g_selfcheck[2], [3])
+    double chk[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) chk[k] = esum[k];
+    block_sum_n<9, NW>(chk, s_buf, flip);
+    const double f9 = (double)R.w[0] * chk[0] + (double)R.w[1] * (chk[1] + chk[2]) + (double)R.w[2] * chk[3] + (double)R.w[3] * chk[4] +
+                      (double)R.w[4] * chk[5] + (double)R.w[5] * chk[6] + (double)R.w[6] * chk[7] + (double)R.w[7] * chk[8];
+    if (tid == 0) {
+      atomicAdd(&g_selfcheck[2], 1ull);
+      if (!(fabs(f9 - f_t) <= 1e-9 * fabs(f9) + 1e-9)) atomicAdd(&g_selfcheck[3], 1ull);
+    }
+  }
+#endif
 
   // ------------------------------------------------------------------ minimiser state machine (as k_chain, 4 float4 per residue)
   int iter = s_i[SI_ITER], nls = s_i[SI_NLS], hl = s_i[SI_HL], hh = s_i[SI_HH], nh = s_i[SI_NH];

@@ -83,8 +83,22 @@ __device__ __forceinline__ Sup sup_from_sums(const double (&v)[17]) {
   return R;
 }
 
+// pair index -> (i, j).  Rectangular: row-major over n x m.  Symmetric: the k-th pair of the upper triangle i <= j, row by
+// row (row i holds n - i pairs and starts at i n - i (i - 1) / 2): only those pairs are launched, the host mirrors them.
+__device__ __forceinline__ void sup_pair_ij(long k, int n, int m, int symmetric, int& i, int& j) {
+  if (!symmetric) { i = (int)(k / m); j = (int)(k % m); return; }
+  const double b = 2.0 * n + 1.0;
+  long r = (long)((b - sqrt(b * b - 8.0 * (double)k)) * 0.5);
+  if (r < 0) r = 0;
+  if (r > n - 1) r = n - 1;
+  auto start = [&](long q) { return q * n - q * (q - 1) / 2; };
+  while (r > 0 && start(r) > k) r--;
+  while (r < n - 1 && start(r + 1) <= k) r++;
+  i = (int)r; j = (int)(r + (k - start(r)));
+}
 struct SupArgs {
   int n, m, L, nseed, symmetric;
+  long npair;          // pairs launched: n * m, or n (n + 1) / 2 when symmetric
   const float* xa;     // [n][L][3] C-alpha coordinates (as read from the PDB files)
   const float* xb;     // [m][L][3]
   const int2* seeds;   // [nseed] (start, length) of the TM-score program's seed fragments
@@ -97,9 +111,9 @@ struct SupArgs {
 __global__ __launch_bounds__(256) void k_sup_rmsd(SupArgs A) {
   const int lane = threadIdx.x & 63;
   const long pair = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (pair >= (long)A.n * A.m) return;
-  const int i = (int)(pair / A.m), j = (int)(pair % A.m);
-  if (A.symmetric && j < i) return;  // mirrored by the host
+  if (pair >= A.npair) return;
+  int i, j;
+  sup_pair_ij(pair, A.n, A.m, A.symmetric, i, j);  // symmetric: i <= j only, mirrored by the host
   const float* x = A.xa + (size_t)i * A.L * 3;
   const float* y = A.xb + (size_t)j * A.L * 3;
   double v[17];
@@ -130,11 +144,13 @@ __global__ __launch_bounds__(256) void k_sup_rmsd(SupArgs A) {
 template <int RPL>  // residues per lane: L <= 64 RPL
 __global__ __launch_bounds__(256) void k_sup_tm(SupArgs A) {
   const int lane = threadIdx.x & 63;
-  const int seed = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long pair = blockIdx.y;
-  if (seed >= A.nseed) return;
-  const int i = (int)(pair / A.m), j = (int)(pair % A.m);
-  if (A.symmetric && j < i) return;
+  // the pair sits on gridDim.x (up to 2^31 - 1 blocks), the seed block on gridDim.y (a few hundred at most): with the pair on
+  // y, 257 structures against themselves already exceeded the 65 535 blocks that dimension allows
+  const int seed = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const long pair = blockIdx.x;
+  if (seed >= A.nseed || pair >= A.npair) return;
+  int i, j;
+  sup_pair_ij(pair, A.n, A.m, A.symmetric, i, j);
   const int L = A.L;
   const float* x = A.xa + (size_t)i * L * 3;
   const float* y = A.xb + (size_t)j * L * 3;
@@ -193,7 +209,9 @@ __global__ __launch_bounds__(256) void k_sup_tm(SupArgs A) {
       int cnt = 0;
 #pragma unroll
       for (int k = 0; k < RPL; k++) { nw[k] = ok[k] && d2[k] < d * d; cnt += __popcll(__ballot(nw[k])); }
-      if (cnt >= 3 || L <= 3) break;
+      // d2 is finite for finite input (the C ABI rejects anything else); the bound on d keeps a wave from spinning for ever
+      // should a non-finite value get here all the same (NaN < d * d is false for every d)
+      if (cnt >= 3 || L <= 3 || !(d < 1.0e4)) break;
       d += 0.5;
     }
     bool same = true;

@@ -643,14 +643,16 @@ static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_eva
   A.out_xyz = c->out_xyz; A.out_X = c->out_X; A.out_e = c->out_e; A.out_f = c->out_f; A.out_stat = c->out_stat;
   return A;
 }
-static void launch_pair(trx2_ctx* c, int B) {
+// Returns non-zero (with c->err set) when the launch was REFUSED: the caller must stop enqueuing -- a step kernel launched after a
+// refused pair launch would sum stale records of an earlier evaluation and minimise on them.
+static int launch_pair(trx2_ctx* c, int B) {
   // never launch a shape the buffers were not sized for (operand shapes are checked on the host: a kernel that writes out of
   // bounds can reset every GPU of the node)
   if (B < 1 || B > c->Bpad || B > c->Bcap || c->Bpad % c->BW != 0 || (size_t)c->nsplit * B * c->L > c->fa_cap ||
       (size_t)c->Bpad > (size_t)(c->Bcap + 63) / 64 * 64) {
     c->err = "internal: pair-kernel launch shape does not fit the batch buffers";
     fprintf(stderr, "trx2fold: %s (B=%d Bpad=%d Bcap=%d nsplit=%d)\n", c->err.c_str(), B, c->Bpad, c->Bcap, c->nsplit);
-    return;
+    return 1;
   }
   const PairArgs P = pair_args(c, B);
   const dim3 grid(c->L, c->nsplit, c->Bpad / c->BW), block(PAIR_THREADS);
@@ -663,6 +665,7 @@ static void launch_pair(trx2_ctx* c, int B) {
     case 2: hipLaunchKernelGGL((k_pair<2, FAM_ALL>), grid, block, 0, c->stream, P); break;
     default: hipLaunchKernelGGL((k_pair<1, FAM_ALL>), grid, block, 0, c->stream, P); break;
   }
+  return 0;
 }
 static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals) {
   CartArgs A;
@@ -715,7 +718,7 @@ extern "C" int trx2_eval_batch(trx2_ctx* ctx, int B, const float* tors, const fl
   hipLaunchKernelGGL(k_init_torsions, dim3((unsigned)((BL + 255) / 256)), dim3(256), 0, ctx->stream, L, B, 0ull, 0u,
                      ctx->tors0, ctx->X, ctx->XT, ctx->geom);
   launch_chain(ctx, B, MODE_INIT, 1, 1 << 30);
-  launch_pair(ctx, B);
+  if (launch_pair(ctx, B)) { (void)hipStreamSynchronize(ctx->stream); return 1; }
   launch_chain(ctx, B, MODE_FINISH, 1, 1 << 30);
   HIPCHK(hipGetLastError());
   if (e_terms) HIPCHK(hipMemcpyAsync(e_terms, ctx->e_last, sizeof(double) * B * TRX2_NTERMS, hipMemcpyDeviceToHost, ctx->stream));
@@ -835,11 +838,11 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   auto pool_args = [&](ChainArgs& ca) {
     ca.n_total = N; ca.seed = seed; ca.decoy0 = decoy0; ca.tors0_all = tors0 ? ctx->tors0_all : nullptr;
   };
-  auto enqueue_chunk = [&]() {
+  auto enqueue_chunk = [&]() -> int {  // non-zero: a pair launch was refused; nothing was launched after it
     for (int i = 0; i < chunk; i++) {
       const bool samp = pe > 0 && (i % pe) == 0 && (size_t)(3 * prof_used + 2) < ctx->prof_ev.size();
       if (samp) (void)hipEventRecord(ctx->prof_ev[3 * prof_used], ctx->stream);
-      launch_pair(ctx, B);  // bumps the device-side evaluation counter
+      if (launch_pair(ctx, B)) return 1;  // (bumps the device-side evaluation counter) never a step kernel on stale records
       if (samp) (void)hipEventRecord(ctx->prof_ev[3 * prof_used + 1], ctx->stream);
       ChainArgs ca = chain_args(ctx, B, MODE_STEP, nruns, max_evals);
       pool_args(ca);
@@ -862,6 +865,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
         launch_chain_args(ctx, B, ca);
       if (samp) { (void)hipEventRecord(ctx->prof_ev[3 * prof_used + 2], ctx->stream); prof_used++; }
     }
+    return 0;
   };
   // The chunk is a static graph (its only per-evaluation input, the sequence number, lives in device memory): capture it
   // once per (batch shape, protocol length, buffers) and replay it -- 128 launches become one hipGraphLaunch.  Measured on
@@ -874,16 +878,18 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
       if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
       hipGraph_t graph = nullptr;
       HIPCHK(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-      enqueue_chunk();
+      const int refused = enqueue_chunk();
       HIPCHK(hipStreamEndCapture(ctx->stream, &graph));
+      if (refused) { if (graph) (void)hipGraphDestroy(graph); return 1; }
       HIPCHK(hipGraphInstantiate(&ctx->gexec, graph, nullptr, nullptr, 0));
       HIPCHK(hipGraphDestroy(graph));
       memcpy(ctx->g_key, key, sizeof key);
     }
   }
   while (true) {
-    if (no_graph) enqueue_chunk();
-    else HIPCHK(hipGraphLaunch(ctx->gexec, ctx->stream));
+    if (no_graph) {
+      if (enqueue_chunk()) { (void)hipStreamSynchronize(ctx->stream); return 1; }  // ctx->err says which shape was refused
+    } else HIPCHK(hipGraphLaunch(ctx->gexec, ctx->stream));
     launches += chunk;
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(ctx->h_done, ctx->done_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1189,6 +1195,12 @@ extern "C" int trx2_superpose_matrix(trx2_ctx* ctx, int n, int m, int L, const f
   }
   const bool sym = xb == nullptr;
   if (sym) m = n;
+  {  // non-finite coordinates have no superposition (and would keep the TM-score search from ending): refuse them here, at the ABI
+    bool finite = true;
+    for (size_t k = 0; k < (size_t)n * L * 3 && finite; k++) finite = std::isfinite(xa[k]);
+    for (size_t k = 0; xb && k < (size_t)m * L * 3 && finite; k++) finite = std::isfinite(xb[k]);
+    if (!finite) { ctx->err = "trx2_superpose_matrix: non-finite coordinates"; return 1; }
+  }
   HIPCHK(hipSetDevice(ctx->device));
   if (l_norm <= 0) l_norm = L;
   // seed fragments of the TM-score program's search (evaluate.tm_score): lengths L, L/2, .. (at most six, >= 4), then 4
@@ -1202,6 +1214,7 @@ extern "C" int trx2_superpose_matrix(trx2_ctx* ctx, int n, int m, int L, const f
   }
   SupArgs A;
   A.n = n; A.m = m; A.L = L; A.nseed = (int)seeds.size(); A.symmetric = sym;
+  A.npair = sym ? (long)n * (n + 1) / 2 : (long)n * m;
   A.lnorm = l_norm;
   double d0 = l_norm > 21 ? 1.24 * std::pow(l_norm - 15.0, 1.0 / 3.0) - 1.8 : 0.5;
   if (d0 < 0.5) d0 = 0.5;
@@ -1217,10 +1230,10 @@ extern "C" int trx2_superpose_matrix(trx2_ctx* ctx, int n, int m, int L, const f
   HIPCHK(hipStreamSynchronize(ctx->stream));  // `seeds` is read by the copy above
   A.xa = (const float*)base; A.xb = sym ? A.xa : (const float*)(base + o_b);
   A.rmsd = (double*)(base + o_r); A.tm_bits = (unsigned long long*)(base + o_t); A.seeds = (const int2*)(base + o_s);
-  const long pairs = (long)n * m;
+  const long pairs = A.npair;
   if (rmsd) hipLaunchKernelGGL(k_sup_rmsd, dim3((unsigned)((pairs + 3) / 4)), dim3(256), 0, ctx->stream, A);
   if (tm && A.nseed) {
-    const dim3 grid((unsigned)((A.nseed + 3) / 4), (unsigned)pairs);
+    const dim3 grid((unsigned)pairs, (unsigned)((A.nseed + 3) / 4));  // pairs <= 2^24 on x; seed blocks (L <= 1024: < 1600) on y
     if (L <= 128) hipLaunchKernelGGL((k_sup_tm<2>), grid, dim3(256), 0, ctx->stream, A);
     else if (L <= 256) hipLaunchKernelGGL((k_sup_tm<4>), grid, dim3(256), 0, ctx->stream, A);
     else if (L <= 512) hipLaunchKernelGGL((k_sup_tm<8>), grid, dim3(256), 0, ctx->stream, A);
@@ -1255,12 +1268,16 @@ extern "C" int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int s
     p[0] = w[0]; p[1] = w[1]; p[2] = w[2]; p[3] = w[3]; p[4] = (float)sep_lo; p[5] = (float)sep_hi; p[6] = 1.0f; p[7] = w[7];
   }
   HIPCHK(hipMemcpyAsync(ctx->wcur, wc.data(), wc.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  // The decoy-minor copy is rebuilt from the decoy-major one in the FULL layout of this batch: a fold that ended under tail
+  // compaction leaves xyzT in the narrow layout of its last survivors; P is layout-independent.
+  hipLaunchKernelGGL(k_relayout, dim3((unsigned)(((size_t)B * L * 5 + 255) / 256)), dim3(256), 0, ctx->stream, B, L, ctx->BW, (const float4*)ctx->P, ctx->xyzT);
+  if (launch_pair(ctx, B)) return 1;  // warm
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
-  launch_pair(ctx, B);  // warm
   HIPCHK(hipEventRecord(e0, ctx->stream));
-  for (int i = 0; i < n_rep; i++) launch_pair(ctx, B);
+  for (int i = 0; i < n_rep; i++)
+    if (launch_pair(ctx, B)) return 1;
   HIPCHK(hipEventRecord(e1, ctx->stream));
   HIPCHK(hipEventSynchronize(e1));
   float ms = 0;
@@ -1341,6 +1358,17 @@ extern "C" int trx2_last_fold_stats(trx2_ctx* ctx, double* seconds, int* n_launc
   return 0;
 }
 
+#ifdef TRX2_SELFCHECK
+// checking build only (libtrx2fold_check.so): one-sum energy totals compared with the nine-sum totals inside the step kernels
+extern "C" int trx2_debug_selfcheck(unsigned long long* out4, int reset) {
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_selfcheck), sizeof(unsigned long long) * 4) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_selfcheck), z, sizeof z) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 #ifdef TRX2_STAMP
 extern "C" int trx2_debug_chain_stamps(unsigned long long* out32, int reset) {
   if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_cstamp), sizeof(unsigned long long) * 32) != hipSuccess) return 1;

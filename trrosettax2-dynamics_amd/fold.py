@@ -6,7 +6,8 @@ folds all `repeat` decoys of the distogram as ONE batch on the GPU.  `fold_npz` 
 and backs the `folding/folding.py` command-line shim.
 
 Differences from the reference, all deliberate:
-  D  failed folds raise RuntimeError instead of passing silently (utils.py:498 runs subprocess.run unchecked)
+  D  failed folds raise RuntimeError (FoldError) instead of passing silently (utils.py:498 runs subprocess.run unchecked); the
+     decoys of the batch that did fold are written first, the failed ones get no file
   D  start torsions come from an explicit seed (the reference never seeds `random`, utils_ros.py:677)
   D  --fastrelax is accepted and ignored: there is no full-atom stage (folding.py:200-268 is not replicated)
 """
@@ -89,8 +90,36 @@ def set_restraints(ctx, npz, seq, args, ang):
                 ctx.override_rows(ch, a, b, y)
 
 
-def fold_arrays(npz, seq, n_decoys, options="", device=0, seed=None, decoy0=0, lanes=2):
-    """fold n_decoys of one distogram -> dict(xyz[B,L,5,3], status, e_terms, ...); raises on any failed decoy.
+class FoldError(RuntimeError):
+    """some decoys of a batch failed; `.result` holds the whole batch, `.bad` the failed indices (the good decoys' files were written)"""
+
+    def __init__(self, msg, result, bad):
+        super().__init__(msg)
+        self.result, self.bad = result, bad
+
+
+def _failed(r):
+    return np.nonzero((r["status"] != 0) | ~np.isfinite(r["xyz"]).all(axis=(1, 2, 3)))[0]
+
+
+def _write_decoys(r, seq, base_out, names, seed, verbose=False):
+    """Writes the PDB of every decoy that folded; THEN raises FoldError if any did not (never a partial PDB for a
+    failed decoy -- but one diverged decoy no longer discards the other B - 1)."""
+    bad = set(_failed(r).tolist())
+    for k, name in enumerate(names):
+        if k in bad:
+            continue
+        write_pdb(os.path.join(base_out, name), seq, r["xyz"][k], remarks=[f"trx2fold decoy {k} seed {seed} evals {int(r['n_evals'][k])}"])
+        if verbose:
+            print(f"Folded: {os.path.join(base_out, name)}")
+    if bad:
+        b = sorted(bad)
+        raise FoldError(f"fold failed for decoys {b} (status {r['status'][b].tolist()}); the other {len(names) - len(b)} were written", r, b)
+
+
+def fold_arrays(npz, seq, n_decoys, options="", device=0, seed=None, decoy0=0, lanes=2, allow_partial=False):
+    """fold n_decoys of one distogram -> dict(xyz[B,L,5,3], status, e_terms, ...); raises on any failed decoy unless
+    allow_partial (the callers that write files pass it and raise AFTER the good decoys are on disk: _write_decoys).
     lanes=2 (default): 32 or more decoys are folded as two halves on two streams (+24..32 % decoys/s, include/trx2fold.h);
     callers that already fold several chains concurrently (pipeline.run_single with two models) pass lanes=1."""
     args = parse_options(options)
@@ -109,9 +138,10 @@ def fold_arrays(npz, seq, n_decoys, options="", device=0, seed=None, decoy0=0, l
     per_lane = (n_decoys + ctx.lanes - 1) // ctx.lanes if n_decoys >= 32 else n_decoys
     ctx.set_pool(SLOTS_PER_LANE if per_lane > SLOTS_PER_LANE else 0)
     r = ctx.fold_batch(n_decoys, protocol.build_runs(L, args.mode), seed=seed, decoy0=decoy0)
-    bad = np.nonzero((r["status"] != 0) | ~np.isfinite(r["xyz"]).all(axis=(1, 2, 3)))[0]
-    if len(bad):
-        raise RuntimeError(f"fold failed for decoys {bad.tolist()} (status {r['status'][bad].tolist()})")
+    r["seed"] = seed
+    bad = _failed(r)
+    if len(bad) and not allow_partial:
+        raise FoldError(f"fold failed for decoys {bad.tolist()} (status {r['status'][bad].tolist()})", r, bad.tolist())
     return r
 
 
@@ -122,12 +152,9 @@ def folding_with_pred_npz(base_npz, base_fasta, base_out, out_name, options="-m 
     seq = read_fasta(_unquote(base_fasta))
     os.makedirs(base_out, exist_ok=True)
     n = repeat if repeat else 1
-    r = fold_arrays(npz, seq, n, options, device=device, seed=seed, decoy0=start_id)
+    r = fold_arrays(npz, seq, n, options, device=device, seed=seed, decoy0=start_id, allow_partial=True)
     names = [f"{out_name}{i}.pdb" for i in range(start_id, start_id + repeat)] if repeat else [f"{out_name}.pdb"]
-    for k, name in enumerate(names):
-        write_pdb(os.path.join(base_out, name), seq, r["xyz"][k],
-                  remarks=[f"trx2fold decoy {k} seed {seed} evals {int(r['n_evals'][k])}"])
-        print(f"Folded: {os.path.join(base_out, name)}")
+    _write_decoys(r, seq, base_out, names, r["seed"], verbose=True)
     return r
 
 
@@ -142,20 +169,15 @@ def fold_resident_to_pdb(ctx, seq, base_out, names, options="", seed=None, decoy
             _SEED[0] += 1
     os.makedirs(base_out, exist_ok=True)
     r = ctx.fold_batch(len(names), protocol.build_runs(len(seq), args.mode), seed=seed, decoy0=decoy0)
-    bad = np.nonzero((r["status"] != 0) | ~np.isfinite(r["xyz"]).all(axis=(1, 2, 3)))[0]
-    if len(bad):
-        raise RuntimeError(f"fold failed for decoys {bad.tolist()} (status {r['status'][bad].tolist()})")
-    for k, name in enumerate(names):
-        write_pdb(os.path.join(base_out, name), seq, r["xyz"][k], remarks=[f"trx2fold decoy {k} seed {seed} evals {int(r['n_evals'][k])}"])
+    _write_decoys(r, seq, base_out, names, seed)
     return r
 
 
 def fold_arrays_to_pdb(arrays, seq, base_out, names, options="", device=0, seed=None, decoy0=0, lanes=2):
     """folding_with_pred_npz for distograms already in memory: writes base_out/name for every name"""
     os.makedirs(base_out, exist_ok=True)
-    r = fold_arrays(arrays, seq, len(names), options, device=device, seed=seed, decoy0=decoy0, lanes=lanes)
-    for k, name in enumerate(names):
-        write_pdb(os.path.join(base_out, name), seq, r["xyz"][k], remarks=[f"trx2fold decoy {k} seed {seed} evals {int(r['n_evals'][k])}"])
+    r = fold_arrays(arrays, seq, len(names), options, device=device, seed=seed, decoy0=decoy0, lanes=lanes, allow_partial=True)
+    _write_decoys(r, seq, base_out, names, r["seed"])
     return r
 
 

@@ -27,7 +27,7 @@ from .pdbio import as_read_from_pdb, read_backbone, read_fasta
 
 def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz, fasta, N=10, Nmax=500, begin_num=0,
                          sigma=1.0, tta_opt="-m 2 -r no-idp --orient ", angle=True, device=0, seed=None, lanes=2,
-                         write_tmp_npz=False, device_feedback=True):
+                         write_tmp_npz=False, device_feedback=True, timing=None):
     """N initial decoys as one GPU batch -> best by reliability -> feedback -> one decoy per iteration until the
     cumulative `tmp` array moves by < 0.01 or Nmax iterations (run_inference.py:97-139).  Returns the last index.
 
@@ -43,8 +43,21 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     fold context (Context.feedback_step: only the decoy's coordinates go in, the convergence measure comes back, the next
     fold uses the rebuilt tables without any upload).  "arrays": same kernels on host arrays (Context.feedback_labels).
     Both are tested bitwise equal to the numpy path, which is pinned bit for bit to the reference; sigma other than 1
-    falls back to numpy."""
+    falls back to numpy.
+
+    timing: a dict that receives initial_s (initial batch: table build, fold, files, ranking), iteration_s (everything after),
+    iteration_fold_s (the single-decoy folds alone) and iterations -- bench.py's e2e leg."""
+    import time
     os.makedirs(processed_npz_dir, exist_ok=True)
+    t_start = time.perf_counter()
+    tm = dict(initial_s=0.0, iteration_s=0.0, iteration_fold_s=0.0, iterations=0)
+
+    def done(iter_n):
+        tm["iterations"] = iter_n - begin_num
+        tm["iteration_s"] = time.perf_counter() - t_start - tm["initial_s"]
+        if timing is not None:
+            timing.update(tm)
+        return iter_n
 
     resident = device_feedback is True and float(sigma) == 1.0
 
@@ -71,6 +84,7 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
             best_score, best_pdb, best_i = scores[i], os.path.join(pred_pdb_dir, f"initial{i}.pdb"), i
 
     pattern = os.path.join(processed_npz_dir, pdb_name + "{}.npz")
+    tm["initial_s"] = time.perf_counter() - t_start
     if resident:
         # The initial batch left its map in this thread's context.  From here on the distograms never leave the device.
         ctx = get_context(device, lanes)
@@ -88,13 +102,15 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
         while True:
             iter_n += 1
             print(f"Start generating structure {iter_n}")
+            t_f = time.perf_counter()
             r = fold_resident_to_pdb(ctx, seq, pred_pdb_dir, [f"{pdb_name}{iter_n}.pdb"], tta_opt, seed=None if seed is None else seed + iter_n)
+            tm["iteration_fold_s"] += time.perf_counter() - t_f
             print("Done generating structure", iter_n)
             if iter_n - begin_num >= Nmax:
                 break
             if step(r["xyz"][0], iter_n + 1) < 0.01:
                 break
-        return iter_n
+        return done(iter_n)
     base = {k: init[k] for k in (("dist", "theta", "omega", "phi") if angle else ("dist",))}   # no "tmp": falls back to dist
     old_tmp = init["dist"]
     cur = feedback(base, best_pdb)
@@ -105,8 +121,10 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
         iter_n += 1
         old_tmp = cur["tmp"]                             # what np.load(current_npz)["tmp"] gives (run_inference.py:101-102)
         print(f"Start generating structure {iter_n}")
+        t_f = time.perf_counter()
         fold_arrays_to_pdb(cur, seq, pred_pdb_dir, [f"{pdb_name}{iter_n}.pdb"], tta_opt, device=device,
                            seed=None if seed is None else seed + iter_n)
+        tm["iteration_fold_s"] += time.perf_counter() - t_f
         print("Done generating structure", iter_n)
         if iter_n - begin_num >= Nmax:
             break
@@ -115,7 +133,7 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
             np.savez(pattern.format(iter_n + 1), **cur)
         if np.max(np.abs(old_tmp - cur["tmp"])) < 0.01:
             break
-    return iter_n
+    return done(iter_n)
 
 
 def flatten_and_rename(save_pdb_dir, num_conf1_others):
@@ -160,8 +178,9 @@ def flatten_and_rename(save_pdb_dir, num_conf1_others):
 
 
 def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mult_two_models=True, npz_nmr=None,
-               npz_xray=None, device=0, seed=None, keep_tmp_npz=False):
-    """run_inference.py:280-337 without the network front-end: expects the distograms to exist."""
+               npz_xray=None, device=0, seed=None, keep_tmp_npz=False, phase_times=None):
+    """run_inference.py:280-337 without the network front-end: expects the distograms to exist.
+    phase_times: a dict that receives, per chain ("NMR" / "Xray"), generate_npz_and_pdb's timing record."""
     content = os.path.join(save_dir, name)
     npz_dir, pdb_dir, tmp_dir = (os.path.join(content, d) for d in ("pred_npz", "pred_pdb", "tmp_npz"))
     for d in (npz_dir, pdb_dir, tmp_dir):
@@ -187,7 +206,8 @@ def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mu
                                     N=init_num, Nmax=Nmax, begin_num=0, angle=angle, tta_opt=tta_opt, device=device,
                                     seed=None if seed is None else seed + 100000 * len(tag),
                                     lanes=1 if len(maps) == 2 else 2,   # two chains already occupy two streams
-                                    write_tmp_npz=keep_tmp_npz)
+                                    write_tmp_npz=keep_tmp_npz,
+                                    timing=None if phase_times is None else phase_times.setdefault(tag, {}))
 
     if len(maps) == 2:
         with ThreadPoolExecutor(max_workers=2) as ex:
