@@ -3,9 +3,16 @@
 // Not a stand-alone header: it relies on the macros, constant tables and helpers defined above its #include.
 #pragma once
 // =================================================================================================
-// K3/K4: pair terms.  Workgroup = (row residue a, b-range split, decoy group); lane = decoy (BW decoys per
-// wave, 64/BW residues b per wave step).  Each ORDERED pair (a,b) is visited from a's row and only the
-// gradient on a's atoms is kept -> no atomics, no cross-workgroup reduction, deterministic.
+// K3/K4: pair terms.  Workgroup = (row residue a, slice, decoy group); lane = decoy (BW decoys per wave, 64/BW partner
+// residues b per wave step).  Each ORDERED pair (a,b) is handled from a's row and only the gradient on a's atoms is kept
+// -> no atomics, no cross-workgroup reduction, deterministic.
+// Round 3: the kernel no longer visits every pair.  (i) Restraint terms walk row a's COMPACTED LIST of partners that carry
+// any selected restraint (k_build_rows, once per map / feedback step: 47 % of the ordered pairs at L=150 with distances
+// only, ~25 % at L=400), the list cut into equal slices over the workgroups of a row.  (ii) Repulsion / hydrogen-bond
+// CONTACTS depend on the decoy, so they cannot come from a list built per map; they are found by a scan of the partners'
+// C-alpha alone -- the decoy-minor record starts with CA, one float4 -- with the loads of eight visits issued together
+// (one memory round trip per eight visits instead of one per visit), then every lane walks its own contacts as before.
+// What the reference asks Rosetta for with nb_list=True (folding/folding.py:91-102), without a list to keep valid.
 // =================================================================================================
 #define PR_NCOMP 18 /* gradient components per residue: N CA C O CB H */
 #define PR_REC 24   /* floats per record: 18 gradient + 6 energies (dist omega theta phi vdw hb) */
@@ -14,10 +21,12 @@ struct PairArgs {
   int L, B, nsplit, Bpad;
   int kd;       // knots of the distance spline: TRX2_KD, or TRX2_KD_AF2 for gen_rst_af2 tables
   int dist_ca;  // 1: the distance restraint acts on C-alpha (gen_rst_af2), 0: on C-beta
-  const float4* xyzT;  // [ngrp][L][5][BW] float4 : residue record N CA C O CB (+pad) | H, hasH ; decoy-minor
+  const float4* xyzT;  // [ngrp][L][5][BW] float4, decoy-minor: residue record CA N CB C O (xt_pack) | H, hasH
   const float2 *Td, *To, *Tt, *Tp;
-  const unsigned char* mask;  // [L][L] packed: low nibble = selected bits of (a,b), high nibble = those of (b,a)
-  const unsigned char* mask_odr;  // the same without the pairs flagged disordered (mode 3, first stage), or NULL
+  const unsigned* rows;       // [L][L] row a: its row_cnt[a] partners with any selected restraint, ascending b:
+                              //   b | mask << 16 | mask_odr << 24, mask = low nibble selected bits of (a,b), high nibble those of (b,a)
+  const int* row_cnt;         // [L]
+  int has_odr;                // the map has an idr mask: entries carry the packed mask without the flagged pairs (mode 3, first stage)
   const float* knots;         // [kd + 72] float
   const float* wcur;          // [B][8] : w_ap w_dih w_ang w_vdw sep_lo sep_hi active (2: ordered pairs only) w_hb
   float* FA;                  // [nsplit][B][L][24] per (slab, decoy, residue a): gradient on N CA C O CB H, then the raw energies
@@ -25,31 +34,11 @@ struct PairArgs {
   int* seq_ctr;               // evaluation counter in device memory: bumped here, read by the step kernel that follows
 };
 
-// ikn[i] = 1 / (kn[i+1] - kn[i]), precomputed once per workgroup
-__device__ __forceinline__ void spline_eval_dev(const float2* __restrict__ row, const float* kn, const float* ikn, int K,
-                                                int idx, float x, float& e, float& de) {
-  // idx is a guess; fix up against the (rounded, slightly non-uniform) knots
-  idx = max(0, min(K - 2, idx));
-  if (x < kn[idx]) idx = max(0, idx - 1);
-  else if (x >= kn[idx + 1]) idx = min(K - 2, idx + 1);
-  float lo = kn[idx], hi = kn[idx + 1];
-  float2 k0 = row[idx], k1 = row[idx + 1];
-  // the segment's cubic in t = x - lo, formed from (y, y'') of its two knots and evaluated by Horner:
-  //   c1 = (y1-y0)/h - h (2 y0'' + y1'')/6,  c2 = y0''/2,  c3 = (y1''-y0'')/(6h)
-  float h = hi - lo, ih = ikn[idx], t = x - lo;
-  bool inside = (x > kn[0]) && (x < kn[K - 1]);
-  float c1 = fmaf(-h * (1.0f / 6.0f), fmaf(2.0f, k0.y, k1.y), (k1.x - k0.x) * ih);
-  float c3 = (k1.y - k0.y) * (ih * (1.0f / 6.0f));
-  float ev = fmaf(fmaf(fmaf(c3, t, 0.5f * k0.y), t, c1), t, k0.x);
-  float dv = fmaf(fmaf(3.0f * c3, t, k0.y), t, c1);
-  // outside the knot range: constant end value, zero slope (SplineFunc)
-  e = inside ? ev : (x <= kn[0] ? k0.x : k1.x);
-  de = inside ? dv : 0.0f;
-}
-
-// The same evaluation in three stages, so that the lookups of all the terms of a visit can travel together: seek (ONE round of
+// One spline evaluation in three stages, so that the lookups of all the terms of a visit can travel together: seek (ONE round of
 // LDS reads: the guessed segment's ends and its neighbours' far ends), fetch (the segment's two knots: one 16-byte gather) and
-// value (arithmetic only).  Term by term, a visit with all channels on was six dependent LDS -> LDS -> gather chains in a row.
+// value (arithmetic only: the segment's cubic in t = x - lo from (y, y'') of its two knots by Horner; outside the knot range the
+// constant end value and zero slope -- SplineFunc).  Term by term, a visit with all channels on was six dependent
+// LDS -> LDS -> gather chains in a row.
 struct SplSeg { int idx; float t, h, lo0, hi0; };
 __device__ __forceinline__ SplSeg spline_seek(const float* kn, int K, int guess, float x) {
   const int idx = max(0, min(K - 2, guess));
@@ -94,9 +83,13 @@ __device__ __forceinline__ float hbond_dev(f3 N, f3 H, f3 O, f3 C, float s, f3& 
 }
 
 // PAIR_MIN_WAVES (waves per SIMD the register allocator must admit) is a build-time knob so that occupancy-vs-spill
-// variants can be A/B-timed on hardware: 2 = no spills (220 VGPRs), 3 = 62 spilled, 4 = 104 spilled (profiles/README.md)
+// variants can be A/B-timed on hardware: 2 = no spills with all channels (217 VGPRs), 3 = 62 spilled, 4 = 104 spilled
+// (profiles/README.md).  The distance-only instantiation (no angular code) fits 128 registers: 4 waves per SIMD.
 #ifndef PAIR_MIN_WAVES
 #define PAIR_MIN_WAVES 2
+#endif
+#ifndef PAIR_MIN_WAVES_DIST
+#define PAIR_MIN_WAVES_DIST 4
 #endif
 // Diagnostic build only (-DTRX2_STAMP, never the shipped library): wave 0 of the workgroup (a = L/2, split 0, group 0)
 // accumulates s_memtime cycles per phase; every stamp first drains the memory counters so that a load's latency is charged
@@ -114,14 +107,49 @@ __device__ unsigned long long g_stamp[32];
 #define STAMP(k)
 #define STAMP_FLUSH
 #endif
-// FAM selects the term families an instantiation evaluates: the monolithic kernel (all three) is register-bound at 220
-// VGPRs = 2 waves per SIMD (profiles/README.md); each family alone has a much smaller live state.
-#define FAM_SYM 1   /* dist + omega: needs CA, CB */
-#define FAM_ASYM 2  /* theta + phi (both directions): needs N, CA, CB */
-#define FAM_VDW 4   /* soft-sphere repulsion: needs all five atoms, no tables */
+// FAM selects the term families an instantiation evaluates.  Maps with the angle channels run FAM_ALL; distance-only maps
+// (--no-orient, gen_rst_af2) run FAM_DIST | FAM_VDW, which leaves the whole angular block out of the instruction stream and
+// out of the register allocation.
+#define FAM_DIST 1  /* distance spline: needs CA (AF2 tables) or CB */
+#define FAM_ANG 2   /* omega, theta, phi (both directions): needs N, CA, CB */
+#define FAM_VDW 4   /* soft-sphere repulsion + backbone hydrogen bonds: all atoms, no tables */
 #define FAM_ALL 7
+#define PAIR_ROW_B_BITS 0x3ffu /* partner index in a row entry: L <= 1024 */
+
+// Row lists (once per map and per feedback step, after k_pack_masks): row a keeps, in ascending order, every partner b != a
+// whose packed mask byte has any bit -- a selected restraint of (a,b) or of (b,a).  One workgroup per row, order-preserving
+// compaction by wave ballots.  Fixed row stride L: no prefix sum over rows.
+__global__ __launch_bounds__(256) void k_build_rows(int L, const unsigned char* __restrict__ mask, const unsigned char* __restrict__ mask_odr,
+                                                     unsigned* __restrict__ rows, int* __restrict__ row_cnt) {
+  const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int s_w[4];
+  __shared__ int s_base;
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int b0 = 0; b0 < L; b0 += 256) {
+    const int b = b0 + tid;
+    unsigned m = 0, mo = 0;
+    if (b < L && b != a) {
+      m = mask[(size_t)a * L + b];
+      mo = mask_odr ? mask_odr[(size_t)a * L + b] : m;
+    }
+    const bool keep = m != 0;
+    const unsigned long long bal = __ballot(keep);
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_w[wave] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; w++) off += s_w[w];
+    if (keep) rows[(size_t)a * L + off + pre] = (unsigned)b | (m << 16) | (mo << 24);
+    __syncthreads();
+    if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
+  }
+  if (tid == 0) row_cnt[a] = s_base;
+}
+
 template <int BW, int FAM>
-__global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs A) {
+__global__ __launch_bounds__(PAIR_THREADS, (FAM & FAM_ANG) ? PAIR_MIN_WAVES : PAIR_MIN_WAVES_DIST) void k_pair(PairArgs A) {
   constexpr int PW = 64 / BW;
   const int L = A.L;
   const int a = blockIdx.x, split = blockIdx.y, grp = blockIdx.z;
@@ -132,10 +160,9 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   const int decc = min(dec, A.B - 1);
 
   STAMP_DECL
-  __shared__ float s_kn[TRX2_KTOT_MAX], s_ikn[TRX2_KTOT_MAX];
+  __shared__ float s_kn[TRX2_KTOT_MAX];
   __shared__ float s_red[PAIR_WAVES * 64 * RED_STRIDE];  // [wave][decoy][24 (+1 pad: bank-conflict-free)]
-  __shared__ unsigned char s_mask[1024];  // packed masks of this workgroup's residues b (chunk <= L <= 1024)
-  __shared__ unsigned char s_mask_o[1024];  // ... without the disordered pairs (only when the map has an idr mask)
+  __shared__ unsigned s_ent[1024];                       // this workgroup's slice of row a's list (a row has < L <= 1024 entries)
   // One evaluation = one sequence number.  Kept in device memory (not a kernel argument) so that a chunk of
   // (pair, step) launches is a STATIC graph that can be replayed.  The step kernel of this evaluation starts after this
   // kernel has finished (same stream), so every one of its workgroups reads the same, final value.
@@ -147,23 +174,16 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   const float4* xa = A.xyzT + ((size_t)(grp * L + a) * 5) * BW + d;
   const float4 q0 = xa[0], q1 = xa[BW], q2 = xa[2 * BW], q3 = xa[3 * BW], q4 = xa[4 * BW];
   const int kd = A.kd, ktot = kd + 2 * KO + KP;
-  for (int i = threadIdx.x; i < ktot; i += PAIR_THREADS) {
-    s_kn[i] = A.knots[i];
-    s_ikn[i] = i + 1 < ktot ? 1.0f / (A.knots[i + 1] - A.knots[i]) : 0.0f;  // entries straddling two tables are never read
-  }
-  {
-    const int chunk0 = (L + A.nsplit - 1) / A.nsplit, lo0 = split * chunk0, hi0 = min(L, lo0 + chunk0);
-    for (int i = lo0 + threadIdx.x; i < hi0; i += PAIR_THREADS) {
-      s_mask[i - lo0] = A.mask[(size_t)a * L + i];
-      if (A.mask_odr) s_mask_o[i - lo0] = A.mask_odr[(size_t)a * L + i];
-    }
-  }
+  for (int i = threadIdx.x; i < ktot; i += PAIR_THREADS) s_kn[i] = A.knots[i];
+  // equal slices of the row's list: every workgroup of a row gets the same number of restraint visits, whatever the residues
+  const int cnt = A.row_cnt[a];
+  const int e_lo = (int)(((long)cnt * split) / A.nsplit), e_hi = (int)(((long)cnt * (split + 1)) / A.nsplit);
+  for (int i = e_lo + (int)threadIdx.x; i < e_hi; i += PAIR_THREADS) s_ent[i - e_lo] = A.rows[(size_t)a * L + i];
   __syncthreads();
   const float* knd = s_kn;
   const float* kno = s_kn + kd;
   const float* knt = s_kn + kd + KO;
   const float* knp = s_kn + kd + 2 * KO;
-  const float *iknd = s_ikn, *ikno = s_ikn + kd, *iknt = s_ikn + kd + KO, *iknp = s_ikn + kd + 2 * KO;
   const float inv_o = 1.0f / (kno[1] - kno[0]), inv_p = 1.0f / (knp[1] - knp[0]);
   // distance knots: three unevenly spaced repulsive ones, then a uniform grid (0 / 2 / 3.5 / 4.25 + 0.5 k; AF2: 0 / 2.325 / 3.575 / 3.875 + 0.3125 k)
   const float kd1 = knd[1], kd2 = knd[2], kd3 = knd[3], inv_d = 1.0f / (knd[4] - knd[3]);
@@ -171,58 +191,48 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
   const float w_ap = w0.x, w_dih = w0.y, w_ang = w0.z, w_vdw = w0.w, w_hb = w1.w;
   const int sep_lo = (int)w1.x, sep_hi = (int)w1.y;
   const bool active = live && w1.z != 0.0f;
-  const bool odr_only = w1.z == 2.0f && A.mask_odr != nullptr;
+  const bool odr_only = w1.z == 2.0f && A.has_odr != 0;
 
   // residue a
-  const f3 Na = mk3(q0.x, q0.y, q0.z), CAa = mk3(q0.w, q1.x, q1.y), Ca = mk3(q1.z, q1.w, q2.x),
-           Oa = mk3(q2.y, q2.z, q2.w), CBa = mk3(q3.x, q3.y, q3.z), Ha = mk3(q4.x, q4.y, q4.z);
+  f3 CAa, Na, CBa, Ca, Oa;
+  xt_unpack(q0, q1, q2, q3, CAa, Na, CBa, Ca, Oa);
+  const f3 Ha = mk3(q4.x, q4.y, q4.z);
   const bool donor_a = q4.w != 0.0f;
 
   f3 gN = mk3(0, 0, 0), gCA = gN, gC = gN, gO = gN, gCB = gN, gH = gN;
   float e_d = 0, e_o = 0, e_t = 0, e_p = 0, e_v = 0, e_h = 0;
-
-  const int chunk = (L + A.nsplit - 1) / A.nsplit;
-  const int b_lo = split * chunk, b_hi = min(L, b_lo + chunk);
   const unsigned aL = (unsigned)a * (unsigned)L;
-  STAMP(0)  // prologue: knots to LDS, barrier, weights, residue a
-
-  // The loop runs in blocks of up to 32 visits.  Restraint terms are evaluated in the visit (the pair, hence the table, is
-  // the same for all decoys of the wave).  Repulsion is different: WHICH residues touch depends on the decoy, so in lockstep
-  // the 25 atom pairs ran whenever ANY of the 64 decoys was within the cutoff -- on ~85 % of the visits of a distance-only
-  // fold although ~10 % of (pair, decoy) combinations are in contact (profiles/README.md).  A visit therefore only records
-  // a contact bit per lane; after the block every lane walks ITS OWN bits, gathering its own residue b.  The walk takes
-  // max-over-lanes(contacts) steps instead of count-of-visits-with-any-contact.  Order per lane stays fixed: deterministic.
   constexpr int VSTRIDE = PAIR_WAVES * PW;
-  for (int bb = b_lo + wave * PW; bb < b_hi; bb += 32 * VSTRIDE) {
-  unsigned vmask = 0;
+  STAMP(0)  // prologue: knots and list slice to LDS, barrier, weights, residue a
+
+  // ---- (i) restraint terms: the slice of the row's list, PW entries per wave step (lane = decoy, sub-lane h = entry).  The
+  // pair, hence the table row, is the same for all decoys of a sub-lane.  Skipped outright while no decoy of the wave has a
+  // restraint weight or an open separation window (the declash runs, folding.py:119: no restraints loaded yet).
+  const bool want_rst = active && sep_hi > sep_lo && ((((FAM & FAM_DIST) != 0) && w_ap != 0.0f) || (((FAM & FAM_ANG) != 0) && (w_dih != 0.0f || w_ang != 0.0f)));
+  if (__any((int)want_rst)) {
 #pragma unroll 1
-  for (int v = 0; v < 32; v++) {
-    const int b0 = bb + v * VSTRIDE;
-    if (b0 >= b_hi) break;
-    const int b = b0 + h;
-    const bool valid = live && active && b < b_hi && b != a;
-    const int bc = min(b, L - 1);
-    const int sep = abs(a - bc);
-    // residue b's N, CA, CB: requested before the masks are looked at (the address needs only b), so that the two reads travel
-    // together; a visit that turns out to have nothing to do drops them.  Index arithmetic in 24-bit multiplies (full rate;
-    // L <= 1024, a few decoy groups) instead of the quarter-rate 64-bit multiply-adds of size_t indexing.
+  for (int e0 = e_lo + wave * PW; e0 < e_hi; e0 += VSTRIDE) {
+    const int e = e0 + h;
+    const unsigned ent = s_ent[min(e, e_hi - 1) - e_lo];
+    const int bc = (int)(ent & PAIR_ROW_B_BITS);
+    // residue b's CA, N, CB: requested as soon as the entry is read, before its masks are examined
     const float4* xb = A.xyzT + (__umul24((unsigned)(grp * L + bc), 5u * BW) + (unsigned)d);
-    float4 r0 = xb[0], r1 = xb[BW], r3 = xb[3 * BW];
+    const float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW];
+    const int sep = abs(a - bc);
     unsigned m_ab = 0, m_ba = 0;
-    if (valid && sep >= sep_lo && sep < sep_hi) {
-      const unsigned mm = odr_only ? s_mask_o[bc - b_lo] : s_mask[bc - b_lo];
+    if (want_rst && e < e_hi && sep >= sep_lo && sep < sep_hi) {
+      const unsigned mm = odr_only ? (ent >> 24) : ((ent >> 16) & 0xffu);
       m_ab = mm & 15u;
       m_ba = mm >> 4;
     }
-    if (!(FAM & FAM_SYM)) { m_ab &= ~(TRX2_M_DIST | TRX2_M_OMEGA); m_ba &= ~(TRX2_M_DIST | TRX2_M_OMEGA); }
-    if (!(FAM & FAM_ASYM)) { m_ab &= ~(TRX2_M_THETA | TRX2_M_PHI); m_ba &= ~(TRX2_M_THETA | TRX2_M_PHI); }
+    if (!(FAM & FAM_DIST)) { m_ab &= ~TRX2_M_DIST; m_ba &= ~TRX2_M_DIST; }
+    if (!(FAM & FAM_ANG)) { m_ab &= TRX2_M_DIST; m_ba &= TRX2_M_DIST; }
     const unsigned msym = (a < bc) ? m_ab : m_ba;  // DIST / OMEGA bits live on the (min,max) row
-    const bool dovdw = (FAM & FAM_VDW) && valid && sep >= TRX2_VDW_MINSEP && (w_vdw != 0.0f || w_hb != 0.0f);
-    STAMP(1)  // masks (2 byte loads) + loop control
-    if (!__any((int)(m_ab | m_ba | (unsigned)dovdw))) continue;
+    STAMP(1)  // entry + masks + loop control
+    if (!__any((int)(m_ab | m_ba))) continue;
 
-    const f3 Nb = mk3(r0.x, r0.y, r0.z), CAb = mk3(r0.w, r1.x, r1.y), CBb = mk3(r3.x, r3.y, r3.z);
-    STAMP(2)  // coordinates of residue b (4 x 16 B per lane)
+    const f3 CAb = mk3(r0.x, r0.y, r0.z), Nb = mk3(r0.w, r1.x, r1.y), CBb = mk3(r1.z, r1.w, r2.x);
+    STAMP(2)  // coordinates of residue b (3 x 16 B per lane)
     const unsigned iab = aL + (unsigned)bc, iba = __umul24((unsigned)bc, (unsigned)L) + (unsigned)a;
     const unsigned isym = (a < bc) ? iab : iba;
     const bool first = a < bc;  // symmetric energies are counted from the lower row only
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
     const f3 u = CBa - CBb;
     const float u2 = dot(u, u), iu = frsq(u2), du = u2 * iu;
     // ---- distance: seek + fetch now, value after the angular lookups have been sent off too
-    const bool on_d = (FAM & FAM_SYM) && (msym & TRX2_M_DIST);
+    const bool on_d = (FAM & FAM_DIST) && (msym & TRX2_M_DIST);
     f3 ud = u;
     float idd = iu, dd = du;
     if (A.dist_ca) { ud = CAa - CAb; const float d2 = dot(ud, ud); idd = frsq(d2); dd = d2 * idd; }
@@ -246,8 +256,9 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       kd0 = row[0]; kd1_ = row[1];
     }
     STAMP(3)  // dist: seek, fetch
-    const unsigned m_om = (FAM & FAM_SYM) ? (msym & TRX2_M_OMEGA) : 0u;
-    const unsigned m_tp_ab = (FAM & FAM_ASYM) ? (m_ab & (TRX2_M_THETA | TRX2_M_PHI)) : 0u, m_tp_ba = (FAM & FAM_ASYM) ? (m_ba & (TRX2_M_THETA | TRX2_M_PHI)) : 0u;
+    if constexpr ((FAM & FAM_ANG) != 0) {
+    const unsigned m_om = msym & TRX2_M_OMEGA;
+    const unsigned m_tp_ab = m_ab & (TRX2_M_THETA | TRX2_M_PHI), m_tp_ba = m_ba & (TRX2_M_THETA | TRX2_M_PHI);
     if (m_om | m_tp_ab | m_tp_ba) {
       // every angle of the pair (those whose channel is off get weight zero: the selections of a pair's channels go together,
       // and straight-line code lets the five lookups share their round trips)
@@ -312,6 +323,7 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
         gCB = fma3(vh - wh * c_p2, -frcp(fmaxf(s_p2, 1e-8f)) * iu * (on * w_ang * de), gCB);
       }
     }
+    }
     if (on_d) {
       float ev, de;
       spline_value(sd, kd0, kd1_, dd, ev, de);
@@ -319,25 +331,53 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       if (A.dist_ca) gCA = fma3(ud, w_ap * de * idd, gCA);
       else gCB = fma3(ud, w_ap * de * idd, gCB);
     }
-    STAMP(8)  // phi(b,a)
-    if ((FAM & FAM_VDW) && dovdw) {
-      f3 dca = CAa - CAb;
-      if (dot(dca, dca) < (float)TRX2_VDW_CUT2) vmask |= 1u << v;
-    }
+    STAMP(8)  // values, gradients
   }
-  {
+  }
+  STAMP(9)  // restraint list done
+
+  // ---- (ii) contacts: this workgroup's b-range of the row (the ranges of a row's workgroups tile 0..L-1).  Which residues
+  // touch depends on the decoy, so in lockstep the 25 atom pairs ran whenever ANY of the 64 decoys was within the cutoff -- on
+  // ~85 % of the visits of a distance-only fold although ~10 % of (pair, decoy) combinations are in contact
+  // (profiles/README.md).  A scan over the partners' C-alpha records one contact bit per lane and visit, the loads of eight
+  // visits in flight together; after a block of up to 32 visits every lane walks ITS OWN bits, gathering its own residue b.
+  // The walk takes max-over-lanes(contacts) steps.  Order per lane stays fixed: deterministic.
+  if constexpr ((FAM & FAM_VDW) != 0) {
+  const bool want_vdw = active && (w_vdw != 0.0f || w_hb != 0.0f);
+  if (__any((int)want_vdw)) {
+  const int chunk = (L + A.nsplit - 1) / A.nsplit;
+  const int b_lo = split * chunk, b_hi = min(L, b_lo + chunk);
+  const float4* xg = A.xyzT + (__umul24((unsigned)(grp * L), 5u * BW) + (unsigned)d);
+  for (int bb = b_lo + wave * PW; bb < b_hi; bb += 32 * VSTRIDE) {
+    unsigned vmask = 0;
+#pragma unroll 1
+    for (int v0 = 0; v0 < 32; v0 += 8) {
+      if (bb + v0 * VSTRIDE >= b_hi) break;
+      float4 c[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) c[q] = xg[__umul24((unsigned)min(bb + (v0 + q) * VSTRIDE + h, L - 1), 5u * BW)];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int b = bb + (v0 + q) * VSTRIDE + h;
+        const f3 dca = CAa - mk3(c[q].x, c[q].y, c[q].z);
+        if (want_vdw && b < b_hi && abs(a - b) >= TRX2_VDW_MINSEP && dot(dca, dca) < (float)TRX2_VDW_CUT2) vmask |= 1u << (v0 + q);
+      }
+    }
+    STAMP(10)  // contact scan
     // per-lane walk: every lane follows its own contact bits (max-over-lanes steps): repulsion over the 5 x 5 atom pairs and
     // the two hydrogen-bond candidates of the pair, gradient on residue a's atoms; symmetric energies counted from the lower row
     while (vmask) {  // per-lane trip count; lanes without further contacts idle
       const int v = __ffs((int)vmask) - 1;
       vmask &= vmask - 1;
       const int b = bb + v * VSTRIDE + h;
-      const float4* xb = A.xyzT + (__umul24((unsigned)(grp * L + b), 5u * BW) + (unsigned)d);
+      const float4* xb = xg + __umul24((unsigned)b, 5u * BW);
       const float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW], r3 = xb[3 * BW], r4 = xb[4 * BW];
-      const f3 Nb = mk3(r0.x, r0.y, r0.z), Cb = mk3(r1.z, r1.w, r2.x), Ob = mk3(r2.y, r2.z, r2.w), Hb = mk3(r4.x, r4.y, r4.z);
+      f3 CAb, Nb, CBb, Cb, Ob;
+      xt_unpack(r0, r1, r2, r3, CAb, Nb, CBb, Cb, Ob);
+      const f3 Hb = mk3(r4.x, r4.y, r4.z);
       if (w_vdw != 0.0f) {
         const f3 pa[5] = {Na, CAa, Ca, Oa, CBa};
-        const f3 pb[5] = {Nb, mk3(r0.w, r1.x, r1.y), Cb, Ob, mk3(r3.x, r3.y, r3.z)};
+        const f3 pb[5] = {Nb, CAb, Cb, Ob, CBb};
         f3 ga[5] = {mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0), mk3(0, 0, 0)};
         float ev = 0;
   #pragma unroll
@@ -365,11 +405,11 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
         if (r4.w != 0.0f) { const float e = hbond_dev(Nb, Hb, Oa, Ca, w_hb, dump, dump, gO, gC); if (a < b) e_h += e; }
       }
     }
+    STAMP(11)  // contact walk
   }
-  STAMP(9)  // vdw
+  }
   }
 
-  STAMP(10) // loop exit
   // ---- reduce over the PW residue sub-lanes (inside the wave) and over the waves (through LDS); write decoy-major records.
   // The sub-lanes of a decoy sit BW lanes apart: a butterfly over the lane distances BW, 2 BW, .. 32 leaves their sum in
   // every one of them.  (Summing all PAIR_WAVES * PW slots from LDS instead made 6 threads add 256 slots each when one
@@ -401,6 +441,6 @@ __global__ __launch_bounds__(PAIR_THREADS, PAIR_MIN_WAVES) void k_pair(PairArgs 
       for (int sl = 0; sl < PAIR_WAVES; sl++) acc[i] += s_red[((size_t)sl * BW + dd) * RED_STRIDE + q * 4 + i];
     reinterpret_cast<float4*>(A.FA + (((size_t)split * A.B + dc) * L + a) * PR_REC)[q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
-  STAMP(11)  // epilogue: LDS image, barrier, column sums, stores
+  STAMP(12)  // epilogue: LDS image, barrier, column sums, stores
   STAMP_FLUSH
 }

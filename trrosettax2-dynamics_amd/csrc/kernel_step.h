@@ -30,7 +30,7 @@ struct ChainArgs {
   float4 *X, *G, *D, *XT;  // [B][L] (phi, psi, omega, -)
   float4 *S, *Y;           // [B][LBM][L]
   float4* P;               // [B][L][5] trial coordinates, decoy-major: N CA C O CB (15 floats + pad) | backbone H, hasH
-  float4* xyzT;            // [ngrp][L][5][BW] decoy-minor copy for the pair kernel (its lanes are decoys)
+  float4* xyzT;            // [ngrp][L][5][BW] decoy-minor copy for the pair kernel (its lanes are decoys), atoms in xt_pack order
   int BW;
   float4* geom;            // [B][L][3] internal geometry per residue (ResGeom)
   float* wcur;             // [B][8]
@@ -75,6 +75,9 @@ __device__ __forceinline__ f3 place_h(f3 Cp, f3 N, f3 CA) {
   return N + u * ((float)TRX2_HB_B_NH * rsqrtf(dot(u, u)));
 }
 
+#ifdef TRX2_DBG
+__device__ double g_dbg[256][12];  // diagnostic build only: decoy 0's line-search record per evaluation (tools/dbg_linesearch.py)
+#endif
 #ifdef TRX2_SELFCHECK
 __device__ unsigned long long g_selfcheck[4];  // torsion role: checks, mismatches; Cartesian role: checks, mismatches
 #endif
@@ -711,6 +714,14 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
         } else new_trial = true;
       }
     }
+#ifdef TRX2_DBG
+    if (dec == 0 && tid == 0 && A.mode == MODE_STEP && n_evals < 256) {
+      double* q = g_dbg[n_evals];
+      q[0] = s_i[SI_PHASE]; q[1] = s_i[SI_RUN]; q[2] = f_t; q[3] = s_d[SD_F]; q[4] = s_d[SD_ALPHA]; q[5] = s_d[SD_GD];
+      q[6] = (double)new_dir + 2.0 * (double)steepest + 4.0 * (double)next_run + 8.0 * (double)new_trial; q[7] = s_i[SI_NLS]; q[8] = s_i[SI_HL];
+      q[9] = fh[0]; q[10] = (double)xt[0].x; q[11] = (double)gt[0].x;
+    }
+#endif
     CSTAMP(4)  // Armijo test; on acceptance the (s, y) pair: one reduction + stores
     if (new_dir) {
       CCOUNT(31)
@@ -985,7 +996,9 @@ next_pair:
       float4* xT = nullptr;
       if (A.xyzT) {
         xT = A.xyzT + ((size_t)((dec / A.BW) * L + r) * 5) * A.BW + dec % A.BW;
-        xT[0] = o0; xT[A.BW] = o1; xT[2 * A.BW] = o2; xT[3 * A.BW] = o3;
+        float4 t0, t1, t2, t3;
+        xt_pack(N, CA, C, O, CB, t0, t1, t2, t3);
+        xT[0] = t0; xT[A.BW] = t1; xT[2 * A.BW] = t2; xT[3 * A.BW] = t3;
       }
       if (r + 1 < L) {
         const f3 Hn = xf_apply(F, place_h(lC, lNn, lCAn));
@@ -1516,8 +1529,9 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
     for (int q = 0; q < 4; q++) xo[q] = xt[q];
     if (A.xyzT) {
       float4* xT = A.xyzT + ((size_t)((dec / A.BW) * L + r) * 5) * A.BW + dec % A.BW;
-#pragma unroll
-      for (int q = 0; q < 4; q++) xT[q * A.BW] = xt[q];
+      float4 t0, t1, t2, t3;
+      xt_pack_from_p(xt[0], xt[1], xt[2], xt[3], t0, t1, t2, t3);
+      xT[0] = t0; xT[A.BW] = t1; xT[2 * A.BW] = t2; xT[3 * A.BW] = t3;
     }
   }
   {  // backbone H of the new trial point: C of the previous residue comes through LDS
@@ -1665,12 +1679,16 @@ __global__ __launch_bounds__(256) void k_compact_move(CompactArgs A) {
 
 // After a compaction below one group of 64: the decoy-minor coordinate copy in the narrower layout, from the decoy-major one
 // (both hold the current trial coordinates)
+// (one thread per residue: the two records hold the atoms in different orders, xt_pack)
 __global__ void k_relayout(int B, int L, int BW, const float4* P, float4* xyzT) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (size_t)B * L * 5) return;
-  const int dec = (int)(i / ((size_t)L * 5));
-  const size_t rq = i % ((size_t)L * 5);
-  xyzT[((size_t)(dec / BW) * L * 5 + rq) * BW + dec % BW] = P[i];
+  if (i >= (size_t)B * L) return;
+  const int dec = (int)(i / (size_t)L), r = (int)(i % (size_t)L);
+  const float4* p = P + i * 5;
+  float4 t0, t1, t2, t3;
+  xt_pack_from_p(p[0], p[1], p[2], p[3], t0, t1, t2, t3);
+  float4* xT = xyzT + ((size_t)((dec / BW) * L + r) * 5) * BW + dec % BW;
+  xT[0] = t0; xT[BW] = t1; xT[2 * BW] = t2; xT[3 * BW] = t3; xT[4 * BW] = p[4];
 }
 
 __global__ void k_init_torsions(int L, int B, uint64_t seed, uint32_t decoy0, const float* tors0, float4* X, float4* XT, float4* geom) {

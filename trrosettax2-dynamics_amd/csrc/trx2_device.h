@@ -70,6 +70,23 @@ __device__ __forceinline__ f3 place_atom(f3 a, f3 b, f3 c, float len, float cang
   return c + bc * (-len * cang) + m * (len * sang * ctor) + n * (len * sang * stor);
 }
 
+// Decoy-minor coordinate record of a residue (xyzT, read by the pair kernel): four float4 holding CA N CB C O in THAT order
+// -- the contact scan reads the first float4 alone (CA), a restraint visit the first three (CA, N, CB), the contact walk all.
+// (The decoy-major record P keeps the order N CA C O CB: it is the Cartesian role's degree-of-freedom vector.)
+__device__ __forceinline__ void xt_pack(f3 N, f3 CA, f3 C, f3 O, f3 CB, float4& q0, float4& q1, float4& q2, float4& q3) {
+  q0 = make_float4(CA.x, CA.y, CA.z, N.x);
+  q1 = make_float4(N.y, N.z, CB.x, CB.y);
+  q2 = make_float4(CB.z, C.x, C.y, C.z);
+  q3 = make_float4(O.x, O.y, O.z, 0.0f);
+}
+__device__ __forceinline__ void xt_unpack(float4 q0, float4 q1, float4 q2, float4 q3, f3& CA, f3& N, f3& CB, f3& C, f3& O) {
+  CA = mk3(q0.x, q0.y, q0.z); N = mk3(q0.w, q1.x, q1.y); CB = mk3(q1.z, q1.w, q2.x); C = mk3(q2.y, q2.z, q2.w); O = mk3(q3.x, q3.y, q3.z);
+}
+// the same from a decoy-major record (N CA C O CB, 15 floats + pad)
+__device__ __forceinline__ void xt_pack_from_p(float4 p0, float4 p1, float4 p2, float4 p3, float4& q0, float4& q1, float4& q2, float4& q3) {
+  xt_pack(mk3(p0.x, p0.y, p0.z), mk3(p0.w, p1.x, p1.y), mk3(p1.z, p1.w, p2.x), mk3(p2.y, p2.z, p2.w), mk3(p3.x, p3.y, p3.z), q0, q1, q2, q3);
+}
+
 // hardware reciprocal (v_rcp_f32, 1 ulp) for the geometric factors below: an IEEE division is ~10 vector instructions and
 // the pair kernel, which is vector-ALU-bound (profiles/README.md), evaluates up to eight of them per residue-pair visit
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }

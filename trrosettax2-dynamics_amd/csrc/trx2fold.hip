@@ -79,6 +79,8 @@ struct trx2_ctx {
   // the flagged pairs; rst_kind 0 gen_rst, 1 gen_idp_rst, 2 gen_rst_af2 (kd = 60 knots, distance on C-alpha, 64-bin map)
   unsigned char *idr = nullptr, *mask_odr = nullptr;
   double* idr_bk = nullptr;
+  // row lists of the pair kernel (k_build_rows): row a's partners with any selected restraint, [L][L] entries + [L] counts
+  unsigned* rows = nullptr; int* row_cnt = nullptr;
   int rst_kind = 0, kd = KD, dist_ca = 0;
   double knots_af2_last = 0;
   float* knots_f = nullptr;
@@ -236,9 +238,10 @@ static void free_map(trx2_ctx* c) {
     trx2_ctx* k = c->child;
     k->Td = k->To = k->Tt = k->Tp = nullptr; k->pd = k->po = k->pt = k->pp = nullptr;
     k->gen = k->sel = k->mask2 = k->hasH = k->idr = k->mask_odr = nullptr; k->knots_f = nullptr; k->knots_d = nullptr; k->L = 0; k->alloc_epoch++;
+    k->rows = nullptr; k->row_cnt = nullptr;
   }
   void* p[] = {c->Td, c->To, c->Tt, c->Tp, c->pd, c->po, c->pt, c->pp, c->gen, c->sel, c->mask2, c->hasH, c->knots_f, c->knots_d,
-               c->idr, c->mask_odr, c->idr_bk,
+               c->idr, c->mask_odr, c->idr_bk, c->rows, c->row_cnt,
                c->cur[0], c->cur[1], c->cur[2], c->cur[3], c->alt[0], c->alt[1], c->alt[2], c->alt[3], c->tmp_cur, c->tmp_alt};
   for (void* q : p)
     if (q && !c->borrows_map) (void)hipFree(q);
@@ -247,6 +250,7 @@ static void free_map(trx2_ctx* c) {
   c->Td = c->To = c->Tt = c->Tp = nullptr;
   c->pd = c->po = c->pt = c->pp = nullptr;
   c->gen = c->sel = c->mask2 = c->hasH = c->idr = c->mask_odr = nullptr; c->idr_bk = nullptr;
+  c->rows = nullptr; c->row_cnt = nullptr;
   c->knots_f = nullptr; c->knots_d = nullptr;
   c->rst_kind = 0; c->kd = KD; c->dist_ca = 0;
   c->L = 0;
@@ -301,6 +305,7 @@ static void lend_map(trx2_ctx* c) {
   k->Td = c->Td; k->To = c->To; k->Tt = c->Tt; k->Tp = c->Tp; k->pd = c->pd; k->po = c->po; k->pt = c->pt; k->pp = c->pp;
   k->gen = c->gen; k->sel = c->sel; k->mask2 = c->mask2; k->hasH = c->hasH; k->knots_f = c->knots_f; k->knots_d = c->knots_d;
   k->idr = c->idr; k->mask_odr = c->mask_odr; k->rst_kind = c->rst_kind; k->kd = c->kd; k->dist_ca = c->dist_ca;
+  k->rows = c->rows; k->row_cnt = c->row_cnt;
   memcpy(k->knots_h, c->knots_h, sizeof c->knots_h);
   k->alloc_epoch++;
 }
@@ -358,6 +363,7 @@ static int build_tables(trx2_ctx* ctx) {
     hipLaunchKernelGGL(k_build_tables_af2, dim3((unsigned)((LL + 127) / 128)), dim3(128), 0, ctx->stream, A);
     hipLaunchKernelGGL(k_pack_masks, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, ctx->stream, L, ctx->sel, (const unsigned char*)nullptr,
                        ctx->mask2, (unsigned char*)nullptr);
+    hipLaunchKernelGGL(k_build_rows, dim3((unsigned)L), dim3(256), 0, ctx->stream, L, (const unsigned char*)ctx->mask2, (const unsigned char*)nullptr, ctx->rows, ctx->row_cnt);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return 0;
@@ -381,6 +387,7 @@ static int build_tables(trx2_ctx* ctx) {
   hipLaunchKernelGGL(k_build_tables, dim3((unsigned)((LL + 127) / 128)), dim3(128), 0, ctx->stream, A);
   hipLaunchKernelGGL(k_pack_masks, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, ctx->stream, L, ctx->sel, (const unsigned char*)ctx->idr,
                      ctx->mask2, ctx->mask_odr);
+  hipLaunchKernelGGL(k_build_rows, dim3((unsigned)L), dim3(256), 0, ctx->stream, L, (const unsigned char*)ctx->mask2, (const unsigned char*)ctx->mask_odr, ctx->rows, ctx->row_cnt);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   return 0;
@@ -448,6 +455,8 @@ static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist
   HIPCHK(hipMalloc((void**)&ctx->gen, LL));
   HIPCHK(hipMalloc((void**)&ctx->sel, LL));
   HIPCHK(hipMalloc((void**)&ctx->mask2, LL));
+  HIPCHK(hipMalloc((void**)&ctx->rows, LL * sizeof(unsigned)));
+  HIPCHK(hipMalloc((void**)&ctx->row_cnt, (size_t)L * sizeof(int)));
   {  // residues that donate a backbone hydrogen bond: every residue with a predecessor except proline (trx2_model.h)
     std::vector<unsigned char> hh((size_t)L);
     for (int i = 0; i < L; i++) hh[i] = (i >= 1 && !(i < (int)ctx->seq.size() && ctx->seq[i] == 'P')) ? 1 : 0;
@@ -625,8 +634,9 @@ static PairArgs pair_args(trx2_ctx* c, int B) {
   PairArgs P;
   P.L = c->L; P.B = B; P.nsplit = c->nsplit; P.Bpad = c->Bpad;
   P.xyzT = c->xyzT; P.Td = c->Td; P.To = c->To; P.Tt = c->Tt; P.Tp = c->Tp;
-  P.mask = c->mask2; P.knots = c->knots_f; P.wcur = c->wcur; P.FA = c->FA; P.seq_ctr = c->seq_ctr;
-  P.kd = c->kd; P.dist_ca = c->dist_ca; P.mask_odr = c->mask_odr;
+  P.rows = c->rows; P.row_cnt = c->row_cnt; P.has_odr = c->mask_odr != nullptr;
+  P.knots = c->knots_f; P.wcur = c->wcur; P.FA = c->FA; P.seq_ctr = c->seq_ctr;
+  P.kd = c->kd; P.dist_ca = c->dist_ca;
   return P;
 }
 static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_evals) {
@@ -656,15 +666,20 @@ static int launch_pair(trx2_ctx* c, int B) {
   }
   const PairArgs P = pair_args(c, B);
   const dim3 grid(c->L, c->nsplit, c->Bpad / c->BW), block(PAIR_THREADS);
+  // maps without the angle channels (--no-orient, gen_rst_af2) run the instantiation without the angular block
+#define LAUNCH_PAIR(W)                                                                                       \
+  if (c->use_orient) hipLaunchKernelGGL((k_pair<W, FAM_ALL>), grid, block, 0, c->stream, P);               \
+  else hipLaunchKernelGGL((k_pair<W, FAM_DIST | FAM_VDW>), grid, block, 0, c->stream, P)
   switch (c->BW) {
-    case 64: hipLaunchKernelGGL((k_pair<64, FAM_ALL>), grid, block, 0, c->stream, P); break;
-    case 32: hipLaunchKernelGGL((k_pair<32, FAM_ALL>), grid, block, 0, c->stream, P); break;
-    case 16: hipLaunchKernelGGL((k_pair<16, FAM_ALL>), grid, block, 0, c->stream, P); break;
-    case 8: hipLaunchKernelGGL((k_pair<8, FAM_ALL>), grid, block, 0, c->stream, P); break;
-    case 4: hipLaunchKernelGGL((k_pair<4, FAM_ALL>), grid, block, 0, c->stream, P); break;
-    case 2: hipLaunchKernelGGL((k_pair<2, FAM_ALL>), grid, block, 0, c->stream, P); break;
-    default: hipLaunchKernelGGL((k_pair<1, FAM_ALL>), grid, block, 0, c->stream, P); break;
+    case 64: LAUNCH_PAIR(64); break;
+    case 32: LAUNCH_PAIR(32); break;
+    case 16: LAUNCH_PAIR(16); break;
+    case 8: LAUNCH_PAIR(8); break;
+    case 4: LAUNCH_PAIR(4); break;
+    case 2: LAUNCH_PAIR(2); break;
+    default: LAUNCH_PAIR(1); break;
   }
+#undef LAUNCH_PAIR
   return 0;
 }
 static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals) {
@@ -933,7 +948,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
         int lg = 0;
         while ((1 << lg) < Bc) lg++;
         ctx->nsplit = ctx->nsplit_w[lg];
-        hipLaunchKernelGGL(k_relayout, dim3((unsigned)(((size_t)Bc * L * 5 + 255) / 256)), dim3(256), 0, ctx->stream, Bc, L, Bc, (const float4*)ctx->P, ctx->xyzT);
+        hipLaunchKernelGGL(k_relayout, dim3((unsigned)(((size_t)Bc * L + 255) / 256)), dim3(256), 0, ctx->stream, Bc, L, Bc, (const float4*)ctx->P, ctx->xyzT);
       }
       HIPCHK(hipGetLastError());
     }
@@ -1270,7 +1285,7 @@ extern "C" int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int s
   HIPCHK(hipMemcpyAsync(ctx->wcur, wc.data(), wc.size() * 4, hipMemcpyHostToDevice, ctx->stream));
   // The decoy-minor copy is rebuilt from the decoy-major one in the FULL layout of this batch: a fold that ended under tail
   // compaction leaves xyzT in the narrow layout of its last survivors; P is layout-independent.
-  hipLaunchKernelGGL(k_relayout, dim3((unsigned)(((size_t)B * L * 5 + 255) / 256)), dim3(256), 0, ctx->stream, B, L, ctx->BW, (const float4*)ctx->P, ctx->xyzT);
+  hipLaunchKernelGGL(k_relayout, dim3((unsigned)(((size_t)B * L + 255) / 256)), dim3(256), 0, ctx->stream, B, L, ctx->BW, (const float4*)ctx->P, ctx->xyzT);
   if (launch_pair(ctx, B)) return 1;  // warm
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
@@ -1367,6 +1382,11 @@ extern "C" int trx2_debug_selfcheck(unsigned long long* out4, int reset) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_selfcheck), z, sizeof z) != hipSuccess) return 1;
   }
   return 0;
+}
+#endif
+#ifdef TRX2_DBG
+extern "C" int trx2_debug_linesearch(double* out /* [256][12] */) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(double) * 256 * 12) != hipSuccess;
 }
 #endif
 #ifdef TRX2_STAMP
