@@ -66,17 +66,22 @@ def test_cartesian_run_tracks_oracle_over_a_short_horizon(ctx, golden_dir, seq):
     assert dmax <= 1.5 * omax + 0.02, (dmax, omax)
 
 
-@pytest.mark.parametrize("tag,refs,med_max,trap_max", [("Xray", ("conf_1_1", "conf_1_2"), 0.60, 0.11), ("NMR", ("conf_2_1", "conf_2_2"), 0.90, 0.08)])
-def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med_max, trap_max):
+@pytest.mark.parametrize("tag,refs,med_max,trap_max,f05_min,f10_min", [("Xray", ("conf_1_1", "conf_1_2"), 0.75, 0.11, 0.40, 0.74),
+                                                                         ("NMR", ("conf_2_1", "conf_2_2"), 0.90, 0.08, 0.0, 0.74)])
+def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med_max, trap_max, f05_min, f10_min):
     """Mode-2 protocol with the Cartesian run on (the default for L <= 512): OUTCOME parity with the reference's PyRosetta decoys
     (the energy model itself is unpinned, DESIGN.md section 2, so this is the only anchor it has).
     Thresholds = measured + margin, not slack.  Measured on 1024 decoys per map
     (profiles/r02_outcome_parity_n1024.txt): median RMSD to the closer initial reference decoy X-ray 0.48 A (quartiles 0.39-0.89),
     NMR 0.76 A (0.63-0.90); decoys > 3 A away 6.2 % / 3.6 %, nearly all of them the mirror-image topology (6.0 % / 3.3 %).
-    With 256 decoys the median's sampling error is ~0.04 A (X-ray: the density around the median is low) and the trapped
-    count's standard deviation 3.9 / 3.0 decoys: asserted are median <= 0.60 / 0.90 A and trapped <= 11 % / 8 % (a regression
-    of 0.15 A or a doubling of the trapped starts fails), and that the far decoys ARE mirror topologies (>= 70 % of them closer
-    to the mirrored reference than to the reference, the criterion of that table)."""
+    The X-ray distribution is BIMODAL -- a cluster at 0.3-0.5 A (half of the decoys) and one at 0.65-1.2 A, almost nothing in
+    between -- so its median jumps across the gap with the sample (0.48 on 1024 decoys; 0.53 and 0.64 on two 256-decoy
+    samples of round 3 whose builds differ by rounding only) and cannot carry a tight bound: for that map the cluster
+    POPULATIONS are asserted (>= 40 % within 0.5 A: measured 53 % / 46-47 %; >= 74 % within 1 A: measured 81 % / 79-81 %; sampling
+    sd of a fraction at n = 256: 3 %) and the median only loosely (<= 0.75).  NMR is unimodal: median <= 0.90 A (sampling error
+    ~0.03), >= 74 % within 1 A (measured 83 %).  Trapped starts <= 11 % / 8 % (sd of the count 3.9 / 3.0 decoys: a doubling fails),
+    and the far decoys ARE mirror topologies (>= 70 % of them closer to the mirrored reference than to the reference, the
+    criterion of that table)."""
     m = np.load(os.path.join(golden_dir, f"seq_{tag}.npz"))
     ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
     dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
@@ -98,6 +103,7 @@ def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med
     print("   <= 0.5 A: %.0f %%, <= 1 A: %.0f %%; > 3 A: %d of %d, of which mirror topologies (closer to the mirrored reference): %d"
           % (100 * (best <= 0.5).mean(), 100 * (best <= 1.0).mean(), len(far), B, n_mirror))
     assert np.median(best) <= med_max, np.sort(best)[::16]
+    assert (best <= 0.5).mean() >= f05_min and (best <= 1.0).mean() >= f10_min, ((best <= 0.5).mean(), (best <= 1.0).mean())
     assert len(far) <= trap_max * B, (len(far), B)
     assert n_mirror >= 0.7 * len(far) - 1, (n_mirror, len(far))
     assert bond_sd < 0.02 and 1.5 < ang_sd < 4.5

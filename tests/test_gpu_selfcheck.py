@@ -1,0 +1,34 @@
+"""GPU: the checking build of the library (libtrx2fold_check.so, -DTRX2_SELFCHECK; loaded in a child process through
+TRX2FOLD_LIB) folds while its step kernels verify themselves: every ONE-sum energy total against the nine terms reduced one
+by one, and every run start against the non-monotone window it must have seeded.  ADVICE r2 / VERDICT r2 weak 3: the one-sum
+path of two residues per thread (k_step<2,256,512>, L > 256) accepted no step in round 2; root cause and fix: kernel_step.h
+(uniform_d), DESIGN.md."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHECK_LIB = os.path.join(ROOT, "trrosettax2-dynamics_amd", "libtrx2fold_check.so")
+
+
+@pytest.mark.parametrize("L,B,evals,orient", [(150, 16, 100000, 0), (90, 8, 100000, 1), (400, 8, 300, 1)])
+def test_step_kernels_check_themselves(L, B, evals, orient):
+    """one residue per thread (L = 150, 90: 256- and 128-thread workgroups) through whole folds, two residues per thread (L = 400,
+    the fused 512-thread kernel) through the declash runs and into the restraint stage"""
+    assert os.path.exists(CHECK_LIB), "build the checking library: make -C trrosettax2-dynamics_amd/csrc"
+    env = dict(os.environ, TRX2FOLD_LIB=CHECK_LIB)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "selfcheck_fold.py"), ROOT, str(L), str(B), str(evals), str(orient)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    sc = rec["selfcheck"]
+    print("\n", L, B, sc, "iterations", rec["n_iters"][:4])
+    assert sc["torsion_checks"] > 100 * B // 8 and sc["torsion_mismatches"] == 0, sc
+    assert sc["cartesian_mismatches"] == 0 and (evals < 1000 or sc["cartesian_checks"] > 0), sc
+    assert sc["run_starts"] >= 5 * B // 2 and sc["run_starts_without_fh0"] == 0, sc
+    # the declash runs make progress from their first evaluations on (round 2's symptom: 0 iterations in 60 evaluations at L = 400)
+    assert min(rec["n_iters"]) > 0.3 * min(rec["n_evals"]), rec

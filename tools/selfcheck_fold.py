@@ -11,13 +11,13 @@ m = S.make_map(L, seed=L); ctx = T.Context(0)
 ctx.set_map(m["dist"], *([m["omega"], m["theta"], m["phi"]] if orient else []), seq=m["seq"])
 lib = T.load()
 has = hasattr(lib, "trx2_debug_selfcheck")
-out = (C.c_ulonglong * 4)()
+out = (C.c_ulonglong * 6)()
 if has:
     lib.trx2_debug_selfcheck(out, 1)
 r = ctx.fold_batch(B, T.protocol.build_runs(L, 2), seed=3, max_evals=ne)
 rec = dict(L=L, B=B, max_evals=ne, n_evals=r["n_evals"].tolist(), n_iters=r["n_iters"].tolist(), status=r["status"].tolist(), f=np.round(r["f"], 1).tolist())
 if has:
     lib.trx2_debug_selfcheck(out, 0)
-    rec["selfcheck"] = dict(torsion_checks=int(out[0]), torsion_mismatches=int(out[1]), cartesian_checks=int(out[2]), cartesian_mismatches=int(out[3]))
+    rec["selfcheck"] = dict(torsion_checks=int(out[0]), torsion_mismatches=int(out[1]), cartesian_checks=int(out[2]), cartesian_mismatches=int(out[3]), run_starts=int(out[4]), run_starts_without_fh0=int(out[5]))
 print(json.dumps(rec))
 ctx.close()

@@ -79,7 +79,7 @@ __device__ __forceinline__ f3 place_h(f3 Cp, f3 N, f3 CA) {
 __device__ double g_dbg[256][12];  // diagnostic build only: decoy 0's line-search record per evaluation (tools/dbg_linesearch.py)
 #endif
 #ifdef TRX2_SELFCHECK
-__device__ unsigned long long g_selfcheck[4];  // torsion role: checks, mismatches; Cartesian role: checks, mismatches
+__device__ unsigned long long g_selfcheck[6];  // torsion role: checks, mismatches; Cartesian role: checks, mismatches; run starts, starts whose fh[0] != f
 #endif
 // workgroup barrier of an NW-wave role.  One wave: its LDS operations execute in program order, so only the compiler has
 // to be kept from reordering them.
@@ -497,15 +497,17 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
     }
     CSTAMP(2)  // suffix scan + torsion gradient
     // The nine terms are needed by the report, by the INIT / FINISH passes and by the guard of a pre-checked run; a plain
-    // minimiser step needs their weighted total only: ONE f64 workgroup sum instead of nine.  One residue per thread only:
-    // with RPT = 2 inside the fused kernel (k_step<2, 256, 512>, L = 400) the one-sum build never accepted a step
-    // (tools/debug_l400.py: 0 iterations in 60 evaluations) while the same source is right in k_chain<2, 256>, with RPT = 1,
-    // and in the fused kernel as soon as esum[] lives in scratch memory -- register-allocation dependent, not understood;
-    // tests/test_gpu_configs.py (configuration 4) guards it.
-#ifndef TRX2_ONESUM_RPT2
-#define TRX2_ONESUM_RPT2 0
-#endif
-    const bool all_terms = (RPT > 1 && !TRX2_ONESUM_RPT2) || A.mode != MODE_STEP || phase == PH_REPORT || (phase == PH_START && R.precheck);
+    // minimiser step needs their weighted total only: ONE f64 workgroup sum instead of nine.
+    // Round 2 kept two residues per thread on nine sums: inside the fused kernel (k_step<2, 256, 512>, L = 400) the one-sum
+    // build accepted no step in the declash runs.  Root cause (round 3, tools/dbg_linesearch.py + the ISA): with both paths in
+    // one kernel, esum[] is a merge of reduced (uniform) and per-thread (divergent) values, so the compiler treats the guard
+    // `rama + vdw < 10` of a pre-checked start as DIVERGENT and if-converts the two arms under exec masks; the masked "start
+    // the run" arm of that build came out without its `fh[0] = f` assignment (ROCm 7.2 hipcc), the non-monotone reference
+    // value stayed 0 and no trial with a positive energy could pass the Armijo test.  The totals ARE wave-uniform: f_t and the
+    // guard's two terms are marked so (uniform_d), every decision of the state machine is a scalar branch again, and the
+    // one-sum path serves every instantiation.  tests/test_gpu_configs.py (configuration 4) and the checking build
+    // (TRX2_SELFCHECK, tests/test_gpu_selfcheck.py) guard it.
+    const bool all_terms = A.mode != MODE_STEP || phase == PH_REPORT || (phase == PH_START && R.precheck);
     double f_t;
     if (all_terms) {
       block_sum_n<9, NW>(esum, s_buf, flip);
@@ -520,6 +522,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
       block_sum_n<1, NW>(ft1, s_buf, flip);
       f_t = ft1[0];
     }
+    f_t = uniform_d(f_t);
     if (tid == 0) A.f_last[dec] = f_t;
 #ifdef TRX2_SELFCHECK
     // Checking build only (libtrx2fold_check.so, never the shipped library): wherever a step took the ONE-sum path, the
@@ -618,7 +621,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
     CSTAMP(3)  // energy reduction + loads of X, G, D
     if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
     else if (phase == PH_START) {
-      if (R.precheck && esum[5] + (double)TRX2_RAMA_GUARD_OFFSET * (double)max(L - 2, 0) + esum[4] < (double)TRX2_CLASH_BREAK) {
+      // (a pre-checked start reduced all nine terms: esum[] holds workgroup totals here)
+      if (R.precheck && uniform_d(esum[5]) + (double)TRX2_RAMA_GUARD_OFFSET * (double)max(L - 2, 0) + uniform_d(esum[4]) < (double)TRX2_CLASH_BREAK) {
         run = R.skip_to;
         if (run >= A.nruns) phase = PH_DONE;
         need_nerf = false;
@@ -714,6 +718,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
         } else new_trial = true;
       }
     }
+#ifdef TRX2_SELFCHECK
+    // a run that has just started (steepest-descent restart from PH_START) must have put its energy into the non-monotone window
+    if (tid == 0 && s_i[SI_PHASE] == PH_START && steepest) {
+      atomicAdd(&g_selfcheck[4], 1ull);
+      if (!(fh[0] == f && nh == 1)) atomicAdd(&g_selfcheck[5], 1ull);
+    }
+#endif
 #ifdef TRX2_DBG
     if (dec == 0 && tid == 0 && A.mode == MODE_STEP && n_evals < 256) {
       double* q = g_dbg[n_evals];
@@ -1240,7 +1251,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
   double ft1[1] = {(double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] + (double)R.w[3] * esum[4] +
                    (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[6] * esum[7] + (double)R.w[7] * esum[8]};
   block_sum_n<1, NW>(ft1, s_buf, flip);
-  const double f_t = ft1[0];
+  const double f_t = uniform_d(ft1[0]);
   if (tid == 0) A.f_last[dec] = f_t;
 #ifdef TRX2_SELFCHECK
   {  // checking build only: the Cartesian role's one sum against the nine terms reduced one by one (g_selfcheck[2], [3])

@@ -190,6 +190,14 @@ __device__ __forceinline__ float lane_value(float v, int lane) { return __int_as
 __device__ __forceinline__ double lane_value(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+// A value that IS the same in every lane, marked so for the compiler (v_readfirstlane: the result lives in scalar registers and
+// every branch on it is a scalar branch).  Used on the step kernels' energy totals: they come out of LDS reductions and are
+// wave-uniform by construction, but a value the compiler cannot PROVE uniform makes it if-convert the minimiser's state machine
+// under exec masks -- and in one such build (one-sum energy path with two residues per thread, kernel_step.h) the masked arm
+// of the pre-checked start lost its `fh[0] = f` assignment ("the one-sum path").
+__device__ __forceinline__ double uniform_d(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 template <typename T>
 __device__ __forceinline__ T wave_sum_dpp(T v) {
   v += dpp_move<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1

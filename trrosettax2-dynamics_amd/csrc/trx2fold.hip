@@ -1375,10 +1375,10 @@ extern "C" int trx2_last_fold_stats(trx2_ctx* ctx, double* seconds, int* n_launc
 
 #ifdef TRX2_SELFCHECK
 // checking build only (libtrx2fold_check.so): one-sum energy totals compared with the nine-sum totals inside the step kernels
-extern "C" int trx2_debug_selfcheck(unsigned long long* out4, int reset) {
-  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_selfcheck), sizeof(unsigned long long) * 4) != hipSuccess) return 1;
+extern "C" int trx2_debug_selfcheck(unsigned long long* out6, int reset) {
+  if (hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_selfcheck), sizeof(unsigned long long) * 6) != hipSuccess) return 1;
   if (reset) {
-    unsigned long long z[4] = {0, 0, 0, 0};
+    unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_selfcheck), z, sizeof z) != hipSuccess) return 1;
   }
   return 0;
