@@ -189,6 +189,8 @@ def test_device_superposition_matrices_equal_host(golden_dir, seq, tmp_path):
     host = EV.run_score(str(nat_d), str(d))
     dev = EV.run_score(str(nat_d), str(d), device=0, save_summary=True, save_dir=str(tmp_path / "sum"))
     assert host == dev
+    # --align (TM-score's -seq): correspondence by sequence alignment, superposition of the aligned pairs on the device
+    assert EV.run_score(str(nat_d), str(d), align=True, device=0) == host
 
 
 def test_superposition_of_more_than_256_structures_and_nonfinite_input(golden_dir):

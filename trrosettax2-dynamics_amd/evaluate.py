@@ -11,7 +11,12 @@ Pinned by the reference's committed example summary (tests): apo 3.018 A / 0.666
 decimals of two proteins; the TM-score program's exact heuristics (its extra seeds from secondary structure, its d0 schedule)
 are not in the tree, so other inputs may differ from the binary in the 3rd-4th decimal.  `device=` computes all pairs of a
 native at once on the GPU (trx2_superpose_matrix: the same search, one wave per pair and seed; equal to tm_score() to 1e-9),
-instead of ~50 k numpy SVDs per pair.  Not mirrored: `--align` (TM-score's -seq sequence alignment) -> NotImplementedError.
+instead of ~50 k numpy SVDs per pair.
+`--align` (evaluate_utils.py:56-58: TMscore's -seq) establishes the residue correspondence by sequence alignment instead of
+residue numbers: nw_align() restates the program's alignment -- Needleman-Wunsch with BLOSUM62, affine gaps (open -11,
+extend -1), gaps beside the termini free, a gap preferred to a substitution on ties -- and is pinned residue pair for residue
+pair to the binary's printed alignments (tests/golden/align_tmscore.json, captured by tests/golden/make_golden_align.py);
+the superposition then runs on the aligned pairs (host or device).
 """
 import argparse
 import os
@@ -30,6 +35,117 @@ def read_ca(path):
             if line.startswith("ATOM") and line[12:16].strip() == "CA" and line[16] in (" ", "A"):
                 out.setdefault(int(line[22:26]), (float(line[30:38]), float(line[38:46]), float(line[46:54])))
     return out
+
+
+_AA = "ARNDCQEGHILKMFPSTWYV"
+_AA3 = dict(ALA="A", ARG="R", ASN="N", ASP="D", CYS="C", GLN="Q", GLU="E", GLY="G", HIS="H", ILE="I", LEU="L", LYS="K", MET="M", PHE="F",
+            PRO="P", SER="S", THR="T", TRP="W", TYR="Y", VAL="V")
+# BLOSUM62 (Henikoff & Henikoff 1992), rows and columns in the order of _AA
+_B62 = np.array([
+    [4, -1, -2, -2, 0, -1, -1, 0, -2, -1, -1, -1, -1, -2, -1, 1, 0, -3, -2, 0], [-1, 5, 0, -2, -3, 1, 0, -2, 0, -3, -2, 2, -1, -3, -2, -1, -1, -3, -2, -3],
+    [-2, 0, 6, 1, -3, 0, 0, 0, 1, -3, -3, 0, -2, -3, -2, 1, 0, -4, -2, -3], [-2, -2, 1, 6, -3, 0, 2, -1, -1, -3, -4, -1, -3, -3, -1, 0, -1, -4, -3, -3],
+    [0, -3, -3, -3, 9, -3, -4, -3, -3, -1, -1, -3, -1, -2, -3, -1, -1, -2, -2, -1], [-1, 1, 0, 0, -3, 5, 2, -2, 0, -3, -2, 1, 0, -3, -1, 0, -1, -2, -1, -2],
+    [-1, 0, 0, 2, -4, 2, 5, -2, 0, -3, -3, 1, -2, -3, -1, 0, -1, -3, -2, -2], [0, -2, 0, -1, -3, -2, -2, 6, -2, -4, -4, -2, -3, -3, -2, 0, -2, -2, -3, -3],
+    [-2, 0, 1, -1, -3, 0, 0, -2, 8, -3, -3, -1, -2, -1, -2, -1, -2, -2, 2, -3], [-1, -3, -3, -3, -1, -3, -3, -4, -3, 4, 2, -3, 1, 0, -3, -2, -1, -3, -1, 3],
+    [-1, -2, -3, -4, -1, -2, -3, -4, -3, 2, 4, -2, 2, 0, -3, -2, -1, -2, -1, 1], [-1, 2, 0, -1, -3, 1, 1, -2, -1, -3, -2, 5, -1, -3, -1, 0, -1, -3, -2, -2],
+    [-1, -1, -2, -3, -1, 0, -2, -3, -2, 1, 2, -1, 5, 0, -2, -1, -1, -1, -1, 1], [-2, -3, -3, -3, -2, -3, -3, -3, -1, 0, 0, -3, 0, 6, -4, -2, -2, 1, 3, -1],
+    [-1, -2, -2, -1, -3, -1, -1, -2, -2, -3, -3, -1, -2, -4, 7, -1, -1, -4, -3, -2], [1, -1, 1, 0, -1, 0, 0, 0, -1, -2, -2, 0, -1, -2, -1, 4, 1, -3, -2, -2],
+    [0, -1, 0, -1, -1, -1, -1, -2, -2, -1, -1, -1, -1, -2, -1, 1, 5, -2, -2, 0], [-3, -3, -4, -4, -2, -2, -3, -2, -2, -3, -2, -3, -1, 1, -4, -3, -2, 11, 2, -3],
+    [-2, -2, -2, -3, -2, -1, -2, -3, 2, -1, -1, -2, -1, 3, -3, -2, -2, 2, 7, -1], [0, -3, -3, -3, -1, -2, -2, -3, -3, 3, 1, -2, 1, -1, -2, -2, 0, -3, -1, 4]])
+_AA_IDX = {a: i for i, a in enumerate(_AA)}
+_ALIGN_CACHE = {}
+
+
+def nw_align(seq_a, seq_b, gap_open=-11, gap_ext=-1):
+    """Residue correspondence of `TMscore a b -seq`: global alignment of the two sequences with BLOSUM62 and affine gaps, gaps
+    beside either terminus free (the first row / column of the score matrix is zero, a gap in the last row / column costs
+    nothing), a gap preferred to a substitution where both are optimal (horizontal before vertical).  -> list of (i, j) index
+    pairs.  Letters outside the twenty standard ones score as the worst substitution (-4) against everything."""
+    key = (seq_a, seq_b, gap_open, gap_ext)
+    if key in _ALIGN_CACHE:
+        return _ALIGN_CACHE[key]
+    n, m = len(seq_a), len(seq_b)
+    ia = [_AA_IDX.get(c, -1) for c in seq_a]
+    ib = [_AA_IDX.get(c, -1) for c in seq_b]
+    neg = -(10 ** 6)
+    S = [[0] * (m + 1) for _ in range(n + 1)]
+    H = [[neg] * (m + 1) for _ in range(n + 1)]
+    V = [[neg] * (m + 1) for _ in range(n + 1)]
+    JH = [[0] * (m + 1) for _ in range(n + 1)]
+    JV = [[0] * (m + 1) for _ in range(n + 1)]
+    P = [[0] * (m + 1) for _ in range(n + 1)]     # bit 1: diagonal optimal, 2: horizontal gap, 4: vertical gap
+    for i in range(1, n + 1):
+        V[i][0], JV[i][0], P[i][0] = 0, i, 4
+    for j in range(1, m + 1):
+        H[0][j], JH[0][j], P[0][j] = 0, j, 2
+    for i in range(1, n + 1):
+        Si, Sp, Hi, Vi, Vp, JHi, JVi, JVp, Pi = S[i], S[i - 1], H[i], V[i], V[i - 1], JH[i], JV[i], JV[i - 1], P[i]
+        row = _B62[ia[i - 1]] if ia[i - 1] >= 0 else None
+        oh, eh = (0, 0) if i == n else (gap_open, gap_ext)
+        for j in range(1, m + 1):
+            a, b = Si[j - 1] + oh, Hi[j - 1] + eh
+            if b >= a:
+                h, JHi[j] = b, JHi[j - 1] + 1
+            else:
+                h, JHi[j] = a, 1
+            ov, ev = (0, 0) if j == m else (gap_open, gap_ext)
+            a, b = Sp[j] + ov, Vp[j] + ev
+            if b >= a:
+                v, JVi[j] = b, JVp[j] + 1
+            else:
+                v, JVi[j] = a, 1
+            Hi[j], Vi[j] = h, v
+            d = Sp[j - 1] + (int(row[ib[j - 1]]) if row is not None and ib[j - 1] >= 0 else -4)
+            best = d if d >= h and d >= v else (h if h >= v else v)
+            Si[j] = best
+            Pi[j] = (1 if d == best else 0) | (2 if h == best else 0) | (4 if v == best else 0)
+    i, j, pairs = n, m, []
+    while i + j:
+        p = P[i][j]
+        if p & 2:
+            j -= JH[i][j]
+        elif p & 4:
+            i -= JV[i][j]
+        else:
+            pairs.append((i - 1, j - 1))
+            i -= 1
+            j -= 1
+    pairs.reverse()
+    _ALIGN_CACHE[key] = pairs
+    return pairs
+
+
+def read_ca_seq(path):
+    """-> (residue numbers, CA xyz [n,3], one-letter sequence) of the first model, in file order"""
+    nums, xyz, seq = [], [], []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("ENDMDL"):
+                break
+            if line.startswith("ATOM") and line[12:16].strip() == "CA" and line[16] in (" ", "A"):
+                k = int(line[22:26])
+                if k in nums:
+                    continue
+                nums.append(k)
+                xyz.append((float(line[30:38]), float(line[38:46]), float(line[46:54])))
+                seq.append(_AA3.get(line[17:20], "X"))
+    return nums, np.array(xyz), "".join(seq)
+
+
+def _matched(native_pdb, pred_pdb, align):
+    """-> (x, y, length of the second structure): CA coordinates of the residue pairs the TM-score program would compare"""
+    if align:
+        _, xa, sa = read_ca_seq(native_pdb)
+        _, xb, sb = read_ca_seq(pred_pdb)
+        pairs = nw_align(sa, sb)
+        if len(pairs) < 3:
+            raise ValueError(f"{native_pdb} and {pred_pdb} align on fewer than three residues")
+        return xa[[i for i, _ in pairs]], xb[[j for _, j in pairs]], len(sb)
+    a, b = read_ca(native_pdb), read_ca(pred_pdb)
+    common = sorted(set(a) & set(b))
+    if len(common) < 3:
+        raise ValueError(f"{native_pdb} and {pred_pdb} share fewer than three residues")
+    return np.array([a[k] for k in common]), np.array([b[k] for k in common]), len(b)
 
 
 def _kabsch(x, y):
@@ -84,35 +200,25 @@ def tm_score(x, y, l_norm=None):
     return float(best)
 
 
-def compare(native_pdb, pred_pdb):
-    """-> (rmsd, tm_score) as the TM-score program reports them for `TMscore native pred`"""
-    a, b = read_ca(native_pdb), read_ca(pred_pdb)
-    common = sorted(set(a) & set(b))
-    if len(common) < 3:
-        raise ValueError(f"{native_pdb} and {pred_pdb} share fewer than three residues")
-    x = np.array([a[k] for k in common])
-    y = np.array([b[k] for k in common])
-    return rmsd_common(x, y), tm_score(x, y, l_norm=len(b))
+def compare(native_pdb, pred_pdb, align=False):
+    """-> (rmsd, tm_score) as the TM-score program reports them for `TMscore native pred` (align: `-seq`)"""
+    x, y, lb = _matched(native_pdb, pred_pdb, align)
+    return rmsd_common(x, y), tm_score(x, y, l_norm=lb)
 
 
-def compare_many(native_pdb, pred_pdbs, device):
-    """compare(native, p) for every p on the GPU: the models are grouped by (residues shared with the native, own length), each
-    group is one trx2_superpose_matrix call"""
+def compare_many(native_pdb, pred_pdbs, device, align=False):
+    """compare(native, p) for every p on the GPU: the models are grouped by (number of matched residues, own length, the
+    native's matched coordinates), each group is one trx2_superpose_matrix call"""
     from ._lib import Context
-    a = read_ca(native_pdb)
     groups, out = {}, [None] * len(pred_pdbs)
     for k, p in enumerate(pred_pdbs):
-        b = read_ca(p)
-        common = tuple(sorted(set(a) & set(b)))
-        if len(common) < 3:
-            raise ValueError(f"{native_pdb} and {p} share fewer than three residues")
-        groups.setdefault((common, len(b)), []).append((k, np.array([b[r] for r in common], np.float32)))
+        x, y, lb = _matched(native_pdb, p, align)
+        groups.setdefault((lb, x.astype(np.float32).tobytes()), []).append((k, x.astype(np.float32), y.astype(np.float32)))
     ctx = Context(int(device))
     try:
-        for (common, lb), items in groups.items():
-            x = np.array([[a[r] for r in common]], np.float32)
-            rm, tm = ctx.superpose_matrix(x, np.stack([y for _, y in items]), l_norm=lb)
-            for (k, _), r, t in zip(items, rm[0], tm[0]):
+        for (lb, _), items in groups.items():
+            rm, tm = ctx.superpose_matrix(items[0][1][None], np.stack([y for _, _, y in items]), l_norm=lb)
+            for (k, _, _), r, t in zip(items, rm[0], tm[0]):
                 out[k] = (float(r), float(t))
     finally:
         ctx.close()
@@ -122,16 +228,14 @@ def compare_many(native_pdb, pred_pdbs, device):
 def run_score(native_pdb_dir, pred_pdb_dir, align=False, save_summary=False, save_dir=None, device=None):
     """evaluate_utils.py:33-100: -> (min_rmsd, max_tmscore, mean_rmsd, mean_tmscore); summary.txt in the reference's format
     (values rounded to the three / four decimals the TM-score program prints)"""
-    if align:
-        raise NotImplementedError("--align (TM-score -seq) is not implemented: residues are matched by number")
     lines, rmsds, tms = [], [], []
     for native in sorted(f for f in os.listdir(native_pdb_dir) if f.endswith(".pdb")):
         best_r, best_t = None, None
         preds = sorted(f for f in os.listdir(pred_pdb_dir) if f.endswith(".pdb")) if os.path.exists(pred_pdb_dir) else []
-        pairs = compare_many(os.path.join(native_pdb_dir, native), [os.path.join(pred_pdb_dir, p) for p in preds], device) \
+        pairs = compare_many(os.path.join(native_pdb_dir, native), [os.path.join(pred_pdb_dir, p) for p in preds], device, align) \
             if device is not None and preds else None
         for k, pred in enumerate(preds):
-            r, t = pairs[k] if pairs else compare(os.path.join(native_pdb_dir, native), os.path.join(pred_pdb_dir, pred))
+            r, t = pairs[k] if pairs else compare(os.path.join(native_pdb_dir, native), os.path.join(pred_pdb_dir, pred), align)
             r, t = round(r, 3), round(t, 4)
             if best_r is None or r < best_r[0]:
                 best_r = (r, pred[:-4])
@@ -160,7 +264,7 @@ def main(argv=None):
     ap.add_argument("-n", "--native_dir", required=True, help="folder of native .pdb files")
     ap.add_argument("-p", "--pred_dir", required=True, help="folder of model .pdb files")
     ap.add_argument("-o", "--output", default=None, help="summary file (*.txt) or folder; the model folder if omitted")
-    ap.add_argument("--align", action="store_true", help="TM-score's -seq alignment: not implemented, raises")
+    ap.add_argument("--align", action="store_true", help="establish the residue correspondence by sequence alignment (TM-score's -seq)")
     ap.add_argument("--device", type=int, default=None, help="superpose on this GPU (extension; numpy if omitted)")
     a = ap.parse_args(argv)
     folder, name = a.pred_dir, "summary.txt"
