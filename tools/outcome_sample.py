@@ -1,0 +1,39 @@
+"""Large-sample outcome parity on the reference's example maps: C-alpha RMSD of folded decoys to the reference's PyRosetta decoys
+(the closer of the two initial decoys of the same map), full protocol.  TRX2FOLD_LIB selects the build (model-constant A/B).
+usage: outcome_sample.py <repo> [n_batches of 64 = 16] [first seed = 1000] [options, e.g. "--fastrelax"]"""
+import importlib, json, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+T = importlib.import_module("trrosettax2-dynamics_amd")
+g = os.path.join(sys.argv[1], "tests", "golden"); dec = np.load(os.path.join(g, "ref_decoys.npz"))
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+relax = len(sys.argv) > 4 and "fastrelax" in sys.argv[4]
+
+
+def rmsd(P, Q):
+    P = P - P.mean(0); Q = Q - Q.mean(0)
+    U, S_, Vt = np.linalg.svd(P.T @ Q)
+    d = np.sign(np.linalg.det(U @ Vt))
+    return float(np.sqrt(max(0.0, ((P ** 2).sum() + (Q ** 2).sum() - 2 * (S_[0] + S_[1] + d * S_[2])) / len(P))))
+
+
+seq = "".join(l.strip() for l in open(os.path.join(g, "seq.fasta")) if not l.startswith(">"))
+ctx = T.Context(0)
+for tag, refs in (("NMR", ("conf_2_1", "conf_2_2")), ("Xray", ("conf_1_1", "conf_1_2"))):
+    m = np.load(os.path.join(g, f"seq_{tag}.npz")); ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+    runs = T.protocol.build_runs(90, 2, fastrelax=True) if relax else T.protocol.build_runs(90, 2)
+    rm, mir, tw, ev, sec = [], [], [], [], 0.0
+    for b in range(nb):
+        r = ctx.fold_batch(64, runs, seed=seed0 + b)
+        assert np.all(r["status"] == 0)
+        sec += r["seconds"]; ev += list(r["n_evals"])
+        for i in range(64):
+            ca = r["xyz"][i, :, 1].astype(np.float64)
+            rm.append(min(rmsd(ca, dec[k][:, 1]) for k in refs)); mir.append(min(rmsd(ca * [1, 1, -1], dec[k][:, 1]) for k in refs))
+            dw = np.degrees(np.abs((r["tors"][i, :-1, 2] % (2 * np.pi)) - np.pi)); tw.append(dw.max() > 60)
+    rm, mir = np.array(rm), np.array(mir); n = len(rm); gross = rm > 3
+    print(f"{os.path.basename(os.environ.get('TRX2FOLD_LIB', 'default')):28s} {tag:4s} n={n}: RMSD median {np.median(rm):.3f}  quartiles {np.percentile(rm,25):.2f}-{np.percentile(rm,75):.2f}  "
+          f"<=0.5A {100*(rm<=0.5).mean():.0f}%  <=1A {100*(rm<=1).mean():.0f}%  >3A {100*gross.mean():.1f}% (mirror {100*(gross&(mir<rm)).mean():.1f}%)  "
+          f"twisted>60 {100*np.mean(tw):.0f}%  evals median {np.median(ev):.0f} mean {np.mean(ev):.0f}  {n/sec:.0f} decoys/s")
+ctx.close()

@@ -93,11 +93,6 @@ __device__ __forceinline__ float hbond_dev(f3 N, f3 H, f3 O, f3 C, float s, f3& 
 #ifndef PAIR_MIN_WAVES_DIST
 #define PAIR_MIN_WAVES_DIST 3
 #endif
-// PAIR_UNROLL2: the restraint loop takes two list entries per trip, both entries' coordinate loads issued before the first
-// entry's arithmetic (A/B knob)
-#ifndef PAIR_UNROLL2
-#define PAIR_UNROLL2 0
-#endif
 // Diagnostic build only (-DTRX2_STAMP, never the shipped library): wave 0 of the workgroup (a = L/2, split 0, group 0)
 // accumulates s_memtime cycles per phase; every stamp first drains the memory counters so that a load's latency is charged
 // to the phase that issued it.  The drains forbid overlaps the real kernel has: read SHARES, not the total.
@@ -217,9 +212,17 @@ __global__ __launch_bounds__(PAIR_THREADS, (FAM & FAM_ANG) ? PAIR_MIN_WAVES : PA
   // restraint weight or an open separation window (the declash runs, folding.py:119: no restraints loaded yet).
   const bool want_rst = active && sep_hi > sep_lo && ((((FAM & FAM_DIST) != 0) && w_ap != 0.0f) || (((FAM & FAM_ANG) != 0) && (w_dih != 0.0f || w_ang != 0.0f)));
   if (__any((int)want_rst)) {
-  // one list entry: `ent` and the first three float4 of its residue's record (CA, N, CB), loaded by the caller
-  auto visit = [&](const int e, const unsigned ent, const float4 r0, const float4 r1, const float4 r2) {
+  // (Measured and not kept, profiles/README.md round 3: the visit as a lambda called from the loop -- the register allocation
+  // of the all-channel instantiations got worse, 41 spilled registers at 16 decoys per wave -- and two entries per trip with
+  // both entries' coordinates requested first: neutral with distances only, 10-25 % slower with all channels.)
+#pragma unroll 1
+  for (int e0 = e_lo + wave * PW; e0 < e_hi; e0 += VSTRIDE) {
+    const int e = e0 + h;
+    const unsigned ent = s_ent[min(e, e_hi - 1) - e_lo];
     const int bc = (int)(ent & PAIR_ROW_B_BITS);
+    // residue b's CA, N, CB: requested as soon as the entry is read, before its masks are examined
+    const float4* xb = A.xyzT + (__umul24((unsigned)(grp * L + bc), 5u * BW) + (unsigned)d);
+    const float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW];
     const int sep = abs(a - bc);
     unsigned m_ab = 0, m_ba = 0;
     if (want_rst && e < e_hi && sep >= sep_lo && sep < sep_hi) {
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(PAIR_THREADS, (FAM & FAM_ANG) ? PAIR_MIN_WAVES : PA
     if (!(FAM & FAM_ANG)) { m_ab &= TRX2_M_DIST; m_ba &= TRX2_M_DIST; }
     const unsigned msym = (a < bc) ? m_ab : m_ba;  // DIST / OMEGA bits live on the (min,max) row
     STAMP(1)  // entry + masks + loop control
-    if (!__any((int)(m_ab | m_ba))) return;
+    if (!__any((int)(m_ab | m_ba))) continue;
 
     const f3 CAb = mk3(r0.x, r0.y, r0.z), Nb = mk3(r0.w, r1.x, r1.y), CBb = mk3(r1.z, r1.w, r2.x);
     STAMP(2)  // coordinates of residue b (3 x 16 B per lane)
@@ -334,29 +337,7 @@ __global__ __launch_bounds__(PAIR_THREADS, (FAM & FAM_ANG) ? PAIR_MIN_WAVES : PA
       else gCB = fma3(ud, w_ap * de * idd, gCB);
     }
     STAMP(8)  // values, gradients
-  };
-#if PAIR_UNROLL2
-#pragma unroll 1
-  for (int e0 = e_lo + wave * PW; e0 < e_hi; e0 += 2 * VSTRIDE) {
-    const int eA = e0 + h, eB = e0 + VSTRIDE + h;
-    const unsigned entA = s_ent[min(eA, e_hi - 1) - e_lo], entB = s_ent[min(eB, e_hi - 1) - e_lo];
-    const float4* xA = A.xyzT + (__umul24((unsigned)(grp * L + (int)(entA & PAIR_ROW_B_BITS)), 5u * BW) + (unsigned)d);
-    const float4* xB = A.xyzT + (__umul24((unsigned)(grp * L + (int)(entB & PAIR_ROW_B_BITS)), 5u * BW) + (unsigned)d);
-    const float4 a0 = xA[0], a1 = xA[BW], a2 = xA[2 * BW], b0 = xB[0], b1 = xB[BW], b2 = xB[2 * BW];
-    visit(eA, entA, a0, a1, a2);
-    if (e0 + VSTRIDE < e_hi) visit(eB, entB, b0, b1, b2);
   }
-#else
-#pragma unroll 1
-  for (int e0 = e_lo + wave * PW; e0 < e_hi; e0 += VSTRIDE) {
-    const int e = e0 + h;
-    const unsigned ent = s_ent[min(e, e_hi - 1) - e_lo];
-    // residue b's CA, N, CB: requested as soon as the entry is read, before its masks are examined
-    const float4* xb = A.xyzT + (__umul24((unsigned)(grp * L + (int)(ent & PAIR_ROW_B_BITS)), 5u * BW) + (unsigned)d);
-    const float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW];
-    visit(e, ent, r0, r1, r2);
-  }
-#endif
   }
   STAMP(9)  // restraint list done
 

@@ -499,14 +499,11 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
     // The nine terms are needed by the report, by the INIT / FINISH passes and by the guard of a pre-checked run; a plain
     // minimiser step needs their weighted total only: ONE f64 workgroup sum instead of nine.
     // Round 2 kept two residues per thread on nine sums: inside the fused kernel (k_step<2, 256, 512>, L = 400) the one-sum
-    // build accepted no step in the declash runs.  Root cause (round 3, tools/dbg_linesearch.py + the ISA): with both paths in
-    // one kernel, esum[] is a merge of reduced (uniform) and per-thread (divergent) values, so the compiler treats the guard
-    // `rama + vdw < 10` of a pre-checked start as DIVERGENT and if-converts the two arms under exec masks; the masked "start
-    // the run" arm of that build came out without its `fh[0] = f` assignment (ROCm 7.2 hipcc), the non-monotone reference
-    // value stayed 0 and no trial with a positive energy could pass the Armijo test.  The totals ARE wave-uniform: f_t and the
-    // guard's two terms are marked so (uniform_d), every decision of the state machine is a scalar branch again, and the
-    // one-sum path serves every instantiation.  tests/test_gpu_configs.py (configuration 4) and the checking build
-    // (TRX2_SELFCHECK, tests/test_gpu_selfcheck.py) guard it.
+    // build accepted no step in the declash runs.  The sums were never at fault (the checking build compares every one-sum
+    // total with the nine-sum total: 0 mismatches): what the one-sum build lost was an assignment in the state machine below
+    // (see `started`).  The totals are wave-uniform by construction and are marked so (uniform_d): every decision of the state
+    // machine is a scalar branch.  tests/test_gpu_configs.py (configuration 4) and the checking build (TRX2_SELFCHECK,
+    // tests/test_gpu_selfcheck.py: run starts whose window was not seeded) guard it.
     const bool all_terms = A.mode != MODE_STEP || phase == PH_REPORT || (phase == PH_START && R.precheck);
     double f_t;
     if (all_terms) {
@@ -616,7 +613,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
     double f = s_d[SD_F], alpha = s_d[SD_ALPHA], gdir = s_d[SD_GD];
     double fh[3] = {s_d[SD_FH0], s_d[SD_FH1], s_d[SD_FH2]};
     double gamma_h = s_d[SD_GAMMA];
-    bool next_run = false, new_dir = false, steepest = false, new_trial = false;
+    bool next_run = false, new_dir = false, steepest = false, new_trial = false, started = false;
     const bool finite_t = isfinite(f_t);
     CSTAMP(3)  // energy reduction + loads of X, G, D
     if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
@@ -630,7 +627,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
         f = f_t;
 #pragma unroll
         for (int k = 0; k < RPT; k++) g[k] = gt[k];
-        hl = 0; hh = 0; nh = 1; fh[0] = f; iter = 0;
+        started = true;   // history and non-monotone window reset below, on the path every arm joins
         steepest = true;
       }
     } else {  // PH_LS
@@ -718,6 +715,13 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
         } else new_trial = true;
       }
     }
+    // A run that has just started: empty history, the window holds its first energy.  Done HERE, after the arms have joined,
+    // and not inside the arm that starts the run: with the one-sum energy path in the same kernel, ROCm 7.2's hipcc emitted
+    // the pre-checked start (`precheck` set, guard not met) without the `fh[0] = f` that its source arm contained -- the
+    // assignment survived only in the arm of runs without a precheck (ISA of k_step<2, 256, 512>, both with divergent and with
+    // scalar branches; profiles/README.md round 3).  fh[0] then kept the previous decoy's or run's value (0 after a reset),
+    // every trial failed the Armijo test against it, and the declash runs made no progress: round 2's "never accepts a step".
+    if (started) { hl = 0; hh = 0; nh = 1; fh[0] = f; iter = 0; }
 #ifdef TRX2_SELFCHECK
     // a run that has just started (steepest-descent restart from PH_START) must have put its energy into the non-monotone window
     if (tid == 0 && s_i[SI_PHASE] == PH_START && steepest) {
