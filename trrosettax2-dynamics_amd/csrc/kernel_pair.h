@@ -18,7 +18,8 @@
 #define PR_REC 24   /* floats per record: 18 gradient + 6 energies (dist omega theta phi vdw hb) */
 
 struct PairArgs {
-  int L, B, nsplit, Bpad;
+  int L, B, Bpad;
+  const unsigned* items;      // work items of a launch, one workgroup each: row a | slice << 10 | slices of that row << 14 (row plan)
   int kd;       // knots of the distance spline: TRX2_KD, or TRX2_KD_AF2 for gen_rst_af2 tables
   int dist_ca;  // 1: the distance restraint acts on C-alpha (gen_rst_af2), 0: on C-beta
   const float4* xyzT;  // [ngrp][L][5][BW] float4, decoy-minor: residue record CA N CB C O (xt_pack) | H, hasH
@@ -29,7 +30,7 @@ struct PairArgs {
   int has_odr;                // the map has an idr mask: entries carry the packed mask without the flagged pairs (mode 3, first stage)
   const float* knots;         // [kd + 72] float
   const float* wcur;          // [B][8] : w_ap w_dih w_ang w_vdw sep_lo sep_hi active (2: ordered pairs only) w_hb
-  float* FA;                  // [nsplit][B][L][24] per (slab, decoy, residue a): gradient on N CA C O CB H, then the raw energies
+  float* FA;                  // [slice][B][L][24] per (slice of the row, decoy, residue a): gradient on N CA C O CB H, then the raw energies
                               // dist omega theta phi vdw hb (PR_REC; the step kernel sums the slabs: sum_pair_records)
   int* seq_ctr;               // evaluation counter in device memory: bumped here, read by the step kernel that follows
 };
@@ -99,7 +100,7 @@ __device__ __forceinline__ float hbond_dev(f3 N, f3 H, f3 O, f3 C, float s, f3& 
 #ifdef TRX2_STAMP
 __device__ unsigned long long g_stamp[32];
 #define STAMP_DECL unsigned long long st_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long st_prev = 0; \
-  const bool st_on = (blockIdx.x == (unsigned)(A.L / 2) && blockIdx.y == 0 && blockIdx.z == 0 && (threadIdx.x >> 6) == 0); \
+  const bool st_on = (blockIdx.x == gridDim.x / 2 && blockIdx.z == 0 && (threadIdx.x >> 6) == 0); \
   if (st_on) { __builtin_amdgcn_s_waitcnt(0); st_prev = __builtin_amdgcn_s_memtime(); }
 #define STAMP(k) if (st_on) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
   __builtin_amdgcn_s_waitcnt(0); st_acc[k] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); }
@@ -154,7 +155,10 @@ template <int BW, int FAM>
 __global__ __launch_bounds__(PAIR_THREADS, (FAM & FAM_ANG) ? PAIR_MIN_WAVES : PAIR_MIN_WAVES_DIST) void k_pair(PairArgs A) {
   constexpr int PW = 64 / BW;
   const int L = A.L;
-  const int a = blockIdx.x, split = blockIdx.y, grp = blockIdx.z;
+  // Work item = (row a, slice, slices of that row): rows are cut into a number of slices that follows their list length (the
+  // row plan, host side), so that no workgroup walks a list twice as long as the others' (rows hold 20 .. 140 partners)
+  const unsigned item = A.items[blockIdx.x];
+  const int a = (int)(item & PAIR_ROW_B_BITS), split = (int)((item >> 10) & 15u), nsl = (int)(item >> 14), grp = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = lane % BW, h = lane / BW;
   const int dec = grp * BW + d;
@@ -177,9 +181,9 @@ __global__ __launch_bounds__(PAIR_THREADS, (FAM & FAM_ANG) ? PAIR_MIN_WAVES : PA
   const float4 q0 = xa[0], q1 = xa[BW], q2 = xa[2 * BW], q3 = xa[3 * BW], q4 = xa[4 * BW];
   const int kd = A.kd, ktot = kd + 2 * KO + KP;
   for (int i = threadIdx.x; i < ktot; i += PAIR_THREADS) s_kn[i] = A.knots[i];
-  // equal slices of the row's list: every workgroup of a row gets the same number of restraint visits, whatever the residues
+  // equal slices of the row's list: every workgroup of a row gets the same number of restraint visits
   const int cnt = A.row_cnt[a];
-  const int e_lo = (int)(((long)cnt * split) / A.nsplit), e_hi = (int)(((long)cnt * (split + 1)) / A.nsplit);
+  const int e_lo = (cnt * split) / nsl, e_hi = (cnt * (split + 1)) / nsl;
   for (int i = e_lo + (int)threadIdx.x; i < e_hi; i += PAIR_THREADS) s_ent[i - e_lo] = A.rows[(size_t)a * L + i];
   __syncthreads();
   const float* knd = s_kn;
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(PAIR_THREADS, (FAM & FAM_ANG) ? PAIR_MIN_WAVES : PA
   if constexpr ((FAM & FAM_VDW) != 0) {
   const bool want_vdw = active && (w_vdw != 0.0f || w_hb != 0.0f);
   if (__any((int)want_vdw)) {
-  const int chunk = (L + A.nsplit - 1) / A.nsplit;
+  const int chunk = (L + nsl - 1) / nsl;
   const int b_lo = split * chunk, b_hi = min(L, b_lo + chunk);
   const float4* xg = A.xyzT + (__umul24((unsigned)(grp * L), 5u * BW) + (unsigned)d);
   for (int bb = b_lo + wave * PW; bb < b_hi; bb += 32 * VSTRIDE) {

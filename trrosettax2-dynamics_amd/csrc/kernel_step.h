@@ -34,8 +34,8 @@ struct ChainArgs {
   int BW;
   float4* geom;            // [B][L][3] internal geometry per residue (ResGeom)
   float* wcur;             // [B][8]
-  const float* FA;         // [nsplit][B][L][24] pair-kernel records: gradient on the six atoms + the pair energies
-  int nsplit;
+  const float* FA;         // [slice][B][L][24] pair-kernel records: gradient on the six atoms + the pair energies
+  const unsigned char* nslice;  // [L] slices the pair kernel cut residue r's row into (the row plan of the launch shape)
   const unsigned char* hasH;  // [L] residue donates a backbone hydrogen bond (has a predecessor, not proline)
   double* e_last;          // [B][NTERMS] raw terms of the last evaluation
   double* f_last;          // [B]
@@ -54,9 +54,10 @@ struct ChainArgs {
   int* out_stat;           // [n_total][4] status, evaluations, accepted iterations, slot
 };
 
-// Sum of the pair kernel's records of residue r of decoy dec over the b-range slabs (24 floats: gradient on N CA C O CB H,
+// Sum of the pair kernel's records of residue r of decoy dec over the slices of its row (24 floats: gradient on N CA C O CB H,
 // then the energies dist omega theta phi vdw hb).  Fixed order: deterministic.
-__device__ __forceinline__ void sum_pair_records(const float* FA, int nsplit, int B, int L, int dec, int r, float (&g)[PR_NCOMP], float (&e)[6]) {
+__device__ __forceinline__ void sum_pair_records(const float* FA, const unsigned char* nslice, int B, int L, int dec, int r, float (&g)[PR_NCOMP], float (&e)[6]) {
+  const int nsplit = nslice[r];
 #pragma unroll
   for (int i = 0; i < PR_NCOMP; i++) g[i] = 0.0f;
 #pragma unroll
@@ -339,9 +340,17 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
   }
   if (tid < SD_N) s_d[tid] = gd_[tid];
   if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
-  constexpr bool HIST_LDS = (RPT == 1);  // one residue per thread: history staged in LDS, recursion in its Gram form
+  constexpr bool HIST_LDS = (RPT == 1 && NT <= 256);  // chains of up to 256 residues: the history staged in LDS for the step
+  // One residue per thread (chains of up to 512 residues on up to 512 threads): the recursion in its Gram form.  The 144
+  // scalars do not depend on the chain length.  Beyond 256 residues the stored vectors are not staged in LDS (128 KB at 512
+  // residues, beside the Cartesian role's static LDS) but read from global memory: the Gram form reads each of them twice
+  // per step, the loads of a pass in flight together, where the two-loop form made 2 x 8 DEPENDENT rounds over them
+  // (30-40 % of the step at L = 400, profiles/r02_stamp_step_c4.txt).  (Two residues per thread on 256 threads, round 2's
+  // shape for 256 < L <= 512, needs ~370 registers in this form -- the fused kernel has 256: 114 spilled -- and carries two
+  // residues through every dependent phase; 512 threads with one residue each fit and halve those chains.)
+  constexpr bool GRAM = (RPT == 1);
   double gr_old0 = 0, gr_old1 = 0;  // this thread's entries of the decoy's Gram scalars as the step finds them
-  if (HIST_LDS && A.mode == MODE_STEP) {
+  if (GRAM && A.mode == MODE_STEP) {
     if (tid < 2 * LBM * LBM) { gr_old0 = A.gram[(size_t)dec * GR_N + tid]; s_gl.gram[tid] = gr_old0; }
     if (tid < 2 * LBM) { gr_old1 = A.gram[(size_t)dec * GR_N + 2 * LBM * LBM + tid]; s_gl.gram[2 * LBM * LBM + tid] = gr_old1; }
   }
@@ -399,7 +408,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
         const float4* xp = A.P + (vb + r) * 5;
         const float4 c0 = xp[0], c1 = xp[1], c2 = xp[2], c3 = xp[3], c4 = xp[4];
         float g[PR_NCOMP], ep[6];
-        sum_pair_records(A.FA, A.nsplit, A.B, L, dec, r, g, ep);
+        sum_pair_records(A.FA, A.nslice, A.B, L, dec, r, g, ep);
         esum[0] += ep[0]; esum[1] += ep[1]; esum[2] += ep[2]; esum[3] += ep[3]; esum[4] += ep[4]; esum[8] += ep[5];
         pN[k] = mk3(c0.x, c0.y, c0.z); pCA[k] = mk3(c0.w, c1.x, c1.y); pC[k] = mk3(c1.z, c1.w, c2.x);
         pO[k] = mk3(c2.y, c2.z, c2.w); pCB[k] = mk3(c3.x, c3.y, c3.z);
@@ -614,6 +623,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
     double fh[3] = {s_d[SD_FH0], s_d[SD_FH1], s_d[SD_FH2]};
     double gamma_h = s_d[SD_GAMMA];
     bool next_run = false, new_dir = false, steepest = false, new_trial = false, started = false;
+    float4 s_new[RPT], y_new[RPT];  // two residues per thread, Gram form: the pair stored in this step, kept for the direction pass
+    bool have_new = false;
+#pragma unroll
+    for (int k = 0; k < RPT; k++) s_new[k] = y_new[k] = make_float4(0, 0, 0, 0);
     const bool finite_t = isfinite(f_t);
     CSTAMP(3)  // energy reduction + loads of X, G, D
     if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
@@ -642,28 +655,39 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
           s[k] = make_float4(xt[k].x - x[k].x, xt[k].y - x[k].y, xt[k].z - x[k].z, 0);
           y[k] = make_float4(gt[k].x - g[k].x, gt[k].y - g[k].y, gt[k].z - g[k].z, 0);
         }
-        if constexpr (HIST_LDS) {
+        if constexpr (GRAM) {
           // every product of the new pair and the new gradient with the stored pairs (age order), one fused reduction
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged history has landed (long ago)
+          if (HIST_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged history has landed (long ago)
           float pv[GV_N];
-          {
-            // all 2 LBM reads issued together (a slot that holds no pair is read and discarded: one wait instead of LBM)
-            float4 so[LBM], yo[LBM];
 #pragma unroll
-            for (int k = 0; k < LBM; k++) {
-              const int j = (hh - 1 - k + LBM) % LBM;
-              so[k] = s_hist[(j * 2 + 0) * NT + tid]; yo[k] = s_hist[(j * 2 + 1) * NT + tid];
-            }
+          for (int q = 0; q < GV_N; q++) pv[q] = 0.0f;
 #pragma unroll
-            for (int k = 0; k < LBM; k++) {
-              const bool on = k < hl && tid < L;
-              pv[GV_A + k] = on ? dot3(so[k], y[0]) : 0.0f; pv[GV_B + k] = on ? dot3(yo[k], y[0]) : 0.0f;
-              if (k < LBM - 1) pv[GV_C + k] = on ? dot3(s[0], yo[k]) : 0.0f;
+          for (int kr = 0; kr < RPT; kr++) {
+            const int r = kr * NT + tid, rc = min(r, L - 1);
+            // the reads of HB pairs issued together (a slot that holds no pair is read and discarded: one wait instead of HB).  Staged
+            // history: all LBM pairs at once; from global memory (chains beyond 256 residues): four pairs at a time (registers)
+            constexpr int HB = HIST_LDS ? LBM : LBM / 2;
+#pragma unroll
+            for (int k0 = 0; k0 < LBM; k0 += HB) {
+              float4 so[HB], yo[HB];
+#pragma unroll
+              for (int k = 0; k < HB; k++) {
+                const int j = (hh - 1 - (k0 + k) + LBM) % LBM;
+                if (HIST_LDS) { so[k] = s_hist[(j * 2 + 0) * NT + tid]; yo[k] = s_hist[(j * 2 + 1) * NT + tid]; }
+                else { so[k] = A.S[((size_t)dec * LBM + j) * L + rc]; yo[k] = A.Y[((size_t)dec * LBM + j) * L + rc]; }
+              }
+#pragma unroll
+              for (int k = 0; k < HB; k++) {
+                const bool on = k0 + k < hl && r < L;
+                pv[GV_A + k0 + k] += on ? dot3(so[k], y[kr]) : 0.0f; pv[GV_B + k0 + k] += on ? dot3(yo[k], y[kr]) : 0.0f;
+                if (k0 + k < LBM - 1) pv[GV_C + k0 + k] += on ? dot3(s[kr], yo[k]) : 0.0f;
+              }
             }
+            // (s, y, gt are zero beyond the chain)
+            pv[GV_SY] += dot3(s[kr], y[kr]); pv[GV_SS] += dot3(s[kr], s[kr]); pv[GV_YY] += dot3(y[kr], y[kr]);
+            pv[GV_SG] += dot3(s[kr], gt[kr]); pv[GV_YG] += dot3(y[kr], gt[kr]); pv[GV_GG] += dot3(gt[kr], gt[kr]);
           }
-          pv[GV_SY] = dot3(s[0], y[0]); pv[GV_SS] = dot3(s[0], s[0]); pv[GV_YY] = dot3(y[0], y[0]);
-          pv[GV_SG] = dot3(s[0], gt[0]); pv[GV_YG] = dot3(y[0], gt[0]); pv[GV_GG] = dot3(gt[0], gt[0]);
-          gram_reduce<HIST_LDS ? NT : 16>(pv, s_gl);
+          gram_reduce<GRAM ? NT : 16>(pv, s_gl);
           v3[0] = s_gl.out[GV_SY]; v3[1] = s_gl.out[GV_SS]; v3[2] = s_gl.out[GV_YY];
         } else {
 #pragma unroll
@@ -683,17 +707,22 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
           if (HIST_LDS) {  // slot hh of the staged copy (the oldest pair: its products are taken)
             s_hist[(hh * 2 + 0) * NT + tid] = s[0];
             s_hist[(hh * 2 + 1) * NT + tid] = y[0];
-          } else {
+          } else if (!GRAM) {
             bsync<NW>();
             if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
           }
           gamma_h = v3[0] / v3[2];
-          if (!HIST_LDS) bsync<NW>();
+          if (!GRAM) bsync<NW>();
+          if (GRAM && !HIST_LDS) {  // the new pair, for the direction pass below (its global copy was stored a moment ago)
+#pragma unroll
+            for (int k = 0; k < RPT; k++) { s_new[k] = s[k]; y_new[k] = y[k]; }
+            have_new = true;
+          }
           hh = (hh + 1) % LBM;
           if (hl < LBM) hl++;
         }
-        if constexpr (HIST_LDS) {
-          gram_advance<HIST_LDS ? NT : 16>(s_gl, store, gr_old0, gr_old1);  // ends with a barrier: the LDS copy of the pair is visible too
+        if constexpr (GRAM) {
+          gram_advance<GRAM ? NT : 16>(s_gl, store, gr_old0, gr_old1);  // ends with a barrier: the LDS copy of the pair is visible too
           gram_dirty = true;
         }
         const double fprev = f;
@@ -748,33 +777,43 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
       // LDS read of rho, the axpy), not by the loads or the barriers.
       double v2[2] = {0, 0};
       auto pair_at = [&](int kk) { return (hh - 1 - kk + LBM) % LBM; };
-      if constexpr (HIST_LDS) {
-        // internal geometry for the NeRF pass: requested here, used after the direction is built
-        const float4* gq0 = A.geom + vb * 3;
-        const int rq = min(tid, L - 1), rn = min(tid + 1, L - 1);
-        gpre[0] = gq0[0]; gpre[1] = gq0[rq * 3]; gpre[2] = gq0[rq * 3 + 1]; gpre[3] = gq0[rq * 3 + 2]; gpre[4] = gq0[rn * 3];
-        gpre_ok = true;
+      if constexpr (GRAM) {
+        if constexpr (HIST_LDS) {
+          // internal geometry for the NeRF pass: requested here, used after the direction is built
+          const float4* gq0 = A.geom + vb * 3;
+          const int rq = min(tid, L - 1), rn = min(tid + 1, L - 1);
+          gpre[0] = gq0[0]; gpre[1] = gq0[rq * 3]; gpre[2] = gq0[rq * 3 + 1]; gpre[3] = gq0[rq * 3 + 2]; gpre[4] = gq0[rn * 3];
+          gpre_ok = true;
+        }
         float cy[LBM], cs[LBM];
         double g_r;
         gram_recursion(s_gl.gram, hl, gamma_h, s_gl.out[GV_GG], cy, cs, g_r);
         CSTAMP(5)  // recurrences on the Gram scalars
         const float gam = (float)gamma_h;
-        float4 q = make_float4(gam * g[0].x, gam * g[0].y, gam * g[0].z, 0);
-        {
-          float4 sm[LBM], ym[LBM];
 #pragma unroll
-          for (int m = 0; m < LBM; m++) {
-            const int j = pair_at(m);
-            sm[m] = s_hist[(j * 2 + 0) * NT + tid]; ym[m] = s_hist[(j * 2 + 1) * NT + tid];
-          }
+        for (int kr = 0; kr < RPT; kr++) {
+          const int r = kr * NT + tid, rc = min(r, L - 1);
+          float4 q = make_float4(gam * g[kr].x, gam * g[kr].y, gam * g[kr].z, 0);
+          constexpr int HB = HIST_LDS ? LBM : LBM / 2;
 #pragma unroll
-          for (int m = 0; m < LBM; m++) {
-            const float a = m < hl ? cs[m] : 0.0f, b = m < hl ? cy[m] : 0.0f;
-            const float4 z = make_float4(0, 0, 0, 0), s_ = m < hl ? sm[m] : z, y_ = m < hl ? ym[m] : z;  // an unused slot may hold anything
-            q.x = fmaf(b, y_.x, fmaf(a, s_.x, q.x)); q.y = fmaf(b, y_.y, fmaf(a, s_.y, q.y)); q.z = fmaf(b, y_.z, fmaf(a, s_.z, q.z));
+          for (int m0 = 0; m0 < LBM; m0 += HB) {
+            float4 sm[HB], ym[HB];
+#pragma unroll
+            for (int m = 0; m < HB; m++) {
+              const int j = pair_at(m0 + m);
+              if (HIST_LDS) { sm[m] = s_hist[(j * 2 + 0) * NT + tid]; ym[m] = s_hist[(j * 2 + 1) * NT + tid]; }
+              else if (m0 + m == 0 && have_new) { sm[0] = s_new[kr]; ym[0] = y_new[kr]; }   // stored a moment ago: from registers
+              else { sm[m] = A.S[((size_t)dec * LBM + j) * L + rc]; ym[m] = A.Y[((size_t)dec * LBM + j) * L + rc]; }
+            }
+#pragma unroll
+            for (int m = 0; m < HB; m++) {
+              const float a = m0 + m < hl ? cs[m0 + m] : 0.0f, b = m0 + m < hl ? cy[m0 + m] : 0.0f;
+              const float4 z = make_float4(0, 0, 0, 0), s_ = m0 + m < hl ? sm[m] : z, y_ = m0 + m < hl ? ym[m] : z;  // an unused slot may hold anything
+              q.x = fmaf(b, y_.x, fmaf(a, s_.x, q.x)); q.y = fmaf(b, y_.y, fmaf(a, s_.y, q.y)); q.z = fmaf(b, y_.z, fmaf(a, s_.z, q.z));
+            }
           }
+          dv[kr] = r < L ? make_float4(-q.x, -q.y, -q.z, 0) : make_float4(0, 0, 0, 0);
         }
-        dv[0] = tid < L ? make_float4(-q.x, -q.y, -q.z, 0) : make_float4(0, 0, 0, 0);
         v2[0] = -g_r; v2[1] = s_gl.out[GV_GG];
         CSTAMP(7)  // direction from the stored vectors
       } else
@@ -888,7 +927,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
       if (r < L) { A.X[vb + r] = x[k]; A.G[vb + r] = g[k]; A.D[vb + r] = dv[k]; A.XT[vb + r] = xt[k]; }
     }
     bsync<NW>();
-    if (HIST_LDS && A.mode == MODE_STEP && (gram_dirty || hl == 0)) {
+    if (GRAM && A.mode == MODE_STEP && (gram_dirty || hl == 0)) {
       // the Gram scalars follow the history; a restarted history starts from zeros (entries of absent pairs are only ever
       // multiplied by zero coefficients, so they must stay finite)
       const bool z = hl == 0;
@@ -1052,7 +1091,7 @@ struct CartArgs {
   float4* xyzT; int BW;      // decoy-minor copy for the pair kernel
   float4 *X, *XT, *geom;     // torsions and internal geometry, written when the run ends
   float* wcur;
-  const float* FA; int nsplit;
+  const float* FA; const unsigned char* nslice;
   const unsigned char* hasH;
   double *e_last, *f_last;
   int* done_count;
@@ -1089,7 +1128,7 @@ __device__ __forceinline__ LinkGrad link_terms(const Res5& P, const Res5& Q) {
 }
 
 template <int NT>
-__device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int* s_runs, GramLds<(NT <= 256) ? NT : 16>& s_gl) {
+__device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int* s_runs) {
   constexpr int NW = NT / 64;  // one residue per thread: NT = 256 for chains up to 256 residues, 512 up to 512
   const int L = A.L, tid = threadIdx.x, r = tid;
   const bool act = r < L;
@@ -1152,7 +1191,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
 #pragma unroll
     for (int q = 0; q < 4; q++) { xt[q] = xp[q]; reinterpret_cast<float4*>(s_xyz + r * 16)[q] = xt[q]; }
     float g[PR_NCOMP], ep[6];
-    sum_pair_records(A.FA, A.nsplit, A.B, L, dec, r, g, ep);
+    sum_pair_records(A.FA, A.nslice, A.B, L, dec, r, g, ep);
     esum[0] += ep[0]; esum[1] += ep[1]; esum[2] += ep[2]; esum[3] += ep[3]; esum[4] += ep[4]; esum[8] += ep[5];
     gt[0] = make_float4(g[0], g[1], g[2], g[3]); gt[1] = make_float4(g[4], g[5], g[6], g[7]);
     gt[2] = make_float4(g[8], g[9], g[10], g[11]); gt[3] = make_float4(g[12], g[13], g[14], 0.0f);
@@ -1633,13 +1672,12 @@ __global__ __launch_bounds__(TN) void k_chain(ChainArgs A) {
 }
 template <int RPT, int TN, int NT>
 __global__ __launch_bounds__(NT) void k_step(ChainArgs A, CartArgs C) {
-  static_assert(((RPT == 1) ? TN : 16) == ((NT <= 256) ? NT : 16), "the two roles share one GramLds");
   __shared__ int s_runs[STEP_RUNS_INTS];
-  __shared__ GramLds<(RPT == 1) ? TN : 16> s_gl;
+  __shared__ GramLds<(RPT == 1) ? TN : 16> s_gl;   // the torsion role's; the Cartesian role keeps the two-loop form
   // the Cartesian role first: its workgroups are the slower ones, and the launch ends with the last of them
   if ((int)blockIdx.x >= A.B) {
     if (NT == TN || threadIdx.x < TN) chain_body<RPT, TN>(A, (int)blockIdx.x - A.B, s_runs, s_gl);  // the other waves of the workgroup exit at once
-  } else cart_body<NT>(C, (int)blockIdx.x, s_runs, s_gl);
+  } else cart_body<NT>(C, (int)blockIdx.x, s_runs);
 }
 
 // ---- Tail of a fold: once the queue is empty the slots retire one by one, but a pair-kernel wave costs the same while ANY of its

@@ -65,6 +65,17 @@ __constant__ float c_cb_ideal[4];
 // =================================================================================================
 // host side
 // =================================================================================================
+#define TRX2_NS_CAP 8  /* slices per row at most (4 bits in a work item) */
+struct RowPlan {
+  int pw = 0, groups = 0;       // launch shape: partner residues per wave step (64 / decoys per wave), decoy groups
+  long epoch = -1;              // rows_epoch the plan was built for
+  int forced = 0;               // TRX2_NSPLIT it was built under (0: the rule)
+  int n_items = 0, ns_max = 1;
+  double ns_avg = 1;
+  unsigned* items = nullptr;        // device [n_items]
+  unsigned char* nslice = nullptr;  // device [L]
+  size_t cap_items = 0, cap_L = 0;
+};
 struct trx2_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -87,10 +98,14 @@ struct trx2_ctx {
   double* knots_d = nullptr;
   double knots_h[TRX2_KTOT_MAX];
   // batch
-  int Bcap = 0, Lcap = 0, BW = 64, Bpad = 0, nsplit = 1;
-  size_t fa_cap = 0;     // pair-kernel records the FA buffer holds: (splits x slots) units of L records
-  std::vector<int> nsplit_g;  // [g]: split of a launch over g groups of 64 decoys (the shapes a fold shrinks through at its tail, fold_impl)
-  int nsplit_w[7] = {1, 1, 1, 1, 1, 1, 1};  // [log2 w]: split of a one-group launch of w decoys per wave
+  int Bcap = 0, Lcap = 0, BW = 64, Bpad = 0;
+  size_t fa_cap = 0;     // pair-kernel records the FA buffer holds: (slices x slots) units of L records
+  // Row plans of the pair kernel: how many slices (workgroups) each row of the restraint lists is cut into for a launch shape
+  // (decoys per wave, decoy groups); built on the host from the rows' list lengths, cached per shape until the lists change.
+  std::vector<int> h_row_cnt;    // host copy of row_cnt (build_tables)
+  long rows_epoch = 0;           // bumped whenever the lists are rebuilt
+  std::vector<RowPlan> plans;
+  int plan_cur = -1;             // index into plans: the shape the next launches use
   int* plan = nullptr;   // compaction plan (device)
   int compact = 1;       // trx2_ctx_set_tail_compaction
   int* st_i = nullptr; double* st_d = nullptr; float* rho = nullptr; double* gram = nullptr;
@@ -232,13 +247,19 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
 }
 
 static void lend_map(trx2_ctx* c);
+static void free_plans(trx2_ctx* c) {
+  for (auto& p : c->plans) { if (p.items) (void)hipFree(p.items); if (p.nslice) (void)hipFree(p.nslice); }
+  c->plans.clear(); c->plan_cur = -1;
+}
 static void free_map(trx2_ctx* c) {
+  free_plans(c);
+  if (c->child) free_plans(c->child);
   if (c->child) {  // the borrower must be idle and forget the tables before they go
     if (c->child->stream) (void)hipStreamSynchronize(c->child->stream);
     trx2_ctx* k = c->child;
     k->Td = k->To = k->Tt = k->Tp = nullptr; k->pd = k->po = k->pt = k->pp = nullptr;
     k->gen = k->sel = k->mask2 = k->hasH = k->idr = k->mask_odr = nullptr; k->knots_f = nullptr; k->knots_d = nullptr; k->L = 0; k->alloc_epoch++;
-    k->rows = nullptr; k->row_cnt = nullptr;
+    k->rows = nullptr; k->row_cnt = nullptr; k->h_row_cnt.clear(); k->rows_epoch++;
   }
   void* p[] = {c->Td, c->To, c->Tt, c->Tp, c->pd, c->po, c->pt, c->pp, c->gen, c->sel, c->mask2, c->hasH, c->knots_f, c->knots_d,
                c->idr, c->mask_odr, c->idr_bk, c->rows, c->row_cnt,
@@ -305,7 +326,7 @@ static void lend_map(trx2_ctx* c) {
   k->Td = c->Td; k->To = c->To; k->Tt = c->Tt; k->Tp = c->Tp; k->pd = c->pd; k->po = c->po; k->pt = c->pt; k->pp = c->pp;
   k->gen = c->gen; k->sel = c->sel; k->mask2 = c->mask2; k->hasH = c->hasH; k->knots_f = c->knots_f; k->knots_d = c->knots_d;
   k->idr = c->idr; k->mask_odr = c->mask_odr; k->rst_kind = c->rst_kind; k->kd = c->kd; k->dist_ca = c->dist_ca;
-  k->rows = c->rows; k->row_cnt = c->row_cnt;
+  k->rows = c->rows; k->row_cnt = c->row_cnt; k->h_row_cnt = c->h_row_cnt; k->rows_epoch++;
   memcpy(k->knots_h, c->knots_h, sizeof c->knots_h);
   k->alloc_epoch++;
 }
@@ -347,6 +368,84 @@ extern "C" void trx2_ctx_destroy(trx2_ctx* ctx) {
 
 extern "C" const char* trx2_last_error(const trx2_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
 
+// the rows' list lengths on the host (the row plans are made from them); ends the table build: the stream is idle afterwards
+static int fetch_row_counts(trx2_ctx* ctx) {
+  ctx->h_row_cnt.assign((size_t)ctx->L, 0);
+  HIPCHK(hipMemcpyAsync(ctx->h_row_cnt.data(), ctx->row_cnt, sizeof(int) * (size_t)ctx->L, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  ctx->rows_epoch++;
+  if (ctx->child) { ctx->child->h_row_cnt = ctx->h_row_cnt; ctx->child->rows_epoch++; }
+  return 0;
+}
+
+// Row plan for a launch shape.  A workgroup's restraint work is its slice of a row's list; rows hold 20 .. 140 partners, so with
+// one slice count for every row the launch lasted as long as its longest rows (2 x the mean).  Here a row is cut into
+// round(length / target) slices, target = ~18 entries per partner residue a wave step covers (4-5 visits per wave); the target
+// shrinks while the launch would have fewer than ~450 workgroups (one resident round is 768 at three waves per SIMD) and grows
+// while it would have more than ~2000.  Every wave keeps at least two residues of the contact scan.  Items are ordered longest
+// slice first.  TRX2_NSPLIT (A/B timing, and tests that pin the split) forces one slice count for every row;
+// TRX2_ROW_TARGET overrides the target.  Deterministic: the same lists and shape give the same plan.
+static int plan_get(trx2_ctx* ctx, int pw, int groups, int* index) {
+  const int L = ctx->L;
+  if ((int)ctx->h_row_cnt.size() != L) { ctx->err = "internal: row counts missing (no map set?)"; return 1; }
+  int forced = 0;
+  if (const char* e = getenv("TRX2_NSPLIT")) { int v = atoi(e); if (v >= 1 && v <= TRX2_NS_CAP) forced = v; }
+  int k = -1;
+  for (size_t i = 0; i < ctx->plans.size(); i++)
+    if (ctx->plans[i].pw == pw && ctx->plans[i].groups == groups) k = (int)i;
+  if (k >= 0 && ctx->plans[(size_t)k].epoch == ctx->rows_epoch && ctx->plans[(size_t)k].forced == forced) { *index = k; return 0; }
+  if (k < 0) { ctx->plans.emplace_back(); k = (int)ctx->plans.size() - 1; ctx->plans[(size_t)k].pw = pw; ctx->plans[(size_t)k].groups = groups; }
+  RowPlan& P = ctx->plans[(size_t)k];
+  const int ns_lim = std::max(1, std::min(TRX2_NS_CAP, L / (2 * PAIR_WAVES * pw)));
+  double target = 18.0;
+  if (const char* e = getenv("TRX2_ROW_TARGET")) { double v = atof(e); if (v >= 1.0 && v <= 1024.0) target = v; }
+  target *= pw;
+  std::vector<unsigned char> ns((size_t)L);
+  auto make = [&](double t) {
+    long tot = 0;
+    for (int a = 0; a < L; a++) {
+      int n = forced ? forced : (int)std::lround((double)ctx->h_row_cnt[(size_t)a] / t);
+      n = std::max(1, std::min(forced ? TRX2_NS_CAP : ns_lim, n));
+      ns[(size_t)a] = (unsigned char)n; tot += n;
+    }
+    return tot;
+  };
+  long tot = make(target);
+  if (!forced) {
+    for (int it = 0; it < 16 && tot * groups < 450 && target > 2.0 * pw; it++) { target *= 0.85; tot = make(target); }
+    for (int it = 0; it < 16 && tot * groups > 2000 && tot > L; it++) { target *= 1.2; tot = make(target); }
+  }
+  std::vector<unsigned> items;
+  items.reserve((size_t)tot);
+  for (int a = 0; a < L; a++)
+    for (int q = 0; q < ns[(size_t)a]; q++) items.push_back((unsigned)a | ((unsigned)q << 10) | ((unsigned)ns[(size_t)a] << 14));
+  std::stable_sort(items.begin(), items.end(), [&](unsigned x, unsigned y) {   // longest slices first (the launch ends with its last workgroup)
+    const double lx = (double)ctx->h_row_cnt[x & 0x3ffu] / (double)(x >> 14), ly = (double)ctx->h_row_cnt[y & 0x3ffu] / (double)(y >> 14);
+    return lx > ly;
+  });
+  HIPCHK(hipStreamSynchronize(ctx->stream));  // nothing in flight reads the old plan while it is replaced
+  if (items.size() > P.cap_items) {
+    if (P.items) (void)hipFree(P.items);
+    P.items = nullptr; P.cap_items = 0;
+    HIPCHK(hipMalloc((void**)&P.items, sizeof(unsigned) * (size_t)L * TRX2_NS_CAP));
+    P.cap_items = (size_t)L * TRX2_NS_CAP;
+  }
+  if ((size_t)L > P.cap_L) {
+    if (P.nslice) (void)hipFree(P.nslice);
+    P.nslice = nullptr; P.cap_L = 0;
+    HIPCHK(hipMalloc((void**)&P.nslice, (size_t)L));
+    P.cap_L = (size_t)L;
+  }
+  HIPCHK(hipMemcpy(P.items, items.data(), sizeof(unsigned) * items.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(P.nslice, ns.data(), (size_t)L, hipMemcpyHostToDevice));
+  P.n_items = (int)items.size(); P.ns_max = 1;
+  for (int a = 0; a < L; a++) P.ns_max = std::max(P.ns_max, (int)ns[(size_t)a]);
+  P.ns_avg = (double)tot / L; P.epoch = ctx->rows_epoch; P.forced = forced;
+  ctx->alloc_epoch++;  // a captured graph holds the old pointers / grid
+  *index = k;
+  return 0;
+}
+
 // restraint tables, selection masks and packed masks from the resident distograms (ctx->cur) and parameters (ctx->prm)
 static int build_tables(trx2_ctx* ctx) {
   const int L = ctx->L;
@@ -365,8 +464,7 @@ static int build_tables(trx2_ctx* ctx) {
                        ctx->mask2, (unsigned char*)nullptr);
     hipLaunchKernelGGL(k_build_rows, dim3((unsigned)L), dim3(256), 0, ctx->stream, L, (const unsigned char*)ctx->mask2, (const unsigned char*)nullptr, ctx->rows, ctx->row_cnt);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return fetch_row_counts(ctx);
   }
   HIPCHK(hipMemsetAsync(ctx->Td, 0, LL * KD * sizeof(float2), ctx->stream));
   if (ctx->use_orient) {
@@ -389,8 +487,7 @@ static int build_tables(trx2_ctx* ctx) {
                      ctx->mask2, ctx->mask_odr);
   hipLaunchKernelGGL(k_build_rows, dim3((unsigned)L), dim3(256), 0, ctx->stream, L, (const unsigned char*)ctx->mask2, (const unsigned char*)ctx->mask_odr, ctx->rows, ctx->row_cnt);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return 0;
+  return fetch_row_counts(ctx);
 }
 
 static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist, const float* omega, const float* theta,
@@ -555,36 +652,24 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
   const int BW = pick_bw(B);
   const int ngrp = (B + BW - 1) / BW;
   const int Bpad = ngrp * BW;
-  // b-range splits: enough workgroups (>= ~2 per CU) while every wave keeps a few residues b
-  // k_pair holds 2 workgroups per CU (232 VGPRs): 512 resident slots.  EMPIRICAL rule from profiles/README.md
-  // (L=150, B=64, splits 2/3/4/6 timed on MI355X): with distances only, the largest split whose grid fits one
-  // round is fastest; with the angle channels on, 600 smaller workgroups win despite the partial second round.
-  // Every wave keeps at least two residues b.
-  auto split_rule = [&](int groups, int bw) {
-    int n_best = 1;
-    const int PW = 64 / bw;
-    const long slots = ctx->use_orient ? 640 : 512;
-    for (int n = 1; n <= 16; n++)
-      if ((long)L * n * groups <= slots && L / n >= PAIR_WAVES * PW * 2) n_best = n;
-    // ... but not fewer than ~450 workgroups when one more split would give them (L=400, 32 decoys: 400 -> 800 workgroups,
-    // 119 -> 133 decoys/s; two groups of 64 at L=150: 300 -> 600)
-    if ((long)L * n_best * groups < 450 && L / (n_best + 1) >= PAIR_WAVES * PW * 2) n_best++;
-    if (const char* e = getenv("TRX2_NSPLIT")) { int v = atoi(e); if (v >= 1 && v <= 16) n_best = v; }  // A/B timing only
-    return n_best;
-  };
-  const int nsplit = split_rule(ngrp, BW);
-  // the tail compaction drops one group of 64 at a time: the record buffer must hold every shape on the way
-  std::vector<int> nsplit_g((size_t)ngrp + 1, nsplit);
-  size_t fa_units = (size_t)nsplit * B;
-  for (int g = 1; g < ngrp; g++) { nsplit_g[g] = split_rule(g, 64); fa_units = std::max(fa_units, (size_t)nsplit_g[g] * g * 64); }
-  int nsplit_w[7];  // ... and then halves the last group: 32, 16, .. 1 decoys per wave
-  for (int k = 0; k < 7; k++) {
-    nsplit_w[k] = split_rule(1, 1 << k);
-    if ((1 << k) < BW || ngrp > 1) fa_units = std::max(fa_units, (size_t)nsplit_w[k] * (1 << k));
+  // row plans of every launch shape this batch can take: its own, and those the tail compaction shrinks through (one decoy group
+  // of 64 fewer at a time, then 32, 16, .. 1 decoys per wave); the record buffer must hold the widest of them
+  int plan_idx = -1;
+  if (plan_get(ctx, 64 / BW, ngrp, &plan_idx)) return 1;
+  size_t fa_units = (size_t)ctx->plans[(size_t)plan_idx].ns_max * B;
+  for (int g = 1; g < ngrp; g++) {
+    int k;
+    if (plan_get(ctx, 1, g, &k)) return 1;
+    fa_units = std::max(fa_units, (size_t)ctx->plans[(size_t)k].ns_max * g * 64);
   }
+  for (int w = 1; w < 64; w <<= 1)
+    if (w < BW || ngrp > 1) {
+      int k;
+      if (plan_get(ctx, 64 / w, 1, &k)) return 1;
+      fa_units = std::max(fa_units, (size_t)ctx->plans[(size_t)k].ns_max * w);
+    }
   const bool layout_changed = BW != ctx->BW || Bpad != ctx->Bpad;
-  ctx->BW = BW; ctx->Bpad = Bpad; ctx->nsplit = nsplit; ctx->nsplit_g = nsplit_g;
-  memcpy(ctx->nsplit_w, nsplit_w, sizeof nsplit_w);
+  ctx->BW = BW; ctx->Bpad = Bpad; ctx->plan_cur = plan_idx;
   if (B <= ctx->Bcap && L <= ctx->Lcap && fa_units * L <= ctx->fa_cap) {
     if (layout_changed) {  // the pad lanes of a group layout must hold finite numbers
       HIPCHK(hipMemsetAsync(ctx->xyzT, 0, sizeof(float4) * (size_t)Bpad * L * 5, ctx->stream));
@@ -632,7 +717,7 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
 
 static PairArgs pair_args(trx2_ctx* c, int B) {
   PairArgs P;
-  P.L = c->L; P.B = B; P.nsplit = c->nsplit; P.Bpad = c->Bpad;
+  P.L = c->L; P.B = B; P.Bpad = c->Bpad; P.items = c->plans[(size_t)c->plan_cur].items;
   P.xyzT = c->xyzT; P.Td = c->Td; P.To = c->To; P.Tt = c->Tt; P.Tp = c->Tp;
   P.rows = c->rows; P.row_cnt = c->row_cnt; P.has_odr = c->mask_odr != nullptr;
   P.knots = c->knots_f; P.wcur = c->wcur; P.FA = c->FA; P.seq_ctr = c->seq_ctr;
@@ -646,7 +731,7 @@ static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_eva
   A.max_evals = max_evals; A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho; A.gram = c->gram;
   A.X = c->X; A.G = c->G; A.D = c->D; A.XT = c->XT; A.S = c->S; A.Y = c->Y; A.P = c->P; A.geom = c->geom;
   A.xyzT = c->xyzT; A.BW = c->BW;
-  A.wcur = c->wcur; A.FA = c->FA; A.nsplit = c->nsplit; A.hasH = c->hasH;
+  A.wcur = c->wcur; A.FA = c->FA; A.nslice = c->plans[(size_t)c->plan_cur].nslice; A.hasH = c->hasH;
   A.e_last = c->e_last; A.f_last = c->f_last;
   A.grad_out = c->grad; A.done_count = c->done_count;
   A.slot_id = c->slot_id; A.next_id = c->next_id; A.n_total = 0; A.seed = 0; A.decoy0 = 0; A.tors0_all = nullptr;
@@ -658,14 +743,15 @@ static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_eva
 static int launch_pair(trx2_ctx* c, int B) {
   // never launch a shape the buffers were not sized for (operand shapes are checked on the host: a kernel that writes out of
   // bounds can reset every GPU of the node)
-  if (B < 1 || B > c->Bpad || B > c->Bcap || c->Bpad % c->BW != 0 || (size_t)c->nsplit * B * c->L > c->fa_cap ||
-      (size_t)c->Bpad > (size_t)(c->Bcap + 63) / 64 * 64) {
-    c->err = "internal: pair-kernel launch shape does not fit the batch buffers";
-    fprintf(stderr, "trx2fold: %s (B=%d Bpad=%d Bcap=%d nsplit=%d)\n", c->err.c_str(), B, c->Bpad, c->Bcap, c->nsplit);
+  const RowPlan* rp = (c->plan_cur >= 0 && c->plan_cur < (int)c->plans.size()) ? &c->plans[(size_t)c->plan_cur] : nullptr;
+  if (!rp || rp->epoch != c->rows_epoch || rp->pw != 64 / c->BW || rp->groups < c->Bpad / c->BW || rp->n_items < c->L || B < 1 || B > c->Bpad ||
+      B > c->Bcap || c->Bpad % c->BW != 0 || (size_t)rp->ns_max * B * c->L > c->fa_cap || (size_t)c->Bpad > (size_t)(c->Bcap + 63) / 64 * 64) {
+    c->err = "internal: pair-kernel launch shape does not fit the batch buffers or its row plan";
+    fprintf(stderr, "trx2fold: %s (B=%d Bpad=%d Bcap=%d BW=%d plan=%d)\n", c->err.c_str(), B, c->Bpad, c->Bcap, c->BW, c->plan_cur);
     return 1;
   }
   const PairArgs P = pair_args(c, B);
-  const dim3 grid(c->L, c->nsplit, c->Bpad / c->BW), block(PAIR_THREADS);
+  const dim3 grid((unsigned)rp->n_items, 1, c->Bpad / c->BW), block(PAIR_THREADS);
   // maps without the angle channels (--no-orient, gen_rst_af2) run the instantiation without the angular block
 #define LAUNCH_PAIR(W)                                                                                       \
   if (c->use_orient) hipLaunchKernelGGL((k_pair<W, FAM_ALL>), grid, block, 0, c->stream, P);               \
@@ -688,7 +774,7 @@ static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals) {
   A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho; A.gram = c->gram;
   A.CX = c->CX; A.CG = c->CG; A.CD = c->CD; A.CS = c->CS; A.CY = c->CY;
   A.P = c->P; A.xyzT = c->xyzT; A.BW = c->BW; A.X = c->X; A.XT = c->XT; A.geom = c->geom; A.wcur = c->wcur;
-  A.FA = c->FA; A.nsplit = c->nsplit; A.hasH = c->hasH;
+  A.FA = c->FA; A.nslice = c->plans[(size_t)c->plan_cur].nslice; A.hasH = c->hasH;
   A.e_last = c->e_last; A.f_last = c->f_last; A.done_count = c->done_count;
   A.hist_lds = 0;
   return A;
@@ -704,7 +790,7 @@ static void launch_chain_args(trx2_ctx* c, int B, const ChainArgs& A) {
   // scan combines two partials instead of four
   if (L <= 128) hipLaunchKernelGGL((k_chain<1, 128>), grid, dim3(128), HIST_LDS_BYTES(128), c->stream, A);
   else if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_chain<1, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), HIST_LDS_BYTES(CHAIN_THREADS), c->stream, A);
-  else if (L <= 2 * CHAIN_THREADS) hipLaunchKernelGGL((k_chain<2, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), 0, c->stream, A);
+  else if (L <= 2 * CHAIN_THREADS) hipLaunchKernelGGL((k_chain<1, 2 * CHAIN_THREADS>), grid, dim3(2 * CHAIN_THREADS), 0, c->stream, A);  // one residue per thread, history from global memory
   else hipLaunchKernelGGL((k_chain<4, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), 0, c->stream, A);
 }
 
@@ -814,7 +900,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   // whoever launches on them next (the pair-kernel replays of trx2_time_pair_kernel, for one) sizes its grid and its record
   // indices by these fields.  (A replay of B slots on the shape the tail compaction had left behind wrote records past the end
   // of the buffer: a GPU memory fault, found under rocprofv3.)
-  struct ShapeGuard { trx2_ctx* c; int bpad, ns, bw; ~ShapeGuard() { c->Bpad = bpad; c->nsplit = ns; c->BW = bw; } } shape_guard{ctx, ctx->Bpad, ctx->nsplit, ctx->BW};
+  struct ShapeGuard { trx2_ctx* c; int bpad, plan, bw; ~ShapeGuard() { c->Bpad = bpad; c->plan_cur = plan; c->BW = bw; } } shape_guard{ctx, ctx->Bpad, ctx->plan_cur, ctx->BW};
   const int L = ctx->L;
   const size_t BL = (size_t)B * L, NL = (size_t)N * L;
   auto t0 = std::chrono::steady_clock::now();
@@ -875,7 +961,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
         }
         if (L <= 128) hipLaunchKernelGGL((k_step<1, 128, 128>), g2, dim3(128), dyn, ctx->stream, ca, cc);
         else if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS>), g2, b1, dyn, ctx->stream, ca, cc);
-        else hipLaunchKernelGGL((k_step<2, CHAIN_THREADS, 2 * CHAIN_THREADS>), g2, b2, 0, ctx->stream, ca, cc);
+        else hipLaunchKernelGGL((k_step<1, 2 * CHAIN_THREADS, 2 * CHAIN_THREADS>), g2, b2, 0, ctx->stream, ca, cc);
       } else
         launch_chain_args(ctx, B, ca);
       if (samp) { (void)hipEventRecord(ctx->prof_ev[3 * prof_used + 2], ctx->stream); prof_used++; }
@@ -888,7 +974,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   // TRX2_GRAPH=1 opts in.
   static const bool no_graph = getenv("TRX2_GRAPH") == nullptr;
   if (!no_graph) {
-    const long key[8] = {B, nruns, max_evals, has_cart ? 1 : 0, (long)L * 4096 + N, (long)(seed ^ ((uint64_t)decoy0 << 40) ^ (tors0 ? 1 : 0)), (long)ctx->nsplit * 128 + ctx->BW, ctx->alloc_epoch};
+    const long key[8] = {B, nruns, max_evals, has_cart ? 1 : 0, (long)L * 4096 + N, (long)(seed ^ ((uint64_t)decoy0 << 40) ^ (tors0 ? 1 : 0)), (long)ctx->plan_cur * 128 + ctx->BW, ctx->alloc_epoch};
     if (!ctx->gexec || memcmp(key, ctx->g_key, sizeof key) != 0) {
       if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
       hipGraph_t graph = nullptr;
@@ -942,12 +1028,16 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
       hipLaunchKernelGGL(k_compact_move, dim3(64), dim3(256), 0, ctx->stream, C);
       B = Bc; ctx->Bpad = Bc;
       if (drop_group) {
-        if (compact_mode == 1) ctx->nsplit = ctx->nsplit_g[(size_t)Bc / 64];
+        if (compact_mode == 1) {  // the narrower shape's own row plan
+          int k;
+          if (plan_get(ctx, 1, Bc / 64, &k)) return 1;
+          ctx->plan_cur = k;
+        }  // mode 2 keeps the plan (a plan made for more groups serves fewer): bitwise equal to the uncompacted fold
       } else {
         ctx->BW = Bc;
-        int lg = 0;
-        while ((1 << lg) < Bc) lg++;
-        ctx->nsplit = ctx->nsplit_w[lg];
+        int k;
+        if (plan_get(ctx, 64 / Bc, 1, &k)) return 1;
+        ctx->plan_cur = k;
         hipLaunchKernelGGL(k_relayout, dim3((unsigned)(((size_t)Bc * L + 255) / 256)), dim3(256), 0, ctx->stream, Bc, L, Bc, (const float4*)ctx->P, ctx->xyzT);
       }
       HIPCHK(hipGetLastError());
@@ -1270,7 +1360,7 @@ extern "C" int trx2_superpose_matrix(trx2_ctx* ctx, int n, int m, int L, const f
 extern "C" int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int sep_lo, int sep_hi, int n_rep,
                                      double* ms_avg, double* term_evals) {
   if (!ctx) return 1;
-  if (!ctx->L || !ctx->P || B > ctx->Bcap || B > ctx->Bpad || B < 1 || n_rep < 1 || (size_t)ctx->nsplit * B * ctx->L > ctx->fa_cap) {
+  if (!ctx->L || !ctx->P || B > ctx->Bcap || B > ctx->Bpad || B < 1 || n_rep < 1 || ctx->plan_cur < 0) {
     ctx->err = "trx2_time_pair_kernel: run an eval/fold batch of this size first";
     return 1;
   }
@@ -1355,8 +1445,8 @@ extern "C" int trx2_ctx_info(const trx2_ctx* ctx, int key, double* value) {
   if (!ctx || !value) return 1;
   switch (key) {
     case TRX2_INFO_GROUP_WIDTH: *value = ctx->BW; return 0;
-    case TRX2_INFO_SLAB_BYTES: *value = (double)ctx->nsplit * PR_REC * 4; return 0;
-    case TRX2_INFO_PAIR_WGS: *value = (double)ctx->L * ctx->nsplit * (ctx->Bpad / ctx->BW); return 0;
+    case TRX2_INFO_SLAB_BYTES: *value = (ctx->plan_cur >= 0 ? ctx->plans[(size_t)ctx->plan_cur].ns_avg : 1.0) * PR_REC * 4; return 0;
+    case TRX2_INFO_PAIR_WGS: *value = (ctx->plan_cur >= 0 ? (double)ctx->plans[(size_t)ctx->plan_cur].n_items : 0.0) * (ctx->Bpad / ctx->BW); return 0;
     case TRX2_INFO_CART_STAGED:
       *value = (ctx->L >= 1 && ctx->L <= CHAIN_THREADS) ? (double)std::min<size_t>(LBM, (size_t)step_dyn_budget(ctx, ctx->L <= 128 ? 0 : 1) / CART_HIST_BYTES(ctx->L)) : 0.0;
       return 0;
