@@ -161,7 +161,22 @@ enum {
 #ifndef TRX2_RAMA_GUARD_OFFSET
 #define TRX2_RAMA_GUARD_OFFSET 0.0
 #endif
-#define TRX2_MAX_RUNS 32
+#define TRX2_MAX_RUNS 48
+
+/* ---- backbone-visible part of the full-atom refinement (folding/folding.py:200-268; "a11-lite") ----------------------
+ * The reference ends every decoy with FastRelax x 2 on ref2015_cart + atom_pair 5 / dihedral 1 / angle 1 (folding.py:202-205)
+ * with restraints RE-SELECTED at PCUT 0.15 (round 1, :230-231) and 0.30 (round 2, :236-237), pairs touching a glycine dropped
+ * (add_rst(.., nogly=True), utils_ros.py:713-717).  No full-atom model exists here; what a backbone sees of it:
+ * the two re-selections and the re-weighted score, run through the ramps of the two FastRelax scripts
+ * (folding/data/1relax_round1.txt: torsion x 2 then Cartesian x 1; 2relax_round2.txt: Cartesian x 2; each four
+ * `ramp_repack_min <fa_rep scale> <tolerance> <coordinate-constraint weight: unused, no such constraints> <iterations>`). */
+#define TRX2_RELAX_PCUT1 0.15
+#define TRX2_RELAX_PCUT2 0.30
+/* trx2_run.pair_filter: which selection of the map's restraints a run sees */
+#define TRX2_FILTER_ALL 0    /* add_rst at the map's PCUT                                       */
+#define TRX2_FILTER_ODR 1    /* ... without the pairs flagged in idr (mode 3, first stage)      */
+#define TRX2_FILTER_RELAX1 2 /* re-selected at RELAX_PCUT1, no pair touching a glycine          */
+#define TRX2_FILTER_RELAX2 3 /* ... at RELAX_PCUT2                                              */
 
 /* one minimiser run of the staged protocol (folding.py:119,164-171; utils_ros.py:699-703) */
 typedef struct trx2_run {
@@ -172,9 +187,9 @@ typedef struct trx2_run {
   int precheck;     /* 1: before running, if rama+vdw (raw) < CLASH_BREAK jump to skip_to      */
   int skip_to;      /* run index to continue with when the precheck fires                      */
   int cartesian;    /* 1: minimise Cartesian coordinates (MinMover.cartesian(True))            */
-  int pair_filter;  /* 1: only restraints of pairs NOT flagged in the map's idr mask (add_idr_rst with the complement, mode 3's
-                       first stage, folding.py:173-179); 0: all selected restraints */
-  int pad1;
+  int pair_filter;  /* TRX2_FILTER_*: 1: only restraints of pairs NOT flagged in the map's idr mask (add_idr_rst with the complement,
+                       mode 3's first stage, folding.py:173-179); 0: all selected restraints; 2 / 3: the relax re-selections */
+  float tol;        /* convergence tolerance of this run (MinMover's / ramp_repack_min's); 0: TRX2_MIN_TOL */
 } trx2_run;
 
 #endif

@@ -21,7 +21,7 @@ class Run(C.Structure):
     """mirror of trx2_run (include/trx2_model.h)"""
     _fields_ = [("w", C.c_float * NW), ("max_iter", C.c_int), ("sep_lo", C.c_int), ("sep_hi", C.c_int),
                 ("precheck", C.c_int), ("skip_to", C.c_int), ("cartesian", C.c_int), ("pair_filter", C.c_int),
-                ("pad1", C.c_int)]
+                ("tol", C.c_float)]
 
 
 class FoldStats(C.Structure):
@@ -68,6 +68,8 @@ def lib():
         L.orc_tables_override_rows.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
         L.orc_tables_filter_pairs.argtypes = [vp, vp, C.c_int]
         L.orc_tables_set_idr.argtypes = [vp, vp]
+        L.orc_select_relax.argtypes = [vp]
+        L.orc_get_relax_selection.argtypes = [vp, C.c_int, vp]
         L.orc_tables_kd.restype = C.c_int
         L.orc_tables_kd.argtypes = [vp]
         L.orc_place_h.argtypes = [vp, vp, vp, vp]
@@ -142,6 +144,14 @@ class Tables:
             if len(seq) != self.L:
                 raise ValueError("sequence length does not match the map")
             lib().orc_tables_set_seq(self.h, seq.encode())
+        # the relax stage's re-selections (PCUT 0.15 / 0.30, no glycine pairs: folding.py:230-237); they need the sequence
+        lib().orc_select_relax(self.h)
+
+    def relax_selection(self, k):
+        """selection bits [L,L] of relax round k = 0 / 1 (runs with pair_filter 2 / 3)"""
+        out = np.zeros((self.L, self.L), np.uint8)
+        lib().orc_get_relax_selection(self.h, int(k), _p(out))
+        return out
 
     def __del__(self):
         try:
@@ -273,6 +283,7 @@ def make_runs(runs):
         arr[i].max_iter = int(r["max_iter"]); arr[i].sep_lo = int(r["sep_lo"]); arr[i].sep_hi = int(r["sep_hi"])
         arr[i].precheck = int(r.get("precheck", 0)); arr[i].skip_to = int(r.get("skip_to", 0))
         arr[i].cartesian = int(r.get("cartesian", 0)); arr[i].pair_filter = int(r.get("pair_filter", 0))
+        arr[i].tol = float(r.get("tol", 0.0))
     return arr
 
 

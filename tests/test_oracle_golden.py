@@ -39,6 +39,35 @@ def test_selection_counts_match_survey(golden_dir):
     assert [int((sel & b > 0).sum()) for b in (1, 2, 4, 8)] == [3226, 2562, 5142, 2541]
 
 
+@pytest.mark.parametrize("tag", ["NMR", "Xray"])
+def test_relax_reselection_matches_add_rst_nogly(golden_dir, seq, tag):
+    """The full-atom stage re-selects the restraints twice (folding.py:230-231,236-237): add_rst(pose, rst, 1, nres, params, True)
+    at PCUT 0.15, then 0.30 -- of the restraints gen_rst generated, p >= pcut (dist), pcut + 0.5 (omega, theta), pcut + 0.6
+    (phi), both residues not glycine (utils_ros.py:713-717).  The reference's generated lists (a, b, p) are the committed golden
+    vectors; the predicate is applied to them here and must give the oracle's selections (runs with pair_filter 2 / 3), pair
+    for pair; the example has 7 glycines, so the filter bites."""
+    npz = np.load(os.path.join(golden_dir, f"seq_{tag}.npz"))
+    gold = np.load(os.path.join(golden_dir, f"gen_rst_{tag}.npz"))
+    T = O.Tables(npz["dist"], npz["omega"], npz["theta"], npz["phi"], seq=seq)
+    gly = np.array([c == "G" for c in seq])
+    assert gly.sum() == 7
+    add = {"dist": 0.0, "omega": 0.5, "theta": 0.5, "phi": 0.6}
+    for k, pcut in enumerate((0.15, 0.30)):
+        sel = T.relax_selection(k)
+        n_sel = []
+        for ch, bit in BITS.items():
+            a, b, p = gold[f"{ch}_a"], gold[f"{ch}_b"], gold[f"{ch}_p"]
+            keep = (np.abs(a - b) >= 1) & (np.abs(a - b) < len(seq)) & ~gly[a] & ~gly[b] & (p >= pcut + add[ch])
+            want = np.zeros((len(seq), len(seq)), bool)
+            want[a[keep], b[keep]] = True
+            assert np.array_equal((sel & bit) > 0, want), (tag, pcut, ch)
+            n_sel.append(int(keep.sum()))
+        base = T.mask(True)
+        assert np.all((sel & ~base) == 0)          # a subset of the PCUT 0.05 selection
+        print(tag, pcut, "selected dist / omega / theta / phi:", n_sel, "of", [int((base & b_ > 0).sum()) for b_ in (1, 2, 4, 8)])
+        assert 0 < n_sel[0] < int((base & 1 > 0).sum())
+
+
 def test_no_orient_builds_dist_only(golden_dir):
     g = json.load(open(os.path.join(golden_dir, "gen_rst_noorient.json")))
     npz = np.load(os.path.join(golden_dir, "seq_NMR.npz"))

@@ -24,7 +24,8 @@ for it in range(iters):
     xyz = r["xyz"][0]
     rows.append(dict(it=it, as_read_ms=1e3 * (t1 - t0), feedback_ms=1e3 * (t2 - t1), fold_ms=1e3 * (t3 - t2), fold_c_ms=1e3 * r["seconds"], evals=int(r["n_evals"][0]),
                      launches=int(r["launches"]), delta=d))
-print(json.dumps(dict(L=L, init_num=N, init_s=t_init, rows=rows[:3] + rows[-2:],
+print(json.dumps(dict(L=L, init_num=N, init_s=t_init, rows=rows[:3] + rows[-2:], evals_by_block_of_50=[float(np.mean([q["evals"] for q in rows[k:k + 50]])) for k in range(0, len(rows), 50)],
+                      delta_by_block_of_50=[float(np.mean([q["delta"] for q in rows[k:k + 50]])) for k in range(0, len(rows), 50)],
                       mean=dict(as_read_ms=np.mean([q["as_read_ms"] for q in rows]), feedback_ms=np.mean([q["feedback_ms"] for q in rows]), fold_ms=np.mean([q["fold_ms"] for q in rows]),
                                 fold_c_ms=np.mean([q["fold_c_ms"] for q in rows]), evals=np.mean([q["evals"] for q in rows]), us_per_eval=1e3 * np.mean([q["fold_c_ms"] for q in rows]) / np.mean([q["evals"] for q in rows])))))
 ctx.close()

@@ -26,7 +26,7 @@ class Params(C.Structure):
 class Run(C.Structure):
     """trx2_run (include/trx2_model.h)"""
     _fields_ = [("w", C.c_float * NW), ("max_iter", C.c_int), ("sep_lo", C.c_int), ("sep_hi", C.c_int),
-                ("precheck", C.c_int), ("skip_to", C.c_int), ("cartesian", C.c_int), ("pair_filter", C.c_int), ("pad1", C.c_int)]
+                ("precheck", C.c_int), ("skip_to", C.c_int), ("cartesian", C.c_int), ("pair_filter", C.c_int), ("tol", C.c_float)]
 
 
 DEFAULT_PARAMS = dict(ebase=-0.5, erep=(10.0, 3.0, 0.5), drep=(0.0, 2.0, 3.5), meff=1e-4, dcut=19.5, alpha=1.57,
@@ -51,6 +51,7 @@ def make_runs(runs):
         arr[i].max_iter, arr[i].sep_lo, arr[i].sep_hi = int(r["max_iter"]), int(r["sep_lo"]), int(r["sep_hi"])
         arr[i].precheck, arr[i].skip_to, arr[i].cartesian = int(r.get("precheck", 0)), int(r.get("skip_to", 0)), int(r.get("cartesian", 0))
         arr[i].pair_filter = int(r.get("pair_filter", 0))
+        arr[i].tol = float(r.get("tol", 0.0))
     return arr
 
 

@@ -27,6 +27,7 @@ struct PairArgs {
   const unsigned* rows;       // [L][L] row a: its row_cnt[a] partners with any selected restraint, ascending b:
                               //   b | mask << 16 | mask_odr << 24, mask = low nibble selected bits of (a,b), high nibble those of (b,a)
   const int* row_cnt;         // [L]
+  const unsigned short* rows_rx;  // [L][L] beside rows: the entry's packed masks of the relax stage's re-selections, round 1 | round 2 << 8
   int has_odr;                // the map has an idr mask: entries carry the packed mask without the flagged pairs (mode 3, first stage)
   const float* knots;         // [kd + 72] float
   const float* wcur;          // [B][8] : w_ap w_dih w_ang w_vdw sep_lo sep_hi active (2: ordered pairs only) w_hb
@@ -123,7 +124,8 @@ __device__ unsigned long long g_stamp[32];
 // whose packed mask byte has any bit -- a selected restraint of (a,b) or of (b,a).  One workgroup per row, order-preserving
 // compaction by wave ballots.  Fixed row stride L: no prefix sum over rows.
 __global__ __launch_bounds__(256) void k_build_rows(int L, const unsigned char* __restrict__ mask, const unsigned char* __restrict__ mask_odr,
-                                                     unsigned* __restrict__ rows, int* __restrict__ row_cnt) {
+                                                     const unsigned char* __restrict__ mask_r1, const unsigned char* __restrict__ mask_r2,
+                                                     unsigned* __restrict__ rows, unsigned short* __restrict__ rows_rx, int* __restrict__ row_cnt) {
   const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __shared__ int s_w[4];
   __shared__ int s_base;
@@ -131,10 +133,11 @@ __global__ __launch_bounds__(256) void k_build_rows(int L, const unsigned char* 
   __syncthreads();
   for (int b0 = 0; b0 < L; b0 += 256) {
     const int b = b0 + tid;
-    unsigned m = 0, mo = 0;
+    unsigned m = 0, mo = 0, mr = 0;
     if (b < L && b != a) {
       m = mask[(size_t)a * L + b];
       mo = mask_odr ? mask_odr[(size_t)a * L + b] : m;
+      mr = (unsigned)mask_r1[(size_t)a * L + b] | ((unsigned)mask_r2[(size_t)a * L + b] << 8);   // subsets of m
     }
     const bool keep = m != 0;
     const unsigned long long bal = __ballot(keep);
@@ -143,7 +146,10 @@ __global__ __launch_bounds__(256) void k_build_rows(int L, const unsigned char* 
     __syncthreads();
     int off = s_base;
     for (int w = 0; w < wave; w++) off += s_w[w];
-    if (keep) rows[(size_t)a * L + off + pre] = (unsigned)b | (m << 16) | (mo << 24);
+    if (keep) {
+      rows[(size_t)a * L + off + pre] = (unsigned)b | (m << 16) | (mo << 24);
+      rows_rx[(size_t)a * L + off + pre] = (unsigned short)mr;
+    }
     __syncthreads();
     if (tid == 0) s_base += s_w[0] + s_w[1] + s_w[2] + s_w[3];
     __syncthreads();
@@ -169,6 +175,7 @@ __global__ __launch_bounds__(PAIR_THREADS, (FAM & FAM_ANG) ? PAIR_MIN_WAVES : PA
   __shared__ float s_kn[TRX2_KTOT_MAX];
   __shared__ float s_red[PAIR_WAVES * 64 * RED_STRIDE];  // [wave][decoy][24 (+1 pad: bank-conflict-free)]
   __shared__ unsigned s_ent[1024];                       // this workgroup's slice of row a's list (a row has < L <= 1024 entries)
+  __shared__ unsigned short s_rx[1024];                  // ... and the entries' relax-stage masks
   // One evaluation = one sequence number.  Kept in device memory (not a kernel argument) so that a chunk of
   // (pair, step) launches is a STATIC graph that can be replayed.  The step kernel of this evaluation starts after this
   // kernel has finished (same stream), so every one of its workgroups reads the same, final value.
@@ -184,7 +191,10 @@ __global__ __launch_bounds__(PAIR_THREADS, (FAM & FAM_ANG) ? PAIR_MIN_WAVES : PA
   // equal slices of the row's list: every workgroup of a row gets the same number of restraint visits
   const int cnt = A.row_cnt[a];
   const int e_lo = (cnt * split) / nsl, e_hi = (cnt * (split + 1)) / nsl;
-  for (int i = e_lo + (int)threadIdx.x; i < e_hi; i += PAIR_THREADS) s_ent[i - e_lo] = A.rows[(size_t)a * L + i];
+  for (int i = e_lo + (int)threadIdx.x; i < e_hi; i += PAIR_THREADS) {
+    s_ent[i - e_lo] = A.rows[(size_t)a * L + i];
+    s_rx[i - e_lo] = A.rows_rx[(size_t)a * L + i];
+  }
   __syncthreads();
   const float* knd = s_kn;
   const float* kno = s_kn + kd;
@@ -197,7 +207,8 @@ __global__ __launch_bounds__(PAIR_THREADS, (FAM & FAM_ANG) ? PAIR_MIN_WAVES : PA
   const float w_ap = w0.x, w_dih = w0.y, w_ang = w0.z, w_vdw = w0.w, w_hb = w1.w;
   const int sep_lo = (int)w1.x, sep_hi = (int)w1.y;
   const bool active = live && w1.z != 0.0f;
-  const bool odr_only = w1.z == 2.0f && A.has_odr != 0;
+  // which selection of the map's restraints this decoy's run sees: 1 + trx2_run.pair_filter (TRX2_FILTER_*)
+  const int fsel = (int)w1.z - 1;
 
   // residue a
   f3 CAa, Na, CBa, Ca, Oa;
@@ -223,6 +234,7 @@ __global__ __launch_bounds__(PAIR_THREADS, (FAM & FAM_ANG) ? PAIR_MIN_WAVES : PA
   for (int e0 = e_lo + wave * PW; e0 < e_hi; e0 += VSTRIDE) {
     const int e = e0 + h;
     const unsigned ent = s_ent[min(e, e_hi - 1) - e_lo];
+    const unsigned erx = s_rx[min(e, e_hi - 1) - e_lo];
     const int bc = (int)(ent & PAIR_ROW_B_BITS);
     // residue b's CA, N, CB: requested as soon as the entry is read, before its masks are examined
     const float4* xb = A.xyzT + (__umul24((unsigned)(grp * L + bc), 5u * BW) + (unsigned)d);
@@ -230,7 +242,8 @@ __global__ __launch_bounds__(PAIR_THREADS, (FAM & FAM_ANG) ? PAIR_MIN_WAVES : PA
     const int sep = abs(a - bc);
     unsigned m_ab = 0, m_ba = 0;
     if (want_rst && e < e_hi && sep >= sep_lo && sep < sep_hi) {
-      const unsigned mm = odr_only ? (ent >> 24) : ((ent >> 16) & 0xffu);
+      const unsigned mm = (fsel == TRX2_FILTER_ODR && A.has_odr) ? (ent >> 24)
+                          : fsel == TRX2_FILTER_RELAX1 ? (erx & 0xffu) : fsel == TRX2_FILTER_RELAX2 ? (erx >> 8) : ((ent >> 16) & 0xffu);
       m_ab = mm & 15u;
       m_ba = mm >> 4;
     }

@@ -732,7 +732,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
         if (nh < TRX2_LS_PAST) fh[nh++] = f;
         else { fh[0] = fh[1]; fh[1] = fh[2]; fh[2] = f; }
         iter++; n_iters++;
-        const bool conv = 2.0 * fabs(fprev - f) <= (double)TRX2_MIN_TOL * (fabs(fprev) + fabs(f) + 1e-10);
+        const bool conv = 2.0 * fabs(fprev - f) <= (R.tol > 0.0f ? (double)R.tol : (double)TRX2_MIN_TOL) * (fabs(fprev) + fabs(f) + 1e-10);
         if (conv || iter >= R.max_iter) next_run = true;
         else new_dir = true;
       } else {
@@ -958,7 +958,7 @@ next_pair:
     float* w = A.wcur + (size_t)dec * 8;
     w[0] = Rn.w[0]; w[1] = Rn.w[1]; w[2] = Rn.w[2]; w[3] = Rn.w[3];
     w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi;
-    w[6] = (phase == PH_DONE && A.mode == MODE_STEP) ? 0.0f : (Rn.pair_filter ? 2.0f : 1.0f);
+    w[6] = (phase == PH_DONE && A.mode == MODE_STEP) ? 0.0f : 1.0f + (float)Rn.pair_filter;  // the pair kernel's selection: 1 + TRX2_FILTER_*
     w[7] = Rn.w[7];
   }
   if (!need_nerf) return;
@@ -1372,7 +1372,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
       if (nh < TRX2_LS_PAST) fh[nh++] = f;
       else { fh[0] = fh[1]; fh[1] = fh[2]; fh[2] = f; }
       iter++; n_iters++;
-      const bool conv = 2.0 * fabs(fprev - f) <= (double)TRX2_MIN_TOL * (fabs(fprev) + fabs(f) + 1e-10);
+      const bool conv = 2.0 * fabs(fprev - f) <= (R.tol > 0.0f ? (double)R.tol : (double)TRX2_MIN_TOL) * (fabs(fprev) + fabs(f) + 1e-10);
       if (conv || iter >= R.max_iter) next_run = true;
       else new_dir = true;
     } else {
@@ -1653,7 +1653,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
     const trx2_run Rn = runs_l[min(run, A.nruns - 1)];
     float* w = A.wcur + (size_t)dec * 8;
     w[0] = Rn.w[0]; w[1] = Rn.w[1]; w[2] = Rn.w[2]; w[3] = Rn.w[3];
-    w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi; w[6] = Rn.pair_filter ? 2.0f : 1.0f; w[7] = Rn.w[7];
+    w[4] = (float)Rn.sep_lo; w[5] = (float)Rn.sep_hi; w[6] = 1.0f + (float)Rn.pair_filter; w[7] = Rn.w[7];
   }
   if (tid < LBM) A.rho[(size_t)dec * LBM + tid] = s_rho[tid];
   if (NT <= 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no LDS-DMA of this workgroup outlives it

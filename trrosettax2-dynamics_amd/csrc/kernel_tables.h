@@ -207,3 +207,33 @@ __global__ void k_pack_masks(int L, const unsigned char* sel, const unsigned cha
   mask2[i] = (unsigned char)((sel[i] & 15) | ((sel[j] & 15) << 4));
   if (mask_odr) mask_odr[i] = (unsigned char)((idr[i] ? 0 : (sel[i] & 15)) | ((idr[j] ? 0 : (sel[j] & 15)) << 4));
 }
+
+// The relax stage's two re-selections, packed like mask2 (folding.py:230-237: add_rst(.., nogly=True) at PCUT 0.15, then 0.30;
+// utils_ros.py:713-717): of the restraints gen_rst GENERATED, those with p >= pcut (dist), pcut + 0.5 (omega, theta),
+// pcut + 0.6 (phi) whose two residues are not glycine.  po / pt / pp are NULL for maps without the angle channels.
+struct RelaxSelArgs {
+  int L;
+  const unsigned char* gen;
+  const float *pd, *po, *pt, *pp;
+  const unsigned char* gly;   // [L] residue is a glycine
+  double pc1, pc2;
+  unsigned char *mask_r1, *mask_r2;
+};
+__device__ __forceinline__ unsigned relax_bits(const RelaxSelArgs& A, size_t ab, double pc) {
+  const unsigned g = A.gen[ab];
+  unsigned m = 0;
+  if ((g & TRX2_M_DIST) && (double)A.pd[ab] >= pc) m |= TRX2_M_DIST;
+  if (A.po && (g & TRX2_M_OMEGA) && (double)A.po[ab] >= pc + 0.5) m |= TRX2_M_OMEGA;
+  if (A.pt && (g & TRX2_M_THETA) && (double)A.pt[ab] >= pc + 0.5) m |= TRX2_M_THETA;
+  if (A.pp && (g & TRX2_M_PHI) && (double)A.pp[ab] >= pc + 0.6) m |= TRX2_M_PHI;
+  return m;
+}
+__global__ void k_relax_masks(RelaxSelArgs A) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)A.L * A.L) return;
+  const int a = (int)(i / A.L), b = (int)(i % A.L);
+  const size_t j = (size_t)b * A.L + a;
+  const bool ok = a != b && !A.gly[a] && !A.gly[b];
+  A.mask_r1[i] = ok ? (unsigned char)(relax_bits(A, i, A.pc1) | (relax_bits(A, j, A.pc1) << 4)) : 0;
+  A.mask_r2[i] = ok ? (unsigned char)(relax_bits(A, i, A.pc2) | (relax_bits(A, j, A.pc2) << 4)) : 0;
+}

@@ -92,6 +92,8 @@ struct trx2_ctx {
   double* idr_bk = nullptr;
   // row lists of the pair kernel (k_build_rows): row a's partners with any selected restraint, [L][L] entries + [L] counts
   unsigned* rows = nullptr; int* row_cnt = nullptr;
+  // relax stage (a11-lite): packed masks of the two re-selections, the entries' copies of them, glycine flags
+  unsigned char *mask_r1 = nullptr, *mask_r2 = nullptr, *gly = nullptr; unsigned short* rows_rx = nullptr;
   int rst_kind = 0, kd = KD, dist_ca = 0;
   double knots_af2_last = 0;
   float* knots_f = nullptr;
@@ -260,9 +262,10 @@ static void free_map(trx2_ctx* c) {
     k->Td = k->To = k->Tt = k->Tp = nullptr; k->pd = k->po = k->pt = k->pp = nullptr;
     k->gen = k->sel = k->mask2 = k->hasH = k->idr = k->mask_odr = nullptr; k->knots_f = nullptr; k->knots_d = nullptr; k->L = 0; k->alloc_epoch++;
     k->rows = nullptr; k->row_cnt = nullptr; k->h_row_cnt.clear(); k->rows_epoch++;
+    k->mask_r1 = k->mask_r2 = k->gly = nullptr; k->rows_rx = nullptr;
   }
   void* p[] = {c->Td, c->To, c->Tt, c->Tp, c->pd, c->po, c->pt, c->pp, c->gen, c->sel, c->mask2, c->hasH, c->knots_f, c->knots_d,
-               c->idr, c->mask_odr, c->idr_bk, c->rows, c->row_cnt,
+               c->idr, c->mask_odr, c->idr_bk, c->rows, c->row_cnt, c->mask_r1, c->mask_r2, c->gly, c->rows_rx,
                c->cur[0], c->cur[1], c->cur[2], c->cur[3], c->alt[0], c->alt[1], c->alt[2], c->alt[3], c->tmp_cur, c->tmp_alt};
   for (void* q : p)
     if (q && !c->borrows_map) (void)hipFree(q);
@@ -272,6 +275,7 @@ static void free_map(trx2_ctx* c) {
   c->pd = c->po = c->pt = c->pp = nullptr;
   c->gen = c->sel = c->mask2 = c->hasH = c->idr = c->mask_odr = nullptr; c->idr_bk = nullptr;
   c->rows = nullptr; c->row_cnt = nullptr;
+  c->mask_r1 = c->mask_r2 = c->gly = nullptr; c->rows_rx = nullptr;
   c->knots_f = nullptr; c->knots_d = nullptr;
   c->rst_kind = 0; c->kd = KD; c->dist_ca = 0;
   c->L = 0;
@@ -327,6 +331,7 @@ static void lend_map(trx2_ctx* c) {
   k->gen = c->gen; k->sel = c->sel; k->mask2 = c->mask2; k->hasH = c->hasH; k->knots_f = c->knots_f; k->knots_d = c->knots_d;
   k->idr = c->idr; k->mask_odr = c->mask_odr; k->rst_kind = c->rst_kind; k->kd = c->kd; k->dist_ca = c->dist_ca;
   k->rows = c->rows; k->row_cnt = c->row_cnt; k->h_row_cnt = c->h_row_cnt; k->rows_epoch++;
+  k->mask_r1 = c->mask_r1; k->mask_r2 = c->mask_r2; k->gly = c->gly; k->rows_rx = c->rows_rx;
   memcpy(k->knots_h, c->knots_h, sizeof c->knots_h);
   k->alloc_epoch++;
 }
@@ -446,6 +451,15 @@ static int plan_get(trx2_ctx* ctx, int pw, int groups, int* index) {
   return 0;
 }
 
+// the relax stage's re-selections from the generated restraints and their probabilities (after k_build_tables*)
+static void launch_relax_masks(trx2_ctx* ctx) {
+  RelaxSelArgs R;
+  R.L = ctx->L; R.gen = ctx->gen; R.pd = ctx->pd; R.po = ctx->po; R.pt = ctx->pt; R.pp = ctx->pp; R.gly = ctx->gly;
+  R.pc1 = TRX2_RELAX_PCUT1; R.pc2 = TRX2_RELAX_PCUT2; R.mask_r1 = ctx->mask_r1; R.mask_r2 = ctx->mask_r2;
+  const size_t LL = (size_t)ctx->L * ctx->L;
+  hipLaunchKernelGGL(k_relax_masks, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, ctx->stream, R);
+}
+
 // restraint tables, selection masks and packed masks from the resident distograms (ctx->cur) and parameters (ctx->prm)
 static int build_tables(trx2_ctx* ctx) {
   const int L = ctx->L;
@@ -462,7 +476,9 @@ static int build_tables(trx2_ctx* ctx) {
     hipLaunchKernelGGL(k_build_tables_af2, dim3((unsigned)((LL + 127) / 128)), dim3(128), 0, ctx->stream, A);
     hipLaunchKernelGGL(k_pack_masks, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, ctx->stream, L, ctx->sel, (const unsigned char*)nullptr,
                        ctx->mask2, (unsigned char*)nullptr);
-    hipLaunchKernelGGL(k_build_rows, dim3((unsigned)L), dim3(256), 0, ctx->stream, L, (const unsigned char*)ctx->mask2, (const unsigned char*)nullptr, ctx->rows, ctx->row_cnt);
+    launch_relax_masks(ctx);
+    hipLaunchKernelGGL(k_build_rows, dim3((unsigned)L), dim3(256), 0, ctx->stream, L, (const unsigned char*)ctx->mask2, (const unsigned char*)nullptr,
+                       (const unsigned char*)ctx->mask_r1, (const unsigned char*)ctx->mask_r2, ctx->rows, ctx->rows_rx, ctx->row_cnt);
     HIPCHK(hipGetLastError());
     return fetch_row_counts(ctx);
   }
@@ -485,7 +501,9 @@ static int build_tables(trx2_ctx* ctx) {
   hipLaunchKernelGGL(k_build_tables, dim3((unsigned)((LL + 127) / 128)), dim3(128), 0, ctx->stream, A);
   hipLaunchKernelGGL(k_pack_masks, dim3((unsigned)((LL + 255) / 256)), dim3(256), 0, ctx->stream, L, ctx->sel, (const unsigned char*)ctx->idr,
                      ctx->mask2, ctx->mask_odr);
-  hipLaunchKernelGGL(k_build_rows, dim3((unsigned)L), dim3(256), 0, ctx->stream, L, (const unsigned char*)ctx->mask2, (const unsigned char*)ctx->mask_odr, ctx->rows, ctx->row_cnt);
+  launch_relax_masks(ctx);
+  hipLaunchKernelGGL(k_build_rows, dim3((unsigned)L), dim3(256), 0, ctx->stream, L, (const unsigned char*)ctx->mask2, (const unsigned char*)ctx->mask_odr,
+                     (const unsigned char*)ctx->mask_r1, (const unsigned char*)ctx->mask_r2, ctx->rows, ctx->rows_rx, ctx->row_cnt);
   HIPCHK(hipGetLastError());
   return fetch_row_counts(ctx);
 }
@@ -554,6 +572,15 @@ static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist
   HIPCHK(hipMalloc((void**)&ctx->mask2, LL));
   HIPCHK(hipMalloc((void**)&ctx->rows, LL * sizeof(unsigned)));
   HIPCHK(hipMalloc((void**)&ctx->row_cnt, (size_t)L * sizeof(int)));
+  HIPCHK(hipMalloc((void**)&ctx->rows_rx, LL * sizeof(unsigned short)));
+  HIPCHK(hipMalloc((void**)&ctx->mask_r1, LL));
+  HIPCHK(hipMalloc((void**)&ctx->mask_r2, LL));
+  {  // glycines: the relax stage's re-selections drop every pair that touches one (utils_ros.py:713-717)
+    std::vector<unsigned char> gg((size_t)L);
+    for (int i = 0; i < L; i++) gg[(size_t)i] = (i < (int)ctx->seq.size() && ctx->seq[(size_t)i] == 'G') ? 1 : 0;
+    HIPCHK(hipMalloc((void**)&ctx->gly, (size_t)L));
+    HIPCHK(hipMemcpy(ctx->gly, gg.data(), (size_t)L, hipMemcpyHostToDevice));
+  }
   {  // residues that donate a backbone hydrogen bond: every residue with a predecessor except proline (trx2_model.h)
     std::vector<unsigned char> hh((size_t)L);
     for (int i = 0; i < L; i++) hh[i] = (i >= 1 && !(i < (int)ctx->seq.size() && ctx->seq[i] == 'P')) ? 1 : 0;
@@ -719,7 +746,7 @@ static PairArgs pair_args(trx2_ctx* c, int B) {
   PairArgs P;
   P.L = c->L; P.B = B; P.Bpad = c->Bpad; P.items = c->plans[(size_t)c->plan_cur].items;
   P.xyzT = c->xyzT; P.Td = c->Td; P.To = c->To; P.Tt = c->Tt; P.Tp = c->Tp;
-  P.rows = c->rows; P.row_cnt = c->row_cnt; P.has_odr = c->mask_odr != nullptr;
+  P.rows = c->rows; P.row_cnt = c->row_cnt; P.rows_rx = c->rows_rx; P.has_odr = c->mask_odr != nullptr;
   P.knots = c->knots_f; P.wcur = c->wcur; P.FA = c->FA; P.seq_ctr = c->seq_ctr;
   P.kd = c->kd; P.dist_ca = c->dist_ca;
   return P;
@@ -886,7 +913,10 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   if (!ctx->L) { ctx->err = "trx2_fold_batch: no map set"; return 1; }
   if (N < 1 || !runs || nruns < 1 || nruns > TRX2_MAX_RUNS) { ctx->err = "trx2_fold_batch: bad arguments"; return 1; }
   bool has_cart = false, has_filter = false;
-  for (int i = 0; i < nruns; i++) { has_cart |= runs[i].cartesian != 0; has_filter |= runs[i].pair_filter != 0; }
+  for (int i = 0; i < nruns; i++) {
+    has_cart |= runs[i].cartesian != 0; has_filter |= runs[i].pair_filter == TRX2_FILTER_ODR;
+    if (runs[i].pair_filter < 0 || runs[i].pair_filter > TRX2_FILTER_RELAX2 || !(runs[i].tol >= 0.0f)) { ctx->err = "trx2_fold_batch: a run's pair_filter / tol is out of range"; return 1; }
+  }
   if (has_cart && ctx->L > 2 * CHAIN_THREADS) { ctx->err = "trx2_fold_batch: Cartesian-space runs support chains of up to 512 residues"; return 1; }
   if (has_filter && !ctx->mask_odr) { ctx->err = "trx2_fold_batch: a run filters by the idr mask, but the map was set without one (trx2_set_map_ex)"; return 1; }
   if (max_evals <= 0) max_evals = 1 << 30;

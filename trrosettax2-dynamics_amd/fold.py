@@ -9,7 +9,9 @@ Differences from the reference, all deliberate:
   D  failed folds raise RuntimeError (FoldError) instead of passing silently (utils.py:498 runs subprocess.run unchecked); the
      decoys of the batch that did fold are written first, the failed ones get no file
   D  start torsions come from an explicit seed (the reference never seeds `random`, utils_ros.py:677)
-  D  --fastrelax is accepted and ignored: there is no full-atom stage (folding.py:200-268 is not replicated)
+  D  there is no full-atom stage (folding.py:200-268: side chains, ref2015_cart, idealize).  Its backbone-visible part -- the two
+     restraint re-selections without glycine pairs and the re-weighted score through the FastRelax ramps (protocol.relax_runs)
+     -- runs when --fastrelax is given AND TRX2_FASTRELAX_LITE=1 is set (off by default: measured effect DESIGN.md section 2)
 """
 import argparse
 import os
@@ -50,6 +52,11 @@ def parse_options(options):
     if args.rst == "gpcr" and not args.KNOWN:
         raise ValueError("-r gpcr needs -KNOWN (npz with the 6-D geometry of the known structures, folding.py:66-67)")
     return args
+
+
+def relax_lite(args):
+    """the backbone-visible part of the full-atom stage: on only when the reference's flag is on AND the opt-in switch is set"""
+    return bool(args.fastrelax) and os.environ.get("TRX2_FASTRELAX_LITE", "0") == "1"
 
 
 def _unquote(p):
@@ -137,7 +144,7 @@ def fold_arrays(npz, seq, n_decoys, options="", device=0, seed=None, decoy0=0, l
     # launch over more slots takes proportionally longer: profiles/README.md, "How many slots")
     per_lane = (n_decoys + ctx.lanes - 1) // ctx.lanes if n_decoys >= 32 else n_decoys
     ctx.set_pool(SLOTS_PER_LANE if per_lane > SLOTS_PER_LANE else 0)
-    r = ctx.fold_batch(n_decoys, protocol.build_runs(L, args.mode), seed=seed, decoy0=decoy0)
+    r = ctx.fold_batch(n_decoys, protocol.build_runs(L, args.mode, fastrelax=relax_lite(args)), seed=seed, decoy0=decoy0)
     r["seed"] = seed
     bad = _failed(r)
     if len(bad) and not allow_partial:
@@ -168,7 +175,7 @@ def fold_resident_to_pdb(ctx, seq, base_out, names, options="", seed=None, decoy
             seed = _SEED[0]
             _SEED[0] += 1
     os.makedirs(base_out, exist_ok=True)
-    r = ctx.fold_batch(len(names), protocol.build_runs(len(seq), args.mode), seed=seed, decoy0=decoy0)
+    r = ctx.fold_batch(len(names), protocol.build_runs(len(seq), args.mode, fastrelax=relax_lite(args)), seed=seed, decoy0=decoy0)
     _write_decoys(r, seq, base_out, names, seed)
     return r
 

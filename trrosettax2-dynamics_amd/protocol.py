@@ -26,9 +26,9 @@ N_REPEAT = 3         # folding.py:104
 N_DECLASH = 5        # utils_ros.py:700
 
 
-def _run(w, max_iter, sep_lo, sep_hi, precheck=0, skip_to=0, cartesian=0, pair_filter=0):
+def _run(w, max_iter, sep_lo, sep_hi, precheck=0, skip_to=0, cartesian=0, pair_filter=0, tol=0.0):
     return dict(w=list(w), max_iter=max_iter, sep_lo=sep_lo, sep_hi=sep_hi, precheck=precheck, skip_to=skip_to,
-                cartesian=cartesian, pair_filter=pair_filter)
+                cartesian=cartesian, pair_filter=pair_filter, tol=tol)
 
 
 def _declash(runs, w, max_iter, sep_lo, sep_hi, pair_filter=0):
@@ -40,15 +40,55 @@ def _declash(runs, w, max_iter, sep_lo, sep_hi, pair_filter=0):
 
 CART_MAX_L = 512  # the Cartesian step kernel handles one residue per thread, up to 512 threads (csrc/kernel_step.h, cart_body)
 
+# ---- backbone-visible part of the full-atom refinement (folding.py:200-268; include/trx2_model.h "a11-lite") ----------------
+# scorefxn_fa = ref2015_cart + atom_pair 5 / dihedral 1 / angle 1, pro_close 0 (folding.py:202-205).  ref2015_cart's own terms
+# live in the Rosetta database, not in the tree; what this build has of them are the backbone surrogates of the centroid stage,
+# weighted here with ref2015_cart's published weights for the terms they stand in for [Rosetta, from memory -- unverified]:
+# fa_rep 0.55 -> vdw (times the script's ramp), rama_prepro 0.45 -> rama, omega 0.4, cart_bonded 0.5, hbond_sr_bb = hbond_lr_bb 1.0.
+SF_FA = [5.0, 1.0, 1.0, 0.55, 0.45, 0.4, 0.5, 1.0]
+# folding/data/1relax_round1.txt, 2relax_round2.txt: `ramp_repack_min <fa_rep scale> <min tolerance> <coord-cst weight> <max iter>`
+RELAX_RAMP_TORSION = [(0.02, 0.01, 100), (0.25, 0.01, 100), (0.55, 0.01, 100), (1.0, 0.00001, 100)]
+RELAX_RAMP_CART = [(0.02, 0.01, 50), (0.25, 0.01, 50), (0.55, 0.01, 100), (1.0, 0.00001, 200)]
+# The reference hands MinMover 1e-4 and this minimiser needs 1e-6 for the same outcome (include/trx2_model.h TRX2_MIN_TOL,
+# DESIGN.md deviation 1): the scripts' tolerances are scaled by the same factor 0.01.
+RELAX_TOL_SCALE = 0.01
+FILTER_RELAX1, FILTER_RELAX2 = 2, 3   # include/trx2_model.h TRX2_FILTER_RELAX*
 
-def build_runs(L, mode=2, cartesian_stage=None):
+
+def relax_runs(L, cartesian_stage=True):
+    """The two FastRelax rounds as minimiser runs on the backbone (no side chains to repack): round 1 = restraints re-selected at
+    PCUT 0.15 without glycine pairs, torsion ramps x 2 then Cartesian ramps x 1 (1relax_round1.txt); round 2 = PCUT 0.30,
+    Cartesian ramps x 2 (2relax_round2.txt); then the closing Cartesian minimisation without restraints (folding.py:257-263:
+    ref2015_cart, tolerance 1e-5, 100 iterations).  `accept_to_best` and the idealize step are not replicated."""
+    runs = []
+
+    def ramps(table, cart, flt, repeat):
+        for _ in range(repeat):
+            for scale, tol, it in table:
+                w = list(SF_FA)
+                w[3] = SF_FA[3] * scale
+                if not cart:
+                    w[6] = 0.0
+                runs.append(_run(w, it, 1, L, cartesian=1 if cart else 0, pair_filter=flt, tol=tol * RELAX_TOL_SCALE))
+
+    ramps(RELAX_RAMP_TORSION, False, FILTER_RELAX1, 2)
+    ramps(RELAX_RAMP_CART, cartesian_stage, FILTER_RELAX1, 1)
+    ramps(RELAX_RAMP_CART, cartesian_stage, FILTER_RELAX2, 2)
+    w = [0.0, 0.0, 0.0] + SF_FA[3:]
+    runs.append(_run(w, 100, 1, L, cartesian=1 if cartesian_stage else 0, pair_filter=FILTER_RELAX2, tol=0.00001 * RELAX_TOL_SCALE))
+    return runs
+
+
+def build_runs(L, mode=2, cartesian_stage=None, fastrelax=False):
     """Run list for `-m mode` (folding/utils_ros/arguments.py:12).  Mode 3 (folding.py:173-186) first loads the restraints of
     the ORDERED pairs only (add_idr_rst with 1 - idr: runs with pair_filter = 1), then all of them; it needs a map set with its
     idr mask (Context.set_map(idr=...)).
 
     cartesian_stage: run min_mover_cart (folding.py:100-102,170) in Cartesian space, as the reference does.  None = yes for
     chains the Cartesian kernel supports (L <= 512); longer chains run that stage in torsion space with sf_cart's
-    weights (no bonded term), which is what every chain did before the kernel existed."""
+    weights (no bonded term), which is what every chain did before the kernel existed.
+
+    fastrelax: append the backbone-visible part of the reference's full-atom refinement (relax_runs)."""
     if cartesian_stage is None:
         cartesian_stage = L <= CART_MAX_L
     runs = []
@@ -72,4 +112,6 @@ def build_runs(L, mode=2, cartesian_stage=None):
         w_cart = SF_CART if cartesian_stage else SF_CART[:6] + [0.0, SF_CART[7]]  # no bonded term in torsion space
         runs.append(_run(w_cart, MAX_ITER, lo, hi, cartesian=1 if cartesian_stage else 0, pair_filter=flt))
         _declash(runs, SF1, MAX_ITER, lo, hi, pair_filter=flt)    # remove_clash(sf_vdw, min_mover1, pose)
+    if fastrelax:
+        runs += relax_runs(L, cartesian_stage)
     return runs
