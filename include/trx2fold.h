@@ -51,8 +51,11 @@ void trx2_ctx_destroy(trx2_ctx* ctx);
  * host thread), so that one half's step kernel overlaps the other half's pair kernel: +24 % (distances only) / +32 % (all
  * channels) decoys/s at L=150, B=64 on MI355X.  The reference has no counterpart: its decoys are separate OS processes
  * (utils_trX2dy/utils.py:501-503).  Every decoy keeps its identity (seed, decoy0 + index); results equal those of folding the
- * two halves as separate batches.  lanes = 1 (default) restores one stream.  More than three streams folding at once in a
- * process need GPU_MAX_HW_QUEUES=8 (HIP runtime). */
+ * two halves as separate batches.  lanes = 1 (default) restores one stream.  Measured on MI355X, round 3 (one call of 64 decoys,
+ * L=150): two lanes 404 against 344 decoys/s with distances only; two CHAINS of 64 on their own contexts (two streams already)
+ * fold faster with one lane each (637 against 495), L=400 with 32 decoys 90 against 78.  GPU_MAX_HW_QUEUES=8 (HIP runtime) changes
+ * nothing at two or three concurrent streams and costs 16 % at four (2 chains x 2 lanes): the library neither needs nor sets it;
+ * keep a process at two to three folding streams (pipeline.run_single and fold.fold_arrays choose the lanes accordingly). */
 int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes);
 /* Slot pool.  trx2_fold_batch folds its B decoys on min(B, slots) decoy slots; every launch pair serves the slots, and a slot
  * whose decoy has finished takes the next decoy of the batch on the device (no host round trip).  A batch ends with its slowest
@@ -65,9 +68,15 @@ int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes);
 int trx2_ctx_set_pool(trx2_ctx* ctx, int slots);
 /* Tail of a fold.  Once the queue is empty the slots retire one by one, but a launch over several decoy groups (more than 64 slots)
  * keeps its full length while every group still holds a live decoy.  mode 1 (default): whenever the live decoys fit into one group
- * fewer, those of the last group are moved into retired slots on the device and the launches shrink by a group (with that shape's split of the pair kernel: results
- * equal those of mode 0 up to the order in which a residue's gradient records are added).  mode 2: the same with the split kept
- * (bitwise equal to mode 0; slower).  mode 0: off.  No counterpart in the reference (its decoys are separate processes). */
+ * fewer, those of the last group are moved into retired slots on the device and the launches shrink by a group, and below one group
+ * the decoys per wave halve (32, 16, ..), each shape with its own row plan of the pair kernel (how many workgroups a row of the
+ * restraint lists is cut into).  A decoy's arithmetic then differs from mode 0 by the ORDER in which the records of a residue are
+ * added from the moment the shape changes -- rounding, which thousands of minimiser steps amplify: the same kind of difference
+ * as folding the decoy in a batch of another size (measured at L=150, 1280 decoys on 2 x 192 slots: tests/test_gpu_configs.py).
+ * mode 2: groups are dropped with the row plan kept and the waves are never narrowed: bitwise equal to mode 0, ~9 % slower per
+ * call of 64 decoys.  mode 0: off.  No counterpart in the reference (its decoys are separate processes).
+ * Environment (A/B timing and tests only): TRX2_NSPLIT=n cuts every row into n slices whatever the shape; TRX2_ROW_TARGET=t sets
+ * the plan's target of list entries per slice and partner residue of a wave step (default 18). */
 int trx2_ctx_set_tail_compaction(trx2_ctx* ctx, int mode);
 int trx2_last_fold_slot_efficiency(trx2_ctx* ctx, double* eff);
 const char* trx2_last_error(const trx2_ctx* ctx);

@@ -209,7 +209,9 @@ def test_superposition_of_more_than_256_structures_and_nonfinite_input(golden_di
         rm, tm = ctx.superpose_matrix(pts)
         assert rm.shape == (n, n) and np.array_equal(rm, rm.T) and np.array_equal(tm, tm.T)
         assert np.allclose(np.diag(rm), 0, atol=1e-6) and np.allclose(np.diag(tm), 1.0)
-        for i, j in [(0, 1), (0, 299), (255, 256), (256, 257), (299, 298), (128, 290), (7, 7)] + [tuple(rng.integers(0, n, 2)) for _ in range(12)]:
+        for i, j in [(0, 1), (0, 299), (255, 256), (256, 257), (299, 298), (128, 290)] + [tuple(rng.integers(0, n, 2)) for _ in range(12)]:
+            if i == j:   # the diagonal is a square root of rounding noise (1e-7 against 1e-15): checked above with its own tolerance
+                continue
             x, y = pts[i].astype(np.float64), pts[j].astype(np.float64)
             assert abs(rm[i, j] - EV.rmsd_common(x, y)) < 1e-9 and abs(tm[i, j] - EV.tm_score(x, y)) < 1e-9, (i, j)
         # rectangular, more than 65 535 pairs: 300 x 260
