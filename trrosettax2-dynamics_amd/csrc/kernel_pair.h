@@ -157,8 +157,14 @@ __global__ __launch_bounds__(256) void k_build_rows(int L, const unsigned char* 
   if (tid == 0) row_cnt[a] = s_base;
 }
 
+// Register budget: three waves per SIMD where the instantiation fits 168 registers without spilling (all channels at 64 and at 1
+// decoys per wave, every distance-only one), two otherwise: the all-channel kernels at 2 .. 32 decoys per wave spill 1-9
+// registers at three, inside the visit loop -- 19 MB of scratch stores and as many reloads per launch at L=400 with 16 decoys
+// per wave (WRITE_SIZE 19.5 MB against 0.8 MB of records, profiles/r03_traffic.json) for no gain in time (32.5 against 31.9 us).
 template <int BW, int FAM>
-__global__ __launch_bounds__(PAIR_THREADS, (FAM & FAM_ANG) ? PAIR_MIN_WAVES : PAIR_MIN_WAVES_DIST) void k_pair(PairArgs A) {
+constexpr int pair_min_waves() { return (FAM & FAM_ANG) ? ((BW == 64 || BW == 1) ? PAIR_MIN_WAVES : 2) : PAIR_MIN_WAVES_DIST; }
+template <int BW, int FAM>
+__global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_pair(PairArgs A) {
   constexpr int PW = 64 / BW;
   const int L = A.L;
   // Work item = (row a, slice, slices of that row): rows are cut into a number of slices that follows their list length (the
