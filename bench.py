@@ -502,7 +502,7 @@ def main():
                 # the other single-GPU configs of BASELINE.json, shorter legs of the same measurement
                 sub = {}
                 for c in (3, 4):
-                    r, _, _ = single_target(args, CONFIGS[c], c, T, synth, rank, local_rank, world, dist, forced, max(1, min(2, args.steps)), 1, False)
+                    r, _, _ = single_target(args, CONFIGS[c], c, T, synth, rank, local_rank, world, dist, forced, max(1, min(5, args.steps)), 1, False)
                     sub[f"config{c}"] = compact(r)
                 out["sub_records"] = sub
             else:

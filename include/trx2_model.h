@@ -80,9 +80,11 @@ enum {
 #define TRX2_VDW_SCALE 0.8
 #define TRX2_VDW_MINSEP 3
 /* skip residue pairs with |CA-CA|^2 above this.  An atom pair contributes only when d < r0, and d >= |CA-CA| - |CA-X_a| -
- * |CA-X_b|; with the ideal extents (N 1.458, C 1.524, CB 1.53, O 2.40) the largest r0 + extents is O-O: 3.01 + 4.80 = 7.81,
- * so 8.5 leaves 0.7 A for distorted Cartesian-stage geometry. */
-#define TRX2_VDW_CUT2 (8.5 * 8.5)
+ * |CA-X_b|; with the ideal extents (N 1.458, C 1.524, CB 1.53, O 2.40) the largest r0 + extents is O-O: 3.01 + 4.80 = 7.81
+ * (next: C-O 7.30, CB-CB 7.21), and a hydrogen bond needs |CA-CA| <= 1.458 + 1.01 + 3.00 + 2.40 = 7.87 (N-H...O within its
+ * support).  8.0 leaves 0.13-0.19 A for the Cartesian stage's geometry, whose bonded term holds bonds to 0.01 A (measured sd).
+ * (8.5 until round 3: a sixth more contacts to walk, none of which can contribute.) */
+#define TRX2_VDW_CUT2 (8.0 * 8.0)
 /* r0 by atom-type pair, order N CA C O CB (0.1-percentile closest approach, |i-j|>=3, in the decoys) */
 #define TRX2_VDW_R0_INIT                                                                               \
   {                                                                                                    \
