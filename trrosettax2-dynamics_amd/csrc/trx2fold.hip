@@ -171,6 +171,42 @@ static double round_txt(double v, int dp) {
 
 static std::atomic<int> g_live_contexts{0};  // contexts alive in this process (lanes are contexts too): step_dyn_budget
 
+// Stream pool.  HIP maps a process's streams onto GPU_MAX_HW_QUEUES = 4 hardware queues, and a stream that has launched work keeps
+// its queue while it lives: with two used streams left alive (contexts a caller cached and never closed: bench.py's e2e leg did),
+// the streams of the next two contexts came to share ONE hardware queue -- their kernels serialised and two concurrent chains
+// folded at 493 instead of 805 decoys/s (profiles/README.md, round 3).  So the library owns four streams per device, created
+// together (consecutive hardware queues), for the life of the process, and a context takes the least-used one: up to four
+// concurrently folding contexts (two chains x two lanes) never share a queue, whatever was created, used and leaked before.
+// More than four share streams in turn (their work serialises per stream, which two streams on one queue did anyway).
+#include <map>
+#include <mutex>
+#define TRX2_POOL_STREAMS 4
+struct StreamPool { hipStream_t s[TRX2_POOL_STREAMS] = {nullptr, nullptr, nullptr, nullptr}; int use[TRX2_POOL_STREAMS] = {0, 0, 0, 0}; bool ready = false; };
+static std::mutex g_pool_mutex;
+static std::map<int, StreamPool> g_pools;
+static hipStream_t pool_acquire(int device) {
+  std::lock_guard<std::mutex> lk(g_pool_mutex);
+  StreamPool& P = g_pools[device];
+  if (!P.ready) {
+    for (int k = 0; k < TRX2_POOL_STREAMS; k++)
+      if (hipStreamCreateWithFlags(&P.s[k], hipStreamNonBlocking) != hipSuccess) {
+        for (int q = 0; q < k; q++) { (void)hipStreamDestroy(P.s[q]); P.s[q] = nullptr; }
+        return nullptr;
+      }
+    P.ready = true;
+  }
+  int best = 0;
+  for (int k = 1; k < TRX2_POOL_STREAMS; k++) if (P.use[k] < P.use[best]) best = k;
+  P.use[best]++;
+  return P.s[best];
+}
+static void pool_release(int device, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_pool_mutex);
+  auto it = g_pools.find(device);
+  if (it == g_pools.end()) return;
+  for (int k = 0; k < TRX2_POOL_STREAMS; k++) if (it->second.s[k] == st && it->second.use[k] > 0) it->second.use[k]--;
+}
+
 extern "C" int trx2_abi_version(void) { return 1; }
 
 extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
@@ -179,7 +215,7 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return 2;
   trx2_ctx* ctx = new trx2_ctx();
   ctx->device = device;
-  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipSetDevice(device) != hipSuccess || (ctx->stream = pool_acquire(device)) == nullptr) {
     delete ctx;
     return 3;
   }
@@ -214,6 +250,7 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
       ok = hipFuncSetAttribute(fstep[k], hipFuncAttributeMaxDynamicSharedMemorySize, dyn) == hipSuccess;
     }
     if (!ok) {
+      pool_release(device, ctx->stream);
       delete ctx;
       return 4;
     }
@@ -240,6 +277,7 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
       hipMemcpyToSymbol(HIP_SYMBOL(c_rama), rm, sizeof rm) != hipSuccess ||
       hipMemcpyToSymbol(HIP_SYMBOL(c_rama_sc), rsc, sizeof rsc) != hipSuccess ||
       hipHostMalloc((void**)&ctx->h_done, sizeof(int)) != hipSuccess) {
+    pool_release(device, ctx->stream);
     delete ctx;
     return 4;
   }
@@ -367,7 +405,7 @@ extern "C" void trx2_ctx_destroy(trx2_ctx* ctx) {
   free_batch(ctx);
   if (ctx->fb_buf) (void)hipFree(ctx->fb_buf);
   if (ctx->h_done) (void)hipHostFree(ctx->h_done);
-  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream) pool_release(ctx->device, ctx->stream);  // the stream itself belongs to the pool (synchronised above)
   delete ctx;
 }
 

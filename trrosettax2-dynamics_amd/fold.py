@@ -76,6 +76,15 @@ def get_context(device=0, lanes=1):
     return _CTX[key]
 
 
+def close_contexts(all_threads=False):
+    """Close the calling thread's cached context(s) (all_threads: every cached one -- only when no other thread is folding).
+    A context holds a stream, its maps and its batch buffers on the GPU; a worker thread that ends without this leaves them
+    allocated until the process ends."""
+    me = threading.get_ident()
+    for key in [k for k in list(_CTX) if all_threads or k[1] == me]:
+        _CTX.pop(key).close()
+
+
 def set_restraints(ctx, npz, seq, args, ang):
     """the `-r` switch of folding/folding.py:60-68 + the idr mask mode 3 needs (folding.py:174)"""
     need_idr = args.rst in ("idp", "gpcr") or args.mode == 3

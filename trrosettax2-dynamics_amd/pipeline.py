@@ -21,7 +21,7 @@ import numpy as np
 
 from . import sched
 from .feedback import calculate_reliability_score, feedback_labels
-from .fold import fold_arrays_to_pdb, fold_resident_to_pdb, get_context
+from .fold import close_contexts, fold_arrays_to_pdb, fold_resident_to_pdb, get_context
 from .pdbio import as_read_from_pdb, read_backbone, read_fasta
 
 
@@ -198,6 +198,12 @@ def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mu
         paths[tag] = path
 
     def chain(tag, name_offset):
+        try:
+            return chain_(tag, name_offset)
+        finally:
+            close_contexts()     # this worker thread's context: its stream, maps and buffers go with the thread
+
+    def chain_(tag, name_offset):
         # The reference runs the X-ray chain after the NMR one and continues its file numbering (begin_num = number of NMR
         # iterations, run_inference.py:315-318).  The chains are otherwise independent, so here they are folded
         # CONCURRENTLY (one context = one stream each; x1.7 on one GPU) with provisional names, and the X-ray iteration
@@ -219,7 +225,7 @@ def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mu
             os.rename(os.path.join(xdir, f"{name}__x{k}.pdb"), os.path.join(xdir, f"{name}{num + k}.pdb"))
         total = num + nx
     else:
-        num = total = chain("NMR", "")
+        num = total = chain_("NMR", "")   # on the calling thread: its context stays cached for the next target
     n_out = total + init_num * len(maps)
     print("All structures generation finished.")
     print(f"Total structures generated: {n_out}")
