@@ -447,8 +447,18 @@ __global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_p
   {
     float vals[PR_REC] = {gN.x, gN.y, gN.z, gCA.x, gCA.y, gCA.z, gC.x, gC.y, gC.z, gO.x, gO.y, gO.z,
                            gCB.x, gCB.y, gCB.z, gH.x, gH.y, gH.z, e_d, e_o, e_t, e_p, e_v, e_h};
+    // lane distances below 16: rotations inside the rows of 16 lanes (DPP row_ror, VALU speed; every lane of a decoy ends with
+    // the row's sum, in its own order of additions -- only the h = 0 lane is used); 16 and 32: ds_bpermute
 #pragma unroll
-    for (int o = BW; o < 64; o <<= 1)
+    for (int o = BW; o < 16; o <<= 1)
+#pragma unroll
+      for (int k = 0; k < PR_REC; k++)
+        vals[k] += __int_as_float(o == 1 ? __builtin_amdgcn_update_dpp(0, __float_as_int(vals[k]), 0x121, 0xF, 0xF, false)
+                                  : o == 2 ? __builtin_amdgcn_update_dpp(0, __float_as_int(vals[k]), 0x122, 0xF, 0xF, false)
+                                  : o == 4 ? __builtin_amdgcn_update_dpp(0, __float_as_int(vals[k]), 0x124, 0xF, 0xF, false)
+                                           : __builtin_amdgcn_update_dpp(0, __float_as_int(vals[k]), 0x128, 0xF, 0xF, false));
+#pragma unroll
+    for (int o = (BW < 16 ? 16 : BW); o < 64; o <<= 1)
 #pragma unroll
       for (int k = 0; k < PR_REC; k++) vals[k] += __shfl_xor(vals[k], o, 64);
     if (h == 0) {

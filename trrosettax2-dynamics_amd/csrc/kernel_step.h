@@ -54,20 +54,36 @@ struct ChainArgs {
   int* out_stat;           // [n_total][4] status, evaluations, accepted iterations, slot
 };
 
-// Sum of the pair kernel's records of residue r of decoy dec over the slices of its row (24 floats: gradient on N CA C O CB H,
-// then the energies dist omega theta phi vdw hb).  Fixed order: deterministic.
-__device__ __forceinline__ void sum_pair_records(const float* FA, const unsigned char* nslice, int B, int L, int dec, int r, float (&g)[PR_NCOMP], float (&e)[6]) {
-  const int nsplit = nslice[r];
+// Sum of the pair kernel's records of residue r of decoy dec over the nsplit slices of its row (24 floats: gradient on N CA C O
+// CB H, then the energies dist omega theta phi vdw hb).  Fixed order: deterministic.
+template <bool PRE0>
+__device__ __forceinline__ void sum_pair_records(const float* FA, int nsplit, int B, int L, int dec, int r, float (&g)[PR_NCOMP], float (&e)[6], const float4 (&p0)[6]) {
 #pragma unroll
   for (int i = 0; i < PR_NCOMP; i++) g[i] = 0.0f;
 #pragma unroll
   for (int i = 0; i < 6; i++) e[i] = 0.0f;
-  for (int sl = 0; sl < nsplit; sl++) {
+  if (PRE0) {  // slice 0 (every row has one) came with the caller's early requests
+    g[0] += p0[0].x; g[1] += p0[0].y; g[2] += p0[0].z; g[3] += p0[0].w; g[4] += p0[1].x; g[5] += p0[1].y; g[6] += p0[1].z; g[7] += p0[1].w;
+    g[8] += p0[2].x; g[9] += p0[2].y; g[10] += p0[2].z; g[11] += p0[2].w; g[12] += p0[3].x; g[13] += p0[3].y; g[14] += p0[3].z; g[15] += p0[3].w;
+    g[16] += p0[4].x; g[17] += p0[4].y; e[0] += p0[4].z; e[1] += p0[4].w; e[2] += p0[5].x; e[3] += p0[5].y; e[4] += p0[5].z; e[5] += p0[5].w;
+  }
+  // two slices per trip, both requested before either is added (one round trip per two slices; a row has 1 .. 8 of them, and
+  // the caller asked for the count -- nslice[r] -- at the top of the kernel: it was one more dependent round trip here).  The
+  // additions keep their order, slice by slice.
+  for (int sl = PRE0 ? 1 : 0; sl < nsplit; sl += 2) {
+    const bool two = sl + 1 < nsplit;
     const float4* f = reinterpret_cast<const float4*>(FA + (((size_t)sl * B + dec) * L + r) * PR_REC);
+    const float4* h = reinterpret_cast<const float4*>(FA + (((size_t)(two ? sl + 1 : sl) * B + dec) * L + r) * PR_REC);
     const float4 v0 = f[0], v1 = f[1], v2 = f[2], v3 = f[3], v4 = f[4], v5 = f[5];
+    const float4 u0 = h[0], u1 = h[1], u2 = h[2], u3 = h[3], u4 = h[4], u5 = h[5];
     g[0] += v0.x; g[1] += v0.y; g[2] += v0.z; g[3] += v0.w; g[4] += v1.x; g[5] += v1.y; g[6] += v1.z; g[7] += v1.w;
     g[8] += v2.x; g[9] += v2.y; g[10] += v2.z; g[11] += v2.w; g[12] += v3.x; g[13] += v3.y; g[14] += v3.z; g[15] += v3.w;
     g[16] += v4.x; g[17] += v4.y; e[0] += v4.z; e[1] += v4.w; e[2] += v5.x; e[3] += v5.y; e[4] += v5.z; e[5] += v5.w;
+    if (two) {
+      g[0] += u0.x; g[1] += u0.y; g[2] += u0.z; g[3] += u0.w; g[4] += u1.x; g[5] += u1.y; g[6] += u1.z; g[7] += u1.w;
+      g[8] += u2.x; g[9] += u2.y; g[10] += u2.z; g[11] += u2.w; g[12] += u3.x; g[13] += u3.y; g[14] += u3.z; g[15] += u3.w;
+      g[16] += u4.x; g[17] += u4.y; e[0] += u4.z; e[1] += u4.w; e[2] += u5.x; e[3] += u5.y; e[4] += u5.z; e[5] += u5.w;
+    }
   }
 }
 // backbone H from C of the previous residue, N, CA: in-plane bisector (trx2_model.h; oracle: orc_place_h)
@@ -340,6 +356,35 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
   }
   if (tid < SD_N) s_d[tid] = gd_[tid];
   if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
+  // per-residue constants of the map and of the launch shape, requested with the state: the slice count of this residue's row
+  // (the record sums depend on it) and whether the next residue carries a backbone H (the last store of the kernel does)
+  int nsl_pre = 0;
+  bool hH_next = false;
+  // ... and everything of the evaluation this residue consumes that does not depend on the decoy's state: trial torsions and
+  // coordinates, the first slice of the pair records, the accepted point with its gradient and direction.  Requested before the
+  // role test instead of after it, their round trip runs beside the state's instead of behind it (~2000 cycles of a step).  A
+  // workgroup whose role is not the decoy's current one has asked in vain: 13 % of the torsion role's launches.
+  float4 e_xt, e_c[6], e_fa[6], e_x, e_g, e_dv;
+  e_xt = e_x = e_g = e_dv = make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int q = 0; q < 6; q++) e_c[q] = e_fa[q] = make_float4(0, 0, 0, 0);
+  if (RPT == 1) {
+    const int rc = min(tid, L - 1);
+    hH_next = A.hasH[min(tid + 1, L - 1)] != 0;
+    if (A.mode != MODE_INIT) {
+      nsl_pre = A.nslice[rc];
+      const size_t vr = (size_t)dec * L + rc;
+      e_xt = A.XT[vr];
+      const float4* xp = A.P + vr * 5;
+#pragma unroll
+      for (int q = 0; q < 5; q++) e_c[q] = xp[q];
+      e_c[5] = xp[rc + 1 < L ? 5 : 0];
+      const float4* f0 = reinterpret_cast<const float4*>(A.FA + ((size_t)dec * L + rc) * PR_REC);
+#pragma unroll
+      for (int q = 0; q < 6; q++) e_fa[q] = f0[q];
+      if (A.mode == MODE_STEP) { e_x = A.X[vr]; e_g = A.G[vr]; e_dv = A.D[vr]; }
+    }
+  }
   constexpr bool HIST_LDS = (RPT == 1 && NT <= 256);  // chains of up to 256 residues: the history staged in LDS for the step
   // One residue per thread (chains of up to 512 residues on up to 512 threads): the recursion in its Gram form.  The 144
   // scalars do not depend on the chain length.  Beyond 256 residues the stored vectors are not staged in LDS (128 KB at 512
@@ -392,23 +437,33 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
     for (int k = 0; k < RPT; k++) {
       const int r = k * NT + tid;
       x[k] = g[k] = dv[k] = make_float4(0, 0, 0, 0);
-      if (r < L && A.mode == MODE_STEP) { x[k] = A.X[vb + r]; g[k] = A.G[vb + r]; dv[k] = A.D[vb + r]; }
+      if (RPT == 1) { if (r < L) { x[k] = e_x; g[k] = e_g; dv[k] = e_dv; } }   // (zeros unless MODE_STEP)
+      else if (r < L && A.mode == MODE_STEP) { x[k] = A.X[vb + r]; g[k] = A.G[vb + r]; dv[k] = A.D[vb + r]; }
     }
     double esum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     f3 g2[RPT], g1[RPT];       // per-residue sums of gradient / x cross gradient
     f3 gO_[RPT], gC_[RPT], gCB_[RPT], pN[RPT], pCA[RPT], pC[RPT], pO[RPT], pCB[RPT];
+    float4 nxq[RPT];  // N of the next residue (the omega axis ends there): requested with this residue's atoms, used after the scan
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
       const int r = k * NT + tid;
       xt[k] = make_float4(0, 0, 0, 0);
+      nxq[k] = make_float4(0, 0, 0, 0);
       gt[k] = make_float4(0, 0, 0, 0);
       g2[k] = g1[k] = gO_[k] = gC_[k] = gCB_[k] = pN[k] = pCA[k] = pC[k] = pO[k] = pCB[k] = mk3(0, 0, 0);
       if (r < L) {
-        xt[k] = A.XT[vb + r];
         const float4* xp = A.P + (vb + r) * 5;
-        const float4 c0 = xp[0], c1 = xp[1], c2 = xp[2], c3 = xp[3], c4 = xp[4];
+        float4 c0, c1, c2, c3, c4;
         float g[PR_NCOMP], ep[6];
-        sum_pair_records(A.FA, A.nslice, A.B, L, dec, r, g, ep);
+        if (RPT == 1) {
+          xt[k] = e_xt; c0 = e_c[0]; c1 = e_c[1]; c2 = e_c[2]; c3 = e_c[3]; c4 = e_c[4]; nxq[k] = e_c[5];
+          sum_pair_records<true>(A.FA, nsl_pre, A.B, L, dec, r, g, ep, e_fa);
+        } else {
+          xt[k] = A.XT[vb + r];
+          c0 = xp[0]; c1 = xp[1]; c2 = xp[2]; c3 = xp[3]; c4 = xp[4];
+          nxq[k] = xp[r + 1 < L ? 5 : 0];
+          sum_pair_records<false>(A.FA, (int)A.nslice[r], A.B, L, dec, r, g, ep, e_fa);
+        }
         esum[0] += ep[0]; esum[1] += ep[1]; esum[2] += ep[2]; esum[3] += ep[3]; esum[4] += ep[4]; esum[8] += ep[5];
         pN[k] = mk3(c0.x, c0.y, c0.z); pCA[k] = mk3(c0.w, c1.x, c1.y); pC[k] = mk3(c1.z, c1.w, c2.x);
         pO[k] = mk3(c2.y, c2.z, c2.w); pCB[k] = mk3(c3.x, c3.y, c3.z);
@@ -455,14 +510,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
 #pragma unroll
     for (int k = RPT - 1; k >= 0; k--) {
       float v[6] = {g2[k].x, g2[k].y, g2[k].z, g1[k].x, g1[k].y, g1[k].z};
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-          float t = __shfl_down(v[i], o, 64);
-          if (lane + o < 64) v[i] += t;
-        }
-      }
+      wave_suffix_sums<6>(v, lane);
       bsync<NW>();
       if (lane == 0)
 #pragma unroll
@@ -484,7 +532,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
       if (r < L) {
         // omega_r: axis C_r -> N_{r+1}
         if (r + 1 < L) {
-          const float4 nx = A.P[(vb + r + 1) * 5];
+          const float4 nx = nxq[k];
           f3 Nn = mk3(nx.x, nx.y, nx.z);
           f3 n = unit(Nn - pC[k]);
           gt[k].z += dot(n, ex1) - dot(cross(n, pC[k]), ex2);
@@ -1006,12 +1054,7 @@ next_pair:
     }
     CSTAMP(10)  // NeRF: geometry loads, sincos, local frames
     // inclusive scan of M within the wave
-    Xf P = M;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      Xf t = xf_shfl_up(P, o);
-      if (lane >= o) P = xf_compose(t, P);
-    }
+    Xf P = xf_wave_scan(M, lane);
     bsync<NW>();
     if (lane == 63) {
 #pragma unroll
@@ -1033,7 +1076,7 @@ next_pair:
     }
     CSTAMP(11)  // NeRF: scan of rigid transforms (in-wave + across waves)
     // frame of residue r = pre o (inclusive scan of the previous lane)
-    Xf prev = xf_shfl_up(P, 1);
+    Xf prev = xf_from_lane_below(P);
     Xf F = (lane == 0) ? pre : xf_compose(pre, prev);
     carry = tot;
     if (r < L) {
@@ -1056,7 +1099,7 @@ next_pair:
       }
       if (r + 1 < L) {
         const f3 Hn = xf_apply(F, place_h(lC, lNn, lCAn));
-        const float4 hv = make_float4(Hn.x, Hn.y, Hn.z, A.hasH[r + 1] ? 1.0f : 0.0f);
+        const float4 hv = make_float4(Hn.x, Hn.y, Hn.z, (RPT == 1 ? hH_next : A.hasH[r + 1] != 0) ? 1.0f : 0.0f);
         xo[5 + 4] = hv;
         if (xT) xT[(5 + 4) * A.BW] = hv;
       }
@@ -1127,8 +1170,20 @@ __device__ __forceinline__ LinkGrad link_terms(const Res5& P, const Res5& Q) {
   G.e = e; return G;
 }
 
+// One stored pair of the Cartesian role for this thread's residue: from its staged LDS slot, or from global memory (pair j).
 template <int NT>
-__device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int* s_runs) {
+__device__ __forceinline__ void cart_hist_fetch(const CartArgs& A, int dec, int L, int rc, bool staged, int slot, int j, float4 (&s_)[4], float4 (&y_)[4]) {
+  if (NT <= 256 && staged) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) { s_[q] = s_hist[(size_t)((slot * 2 + 0) * 4 + q) * L + rc]; y_[q] = s_hist[(size_t)((slot * 2 + 1) * 4 + q) * L + rc]; }
+  } else {
+    const size_t o = ((size_t)dec * LBM + j) * 4 * L + rc;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { s_[q] = A.CS[o + (size_t)q * L]; y_[q] = A.CY[o + (size_t)q * L]; }
+  }
+}
+template <int NT>
+__device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int* s_runs, GramLds<NT>& s_gl) {
   constexpr int NW = NT / 64;  // one residue per thread: NT = 256 for chains up to 256 residues, 512 up to 512
   const int L = A.L, tid = threadIdx.x, r = tid;
   const bool act = r < L;
@@ -1153,6 +1208,19 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
   }
   if (tid < SD_N) s_d[tid] = gd_[tid];
   if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
+  const int nsl_pre = A.nslice[min(tid, L - 1)];       // slices of this residue's row; backbone H of this residue: requested with the state
+  const bool hH_me = A.hasH[min(tid, L - 1)] != 0;
+  // The decoy's Gram scalars (kernel_step.h, "Gram form"): one set per decoy serves both roles -- a decoy is in one role at a
+  // time and every run starts from an empty history, whose scalars are zeros.
+  double gr_old0 = 0, gr_old1 = 0;
+  // Chains of more than 256 residues (512 threads, 256 registers per thread, no staged history) keep the two-loop form: the
+  // Gram form holds the new pair and two buffered pairs beside the recurrences and spilled 204 registers there.
+  constexpr bool CG = NT <= 256;
+  if (CG) {
+    if (tid < 2 * LBM * LBM) { gr_old0 = A.gram[(size_t)dec * GR_N + tid]; s_gl.gram[tid] = gr_old0; }
+    if (tid < 2 * LBM) { gr_old1 = A.gram[(size_t)dec * GR_N + 2 * LBM * LBM + tid]; s_gl.gram[2 * LBM * LBM + tid] = gr_old1; }
+  }
+  bool gram_dirty = false;
   __syncthreads();
   const trx2_run* runs_l = reinterpret_cast<const trx2_run*>(s_runs);
   int run = s_i[SI_RUN], phase = s_i[SI_PHASE];
@@ -1160,10 +1228,10 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
   const trx2_run R = runs_l[min(run, A.nruns - 1)];
   if (!R.cartesian) return;
   const size_t vb = (size_t)dec * L;
-  // The stored pairs, newest first, requested into LDS now and read by the two-loop a phase later (as the torsion role does):
+  // The stored pairs, newest first, requested into LDS now and read by the recursion a phase later (as the torsion role does):
   // slot t = the t-th newest pair, [s | y][4 components][L] float4.  The rows are exactly L long -- lanes beyond the chain
   // are switched off, LDS-DMA writes only for active lanes -- so that 7 pairs of a 150-residue chain fit beside the
-  // kernel's static LDS; what does not fit (long chains) is read from global memory in the recursion.
+  // kernel's static LDS; what does not fit is read from global memory in the recursion.
   const int hl0 = s_i[SI_HL], hh0 = s_i[SI_HH];
   const int nl = (NT <= 256) ? min(hl0, A.hist_lds) : 0;
   if (NT <= 256 && act) {
@@ -1191,7 +1259,8 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
 #pragma unroll
     for (int q = 0; q < 4; q++) { xt[q] = xp[q]; reinterpret_cast<float4*>(s_xyz + r * 16)[q] = xt[q]; }
     float g[PR_NCOMP], ep[6];
-    sum_pair_records(A.FA, A.nslice, A.B, L, dec, r, g, ep);
+    const float4 none[6] = {};
+    sum_pair_records<false>(A.FA, nsl_pre, A.B, L, dec, r, g, ep, none);
     esum[0] += ep[0]; esum[1] += ep[1]; esum[2] += ep[2]; esum[3] += ep[3]; esum[4] += ep[4]; esum[8] += ep[5];
     gt[0] = make_float4(g[0], g[1], g[2], g[3]); gt[1] = make_float4(g[4], g[5], g[6], g[7]);
     gt[2] = make_float4(g[8], g[9], g[10], g[11]); gt[3] = make_float4(g[12], g[13], g[14], 0.0f);
@@ -1347,8 +1416,61 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
       for (int q = 0; q < 4; q++) {
         sv[q] = make_float4(xt[q].x - x[q].x, xt[q].y - x[q].y, xt[q].z - x[q].z, xt[q].w - x[q].w);
         yv[q] = make_float4(gt[q].x - g[q].x, gt[q].y - g[q].y, gt[q].z - g[q].z, gt[q].w - g[q].w);
-        v3[0] += (double)dot4(sv[q], yv[q]); v3[1] += (double)dot4(sv[q], sv[q]); v3[2] += (double)dot4(yv[q], yv[q]);
       }
+      if constexpr (CG) {
+        // Every product of the new pair and the new gradient with the stored pairs, ONE fused reduction (as the torsion role;
+        // the two-loop form made 2 x 8 dependent rounds of { dot, workgroup sum, axpy } here: 42 % of this role's step at
+        // L = 150, profiles/README.md round 3).  The stored pairs by their age BEFORE this step: age k < nl was staged in
+        // LDS slot k at the top of the step, the others come from global memory, two pairs at a time.  Everything is indexed
+        // by compile-time constants (a runtime index would move pv[] to scratch); the tests on hl / nl are wave-uniform.
+        if (NT <= 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged pairs have landed (long ago)
+        float pv[GV_N];
+#pragma unroll
+        for (int q = 0; q < GV_N; q++) pv[q] = 0.0f;
+        const int rc = min(r, L - 1);
+        // two named buffers: pair k + 1 is requested before pair k is consumed; the scheduling barrier keeps the compiler from
+        // hoisting every load of the unrolled loop to the top (362 registers, 206 spilled on 512 threads)
+        float4 b0s[4], b0y[4], b1s[4], b1y[4];
+        if (0 < hl) cart_hist_fetch<NT>(A, dec, L, rc, 0 < nl, 0, (hh - 1 + LBM) % LBM, b0s, b0y);
+#pragma unroll
+        for (int k = 0; k < LBM; k++) {
+          float4 (&cs_)[4] = (k & 1) ? b1s : b0s; float4 (&cy_)[4] = (k & 1) ? b1y : b0y;
+          float4 (&ns_)[4] = (k & 1) ? b0s : b1s; float4 (&ny_)[4] = (k & 1) ? b0y : b1y;
+          if (k + 1 < LBM && k + 1 < hl) cart_hist_fetch<NT>(A, dec, L, rc, k + 1 < nl, k + 1, (hh - 2 - k + 2 * LBM) % LBM, ns_, ny_);
+          if (k < hl) {
+            float a = 0, b = 0, c = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { a += dot4(cs_[q], yv[q]); b += dot4(cy_[q], yv[q]); c += dot4(sv[q], cy_[q]); }
+            // idle threads hold copies of the last residue: selected out
+            pv[GV_A + k] = act ? a : 0.0f; pv[GV_B + k] = act ? b : 0.0f;
+            if (k < LBM - 1) pv[GV_C + k] = act ? c : 0.0f;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {  // (s, y, gt are zero in idle threads)
+          pv[GV_SY] += dot4(sv[q], yv[q]); pv[GV_SS] += dot4(sv[q], sv[q]); pv[GV_YY] += dot4(yv[q], yv[q]);
+          pv[GV_SG] += dot4(sv[q], gt[q]); pv[GV_YG] += dot4(yv[q], gt[q]); pv[GV_GG] += dot4(gt[q], gt[q]);
+        }
+        gram_reduce<NT>(pv, s_gl);
+        v3[0] = s_gl.out[GV_SY]; v3[1] = s_gl.out[GV_SS]; v3[2] = s_gl.out[GV_YY];
+        if (v3[0] > 1e-12 * sqrt(v3[1] * v3[2])) {
+          if (act)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              A.CS[(((size_t)dec * LBM + hh) * 4 + q) * L + r] = sv[q];
+              A.CY[(((size_t)dec * LBM + hh) * 4 + q) * L + r] = yv[q];
+            }
+          stored = true;
+          gamma_h = v3[0] / v3[2];
+          hh = (hh + 1) % LBM;
+          if (hl < LBM) hl++;
+        }
+        gram_advance<NT>(s_gl, stored, gr_old0, gr_old1);  // ends with a barrier
+        gram_dirty = true;
+      } else {
+#pragma unroll
+      for (int q = 0; q < 4; q++) { v3[0] += (double)dot4(sv[q], yv[q]); v3[1] += (double)dot4(sv[q], sv[q]); v3[2] += (double)dot4(yv[q], yv[q]); }
       block_sum_n<3, NW>(v3, s_buf, flip);
       if (v3[0] > 1e-12 * sqrt(v3[1] * v3[2])) {
         if (act)
@@ -1364,6 +1486,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
         __syncthreads();
         hh = (hh + 1) % LBM;
         if (hl < LBM) hl++;
+      }
       }
       const double fprev = f;
 #pragma unroll
@@ -1387,11 +1510,54 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
   CSTAMP(22)  // Armijo / (s, y) pair
   if (new_dir) {
     CCOUNT(29)
-    // Two-loop recursion, 8 float4 per thread and stored pair.  Loads are branch-free (index clamped to the last residue; idle
-    // threads are masked out of the dot and the update instead) so that a pair's eight loads issue together -- guarded
-    // per element, each load had its own branch and wait (~2000 cycles per round, 57 % of a Cartesian step: s_memtime
-    // stamps, profiles/README.md).  Two named buffers and a loop unrolled by two keep the next pair in flight without a
-    // register copy (a copy makes the compiler wait for the load it has just issued).
+    if constexpr (CG) {
+    // The recurrences on the Gram scalars (every thread, no barrier), then ONE pass over the stored vectors: r = gamma g + sum_m
+    // cy_m y_m + cs_m s_m with m the age AFTER this step -- m = 0 is the pair stored a moment ago (registers), age m was age
+    // m - 1 before (staged slot m - 1, or global memory).
+    float4 qv[4];
+    {
+      float cy[LBM], cs[LBM];
+      double g_r;
+      gram_recursion(s_gl.gram, hl, gamma_h, s_gl.out[GV_GG], cy, cs, g_r);
+      CSTAMP(23)  // recurrences on the Gram scalars
+      const float gam = (float)gamma_h;
+#pragma unroll
+      for (int q = 0; q < 4; q++) qv[q] = make_float4(gam * g[q].x, gam * g[q].y, gam * g[q].z, gam * g[q].w);
+      const int rc = min(r, L - 1), sh = stored ? 1 : 0;
+      float4 b0s[4], b0y[4], b1s[4], b1y[4];
+      if (sh) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) { b0s[q] = sv[q]; b0y[q] = yv[q]; }
+      } else if (0 < hl) cart_hist_fetch<NT>(A, dec, L, rc, 0 < nl, 0, (hh - 1 + LBM) % LBM, b0s, b0y);
+#pragma unroll
+      for (int m = 0; m < LBM; m++) {
+        float4 (&cs_)[4] = (m & 1) ? b1s : b0s; float4 (&cy_)[4] = (m & 1) ? b1y : b0y;
+        float4 (&ns_)[4] = (m & 1) ? b0s : b1s; float4 (&ny_)[4] = (m & 1) ? b0y : b1y;
+        if (m + 1 < LBM && m + 1 < hl) cart_hist_fetch<NT>(A, dec, L, rc, m + 1 - sh < nl, m + 1 - sh, (hh - 2 - m + 2 * LBM) % LBM, ns_, ny_);
+        if (m < hl) {
+          const float a = cs[m], b = cy[m];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            qv[q].x = fmaf(b, cy_[q].x, fmaf(a, cs_[q].x, qv[q].x)); qv[q].y = fmaf(b, cy_[q].y, fmaf(a, cs_[q].y, qv[q].y));
+            qv[q].z = fmaf(b, cy_[q].z, fmaf(a, cs_[q].z, qv[q].z)); qv[q].w = fmaf(b, cy_[q].w, fmaf(a, cs_[q].w, qv[q].w));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      CSTAMP(25)  // direction from the stored vectors
+      const float4 z4 = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; q++) dv[q] = act ? make_float4(-qv[q].x, -qv[q].y, -qv[q].z, -qv[q].w) : z4;
+      const double gd = -g_r, gg = s_gl.out[GV_GG];
+      if (!(gg > 0)) next_run = true;
+      else if (hl == 0 || !(gd < 0)) { hl = 0; steepest = true; }
+      else { gdir = gd; alpha = 1.0; nls = 0; new_trial = true; }
+    }
+    } else {
+    // Chains of 257-512 residues: two-loop recursion on global memory, 8 float4 per thread and stored pair.  Loads are branch-free
+    // (index clamped to the last residue; idle threads are masked out of the dot and the update instead) so that a pair's eight
+    // loads issue together -- guarded per element, each load had its own branch and wait (~2000 cycles per round: s_memtime
+    // stamps, profiles/README.md).
     float4 qv[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) qv[q] = g[q];
@@ -1424,80 +1590,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
 #pragma unroll
       for (int q = 0; q < 4; q++) { qv[q].x += c * s_[q].x; qv[q].y += c * s_[q].y; qv[q].z += c * s_[q].z; qv[q].w += c * s_[q].w; }
     };
-    // Where the pairs come from, newest (kk = 0) to oldest.  NT <= 256: the pair stored a moment ago is still in registers;
-    // the pairs staged at the top of the step follow (slot t held the t-th newest pair then, so it is pair t + 1 now); what
-    // the launch had no LDS for comes from global memory -- the first two of those are requested before the first loop
-    // starts and kept for the second, which begins with them.  At L = 150 nothing is read from global memory here: the
-    // recursion read the 150 KB history through three rotating register buffers before, ~1400 cycles per dependent round
-    // against ~700 in the torsion role (profiles/README.md).
-    if constexpr (NT <= 256) {
-      const int sh = stored ? 1 : 0, kg0 = nl + sh;  // first pair that is neither in registers nor staged
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged pairs have landed (long ago)
-#ifdef TRX2_STAMP
-      if (act) {  // diagnostic build: every staged entry against the global copy it was requested from (counter 27: must stay 0)
-        unsigned bad = 0;
-        for (int t = 0; t < nl; t++) {
-          const int j = (hh0 - 1 - t + LBM) % LBM;
-          if (stored && j == (hh + LBM - 1) % LBM) continue;  // the slot the new pair has just overwritten in global memory
-          for (int q = 0; q < 4; q++) {
-            const float4 a = s_hist[(size_t)((t * 2 + 0) * 4 + q) * L + r], b = A.CS[(((size_t)dec * LBM + j) * 4 + q) * L + r];
-            const float4 c = s_hist[(size_t)((t * 2 + 1) * 4 + q) * L + r], d = A.CY[(((size_t)dec * LBM + j) * 4 + q) * L + r];
-            bad += (a.x != b.x) + (a.y != b.y) + (a.z != b.z) + (a.w != b.w) + (c.x != d.x) + (c.y != d.y) + (c.z != d.z) + (c.w != d.w);
-          }
-        }
-        if (bad) atomicAdd(&g_cstamp[27], (unsigned long long)bad);
-      }
-#endif
-      float4 e0s[4], e0y[4], e1s[4], e1y[4];
-      if (kg0 < hl) load_pair(kg0, e0s, e0y);
-      if (kg0 + 1 < hl) load_pair(kg0 + 1, e1s, e1y);
-      auto staged = [&](int t, float4 (&s_)[4], float4 (&y_)[4]) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) { s_[q] = s_hist[(size_t)((t * 2 + 0) * 4 + q) * L + rc]; y_[q] = s_hist[(size_t)((t * 2 + 1) * 4 + q) * L + rc]; }
-      };
-      // the staged pairs alternate between two named buffers, the next one requested from LDS before the current round's
-      // reduction (no register copy: a copy would wait for the read just issued)
-      const int ns = min(kg0, hl) - sh;  // staged pairs in use: kk = sh .. sh + ns - 1 is slot kk - sh
-      float4 as[4], ay[4], bs[4], by[4];
-      if (sh) round1(0, sv, yv);
-      if (ns > 0) staged(0, as, ay);
-#pragma unroll 1
-      for (int t = 0; t < ns; t += 2) {
-        if (t + 1 < ns) staged(t + 1, bs, by);
-        round1(t + sh, as, ay);
-        if (t + 1 < ns) {
-          if (t + 2 < ns) staged(t + 2, as, ay);
-          round1(t + 1 + sh, bs, by);
-        }
-      }
-      if (kg0 < hl) round1(kg0, e0s, e0y);
-      if (kg0 + 1 < hl) round1(kg0 + 1, e1s, e1y);
-#pragma unroll 1
-      for (int kk = kg0 + 2; kk < hl; kk++) { float4 s_[4], y_[4]; load_pair(kk, s_, y_); round1(kk, s_, y_); }
-      CSTAMP(23)  // two-loop: first loop
-      if (hl > 0) {
-        const float gam = (float)gamma_h;
-#pragma unroll
-        for (int q = 0; q < 4; q++) { qv[q].x *= gam; qv[q].y *= gam; qv[q].z *= gam; qv[q].w *= gam; }
-      }
-      __syncthreads();
-      CSTAMP(24)  // two-loop: gamma
-#pragma unroll 1
-      for (int kk = hl - 1; kk >= kg0 + 2; kk--) { float4 s_[4], y_[4]; load_pair(kk, s_, y_); round2(kk, s_, y_); }
-      if (kg0 + 1 < hl) round2(kg0 + 1, e1s, e1y);
-      if (kg0 < hl) round2(kg0, e0s, e0y);
-      if (ns > 0) staged(ns - 1, as, ay);
-#pragma unroll 1
-      for (int t = ns - 1; t >= 0; t -= 2) {
-        if (t >= 1) staged(t - 1, bs, by);
-        round2(t + sh, as, ay);
-        if (t >= 1) {
-          if (t >= 2) staged(t - 2, as, ay);
-          round2(t - 1 + sh, bs, by);
-        }
-      }
-      if (sh) round2(0, sv, yv);
-    } else {
+    {
       // Three rotating buffers, loops advancing in groups of three so that the buffer of pair kk (kk % 3) is a compile-time
       // choice: two pairs are always in flight.  With 64 decoys the histories (460 KB each at L=150) do not stay in L2 and a
       // round is shorter than one memory round trip, so one pair ahead was not enough (profiles/README.md).
@@ -1545,6 +1638,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
     if (!(v2[1] > 0)) next_run = true;
     else if (hl == 0 || !(v2[0] < 0)) { hl = 0; steepest = true; }
     else { gdir = v2[0]; alpha = 1.0; nls = 0; new_trial = true; }
+    }
   }
   if (steepest) {
     double v1[1] = {0};
@@ -1600,7 +1694,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
       if (r > 0) {
         const Res5 P3 = unpack5(s_xyz + (r - 1) * 16);
         const f3 Hn = place_h(P3.C, M3.N, M3.CA);
-        hv = make_float4(Hn.x, Hn.y, Hn.z, A.hasH[r] ? 1.0f : 0.0f);
+        hv = make_float4(Hn.x, Hn.y, Hn.z, hH_me ? 1.0f : 0.0f);
       }
       A.P[(vb + r) * 5 + 4] = hv;
       if (A.xyzT) A.xyzT[((size_t)((dec / A.BW) * L + r) * 5 + 4) * A.BW + dec % A.BW] = hv;
@@ -1644,6 +1738,11 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
     }
   }
   __syncthreads();
+  if (CG && (gram_dirty || hl == 0)) {  // the scalars follow the history; a restarted history starts from zeros (they must stay finite)
+    const bool z = hl == 0;
+    if (tid < 2 * LBM * LBM) A.gram[(size_t)dec * GR_N + tid] = z ? 0.0 : s_gl.gram[tid];
+    if (tid < 2 * LBM) A.gram[(size_t)dec * GR_N + 2 * LBM * LBM + tid] = z ? 0.0 : s_gl.gram[2 * LBM * LBM + tid];
+  }
   if (tid == 0) {
     gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
     gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
@@ -1673,11 +1772,14 @@ __global__ __launch_bounds__(TN) void k_chain(ChainArgs A) {
 template <int RPT, int TN, int NT>
 __global__ __launch_bounds__(NT) void k_step(ChainArgs A, CartArgs C) {
   __shared__ int s_runs[STEP_RUNS_INTS];
-  __shared__ GramLds<(RPT == 1) ? TN : 16> s_gl;   // the torsion role's; the Cartesian role keeps the two-loop form
+  __shared__ GramLds<(RPT == 1) ? TN : 16> s_gl;   // either role's (a workgroup is in one)
   // the Cartesian role first: its workgroups are the slower ones, and the launch ends with the last of them
   if ((int)blockIdx.x >= A.B) {
     if (NT == TN || threadIdx.x < TN) chain_body<RPT, TN>(A, (int)blockIdx.x - A.B, s_runs, s_gl);  // the other waves of the workgroup exit at once
-  } else cart_body<NT>(C, (int)blockIdx.x, s_runs);
+  } else {
+    static_assert(RPT != 1 || TN == NT, "the two roles share the workgroup's Gram scratch");
+    if constexpr (RPT == 1) cart_body<NT>(C, (int)blockIdx.x, s_runs, s_gl);
+  }
 }
 
 // ---- Tail of a fold: once the queue is empty the slots retire one by one, but a pair-kernel wave costs the same while ANY of its

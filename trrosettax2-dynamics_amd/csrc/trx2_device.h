@@ -53,15 +53,32 @@ __device__ __forceinline__ Xf xf_from_atoms(f3 N, f3 CA, f3 C) {
   f3 ez = cross(ex, ey);
   return Xf{{ex.x, ey.x, ez.x, ex.y, ey.y, ez.y, ex.z, ey.z, ez.z}, {CA.x, CA.y, CA.z}};
 }
-__device__ __forceinline__ Xf xf_shfl_up(const Xf& v, int off) {
+// DPP move of all twelve components: lanes the control gives no source (or whose row the mask leaves out) keep their own value
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Xf xf_dpp(const Xf& v) {
   Xf o;
 #pragma unroll
-  for (int i = 0; i < 9; i++) o.r[i] = __shfl_up(v.r[i], off, 64);
+  for (int i = 0; i < 9; i++) o.r[i] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v.r[i]), __float_as_int(v.r[i]), CTRL, ROW_MASK, 0xF, false));
 #pragma unroll
-  for (int i = 0; i < 3; i++) o.t[i] = __shfl_up(v.t[i], off, 64);
+  for (int i = 0; i < 3; i++) o.t[i] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v.t[i]), __float_as_int(v.t[i]), CTRL, ROW_MASK, 0xF, false));
   return o;
 }
-
+// Inclusive scan of rigid transforms over the 64 lanes of a wave: P_i = M_0 o M_1 o ... o M_i.  Kogge-Stone inside each row of 16
+// lanes on DPP row shifts (row_shr:1, 2, 4, 8), then the two row broadcasts of the gfx9 wave scan (row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2 and 3): six rounds of twelve DPP moves at VALU speed.  (__shfl_up is a ds_bpermute through the LDS
+// crossbar: twelve of them per round were ~220 of a round's ~370 cycles, profiles/README.md round 3.)
+__device__ __forceinline__ Xf xf_wave_scan(Xf P, int lane) {
+  const int li = lane & 15;
+  { const Xf t = xf_dpp<0x111, 0xF>(P); if (li >= 1) P = xf_compose(t, P); }
+  { const Xf t = xf_dpp<0x112, 0xF>(P); if (li >= 2) P = xf_compose(t, P); }
+  { const Xf t = xf_dpp<0x114, 0xF>(P); if (li >= 4) P = xf_compose(t, P); }
+  { const Xf t = xf_dpp<0x118, 0xF>(P); if (li >= 8) P = xf_compose(t, P); }
+  { const Xf t = xf_dpp<0x142, 0xA>(P); if (lane & 16) P = xf_compose(t, P); }
+  { const Xf t = xf_dpp<0x143, 0xC>(P); if (lane & 32) P = xf_compose(t, P); }
+  return P;
+}
+// the value of the lane below (lane 0 keeps its own): wave_shr:1
+__device__ __forceinline__ Xf xf_from_lane_below(const Xf& v) { return xf_dpp<0x138, 0xF>(v); }
 // place atom d: |cd| = len, angle(b,c,d) = ang, dihedral(a,b,c,d) = tor   (cs = cos/sin of ang, tor)
 __device__ __forceinline__ f3 place_atom(f3 a, f3 b, f3 c, float len, float cang, float sang, float ctor, float stor) {
   f3 bc = unit(c - b);
@@ -208,3 +225,21 @@ __device__ __forceinline__ T wave_sum_dpp(T v) {
 }
 __device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 __device__ __forceinline__ double wave_sum(double v) { return wave_sum_dpp(v); }
+// Inclusive SUFFIX sums over the wave (lane i: sum over lanes >= i) of K floats: row_shl:1, 2, 4, 8 inside the rows of 16, then
+// the totals of the rows above (lanes 16, 32, 48 after the row stage) by v_readlane.
+template <int K>
+__device__ __forceinline__ void wave_suffix_sums(float (&v)[K], int lane) {
+  const int li = lane & 15;
+#pragma unroll
+  for (int i = 0; i < K; i++) {
+    float x = v[i], t;
+    t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x101, 0xF, 0xF, false)); if (li < 15) x += t;
+    t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x102, 0xF, 0xF, false)); if (li < 14) x += t;
+    t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104, 0xF, 0xF, false)); if (li < 12) x += t;
+    t = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x108, 0xF, 0xF, false)); if (li < 8) x += t;
+    const float r1 = lane_value(x, 16), r2 = lane_value(x, 32), r3 = lane_value(x, 48);
+    const float above = lane < 16 ? (r1 + (r2 + r3)) : lane < 32 ? (r2 + r3) : lane < 48 ? r3 : 0.0f;
+    v[i] = x + above;
+  }
+}
+
