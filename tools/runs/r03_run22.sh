@@ -1,0 +1,13 @@
+# work items with their slice bounds: full GPU suite, A/B against the previous build
+O=gpurun_out/r22
+mkdir -p $O
+X=$PWD/trrosettax2-dynamics_amd/csrc/_exp
+run() { local t=$1; shift; timeout -k 10 $t "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT/KILL rc=$rc: $*"; exit $rc; fi; return $rc; }
+run 900 python3 -m pytest tests -m gpu -x -q > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest.txt
+for lib in "" $X/libtrx2fold_r18.so "" $X/libtrx2fold_r18.so; do
+  echo "== lib=$lib"
+  for cfg in "2 2" "3 1" "4 2"; do
+    TRX2FOLD_LIB=$lib run 300 python3 tools/percall.py $PWD $cfg 6 2>&1 | tail -1 | cut -c1-150
+  done
+  TRX2FOLD_LIB=$lib run 300 python3 tools/single_decoy_trace.py $PWD 150 1 8 2>&1 | tail -1
+done > $O/ab.txt 2>&1; cat $O/ab.txt

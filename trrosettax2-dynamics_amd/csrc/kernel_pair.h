@@ -19,7 +19,8 @@
 
 struct PairArgs {
   int L, B, Bpad;
-  const unsigned* items;      // work items of a launch, one workgroup each: row a | slice << 10 | slices of that row << 14 (row plan)
+  const uint2* items;         // work items of a launch, one workgroup each (row plan): x = row a | slice << 10 | slices of that row << 14,
+                              // y = first entry of the slice in the row's list | one past its last << 16 (a row has < 1024 entries)
   int kd;       // knots of the distance spline: TRX2_KD, or TRX2_KD_AF2 for gen_rst_af2 tables
   int dist_ca;  // 1: the distance restraint acts on C-alpha (gen_rst_af2), 0: on C-beta
   const float4* xyzT;  // [ngrp][L][5][BW] float4, decoy-minor: residue record CA N CB C O (xt_pack) | H, hasH
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_p
   const int L = A.L;
   // Work item = (row a, slice, slices of that row): rows are cut into a number of slices that follows their list length (the
   // row plan, host side), so that no workgroup walks a list twice as long as the others' (rows hold 20 .. 140 partners)
-  const unsigned item = A.items[blockIdx.x];
+  const uint2 item2 = A.items[blockIdx.x];
+  const unsigned item = item2.x;
   const int a = (int)(item & PAIR_ROW_B_BITS), split = (int)((item >> 10) & 15u), nsl = (int)(item >> 14), grp = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = lane % BW, h = lane / BW;
@@ -194,9 +196,10 @@ __global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_p
   const float4 q0 = xa[0], q1 = xa[BW], q2 = xa[2 * BW], q3 = xa[3 * BW], q4 = xa[4 * BW];
   const int kd = A.kd, ktot = kd + 2 * KO + KP;
   for (int i = threadIdx.x; i < ktot; i += PAIR_THREADS) s_kn[i] = A.knots[i];
-  // equal slices of the row's list: every workgroup of a row gets the same number of restraint visits
-  const int cnt = A.row_cnt[a];
-  const int e_lo = (cnt * split) / nsl, e_hi = (cnt * (split + 1)) / nsl;
+  // equal slices of the row's list: every workgroup of a row gets the same number of restraint visits.  The bounds come with the
+  // work item (the host made the plan from the rows' lengths): reading the length here was one more dependent round trip in
+  // front of the list itself.
+  const int e_lo = (int)(item2.y & 0xffffu), e_hi = (int)(item2.y >> 16);
   for (int i = e_lo + (int)threadIdx.x; i < e_hi; i += PAIR_THREADS) {
     s_ent[i - e_lo] = A.rows[(size_t)a * L + i];
     s_rx[i - e_lo] = A.rows_rx[(size_t)a * L + i];

@@ -72,7 +72,7 @@ struct RowPlan {
   int forced = 0;               // TRX2_NSPLIT it was built under (0: the rule)
   int n_items = 0, ns_max = 1;
   double ns_avg = 1;
-  unsigned* items = nullptr;        // device [n_items]
+  uint2* items = nullptr;           // device [n_items]
   unsigned char* nslice = nullptr;  // device [L]
   size_t cap_items = 0, cap_L = 0;
 };
@@ -458,19 +458,23 @@ static int plan_get(trx2_ctx* ctx, int pw, int groups, int* index) {
     for (int it = 0; it < 16 && tot * groups < 450 && target > 2.0 * pw; it++) { target *= 0.85; tot = make(target); }
     for (int it = 0; it < 16 && tot * groups > 2000 && tot > L; it++) { target *= 1.2; tot = make(target); }
   }
-  std::vector<unsigned> items;
+  std::vector<uint2> items;
   items.reserve((size_t)tot);
-  for (int a = 0; a < L; a++)
-    for (int q = 0; q < ns[(size_t)a]; q++) items.push_back((unsigned)a | ((unsigned)q << 10) | ((unsigned)ns[(size_t)a] << 14));
-  std::stable_sort(items.begin(), items.end(), [&](unsigned x, unsigned y) {   // longest slices first (the launch ends with its last workgroup)
-    const double lx = (double)ctx->h_row_cnt[x & 0x3ffu] / (double)(x >> 14), ly = (double)ctx->h_row_cnt[y & 0x3ffu] / (double)(y >> 14);
-    return lx > ly;
+  for (int a = 0; a < L; a++) {
+    const int n = ns[(size_t)a], cnt = ctx->h_row_cnt[(size_t)a];
+    for (int q = 0; q < n; q++) {  // the slice's bounds in the row's list travel with the item (kernel_pair.h)
+      const unsigned e_lo = (unsigned)((cnt * q) / n), e_hi = (unsigned)((cnt * (q + 1)) / n);
+      items.push_back(make_uint2((unsigned)a | ((unsigned)q << 10) | ((unsigned)n << 14), e_lo | (e_hi << 16)));
+    }
+  }
+  std::stable_sort(items.begin(), items.end(), [&](const uint2& x, const uint2& y) {   // longest slices first (the launch ends with its last workgroup)
+    return (x.y >> 16) - (x.y & 0xffffu) > (y.y >> 16) - (y.y & 0xffffu);
   });
   HIPCHK(hipStreamSynchronize(ctx->stream));  // nothing in flight reads the old plan while it is replaced
   if (items.size() > P.cap_items) {
     if (P.items) (void)hipFree(P.items);
     P.items = nullptr; P.cap_items = 0;
-    HIPCHK(hipMalloc((void**)&P.items, sizeof(unsigned) * (size_t)L * TRX2_NS_CAP));
+    HIPCHK(hipMalloc((void**)&P.items, sizeof(uint2) * (size_t)L * TRX2_NS_CAP));
     P.cap_items = (size_t)L * TRX2_NS_CAP;
   }
   if ((size_t)L > P.cap_L) {
@@ -479,7 +483,7 @@ static int plan_get(trx2_ctx* ctx, int pw, int groups, int* index) {
     HIPCHK(hipMalloc((void**)&P.nslice, (size_t)L));
     P.cap_L = (size_t)L;
   }
-  HIPCHK(hipMemcpy(P.items, items.data(), sizeof(unsigned) * items.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(P.items, items.data(), sizeof(uint2) * items.size(), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(P.nslice, ns.data(), (size_t)L, hipMemcpyHostToDevice));
   P.n_items = (int)items.size(); P.ns_max = 1;
   for (int a = 0; a < L; a++) P.ns_max = std::max(P.ns_max, (int)ns[(size_t)a]);
@@ -1548,6 +1552,9 @@ extern "C" int trx2_debug_linesearch(double* out /* [256][12] */) {
 }
 #endif
 #ifdef TRX2_STAMP
+extern "C" int trx2_debug_stamps(unsigned long long* out32) {  // the pair kernel's phase stamps of its last launch (tools/stamp_pair.py)
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 32) != hipSuccess;
+}
 extern "C" int trx2_debug_chain_stamps(unsigned long long* out32, int reset) {
   if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_cstamp), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
   if (reset) {
