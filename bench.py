@@ -197,7 +197,7 @@ def sampled_fold(ctx, B, runs, seed, decoy0):
         ctx.set_profiling(0)
 
 
-def e2e_leg(pipe_mod, synth, L, init_num, seed=7):
+def e2e_leg(pipe_mod, synth, L, init_num, seed=7, candidates=1):
     """The job the reference runs (run_inference.py:16-143,280-337; VERDICT r2 missing 2): both models of one target end to end --
     init_num initial decoys per model as one batch, the best one fed back, then ONE decoy per iteration (fold + feedback on the
     resident distograms) until the cumulative array moves by < 0.01 or Nmax = 300 (the CLI default) -- every decoy written as a
@@ -217,7 +217,7 @@ def e2e_leg(pipe_mod, synth, L, init_num, seed=7):
         phases = {}
         t0 = time.perf_counter()
         n_out = pipe_mod.run_single(name, fasta, os.path.join(work, "out"), init_num=init_num, Nmax=300, angle=True, mult_two_models=True,
-                                    npz_nmr=paths[0], npz_xray=paths[1], device=0, seed=seed, phase_times=phases)
+                                    npz_nmr=paths[0], npz_xray=paths[1], device=0, seed=seed, phase_times=phases, candidates=candidates)
         wall = time.perf_counter() - t0
         n_files = len([f for f in os.listdir(os.path.join(work, "out", name, "pred_pdb")) if f.endswith(".pdb")])
         it = {k: v for k, v in phases.items()}
@@ -225,7 +225,8 @@ def e2e_leg(pipe_mod, synth, L, init_num, seed=7):
         t_init = max(v["initial_s"] for v in it.values())           # the two chains run concurrently
         t_iter = max(v["iteration_s"] for v in it.values())
         return {"workload": f"run_inference end to end: L={L}, init_num={init_num} per model, two models (synthetic maps seed {L}, {L + 1}), all channels, "
-                            "Nmax=300, PDB files written", "value": n_out / wall, "unit": "decoys/sec", "decoys_written": n_out, "pdb_files": n_files,
+                            "Nmax=300, PDB files written" + ("" if candidates == 1 else f"; EXTENSION (off by default): {candidates} decoys folded and written per "
+                            "feedback iteration, candidate 0 fed back"), "value": n_out / wall, "unit": "decoys/sec", "decoys_written": n_out, "pdb_files": n_files,
                 "wall_s": wall, "initial_phase_s": t_init, "iteration_phase_s": t_iter, "iterations": {k: v["iterations"] for k, v in it.items()},
                 "ms_per_iteration": 1e3 * sum(v["iteration_s"] for v in it.values()) / max(n_iter, 1),
                 "ms_per_iteration_fold": 1e3 * sum(v["iteration_fold_s"] for v in it.values()) / max(n_iter, 1),
@@ -497,6 +498,7 @@ def main():
             import io
             with contextlib.redirect_stdout(io.StringIO()):     # the pipeline prints the reference's progress lines
                 out["e2e"] = {f"init_num_{n}": e2e_leg(pipe_mod, synth, cfg["L"], n) for n in (10, 64)}
+                out["e2e"]["init_num_10_candidates_8"] = e2e_leg(pipe_mod, synth, cfg["L"], 10, candidates=8)
         if args.config == 2 and not args.no_sub_records:
             if world == 1:
                 # the other single-GPU configs of BASELINE.json, shorter legs of the same measurement

@@ -25,6 +25,8 @@ def main(argv=None):
     p.add_argument("--npz_nmr", type=str, default=None, help="precomputed NMR-model distogram (extension)")
     p.add_argument("--npz_xray", type=str, default=None, help="precomputed X-ray-model distogram (extension)")
     p.add_argument("--seed", type=int, default=None, help="seed of the random start torsions (extension)")
+    p.add_argument("--candidates", type=int, default=1, help="decoys folded and written per feedback iteration, candidate 0 fed back "
+                   "(extension; 1 = the reference's chain)")
     p.add_argument("--keep_tmp_npz", action="store_true", help="write tmp_npz/{name}{k}.npz for every iteration as the reference does "
                    "(nothing reads them here; the directory is deleted at the end either way) (extension)")
     a = p.parse_args(argv)
@@ -36,7 +38,7 @@ def main(argv=None):
     dev = int(a.device.split(":")[1]) if ":" in a.device else 0
     pipe = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
     kw = dict(init_num=a.init_num, Nmax=a.Nmax, angle=a.angle, mult_two_models=a.mult_two_models, device=dev, seed=a.seed,
-              keep_tmp_npz=a.keep_tmp_npz)
+              keep_tmp_npz=a.keep_tmp_npz, candidates=a.candidates)
     if a.name_lst:
         # run_inference.py:343-348, sharded over ranks when launched by torch.distributed.run (one process per GPU):
         # targets are independent, the only communication is the final gather of the per-rank summaries

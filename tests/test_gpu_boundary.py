@@ -80,6 +80,28 @@ def test_run_single_reproduces_the_example_layout(golden_dir, tmp_path):
     print("  best apo %.2f (reference 3.02)  best holo %.2f (reference 3.93)" % (min(r[2] for r in rows), min(r[3] for r in rows)))
 
 
+def test_candidates_extension_writes_k_decoys_per_iteration(golden_dir, tmp_path):
+    """`--candidates K` (extension, off by default): every feedback iteration folds and writes K decoys of the same re-weighted
+    maps; candidate 0 -- the decoy identity the default chain folds -- is fed back.  File layout and numbering follow the
+    reference's rules (NMR iteration files first, X-ray numbering continues), every file is a finite backbone."""
+    save = str(tmp_path / "out")
+    n = PL.run_single("seq", os.path.join(golden_dir, "seq.fasta"), save, init_num=2, Nmax=2, angle=True, mult_two_models=True,
+                      npz_nmr=os.path.join(golden_dir, "seq_NMR.npz"), npz_xray=os.path.join(golden_dir, "seq_Xray.npz"), seed=11, candidates=3)
+    pdb_dir = os.path.join(save, "seq", "pred_pdb")
+    files = sorted(os.listdir(pdb_dir), key=lambda f: (f.split("_")[1], int(f.split("_")[2][:-4])))
+    assert files == [f"conf_{m}_{k}.pdb" for m in (1, 2) for k in range(1, 2 + 2 * 3 + 1)] and n == 16, files
+    dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    rm = []
+    for f in files:
+        xyz, _ = P.read_backbone(os.path.join(pdb_dir, f))
+        assert xyz.shape == (90, 5, 3) and np.all(np.isfinite(xyz[:, :4]))   # (glycines carry no CB)
+        rm.append(min(kabsch_rmsd(xyz[:, 1], dec[k][:, 1]) for k in ("conf_1_1", "conf_1_2", "conf_2_1", "conf_2_2")))
+    assert np.median(rm) < 2.5, rm
+    with pytest.raises(ValueError):
+        PL.generate_npz_and_pdb("t", str(tmp_path / "a"), str(tmp_path / "b"), os.path.join(golden_dir, "seq_NMR.npz"), os.path.join(golden_dir, "seq.fasta"),
+                                N=2, Nmax=1, candidates=2, device_feedback=False)
+
+
 def test_no_angle_iteration_converges_or_stops_at_nmax(golden_dir, tmp_path):
     """--no-angle path (BASELINE configs[0]): dist-only restraints and dist/tmp-only npz files"""
     tmpd, pdbd = str(tmp_path / "tmp"), str(tmp_path / "pdb")

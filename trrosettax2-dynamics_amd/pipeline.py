@@ -27,7 +27,7 @@ from .pdbio import as_read_from_pdb, read_backbone, read_fasta
 
 def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz, fasta, N=10, Nmax=500, begin_num=0,
                          sigma=1.0, tta_opt="-m 2 -r no-idp --orient ", angle=True, device=0, seed=None, lanes=2,
-                         write_tmp_npz=False, device_feedback=True, timing=None):
+                         write_tmp_npz=False, device_feedback=True, timing=None, candidates=1):
     """N initial decoys as one GPU batch -> best by reliability -> feedback -> one decoy per iteration until the
     cumulative `tmp` array moves by < 0.01 or Nmax iterations (run_inference.py:97-139).  Returns the last index.
 
@@ -45,6 +45,13 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     Both are tested bitwise equal to the numpy path, which is pinned bit for bit to the reference; sigma other than 1
     falls back to numpy.
 
+    candidates: K > 1 is an EXTENSION, off by default (hard part 5): every iteration folds K
+    decoys of the same re-weighted distograms as one batch instead of one -- decoy identities (seed, 0 .. K-1), so candidate 0
+    starts where the reference-order chain's decoy starts -- writes all K ({name}{(it-1) K + c + 1}.pdb) and feeds candidate 0
+    back.  The chain of maps is the reference's (up to the rounding a batch of another width brings); the ensemble holds K decoys
+    per state of the maps instead of one, for ~1.3 x (K = 8) the time of an iteration: a single-decoy fold leaves the chip idle.
+    Returns the number of iteration files (K per iteration).  Needs the resident feedback path.
+
     timing: a dict that receives initial_s (initial batch: table build, fold, files, ranking), iteration_s (everything after),
     iteration_fold_s (the single-decoy folds alone) and iterations -- bench.py's e2e leg."""
     import time
@@ -60,6 +67,9 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
         return iter_n
 
     resident = device_feedback is True and float(sigma) == 1.0
+    K = int(candidates)
+    if K < 1 or (K > 1 and not resident):
+        raise ValueError("candidates: a positive number; more than one needs the device feedback on resident distograms (sigma = 1)")
 
     def feedback(arrays, pdb):
         if device_feedback and float(sigma) == 1.0:
@@ -103,14 +113,17 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
             iter_n += 1
             print(f"Start generating structure {iter_n}")
             t_f = time.perf_counter()
-            r = fold_resident_to_pdb(ctx, seq, pred_pdb_dir, [f"{pdb_name}{iter_n}.pdb"], tta_opt, seed=None if seed is None else seed + iter_n)
+            first = begin_num + (iter_n - begin_num - 1) * K + 1      # K = 1: iter_n
+            r = fold_resident_to_pdb(ctx, seq, pred_pdb_dir, [f"{pdb_name}{first + c}.pdb" for c in range(K)], tta_opt,
+                                     seed=None if seed is None else seed + iter_n)
             tm["iteration_fold_s"] += time.perf_counter() - t_f
             print("Done generating structure", iter_n)
             if iter_n - begin_num >= Nmax:
                 break
             if step(r["xyz"][0], iter_n + 1) < 0.01:
                 break
-        return done(iter_n)
+        done(iter_n)
+        return begin_num + (iter_n - begin_num) * K
     base = {k: init[k] for k in (("dist", "theta", "omega", "phi") if angle else ("dist",))}   # no "tmp": falls back to dist
     old_tmp = init["dist"]
     cur = feedback(base, best_pdb)
@@ -178,9 +191,10 @@ def flatten_and_rename(save_pdb_dir, num_conf1_others):
 
 
 def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mult_two_models=True, npz_nmr=None,
-               npz_xray=None, device=0, seed=None, keep_tmp_npz=False, phase_times=None):
+               npz_xray=None, device=0, seed=None, keep_tmp_npz=False, phase_times=None, candidates=1):
     """run_inference.py:280-337 without the network front-end: expects the distograms to exist.
-    phase_times: a dict that receives, per chain ("NMR" / "Xray"), generate_npz_and_pdb's timing record."""
+    phase_times: a dict that receives, per chain ("NMR" / "Xray"), generate_npz_and_pdb's timing record.
+    candidates: decoys folded and written per feedback iteration (extension, default 1: generate_npz_and_pdb)."""
     content = os.path.join(save_dir, name)
     npz_dir, pdb_dir, tmp_dir = (os.path.join(content, d) for d in ("pred_npz", "pred_pdb", "tmp_npz"))
     for d in (npz_dir, pdb_dir, tmp_dir):
@@ -212,7 +226,7 @@ def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mu
                                     N=init_num, Nmax=Nmax, begin_num=0, angle=angle, tta_opt=tta_opt, device=device,
                                     seed=None if seed is None else seed + 100000 * len(tag),
                                     lanes=1 if len(maps) == 2 else 2,   # two chains already occupy two streams
-                                    write_tmp_npz=keep_tmp_npz,
+                                    write_tmp_npz=keep_tmp_npz, candidates=candidates,
                                     timing=None if phase_times is None else phase_times.setdefault(tag, {}))
 
     if len(maps) == 2:
