@@ -1428,8 +1428,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
 #pragma unroll
         for (int q = 0; q < GV_N; q++) pv[q] = 0.0f;
         const int rc = min(r, L - 1);
-        // two named buffers: pair k + 1 is requested before pair k is consumed; the scheduling barrier keeps the compiler from
-        // hoisting every load of the unrolled loop to the top (362 registers, 206 spilled on 512 threads)
+        // two named buffers: pair k + 1 is requested before pair k is consumed
         float4 b0s[4], b0y[4], b1s[4], b1y[4];
         if (0 < hl) cart_hist_fetch<NT>(A, dec, L, rc, 0 < nl, 0, (hh - 1 + LBM) % LBM, b0s, b0y);
 #pragma unroll
@@ -1445,7 +1444,6 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
             pv[GV_A + k] = act ? a : 0.0f; pv[GV_B + k] = act ? b : 0.0f;
             if (k < LBM - 1) pv[GV_C + k] = act ? c : 0.0f;
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) {  // (s, y, gt are zero in idle threads)
@@ -1542,7 +1540,6 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
             qv[q].z = fmaf(b, cy_[q].z, fmaf(a, cs_[q].z, qv[q].z)); qv[q].w = fmaf(b, cy_[q].w, fmaf(a, cs_[q].w, qv[q].w));
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
       CSTAMP(25)  // direction from the stored vectors
       const float4 z4 = make_float4(0, 0, 0, 0);
