@@ -318,8 +318,8 @@ def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, wit
             "per_rank": [{"rank": k, "decoys": p["decoys"], "seconds": p["seconds"], "items": p["items"]} for k, p in enumerate(stats)],
         }
         if mine:
-            it = mine[0]  # rank 0's heaviest item: its pair kernel on the coordinates of the last batch
-            out["roofline"] = pair_roofline(ctxs[0], T, it.n, it.L, 5)
+            it = mine[0]  # rank 0's heaviest item: its pair kernel on the final coordinates of its last batch
+            out["roofline"] = pair_roofline(ctxs[0], T, res[-len(mine)]["tors"], it.L, 5)
             out["roofline"]["kernel"] += f" of target {it.target}"
         if with_cpu:
             L0 = min(cfg["targets"])

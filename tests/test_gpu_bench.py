@@ -1,0 +1,39 @@
+"""GPU: bench.py's other entry paths run and print the contract's line -- the multi-target workload (config 5, what every rank of an
+N > 1 launch also runs as `batch_mode`) and the launch the driver uses for N > 1 (`python -m torch.distributed.run ... bench.py
+--gpus N`), rehearsed with two ranks on the one GPU of the box (TRX2_BENCH_FORCE_DEVICE=0: gloo instead of RCCL, which refuses two
+ranks on one device).  Control flow only: no performance is read off these runs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def last_json(out):
+    return json.loads([l for l in out.strip().splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_multi_target_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "5", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d["metric"] == "decoys/sec" and d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 0 and d["all_decoys_converged"]
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and len(d["per_rank"]) == 1
+
+
+def test_bench_two_ranks_on_one_gpu():
+    env = dict(os.environ, TRX2_BENCH_FORCE_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["all_decoys_converged"]
+    assert d["config"]["decoys_per_step"] == 64 and len(d["per_rank_seconds"]) == 2 and d["roofline"]["frac"] > 0
+    bm = d["batch_mode"]
+    assert bm["scaling"] == "strong" and len(bm["per_rank"]) == 2 and bm["all_decoys_converged"] and bm["value"] > 0
