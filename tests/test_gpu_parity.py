@@ -252,3 +252,36 @@ def test_minimiser_tracks_oracle_over_short_horizons(ctx, maps, seq):
     print("\naccepted iterations, device / oracle:", {k: round(float(v), 2) for k, v in ratio.items()}, "identical counts:", same)
     assert ratio[20] >= 0.95 and same[20] >= B - 3, (ratio, same)   # measured 0.98-1.01 and 10-11
     assert ratio[80] >= 0.80, ratio                                  # measured 0.85-0.92; the broken variant scored 0.69
+
+
+@pytest.mark.parametrize("tag,refs", [("NMR", ("conf_2_1", "conf_2_2")), ("Xray", ("conf_1_1", "conf_1_2"))])
+def test_full_fold_outcome_distribution_matches_oracle(ctx, maps, seq, golden_dir, tag, refs):
+    """The whole protocol on both sides from the SAME random starts (device float32, oracle float64, OpenMP over decoys).  Their
+    trajectories separate after some tens of evaluations (test above), so what is compared is what a user sees: the
+    distributions of the final energy, of the C-alpha RMSD to the reference's PyRosetta decoys of the map and of the evaluation
+    count over 64 decoys.  Measured on MI355X (round 3), device / oracle: NMR map: energy quartiles -100020 -99939 -99875 / -100030
+    -99982 -99826, RMSD 0.652 0.790 0.963 / 0.642 0.773 0.934 A, evaluations 1439 1566 1708 / 1413 1590 1743; X-ray map: energy
+    -128826 -128490 -127598 / -128827 -128744 -128452, RMSD 0.438 0.477 0.982 / 0.444 0.478 0.968 A, evaluations 1557 1748 1946 /
+    1607 1797 2092.  Bounds: energy median within 0.5 %, quartiles within 1.5 % of the median's magnitude, RMSD median within
+    0.08 A, median evaluation count within -15 % .. +20 %."""
+    m = maps[tag]
+    ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+    Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+    runs = T.protocol.build_runs(90, 2)
+    B = 64
+    t0 = np.stack([O.random_torsions(90, 321, d) for d in range(B)]).astype(np.float32)
+    r = ctx.fold_batch(B, runs, tors0=t0)
+    _, xo, st, _ = O.fold_batch(Tb, t0.astype(np.float64), runs)
+    assert np.all(r["status"] == 0) and all(s["status"] == 0 for s in st)
+    dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    rm_g = np.array([min(kabsch_rmsd(r["xyz"][d, :, 1].astype(np.float64), dec[k][:, 1]) for k in refs) for d in range(B)])
+    rm_o = np.array([min(kabsch_rmsd(np.asarray(xo[d])[:, 1], dec[k][:, 1]) for k in refs) for d in range(B)])
+    f_g, f_o = r["f"], np.array([s["f_final"] for s in st])
+    e_g, e_o = r["n_evals"], np.array([s["n_evals"] for s in st])
+    q = lambda v: np.round(np.percentile(v, [25, 50, 75]), 3)
+    print(f"\n{tag}: final energy quartiles device {q(f_g)} oracle {q(f_o)}; RMSD to the reference decoys device {q(rm_g)} oracle {q(rm_o)}; "
+          f"evaluations device {q(e_g)} oracle {q(e_o)}")
+    assert abs(np.median(f_g) - np.median(f_o)) <= 0.005 * abs(np.median(f_o))
+    assert np.all(np.abs(np.percentile(f_g, [25, 75]) - np.percentile(f_o, [25, 75])) <= 0.015 * abs(np.median(f_o)))
+    assert abs(np.median(rm_g) - np.median(rm_o)) <= 0.08
+    assert 0.85 <= np.median(e_g) / np.median(e_o) <= 1.2
