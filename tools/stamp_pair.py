@@ -12,7 +12,7 @@ w = np.array(T.protocol.SF, np.float32)
 ctx.eval_batch(tors, w)
 ms, _ = ctx.time_pair_kernel(B, w, 1, L, n_rep=20)
 out = (C.c_ulonglong * 32)(); assert T.load().trx2_debug_stamps(out) == 0
-v = np.array(out[:13], float); names = ["prologue", "entry+masks", "coords of b", "dist seek+fetch", "angles: seeks+fetches", "-", "-", "-", "values, gradients", "list done", "contact scan", "contact walk", "epilogue"]
+v = np.array(out[:15], float); names = ["prologue", "entry+masks", "coords of b", "dist seek+fetch", "angles: seeks+fetches", "-", "-", "-", "values, gradients", "list done", "contact scan", "contact walk", "epilogue: column sums, stores", "epilogue: sub-lane sums, LDS image", "epilogue: barrier"]
 print("config %s (stamped build: %.1f us per launch; shares matter, not the total)  wave total %.0f cycles" % (sys.argv[2], ms * 1e3, v.sum()))
 for n, x in zip(names, v): print("   %-12s %8.0f cycles  %5.1f %%" % (n, x, 100 * x / v.sum()))
 ctx.close()

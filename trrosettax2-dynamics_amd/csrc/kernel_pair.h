@@ -470,7 +470,9 @@ __global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_p
       for (int k = 0; k < PR_REC; k++) s[k] = vals[k];
     }
   }
+  STAMP(13)  // epilogue: sums over the sub-lanes, LDS image
   __syncthreads();
+  STAMP(14)  // epilogue: barrier (the other waves of the workgroup)
   for (int t = threadIdx.x; t < 6 * BW; t += PAIR_THREADS) {  // 6 quads per decoy = one 24-float record
     const int dd = t / 6, q = t % 6;
     const int dc = grp * BW + dd;
