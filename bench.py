@@ -13,7 +13,7 @@ on K.  Workload at N=1 = BASELINE.json configs[1]: L=150 single target, init_num
 SURVEY.md 8d -- the reference ships data for L=90 only).
 
 Named legs beside `value` (N=1 only; none of them is `value`):
-  pooled_queue   ONE call over a queue of 1280 decoys on 2 lanes x 192 decoy slots that refill on the device
+  pooled_queue   ONE call over a queue of 1280 decoys on 2 lanes x 640 decoy slots (every decoy in flight; a longer queue refills on the device)
                  (trx2_ctx_set_pool): the throughput mode of a job that has that many independent decoys (round 2's headline)
   in_flight_B    a queue of 320 decoys with init_num in flight: two lanes of init_num/2 slots
   single_stream  the same queue on ONE stream of init_num slots
@@ -57,7 +57,8 @@ CONFIGS = {
             name="eight targets L in {100,140,180,220,260,300,350,400}, init_num=32 each, dist+omega+theta+phi, synthetic maps "
                  "seed L; (target, decoy-block) items assigned to ranks longest-processing-time-first"),
 }
-MAX_SLOTS = 192  # decoy slots per lane (three groups of 64 decoys in the pair kernel): tools/pool_sweep.py
+MAX_SLOTS = 640  # decoy slots per lane of the pooled leg = every decoy of its queue in flight (the library's policy, fold.SLOTS_PER_LANE: up to 1280;
+                 # tools/pool_sweep.py, round 3: 1280 decoys on 2 x 192 / 320 / 640 slots -> 1110 / 1254 / 1384 decoys/s)
 POOLED_QUEUE = 1280  # decoys of the pooled_queue leg (fixed: the leg does not depend on --steps)
 LEG_QUEUE = 320      # decoys of the in_flight_B / single_stream legs
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
@@ -397,8 +398,8 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
                     "all_decoys_converged": bool(all(np.all(r["status"] == 0) for r in rs))}, rs
         if lanes == 2:
             legs["pooled_queue"], rs_pool = leg(2, MAX_SLOTS, POOLED_QUEUE, f"ONE call over a queue of {POOLED_QUEUE} decoys of the same map on 2 lanes x {MAX_SLOTS} "
-                                                f"decoy slots that refill on the device (round 2's headline mode)")
-            # kernel records at the pooled shape: 192 decoys per launch on lane 0
+                                                f"decoy slots, the library's slot policy (round 2's headline mode ran the same queue on 2 x 192 slots)")
+            # kernel records at the pooled shape: MAX_SLOTS decoys per launch on lane 0
             ctx.set_lanes(1); ctx.set_pool(MAX_SLOTS)
             ftp = sampled_fold(ctx, 2 * MAX_SLOTS, runs, 150, 902 * B)
             legs["pooled_queue"]["roofline"] = compact_roofline(pair_roofline(ctx, T, rs_pool[0]["tors"][:MAX_SLOTS], L, config, ftp))

@@ -412,15 +412,17 @@ def test_tail_compaction_with_slot_pool_and_two_lanes(golden_dir, seq):
         ctx.close()
 
 
-# ---- the shape bench.py's `pooled_queue` leg times: L=150, two lanes x 192 slots, a queue of 1280 decoys -------------------------
+# ---- the shapes bench.py's `pooled_queue` leg has timed: L=150, a queue of 1280 decoys on two lanes x 192 slots (round 2, first half of
+# ---- round 3: slots refill on the device) and on two lanes x 640 slots (every decoy in flight: the library's slot policy since) -------
 def test_bench_pooled_shape_two_lanes_192_slots():
     """the benched shape was never compared with the oracle.  Config-size parity tests run one lane, <= 64 slots,
     one decoy group; the pooled queue runs 2 lanes x 192 slots (three decoy groups per launch, that shape's split of the pair kernel,
     slot refill, tail compaction).  Here, at L=150 with distances only (BASELINE config 2's map):
-      (a) one evaluation of 192 and of 384 decoys (three / six groups) against the oracle on EVERY decoy; and the shape of
-          bench.py's `value` (one call of 64 decoys on two lanes) against two 32-decoy calls, bit for bit;
+      (a) one evaluation of 192, of 384 and of 640 decoys (three / six / ten groups of the pair kernel) against the oracle on EVERY
+          decoy; and the shape of bench.py's `value` (one call of 64 decoys on two lanes) against two 32-decoy calls, bit for bit;
       (b) the pooled fold of 1280 decoys with the pair kernel's split kept (compaction mode 2) against separate 64-decoy calls,
-          one slot per decoy, no compaction, the same split: bit for bit, every decoy, every output;
+          one slot per decoy, no compaction, the same split: bit for bit, every decoy, every output -- on 2 x 192 slots (refill) and
+          on 2 x 640 (every decoy in flight);
       (c) the default compaction (mode 1: each shape's own split, wave narrowing below one group) against (b) decoy by decoy:
           it differs by the summation order of a residue's gradient records from the moment the launch shape changes (another
           row plan, narrower waves), i.e. by rounding that a ~3000-evaluation minimisation amplifies -- the same kind of
@@ -437,7 +439,7 @@ def test_bench_pooled_shape_two_lanes_192_slots():
     try:
         ctx.set_map(m["dist"], seq=m["seq"])
         ref.set_map(m["dist"], seq=m["seq"])
-        for B in (192, 384):
+        for B in (192, 384, 640):
             w = check_eval_every_decoy(ctx, Tb, mixed_starts(m, B, 40 + B), SF, 2e-3)
             print(f"\n   eval of {B} decoys at the pooled shape ({int(ctx.info(4))} pair-kernel workgroups, {int(ctx.info(0))} decoys per wave): worst xyz {w['xyz']:.1e} A, term {w['term']:.1e}, gradient {w['grad']:.1e}")
         # bench.py's `value` shape: ONE call of 64 decoys on a two-lane context = lane 0 folds decoys 0..31, lane 1 decoys 32..63, each
@@ -462,6 +464,11 @@ def test_bench_pooled_shape_two_lanes_192_slots():
         parts = [ref.fold_batch(64, runs, seed=150, decoy0=64 * k) for k in range(N // 64)]
         for key in ("xyz", "tors", "e_terms", "f", "status", "n_evals", "n_iters"):
             assert np.array_equal(pinned[key], np.concatenate([p[key] for p in parts])), key
+        ctx.set_pool(640)                       # bench.py's pooled leg since round 3's second half: every decoy in flight
+        wide = ctx.fold_batch(N, runs, seed=150)
+        for key in ("xyz", "tors", "e_terms", "f", "status", "n_evals", "n_iters"):
+            assert np.array_equal(wide[key], pinned[key]), key
+        ctx.set_pool(192)
         os.environ.pop("TRX2_NSPLIT")
         # (c) the library's own plans: plan kept (mode 2) against the default (mode 1)
         out = {}

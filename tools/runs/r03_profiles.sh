@@ -12,7 +12,7 @@ for cfg in 2 3 4; do
   f=$(find /tmp/kt$cfg -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/r03_c${cfg}_kernel_stats.csv && cut -c1-150 $O/r03_c${cfg}_kernel_stats.csv | head -8
   cd $R
 done
-for spec in "2 32" "2 192" "3 64" "4 16"; do
+for spec in "2 32" "2 640" "3 64" "4 16"; do
   set -- $spec
   for k in pair step; do
     bash tools/pmc_run.sh $1 $2 $k r03_profiles/pmc 20 || exit $?
