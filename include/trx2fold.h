@@ -72,7 +72,7 @@ int trx2_ctx_set_pool(trx2_ctx* ctx, int slots);
  * the decoys per wave halve (32, 16, ..), each shape with its own row plan of the pair kernel (how many workgroups a row of the
  * restraint lists is cut into).  A decoy's arithmetic then differs from mode 0 by the ORDER in which the records of a residue are
  * added from the moment the shape changes -- rounding, which thousands of minimiser steps amplify: the same kind of difference
- * as folding the decoy in a batch of another size (measured at L=150, 1280 decoys on 2 x 192 slots: tests/test_gpu_configs.py).
+ * as folding the decoy in a batch of another size (measured at L=150, 1280 decoys on 2 x 192 slots: tests/test_gpu_configs.py; how many slots: INTEGRATION.md).
  * mode 2: groups are dropped with the row plan kept and the waves are never narrowed: bitwise equal to mode 0, ~9 % slower per
  * call of 64 decoys.  mode 0: off.  No counterpart in the reference (its decoys are separate processes).
  * Environment (A/B timing and tests only): TRX2_NSPLIT=n cuts every row into n slices whatever the shape; TRX2_ROW_TARGET=t sets
