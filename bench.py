@@ -236,6 +236,38 @@ def e2e_leg(pipe_mod, synth, L, init_num, seed=7, candidates=1):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def e2e_batch_leg(pipe_mod, synth, L, n_targets=4, nmax=80, seed=3):
+    """Batch mode of run_inference.py (:339-348) on ONE GPU: n_targets targets (the same synthetic pair of maps under different names),
+    init_num=10, both models, Nmax shortened to `nmax` -- one target after the other as the reference's loop does, and two at a time
+    (pipeline.run_batch's default: four chains on four streams; the files are byte-identical either way, tests/test_gpu_boundary.py)."""
+    work = tempfile.mkdtemp(prefix="trx2_e2eb_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        maps = [synth.make_map(L, seed=L + c) for c in range(2)]
+        paths = []
+        for tag, m in zip(("NMR", "Xray"), maps):
+            q = os.path.join(work, f"m_{tag}.npz")
+            np.savez(q, dist=m["dist"], omega=m["omega"], theta=m["theta"], phi=m["phi"])
+            paths.append(q)
+        names = [f"t{i}" for i in range(n_targets)]
+        fdir = os.path.join(work, "fasta")
+        os.makedirs(fdir)
+        for nm in names:
+            with open(os.path.join(fdir, nm + ".fasta"), "w") as f:
+                f.write(f">{nm}\n{maps[0]['seq']}\n")
+        out = {"workload": f"run_inference batch mode on one GPU: {n_targets} targets of L={L}, init_num=10, two models, all channels, Nmax={nmax}, PDB files written"}
+        for k in (1, 2):
+            save = os.path.join(work, f"out{k}")
+            t0 = time.perf_counter()
+            res = pipe_mod.run_batch(names, fdir, save, targets_in_flight=k, init_num=10, Nmax=nmax, angle=True, mult_two_models=True, seed=seed,
+                                     npz_nmr=paths[0], npz_xray=paths[1])
+            el = time.perf_counter() - t0
+            out[f"targets_in_flight_{k}"] = {"value": res["decoys"] / el, "unit": "decoys/sec", "decoys_written": res["decoys"], "wall_s": el, "failed": res["failed"]}
+            shutil.rmtree(save, ignore_errors=True)
+        return out
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def fold_quality(synth, m, results):
     """Does the workload FOLD?  C-alpha RMSD of every decoy of the timed steps to the synthetic map's own target structure and to
     its mirror image (computed after the timed region): a throughput figure on a fold that fails is a cost-per-evaluation
@@ -500,6 +532,7 @@ def main():
             with contextlib.redirect_stdout(io.StringIO()):     # the pipeline prints the reference's progress lines
                 out["e2e"] = {f"init_num_{n}": e2e_leg(pipe_mod, synth, cfg["L"], n) for n in (10, 64)}
                 out["e2e"]["init_num_10_candidates_8"] = e2e_leg(pipe_mod, synth, cfg["L"], 10, candidates=8)
+                out["e2e"]["batch_mode_one_gpu"] = e2e_batch_leg(pipe_mod, synth, cfg["L"])
         if args.config == 2 and not args.no_sub_records:
             if world == 1:
                 # the other single-GPU configs of BASELINE.json, shorter legs of the same measurement

@@ -25,6 +25,8 @@ def main(argv=None):
     p.add_argument("--npz_nmr", type=str, default=None, help="precomputed NMR-model distogram (extension)")
     p.add_argument("--npz_xray", type=str, default=None, help="precomputed X-ray-model distogram (extension)")
     p.add_argument("--seed", type=int, default=None, help="seed of the random start torsions (extension)")
+    p.add_argument("--targets_in_flight", type=int, default=None, help="batch mode: targets a rank folds at a time (extension; default keeps four "
+                   "chains in flight: 2 targets with both models, 4 with one; 1 = one after the other as the reference does)")
     p.add_argument("--candidates", type=int, default=1, help="decoys folded and written per feedback iteration, candidate 0 fed back "
                    "(extension; 1 = the reference's chain)")
     p.add_argument("--keep_tmp_npz", action="store_true", help="write tmp_npz/{name}{k}.npz for every iteration as the reference does "
@@ -59,7 +61,7 @@ def main(argv=None):
                 dist.init_process_group("gloo", timeout=long_)
             kw["device"] = local
         dev_ = kw.pop("device")
-        res = pipe.run_batch(names, a.fasta_dir, a.save_dir, rank=rank, world=world, dist=dist, device=dev_, **kw)
+        res = pipe.run_batch(names, a.fasta_dir, a.save_dir, rank=rank, world=world, dist=dist, device=dev_, targets_in_flight=a.targets_in_flight, **kw)
         if rank == 0:
             print(f"Batch finished: {res['decoys']} structures from {len(names)} targets on {world} rank(s) in {res['seconds']:.1f} s, "
                   f"{res['failed']} failed")

@@ -102,6 +102,27 @@ def test_candidates_extension_writes_k_decoys_per_iteration(golden_dir, tmp_path
                                 N=2, Nmax=1, candidates=2, device_feedback=False)
 
 
+def test_batch_mode_targets_in_flight_change_nothing(golden_dir, tmp_path):
+    """Batch mode folds a rank's targets two at a time (four chains on four streams) where the reference folds them one after the
+    other: with an explicit seed every file of every target must come out byte for byte the same either way."""
+    import shutil
+    fdir = tmp_path / "fasta"
+    fdir.mkdir()
+    names = ["ta", "tb", "tc"]
+    for n in names:
+        shutil.copyfile(os.path.join(golden_dir, "seq.fasta"), fdir / f"{n}.fasta")
+    kw = dict(init_num=2, Nmax=3, angle=True, mult_two_models=True, seed=5,
+              npz_nmr=os.path.join(golden_dir, "seq_NMR.npz"), npz_xray=os.path.join(golden_dir, "seq_Xray.npz"))
+    out = {}
+    for k in (1, 2):
+        save = str(tmp_path / f"out{k}")
+        res = PL.run_batch(names, str(fdir), save, targets_in_flight=k, **kw)
+        assert res["failed"] == 0 and res["decoys"] == 3 * (2 * 2 + 2 * 3), res
+        out[k] = {(n, f): open(os.path.join(save, n, "pred_pdb", f), "rb").read() for n in names for f in sorted(os.listdir(os.path.join(save, n, "pred_pdb")))}
+    assert out[1].keys() == out[2].keys() and len(out[1]) == 30
+    assert all(out[1][key] == out[2][key] for key in out[1])
+
+
 def test_no_angle_iteration_converges_or_stops_at_nmax(golden_dir, tmp_path):
     """--no-angle path (BASELINE configs[0]): dist-only restraints and dist/tmp-only npz files"""
     tmpd, pdbd = str(tmp_path / "tmp"), str(tmp_path / "pdb")
