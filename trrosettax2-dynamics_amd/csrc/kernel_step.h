@@ -176,14 +176,14 @@ __device__ unsigned long long g_cstamp[32];
 #define CSTAMP(k)
 #define CCOUNT(k)
 #endif
-// L-BFGS history of the decoy staged in LDS for the duration of one step: [LBM][s | y][NT] float4, dynamic shared memory
+// L-BFGS history of the decoy staged in LDS for the duration of one step: [LBM][s | y][L] float4, dynamic shared memory
 // (HIST_LDS_BYTES, only the one-residue-per-thread instantiations; gfx950 has 160 KB of LDS per CU).  The two-loop
 // recursion is 2 x LBM DEPENDENT rounds; read from global memory every round exposed an L2 round trip (~500-700 of its
 // ~1000 cycles; the compiler turns a register prefetch into a wait on the load just issued).  Instead the whole history is
 // requested at the top of the step with LDS-DMA loads (global_load_lds_dwordx4: no registers, nothing waits on them until
 // the recursion starts a phase later) and every round reads the thread's own slot from LDS.
 extern __shared__ float4 s_hist[];
-#define HIST_LDS_BYTES(NT) (LBM * 2 * (NT) * 16)
+#define HIST_LDS_BYTES(L) (LBM * 2 * (L) * 16)  /* the torsion role's staged history: [LBM][s | y][L] float4 */
 #define CART_HIST_BYTES(L) ((size_t)(L) * 128)  // one stored pair of the Cartesian role in LDS: [s | y][4][L] float4
 __device__ __forceinline__ void lds_dma16(const float4* src /* per lane */, float4* dst_wave /* wave-uniform: lane i lands at dst + i */) {
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst_wave, 16, 0, 0);
@@ -417,12 +417,15 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
   bool need_nerf = true;
   if (HIST_LDS && A.mode == MODE_STEP) {
     // the hl stored pairs, newest first; lanes beyond L copy the last residue (no branch around the load), never used
-    const int hl0 = s_i[SI_HL], hh0 = s_i[SI_HH], rc = min(tid, L - 1);
-    for (int kk = 0; kk < hl0; kk++) {
-      const int j = (hh0 - 1 - kk + LBM) % LBM;
-      lds_dma16(A.S + ((size_t)dec * LBM + j) * L + rc, s_hist + (j * 2 + 0) * NT + wave * 64);
-      lds_dma16(A.Y + ((size_t)dec * LBM + j) * L + rc, s_hist + (j * 2 + 1) * NT + wave * 64);
-    }
+    // rows exactly L long (lanes beyond the chain are switched off: LDS-DMA writes only for active lanes): a 150-residue chain
+    // stages 38 KB, not 64 -- what lets two step workgroups share a CU's LDS in the launches that have more of them than CUs
+    const int hl0 = s_i[SI_HL], hh0 = s_i[SI_HH];
+    if (tid < L)
+      for (int kk = 0; kk < hl0; kk++) {
+        const int j = (hh0 - 1 - kk + LBM) % LBM;
+        lds_dma16(A.S + ((size_t)dec * LBM + j) * L + tid, s_hist + (j * 2 + 0) * L + wave * 64);
+        lds_dma16(A.Y + ((size_t)dec * LBM + j) * L + tid, s_hist + (j * 2 + 1) * L + wave * 64);
+      }
   }
   CSTAMP(0)  // state load, barrier, role test
   CCOUNT(30)
@@ -721,7 +724,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
 #pragma unroll
               for (int k = 0; k < HB; k++) {
                 const int j = (hh - 1 - (k0 + k) + LBM) % LBM;
-                if (HIST_LDS) { so[k] = s_hist[(j * 2 + 0) * NT + tid]; yo[k] = s_hist[(j * 2 + 1) * NT + tid]; }
+                if (HIST_LDS) { so[k] = s_hist[(j * 2 + 0) * L + rc]; yo[k] = s_hist[(j * 2 + 1) * L + rc]; }
                 else { so[k] = A.S[((size_t)dec * LBM + j) * L + rc]; yo[k] = A.Y[((size_t)dec * LBM + j) * L + rc]; }
               }
 #pragma unroll
@@ -753,8 +756,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
             }
           }
           if (HIST_LDS) {  // slot hh of the staged copy (the oldest pair: its products are taken)
-            s_hist[(hh * 2 + 0) * NT + tid] = s[0];
-            s_hist[(hh * 2 + 1) * NT + tid] = y[0];
+            if (tid < L) {
+              s_hist[(hh * 2 + 0) * L + tid] = s[0];
+              s_hist[(hh * 2 + 1) * L + tid] = y[0];
+            }
           } else if (!GRAM) {
             bsync<NW>();
             if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
@@ -849,7 +854,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
 #pragma unroll
             for (int m = 0; m < HB; m++) {
               const int j = pair_at(m0 + m);
-              if (HIST_LDS) { sm[m] = s_hist[(j * 2 + 0) * NT + tid]; ym[m] = s_hist[(j * 2 + 1) * NT + tid]; }
+              if (HIST_LDS) { sm[m] = s_hist[(j * 2 + 0) * L + rc]; ym[m] = s_hist[(j * 2 + 1) * L + rc]; }
               else if (m0 + m == 0 && have_new) { sm[0] = s_new[kr]; ym[0] = y_new[kr]; }   // stored a moment ago: from registers
               else { sm[m] = A.S[((size_t)dec * LBM + j) * L + rc]; ym[m] = A.Y[((size_t)dec * LBM + j) * L + rc]; }
             }
@@ -871,7 +876,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
         for (int k = 0; k < RPT; k++) q[k] = g[k];
         auto load_pair = [&](int j, float4 (&s_)[RPT], float4 (&y_)[RPT]) {
           if (HIST_LDS) {
-            const float4 z = make_float4(0, 0, 0, 0), sv = s_hist[(j * 2 + 0) * NT + tid], yv = s_hist[(j * 2 + 1) * NT + tid];
+            const float4 z = make_float4(0, 0, 0, 0), sv = s_hist[(j * 2 + 0) * L + min(tid, L - 1)], yv = s_hist[(j * 2 + 1) * L + min(tid, L - 1)];
             s_[0] = tid < L ? sv : z;
             y_[0] = tid < L ? yv : z;
             return;
@@ -1182,7 +1187,10 @@ __device__ __forceinline__ void cart_hist_fetch(const CartArgs& A, int dec, int 
     for (int q = 0; q < 4; q++) { s_[q] = A.CS[o + (size_t)q * L]; y_[q] = A.CY[o + (size_t)q * L]; }
   }
 }
-template <int NT>
+// LOWREG: the instantiation for launches with more step workgroups than the chip has CUs (more than 256 slots): the same
+// arithmetic in the same order, but one stored pair at a time instead of two named buffers, so that the fused kernel fits 256
+// registers and TWO workgroups run on a CU (one wave per SIMD otherwise: 256 + 106 registers).
+template <int NT, bool LOWREG>
 __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int* s_runs, GramLds<NT>& s_gl) {
   constexpr int NW = NT / 64;  // one residue per thread: NT = 256 for chains up to 256 residues, 512 up to 512
   const int L = A.L, tid = threadIdx.x, r = tid;
@@ -1428,21 +1436,37 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
 #pragma unroll
         for (int q = 0; q < GV_N; q++) pv[q] = 0.0f;
         const int rc = min(r, L - 1);
+        if constexpr (LOWREG) {
+#pragma unroll
+          for (int k = 0; k < LBM; k++) {
+            if (k < hl) {
+              float4 cs_[4], cy_[4];
+              cart_hist_fetch<NT>(A, dec, L, rc, k < nl, k, (hh - 1 - k + 2 * LBM) % LBM, cs_, cy_);
+              float a = 0, b = 0, c = 0;
+#pragma unroll
+              for (int q = 0; q < 4; q++) { a += dot4(cs_[q], yv[q]); b += dot4(cy_[q], yv[q]); c += dot4(sv[q], cy_[q]); }
+              pv[GV_A + k] = act ? a : 0.0f; pv[GV_B + k] = act ? b : 0.0f;
+              if (k < LBM - 1) pv[GV_C + k] = act ? c : 0.0f;
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one pair's registers at a time
+          }
+        } else {
         // two named buffers: pair k + 1 is requested before pair k is consumed
-        float4 b0s[4], b0y[4], b1s[4], b1y[4];
-        if (0 < hl) cart_hist_fetch<NT>(A, dec, L, rc, 0 < nl, 0, (hh - 1 + LBM) % LBM, b0s, b0y);
+          float4 b0s[4], b0y[4], b1s[4], b1y[4];
+          if (0 < hl) cart_hist_fetch<NT>(A, dec, L, rc, 0 < nl, 0, (hh - 1 + LBM) % LBM, b0s, b0y);
 #pragma unroll
-        for (int k = 0; k < LBM; k++) {
-          float4 (&cs_)[4] = (k & 1) ? b1s : b0s; float4 (&cy_)[4] = (k & 1) ? b1y : b0y;
-          float4 (&ns_)[4] = (k & 1) ? b0s : b1s; float4 (&ny_)[4] = (k & 1) ? b0y : b1y;
-          if (k + 1 < LBM && k + 1 < hl) cart_hist_fetch<NT>(A, dec, L, rc, k + 1 < nl, k + 1, (hh - 2 - k + 2 * LBM) % LBM, ns_, ny_);
-          if (k < hl) {
-            float a = 0, b = 0, c = 0;
+          for (int k = 0; k < LBM; k++) {
+            float4 (&cs_)[4] = (k & 1) ? b1s : b0s; float4 (&cy_)[4] = (k & 1) ? b1y : b0y;
+            float4 (&ns_)[4] = (k & 1) ? b0s : b1s; float4 (&ny_)[4] = (k & 1) ? b0y : b1y;
+            if (k + 1 < LBM && k + 1 < hl) cart_hist_fetch<NT>(A, dec, L, rc, k + 1 < nl, k + 1, (hh - 2 - k + 2 * LBM) % LBM, ns_, ny_);
+            if (k < hl) {
+              float a = 0, b = 0, c = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) { a += dot4(cs_[q], yv[q]); b += dot4(cy_[q], yv[q]); c += dot4(sv[q], cy_[q]); }
-            // idle threads hold copies of the last residue: selected out
-            pv[GV_A + k] = act ? a : 0.0f; pv[GV_B + k] = act ? b : 0.0f;
-            if (k < LBM - 1) pv[GV_C + k] = act ? c : 0.0f;
+              for (int q = 0; q < 4; q++) { a += dot4(cs_[q], yv[q]); b += dot4(cy_[q], yv[q]); c += dot4(sv[q], cy_[q]); }
+              // idle threads hold copies of the last residue: selected out
+              pv[GV_A + k] = act ? a : 0.0f; pv[GV_B + k] = act ? b : 0.0f;
+              if (k < LBM - 1) pv[GV_C + k] = act ? c : 0.0f;
+            }
           }
         }
 #pragma unroll
@@ -1522,22 +1546,42 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
 #pragma unroll
       for (int q = 0; q < 4; q++) qv[q] = make_float4(gam * g[q].x, gam * g[q].y, gam * g[q].z, gam * g[q].w);
       const int rc = min(r, L - 1), sh = stored ? 1 : 0;
+      if constexpr (LOWREG) {
+#pragma unroll
+        for (int m = 0; m < LBM; m++) {
+          if (m < hl) {
+            float4 cs_[4], cy_[4];
+            if (m == 0 && sh) {
+#pragma unroll
+              for (int q = 0; q < 4; q++) { cs_[q] = sv[q]; cy_[q] = yv[q]; }
+            } else cart_hist_fetch<NT>(A, dec, L, rc, m - sh < nl, m - sh, (hh - 1 - m + 2 * LBM) % LBM, cs_, cy_);
+            const float a = cs[m], b = cy[m];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              qv[q].x = fmaf(b, cy_[q].x, fmaf(a, cs_[q].x, qv[q].x)); qv[q].y = fmaf(b, cy_[q].y, fmaf(a, cs_[q].y, qv[q].y));
+              qv[q].z = fmaf(b, cy_[q].z, fmaf(a, cs_[q].z, qv[q].z)); qv[q].w = fmaf(b, cy_[q].w, fmaf(a, cs_[q].w, qv[q].w));
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
       float4 b0s[4], b0y[4], b1s[4], b1y[4];
-      if (sh) {
+        if (sh) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) { b0s[q] = sv[q]; b0y[q] = yv[q]; }
-      } else if (0 < hl) cart_hist_fetch<NT>(A, dec, L, rc, 0 < nl, 0, (hh - 1 + LBM) % LBM, b0s, b0y);
+          for (int q = 0; q < 4; q++) { b0s[q] = sv[q]; b0y[q] = yv[q]; }
+        } else if (0 < hl) cart_hist_fetch<NT>(A, dec, L, rc, 0 < nl, 0, (hh - 1 + LBM) % LBM, b0s, b0y);
 #pragma unroll
-      for (int m = 0; m < LBM; m++) {
-        float4 (&cs_)[4] = (m & 1) ? b1s : b0s; float4 (&cy_)[4] = (m & 1) ? b1y : b0y;
-        float4 (&ns_)[4] = (m & 1) ? b0s : b1s; float4 (&ny_)[4] = (m & 1) ? b0y : b1y;
-        if (m + 1 < LBM && m + 1 < hl) cart_hist_fetch<NT>(A, dec, L, rc, m + 1 - sh < nl, m + 1 - sh, (hh - 2 - m + 2 * LBM) % LBM, ns_, ny_);
-        if (m < hl) {
-          const float a = cs[m], b = cy[m];
+        for (int m = 0; m < LBM; m++) {
+          float4 (&cs_)[4] = (m & 1) ? b1s : b0s; float4 (&cy_)[4] = (m & 1) ? b1y : b0y;
+          float4 (&ns_)[4] = (m & 1) ? b0s : b1s; float4 (&ny_)[4] = (m & 1) ? b0y : b1y;
+          if (m + 1 < LBM && m + 1 < hl) cart_hist_fetch<NT>(A, dec, L, rc, m + 1 - sh < nl, m + 1 - sh, (hh - 2 - m + 2 * LBM) % LBM, ns_, ny_);
+          if (m < hl) {
+            const float a = cs[m], b = cy[m];
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            qv[q].x = fmaf(b, cy_[q].x, fmaf(a, cs_[q].x, qv[q].x)); qv[q].y = fmaf(b, cy_[q].y, fmaf(a, cs_[q].y, qv[q].y));
-            qv[q].z = fmaf(b, cy_[q].z, fmaf(a, cs_[q].z, qv[q].z)); qv[q].w = fmaf(b, cy_[q].w, fmaf(a, cs_[q].w, qv[q].w));
+            for (int q = 0; q < 4; q++) {
+              qv[q].x = fmaf(b, cy_[q].x, fmaf(a, cs_[q].x, qv[q].x)); qv[q].y = fmaf(b, cy_[q].y, fmaf(a, cs_[q].y, qv[q].y));
+              qv[q].z = fmaf(b, cy_[q].z, fmaf(a, cs_[q].z, qv[q].z)); qv[q].w = fmaf(b, cy_[q].w, fmaf(a, cs_[q].w, qv[q].w));
+            }
           }
         }
       }
@@ -1766,8 +1810,8 @@ __global__ __launch_bounds__(TN) void k_chain(ChainArgs A) {
   __shared__ GramLds<(RPT == 1) ? TN : 16> s_gl;
   chain_body<RPT, TN>(A, blockIdx.x, s_runs, s_gl);
 }
-template <int RPT, int TN, int NT>
-__global__ __launch_bounds__(NT) void k_step(ChainArgs A, CartArgs C) {
+template <int RPT, int TN, int NT, bool LOWREG = false>
+__global__ __launch_bounds__(NT, (LOWREG ? 2 : 1)) void k_step(ChainArgs A, CartArgs C) {
   __shared__ int s_runs[STEP_RUNS_INTS];
   __shared__ GramLds<(RPT == 1) ? TN : 16> s_gl;   // either role's (a workgroup is in one)
   // the Cartesian role first: its workgroups are the slower ones, and the launch ends with the last of them
@@ -1775,7 +1819,7 @@ __global__ __launch_bounds__(NT) void k_step(ChainArgs A, CartArgs C) {
     if (NT == TN || threadIdx.x < TN) chain_body<RPT, TN>(A, (int)blockIdx.x - A.B, s_runs, s_gl);  // the other waves of the workgroup exit at once
   } else {
     static_assert(RPT != 1 || TN == NT, "the two roles share the workgroup's Gram scratch");
-    if constexpr (RPT == 1) cart_body<NT>(C, (int)blockIdx.x, s_runs, s_gl);
+    if constexpr (RPT == 1) cart_body<NT, LOWREG>(C, (int)blockIdx.x, s_runs, s_gl);
   }
 }
 

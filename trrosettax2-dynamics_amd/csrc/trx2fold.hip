@@ -136,7 +136,10 @@ struct trx2_ctx {
   // trx2_ctx_set_profiling: every prof_every-th evaluation of a fold is bracketed by HIP events on the stream (pair | step)
   int prof_every = 0;
   int step_dyn_max[2] = {0, 0};  // dynamic LDS the fused step kernels may ask for (L <= 128 | L <= 256): 160 KB - their static LDS
-  int step_dyn_floor[2] = {0, 0};  // ... and what the torsion role needs of it (its staged history)
+  int step_dyn_floor[2] = {0, 0};  // ... and the most the torsion role needs of it (its staged history at 128 / 256 residues)
+  int step_static[2] = {0, 0};     // static LDS of the two fused step kernels
+  int step2_static = 0;            // ... and of the low-register instantiation (k_step<1, 256, 256, true>)
+  int lds_total = 160 * 1024;      // LDS of a CU
   std::vector<hipEvent_t> prof_ev;
   double prof_pair_ms = 0, prof_step_ms = 0; int prof_n = 0;
   // second lane (trx2_ctx_set_lanes): a context of its own stream and batch buffers that BORROWS this one's tables, so that
@@ -228,9 +231,9 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
     rm[k * 3 + 2] = (float)rama[k][2];
     rsc[k * 4] = (float)sin(ph); rsc[k * 4 + 1] = (float)cos(ph); rsc[k * 4 + 2] = (float)sin(ps); rsc[k * 4 + 3] = (float)cos(ps);
   }
-  // The step kernels of short chains stage the L-BFGS history in dynamic LDS: the torsion role all of it (HIST_LDS_BYTES: 64 KB
-  // with 8 pairs and 256 threads), the Cartesian role as many pairs (CART_HIST_BYTES(L) each) as fit beside the kernel's static
-  // LDS in the 160 KB of a gfx950 workgroup.
+  // The step kernels of short chains stage the L-BFGS history in dynamic LDS: the torsion role all of it (HIST_LDS_BYTES(L): 8
+  // pairs in rows L long, 38 KB at 150 residues, 64 KB at 256), the Cartesian role as many pairs (CART_HIST_BYTES(L) each) as fit
+  // beside the kernel's static LDS in the 160 KB of a gfx950 workgroup.
   {
     int lds_max = 0;
     if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess || lds_max <= 0) lds_max = 65536;
@@ -247,7 +250,19 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
       if (dyn < hist[k]) dyn = hist[k];
       ctx->step_dyn_max[k] = dyn;
       ctx->step_dyn_floor[k] = hist[k];
+      ctx->step_static[k] = (int)fa.sharedSizeBytes;
       ok = hipFuncSetAttribute(fstep[k], hipFuncAttributeMaxDynamicSharedMemorySize, dyn) == hipSuccess;
+    }
+    // the low-register instantiation (launches of more than 256 slots, chains of 129-256 residues): two workgroups per CU
+    if (ok) {
+      hipFuncAttributes fa;
+      const void* f2 = (const void*)k_step<1, CHAIN_THREADS, CHAIN_THREADS, true>;
+      ok = hipFuncGetAttributes(&fa, f2) == hipSuccess;
+      if (ok) {
+        ctx->lds_total = lds_max;
+        ctx->step2_static = (int)fa.sharedSizeBytes;
+        ok = hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max - (int)fa.sharedSizeBytes) == hipSuccess;
+      }
     }
     if (!ok) {
       pool_release(device, ctx->stream);
@@ -857,8 +872,8 @@ static void launch_chain_args(trx2_ctx* c, int B, const ChainArgs& A) {
   const int L = c->L;
   // chains of up to 128 residues (the reference's example has 90) run the step on two waves: every workgroup reduction and
   // scan combines two partials instead of four
-  if (L <= 128) hipLaunchKernelGGL((k_chain<1, 128>), grid, dim3(128), HIST_LDS_BYTES(128), c->stream, A);
-  else if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_chain<1, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), HIST_LDS_BYTES(CHAIN_THREADS), c->stream, A);
+  if (L <= 128) hipLaunchKernelGGL((k_chain<1, 128>), grid, dim3(128), HIST_LDS_BYTES(L), c->stream, A);
+  else if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_chain<1, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), HIST_LDS_BYTES(L), c->stream, A);
   else if (L <= 2 * CHAIN_THREADS) hipLaunchKernelGGL((k_chain<1, 2 * CHAIN_THREADS>), grid, dim3(2 * CHAIN_THREADS), 0, c->stream, A);  // one residue per thread, history from global memory
   else hipLaunchKernelGGL((k_chain<4, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), 0, c->stream, A);
 }
@@ -941,11 +956,24 @@ static int ensure_outputs(trx2_ctx* ctx, size_t N, bool with_tors0) {
 // that fills a CU's LDS keeps it off that CU: two pair-kernel workgroups' worth (2 x 28.0 KB) stay free -- measured at 2 x 160
 // slots: no reserve 837, one workgroup's 865, two 900 decoys/s (all channels 789 -> 840 from one to two); one lane of 64 slots
 // loses 2 % with the reserve, hence the distinction (profiles/README.md).
-static int step_dyn_budget(const trx2_ctx* ctx, int k) {
+static int step_dyn_budget(const trx2_ctx* ctx, int k, int L) {
   static const int env = getenv("TRX2_STEP_LDS_RESERVE") ? atoi(getenv("TRX2_STEP_LDS_RESERVE")) : -1;  // A/B timing only
   const bool shared = g_live_contexts.load() > 1;  // a second lane (a context of its own) or another chain's context in this process
   const int reserve = env >= 0 ? env : (shared ? 58 * 1024 : 0);
-  return std::max(ctx->step_dyn_floor[k], ctx->step_dyn_max[k] - reserve);
+  return std::max(HIST_LDS_BYTES(L), ctx->step_dyn_max[k] - reserve);
+}
+// A fold on more than 256 slots launches more step workgroups than the chip has CUs, and the fused kernel's 256 + 106 registers
+// keep them at one per CU (640 slots: 2.5 rounds, 55 us).  Chains of 129-256 residues whose torsion-role history leaves room
+// then fold on the low-register instantiation -- the same arithmetic, bit for bit (tests), one stored pair at a time in the
+// Cartesian role, 256 registers -- with no more dynamic LDS than lets two workgroups share a CU.  Decided once per fold, by the
+// slots it starts with (the tail compaction shrinks the launches, not the choice).  TRX2_STEP_ONE_PER_CU=1: never (A/B timing).
+static bool step_two_per_cu(const trx2_ctx* ctx, int L, int slots, int* dyn_cap) {
+  static const bool never = getenv("TRX2_STEP_ONE_PER_CU") != nullptr;
+  if (never || slots <= 256 || L <= 128 || L > CHAIN_THREADS) return false;
+  const int cap = (ctx->lds_total - 2 * ctx->step2_static) / 2;
+  if ((int)HIST_LDS_BYTES(L) > cap) return false;
+  *dyn_cap = cap;
+  return true;
 }
 
 static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint64_t seed, uint32_t decoy0,
@@ -1011,6 +1039,8 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   auto pool_args = [&](ChainArgs& ca) {
     ca.n_total = N; ca.seed = seed; ca.decoy0 = decoy0; ca.tors0_all = tors0 ? ctx->tors0_all : nullptr;
   };
+  int two_cap = 0;
+  const bool two_per_cu = has_cart && step_two_per_cu(ctx, L, B0, &two_cap);
   auto enqueue_chunk = [&]() -> int {  // non-zero: a pair launch was refused; nothing was launched after it
     for (int i = 0; i < chunk; i++) {
       const bool samp = pe > 0 && (i % pe) == 0 && (size_t)(3 * prof_used + 2) < ctx->prof_ev.size();
@@ -1025,13 +1055,15 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
         const dim3 g2(2 * B), b1(CHAIN_THREADS), b2(2 * CHAIN_THREADS);
         // dynamic LDS of the launch: the larger of the two roles' staged histories
         const int k = L <= 128 ? 0 : 1;
-        size_t dyn = k == 0 ? HIST_LDS_BYTES(128) : HIST_LDS_BYTES(CHAIN_THREADS);
+        size_t dyn = HIST_LDS_BYTES(L);
         if (L <= CHAIN_THREADS) {
-          cc.hist_lds = (int)std::min<size_t>(LBM, (size_t)step_dyn_budget(ctx, k) / CART_HIST_BYTES(L));
+          const int budget = two_per_cu ? two_cap : step_dyn_budget(ctx, k, L);
+          cc.hist_lds = (int)std::min<size_t>(LBM, (size_t)budget / CART_HIST_BYTES(L));
           if (const char* e = getenv("TRX2_CART_HIST_LDS")) cc.hist_lds = std::min(cc.hist_lds, std::max(0, atoi(e)));  // A/B and debugging only
           dyn = std::max(dyn, cc.hist_lds * CART_HIST_BYTES(L));
         }
         if (L <= 128) hipLaunchKernelGGL((k_step<1, 128, 128>), g2, dim3(128), dyn, ctx->stream, ca, cc);
+        else if (two_per_cu) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS, true>), g2, b1, dyn, ctx->stream, ca, cc);
         else if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS>), g2, b1, dyn, ctx->stream, ca, cc);
         else hipLaunchKernelGGL((k_step<1, 2 * CHAIN_THREADS, 2 * CHAIN_THREADS>), g2, b2, 0, ctx->stream, ca, cc);
       } else
@@ -1520,7 +1552,7 @@ extern "C" int trx2_ctx_info(const trx2_ctx* ctx, int key, double* value) {
     case TRX2_INFO_SLAB_BYTES: *value = (ctx->plan_cur >= 0 ? ctx->plans[(size_t)ctx->plan_cur].ns_avg : 1.0) * PR_REC * 4; return 0;
     case TRX2_INFO_PAIR_WGS: *value = (ctx->plan_cur >= 0 ? (double)ctx->plans[(size_t)ctx->plan_cur].n_items : 0.0) * (ctx->Bpad / ctx->BW); return 0;
     case TRX2_INFO_CART_STAGED:
-      *value = (ctx->L >= 1 && ctx->L <= CHAIN_THREADS) ? (double)std::min<size_t>(LBM, (size_t)step_dyn_budget(ctx, ctx->L <= 128 ? 0 : 1) / CART_HIST_BYTES(ctx->L)) : 0.0;
+      *value = (ctx->L >= 1 && ctx->L <= CHAIN_THREADS) ? (double)std::min<size_t>(LBM, (size_t)step_dyn_budget(ctx, ctx->L <= 128 ? 0 : 1, ctx->L) / CART_HIST_BYTES(ctx->L)) : 0.0;
       return 0;
     case TRX2_INFO_LBFGS_M: *value = LBM; return 0;
     case TRX2_INFO_L: *value = ctx->L; return 0;
