@@ -57,8 +57,8 @@ CONFIGS = {
             name="eight targets L in {100,140,180,220,260,300,350,400}, init_num=32 each, dist+omega+theta+phi, synthetic maps "
                  "seed L; (target, decoy-block) items assigned to ranks longest-processing-time-first"),
 }
-MAX_SLOTS = 640  # decoy slots per lane of the pooled leg = every decoy of its queue in flight (the library's policy, fold.SLOTS_PER_LANE: up to 1280;
-                 # tools/pool_sweep.py, round 3: 1280 decoys on 2 x 192 / 320 / 640 slots -> 1110 / 1254 / 1384 decoys/s)
+MAX_SLOTS = 640  # decoy slots per lane of the pooled leg = every decoy of its queue in flight (the library's policy, fold.SLOTS_PER_LANE: up to 960;
+                 # tools/pool_sweep.py, round 3: 1280 decoys on 2 x 192 / 320 / 640 slots -> 1121 / 1425 / 1675 decoys/s)
 POOLED_QUEUE = 1280  # decoys of the pooled_queue leg (fixed: the leg does not depend on --steps)
 LEG_QUEUE = 320      # decoys of the in_flight_B / single_stream legs
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")

@@ -64,8 +64,8 @@ def _unquote(p):
     return p[1:-1] if len(p) >= 2 and p[0] == p[-1] and p[0] in "\"'" else p
 
 
-SLOTS_PER_LANE = 1280  # every decoy in flight up to this many per lane (tools/pool_sweep.py, round 3, L=150: a queue of 5120 decoys on
-                       # 2 x 640 / 960 / 1280 / 2560 slots -> 1421 / 1499 / 1500 / 1416 decoys/s; 192 was round 2's optimum)
+SLOTS_PER_LANE = 960  # every decoy in flight up to this many per lane (tools/pool_sweep.py, round 3, L=150: a queue of 5120 decoys on
+                      # 2 x 640 / 960 / 1280 / 1920 / 2560 slots -> 1741 / 1803 / 1769 / 1718 / 1646 decoys/s; 192 was round 2's optimum)
 
 
 def get_context(device=0, lanes=1):
