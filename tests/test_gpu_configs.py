@@ -495,3 +495,38 @@ def test_bench_pooled_shape_two_lanes_192_slots():
         else:
             os.environ["TRX2_NSPLIT"] = old
         ctx.close(); ref.close()
+
+
+@pytest.mark.parametrize("L,orient", [(130, True), (150, True), (175, False), (176, True)])
+def test_low_register_step_kernel_is_the_same_arithmetic(L, orient):
+    """Folds that start on more than 256 slots run the fused step kernel's low-register instantiation (two workgroups per CU; chains
+    of 129-175 residues; 176 here takes the ordinary one either way): same operations in the same order, so 400 evaluations of 600
+    decoys (300 slots per lane) -- a short torsion run, the Cartesian run, a torsion run again, from near the target -- must come out
+    bit for bit as with TRX2_STEP_ONE_PER_CU=1 (the ordinary instantiation; read per fold): coordinates, energies, counts."""
+    m = S.make_map(L, seed=L)
+    full = T.protocol.build_runs(L, 2)
+    runs = [dict(full[5], max_iter=40), dict(full[8], max_iter=150), dict(full[5], max_iter=40)]
+    assert runs[1]["cartesian"] == 1 and not runs[0]["precheck"]
+    t0 = near_starts(m, 600, 11)
+    out = {}
+    old = os.environ.get("TRX2_STEP_ONE_PER_CU")
+    try:
+        for one in (False, True):
+            if one:
+                os.environ["TRX2_STEP_ONE_PER_CU"] = "1"
+            else:
+                os.environ.pop("TRX2_STEP_ONE_PER_CU", None)
+            c = T.Context(0, lanes=2)
+            try:
+                c.set_map(m["dist"], *chans(m, orient), seq=m["seq"])
+                out[one] = c.fold_batch(600, runs, tors0=t0, max_evals=400)
+            finally:
+                c.close()
+    finally:
+        if old is None:
+            os.environ.pop("TRX2_STEP_ONE_PER_CU", None)
+        else:
+            os.environ["TRX2_STEP_ONE_PER_CU"] = old
+    assert np.all(np.isfinite(out[False]["xyz"])) and np.all(out[False]["n_iters"] > 45)     # past the first run: the Cartesian run stepped
+    for key in ("xyz", "tors", "e_terms", "f", "status", "n_evals", "n_iters"):
+        assert np.array_equal(out[False][key], out[True][key]), key

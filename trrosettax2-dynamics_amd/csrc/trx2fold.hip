@@ -966,10 +966,10 @@ static int step_dyn_budget(const trx2_ctx* ctx, int k, int L) {
 // keep them at one per CU (640 slots: 2.5 rounds, 55 us).  Chains of 129-256 residues whose torsion-role history leaves room
 // then fold on the low-register instantiation -- the same arithmetic, bit for bit (tests), one stored pair at a time in the
 // Cartesian role, 256 registers -- with no more dynamic LDS than lets two workgroups share a CU.  Decided once per fold, by the
-// slots it starts with (the tail compaction shrinks the launches, not the choice).  TRX2_STEP_ONE_PER_CU=1: never (A/B timing).
+// slots it starts with (the tail compaction shrinks the launches, not the choice).  TRX2_STEP_ONE_PER_CU=1 (read per fold): never
+// (A/B timing, and the test that compares the two instantiations bit for bit).
 static bool step_two_per_cu(const trx2_ctx* ctx, int L, int slots, int* dyn_cap) {
-  static const bool never = getenv("TRX2_STEP_ONE_PER_CU") != nullptr;
-  if (never || slots <= 256 || L <= 128 || L > CHAIN_THREADS) return false;
+  if (getenv("TRX2_STEP_ONE_PER_CU") != nullptr || slots <= 256 || L <= 128 || L > CHAIN_THREADS) return false;
   const int cap = (ctx->lds_total - 2 * ctx->step2_static) / 2;
   if ((int)HIST_LDS_BYTES(L) > cap) return false;
   *dyn_cap = cap;
