@@ -147,16 +147,16 @@ def test_cartesian_run_on_a_chain_longer_than_256(ctx):
 
 @pytest.mark.parametrize("L", [150, 230])
 def test_cartesian_history_staged_in_lds_tracks_oracle(ctx, L):
-    """128 < L <= 256: the role's L-BFGS history is staged in LDS as far as the launch has room -- at L=150 five pairs, two more in
-    register buffers; at L=230 three, two in registers and the rest read from global memory inside the recursion -- and the pair
-    stored a moment ago is used from registers.  40 evaluations fill the 8-pair history and turn it over: every source is used.
+    """128 < L <= 256: the role's L-BFGS history is staged in LDS as far as the launch has room (at L=150 six pairs when the context is alone,
+    three when another stream's pair kernel needs room; at L=230 four / two, the rest read from global memory inside the
+    recursion) and the pair stored a moment ago is used from registers.  40 evaluations fill the 8-pair history and turn it over: every source is used.
     Same short-horizon agreement with the oracle as at L=90 (all pairs staged) and L=300 (none)."""
     S = importlib.import_module("trrosettax2-dynamics_amd.synth")
     B = 4
     m = S.make_map(L, seed=L, n_moves=150)
     ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=m["seq"])
-    # pairs staged in LDS: everything beside the kernel's static LDS when this context is alone in the process, 58 KB less (room for
-    # two workgroups of the other stream's pair kernel) when another context is alive
+    # pairs staged in LDS: everything beside the kernel's static LDS when this context is alone in the process, two pair-kernel
+    # workgroups' worth less (the other stream's) when another context is alive
     assert int(ctx.info(5)) in {150: (6, 3), 230: (4, 2)}[L]
     Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"])
     rng = np.random.default_rng(L)

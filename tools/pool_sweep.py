@@ -1,12 +1,12 @@
 """One queue of N decoys on two lanes x S slots (the slot pool refills on the device): decoys/s against S.
 usage: pool_sweep.py <repo> <config 2|3> <N> [S ...]"""
-import importlib, json, sys, time
+import importlib, json, os, sys, time
 import numpy as np
 sys.path.insert(0, sys.argv[1])
 T = importlib.import_module("trrosettax2-dynamics_amd"); S_ = importlib.import_module("trrosettax2-dynamics_amd.synth")
 cfg, N = int(sys.argv[2]), int(sys.argv[3])
 slots = [int(x) for x in sys.argv[4:]] or [128, 192, 256, 320]
-L, orient = 150, cfg == 3
+L, orient = int(os.environ.get("POOL_L", "150")), cfg == 3   # POOL_L: another chain length
 m = S_.make_map(L, seed=L); runs = T.protocol.build_runs(L, 2)
 for s in slots:
     ctx = T.Context(0, lanes=2, pool=s)

@@ -185,6 +185,7 @@ __device__ unsigned long long g_cstamp[32];
 extern __shared__ float4 s_hist[];
 #define HIST_LDS_BYTES(L) (LBM * 2 * (L) * 16)  /* the torsion role's staged history: [LBM][s | y][L] float4 */
 #define CART_HIST_BYTES(L) ((size_t)(L) * 128)  // one stored pair of the Cartesian role in LDS: [s | y][4][L] float4
+#define CART_ARRAYS_BYTES(L) ((((size_t)(L) * 100) + 15) / 16 * 16)  // the Cartesian role's own LDS arrays, in front of its staged pairs
 __device__ __forceinline__ void lds_dma16(const float4* src /* per lane */, float4* dst_wave /* wave-uniform: lane i lands at dst + i */) {
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src, (void __attribute__((address_space(3)))*)dst_wave, 16, 0, 0);
 }
@@ -1146,7 +1147,8 @@ struct CartArgs {
 };
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, a.w * b.w))); }
 struct Res5 { f3 N, CA, C, O, CB; };
-__device__ __forceinline__ Res5 unpack5(const float* p) {
+template <typename P>
+__device__ __forceinline__ Res5 unpack5(P p) {
   return Res5{mk3(p[0], p[1], p[2]), mk3(p[3], p[4], p[5]), mk3(p[6], p[7], p[8]), mk3(p[9], p[10], p[11]), mk3(p[12], p[13], p[14])};
 }
 __device__ __forceinline__ float wrap_pi_f(float x) { return x - 2.0f * TRX2_PI_F * rintf(x * (0.5f / TRX2_PI_F)); }
@@ -1176,11 +1178,18 @@ __device__ __forceinline__ LinkGrad link_terms(const Res5& P, const Res5& Q) {
 }
 
 // One stored pair of the Cartesian role for this thread's residue: from its staged LDS slot, or from global memory (pair j).
+// (`hist` typed as an LDS pointer: as a plain pointer the compiler merged the two sources into one FLAT load of a selected
+// address -- the LDS reads of the staged pairs went through the flat path.)
+typedef float v4f_t __attribute__((ext_vector_type(4)));   // (a builtin vector: HIP's float4 class has no assignment across address spaces)
+typedef __attribute__((address_space(3))) float lds_f;
+typedef __attribute__((address_space(3))) v4f_t lds_f4;
+__device__ __forceinline__ float4 lds_get(const lds_f4* p) { const v4f_t t = *p; return make_float4(t.x, t.y, t.z, t.w); }
+__device__ __forceinline__ void lds_put(lds_f4* p, float4 v) { const v4f_t t = {v.x, v.y, v.z, v.w}; *p = t; }
 template <int NT>
-__device__ __forceinline__ void cart_hist_fetch(const CartArgs& A, int dec, int L, int rc, bool staged, int slot, int j, float4 (&s_)[4], float4 (&y_)[4]) {
+__device__ __forceinline__ void cart_hist_fetch(const CartArgs& A, const lds_f4* hist, int dec, int L, int rc, bool staged, int slot, int j, float4 (&s_)[4], float4 (&y_)[4]) {
   if (NT <= 256 && staged) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) { s_[q] = s_hist[(size_t)((slot * 2 + 0) * 4 + q) * L + rc]; y_[q] = s_hist[(size_t)((slot * 2 + 1) * 4 + q) * L + rc]; }
+    for (int q = 0; q < 4; q++) { s_[q] = lds_get(hist + (size_t)((slot * 2 + 0) * 4 + q) * L + rc); y_[q] = lds_get(hist + (size_t)((slot * 2 + 1) * 4 + q) * L + rc); }
   } else {
     const size_t o = ((size_t)dec * LBM + j) * 4 * L + rc;
 #pragma unroll
@@ -1201,9 +1210,17 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
   __shared__ int s_i[SI_N];
   __shared__ double s_d[SD_N];
   __shared__ float s_rho[LBM];
-  __shared__ float s_xyz[NT * 16];
-  __shared__ float s_dt[NT * 6];  // gradient a residue's psi, omega and link terms put on N and CA of the residue after it
-  __shared__ float s_gp[NT * 3];  // gradient a residue's phi and backbone H put on C of the residue before it
+  // The role's own arrays: static LDS in the ordinary instantiation (compile-time addresses: carving them from the dynamic buffer
+  // cost 2-5 % at the small launch shapes); in the low-register one they live in the launch's DYNAMIC LDS, in front of the staged
+  // pairs and in rows L long (100 L bytes; the torsion role's workgroups use the same bytes for their history), so that the
+  // kernel's static LDS is 9 KB instead of 35 and two workgroups share a CU up to 256 residues.
+  __shared__ float st_xyz[LOWREG ? 4 : NT * 16];
+  __shared__ float st_dt[LOWREG ? 4 : NT * 6];
+  __shared__ float st_gp[LOWREG ? 4 : NT * 3];
+  lds_f* const s_xyz = LOWREG ? (lds_f*)s_hist : (lds_f*)st_xyz;   // [.][16] trial coordinates (neighbours read each other's)
+  lds_f* const s_dt = LOWREG ? s_xyz + (size_t)L * 16 : (lds_f*)st_dt;  // [.][6] gradient a residue's psi, omega and link terms put on N and CA of the residue after it
+  lds_f* const s_gp = LOWREG ? s_dt + (size_t)L * 6 : (lds_f*)st_gp;    // [.][3] gradient a residue's phi and backbone H put on C of the residue before it
+  lds_f4* const c_hist = (lds_f4*)s_hist + (LOWREG ? CART_ARRAYS_BYTES(L) / 16 : 0);
   int* gi = A.st_i + (size_t)dec * SI_N;
   double* gd_ = A.st_d + (size_t)dec * SD_N;
   KSTAMP_DECL
@@ -1248,8 +1265,8 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
       const int j = (hh0 - 1 - kk + LBM) % LBM;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        lds_dma16(A.CS + (((size_t)dec * LBM + j) * 4 + q) * L + r, s_hist + (size_t)((kk * 2 + 0) * 4 + q) * L + wave * 64);
-        lds_dma16(A.CY + (((size_t)dec * LBM + j) * 4 + q) * L + r, s_hist + (size_t)((kk * 2 + 1) * 4 + q) * L + wave * 64);
+        lds_dma16(A.CS + (((size_t)dec * LBM + j) * 4 + q) * L + r, (float4*)(c_hist + (size_t)((kk * 2 + 0) * 4 + q) * L + wave * 64));
+        lds_dma16(A.CY + (((size_t)dec * LBM + j) * 4 + q) * L + r, (float4*)(c_hist + (size_t)((kk * 2 + 1) * 4 + q) * L + wave * 64));
       }
     }
   }
@@ -1265,7 +1282,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
   if (act) {
     const float4* xp = A.P + (vb + r) * 5;
 #pragma unroll
-    for (int q = 0; q < 4; q++) { xt[q] = xp[q]; reinterpret_cast<float4*>(s_xyz + r * 16)[q] = xt[q]; }
+    for (int q = 0; q < 4; q++) { xt[q] = xp[q]; lds_put((lds_f4*)(s_xyz + r * 16) + q, xt[q]); }
     float g[PR_NCOMP], ep[6];
     const float4 none[6] = {};
     sum_pair_records<false>(A.FA, nsl_pre, A.B, L, dec, r, g, ep, none);
@@ -1441,7 +1458,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
           for (int k = 0; k < LBM; k++) {
             if (k < hl) {
               float4 cs_[4], cy_[4];
-              cart_hist_fetch<NT>(A, dec, L, rc, k < nl, k, (hh - 1 - k + 2 * LBM) % LBM, cs_, cy_);
+              cart_hist_fetch<NT>(A, c_hist, dec, L, rc, k < nl, k, (hh - 1 - k + 2 * LBM) % LBM, cs_, cy_);
               float a = 0, b = 0, c = 0;
 #pragma unroll
               for (int q = 0; q < 4; q++) { a += dot4(cs_[q], yv[q]); b += dot4(cy_[q], yv[q]); c += dot4(sv[q], cy_[q]); }
@@ -1453,12 +1470,12 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
         } else {
         // two named buffers: pair k + 1 is requested before pair k is consumed
           float4 b0s[4], b0y[4], b1s[4], b1y[4];
-          if (0 < hl) cart_hist_fetch<NT>(A, dec, L, rc, 0 < nl, 0, (hh - 1 + LBM) % LBM, b0s, b0y);
+          if (0 < hl) cart_hist_fetch<NT>(A, c_hist, dec, L, rc, 0 < nl, 0, (hh - 1 + LBM) % LBM, b0s, b0y);
 #pragma unroll
           for (int k = 0; k < LBM; k++) {
             float4 (&cs_)[4] = (k & 1) ? b1s : b0s; float4 (&cy_)[4] = (k & 1) ? b1y : b0y;
             float4 (&ns_)[4] = (k & 1) ? b0s : b1s; float4 (&ny_)[4] = (k & 1) ? b0y : b1y;
-            if (k + 1 < LBM && k + 1 < hl) cart_hist_fetch<NT>(A, dec, L, rc, k + 1 < nl, k + 1, (hh - 2 - k + 2 * LBM) % LBM, ns_, ny_);
+            if (k + 1 < LBM && k + 1 < hl) cart_hist_fetch<NT>(A, c_hist, dec, L, rc, k + 1 < nl, k + 1, (hh - 2 - k + 2 * LBM) % LBM, ns_, ny_);
             if (k < hl) {
               float a = 0, b = 0, c = 0;
 #pragma unroll
@@ -1554,7 +1571,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
             if (m == 0 && sh) {
 #pragma unroll
               for (int q = 0; q < 4; q++) { cs_[q] = sv[q]; cy_[q] = yv[q]; }
-            } else cart_hist_fetch<NT>(A, dec, L, rc, m - sh < nl, m - sh, (hh - 1 - m + 2 * LBM) % LBM, cs_, cy_);
+            } else cart_hist_fetch<NT>(A, c_hist, dec, L, rc, m - sh < nl, m - sh, (hh - 1 - m + 2 * LBM) % LBM, cs_, cy_);
             const float a = cs[m], b = cy[m];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -1569,12 +1586,12 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
         if (sh) {
 #pragma unroll
           for (int q = 0; q < 4; q++) { b0s[q] = sv[q]; b0y[q] = yv[q]; }
-        } else if (0 < hl) cart_hist_fetch<NT>(A, dec, L, rc, 0 < nl, 0, (hh - 1 + LBM) % LBM, b0s, b0y);
+        } else if (0 < hl) cart_hist_fetch<NT>(A, c_hist, dec, L, rc, 0 < nl, 0, (hh - 1 + LBM) % LBM, b0s, b0y);
 #pragma unroll
         for (int m = 0; m < LBM; m++) {
           float4 (&cs_)[4] = (m & 1) ? b1s : b0s; float4 (&cy_)[4] = (m & 1) ? b1y : b0y;
           float4 (&ns_)[4] = (m & 1) ? b0s : b1s; float4 (&ny_)[4] = (m & 1) ? b0y : b1y;
-          if (m + 1 < LBM && m + 1 < hl) cart_hist_fetch<NT>(A, dec, L, rc, m + 1 - sh < nl, m + 1 - sh, (hh - 2 - m + 2 * LBM) % LBM, ns_, ny_);
+          if (m + 1 < LBM && m + 1 < hl) cart_hist_fetch<NT>(A, c_hist, dec, L, rc, m + 1 - sh < nl, m + 1 - sh, (hh - 2 - m + 2 * LBM) % LBM, ns_, ny_);
           if (m < hl) {
             const float a = cs[m], b = cy[m];
 #pragma unroll
@@ -1727,7 +1744,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
     __syncthreads();
     if (act)
 #pragma unroll
-      for (int q = 0; q < 4; q++) reinterpret_cast<float4*>(s_xyz + r * 16)[q] = xt[q];
+      for (int q = 0; q < 4; q++) lds_put((lds_f4*)(s_xyz + r * 16) + q, xt[q]);
     __syncthreads();
     if (act) {
       const Res5 M3 = unpack5(s_xyz + r * 16);
@@ -1748,7 +1765,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
     __syncthreads();
     if (act)
 #pragma unroll
-      for (int q = 0; q < 4; q++) reinterpret_cast<float4*>(s_xyz + r * 16)[q] = x[q];
+      for (int q = 0; q < 4; q++) lds_put((lds_f4*)(s_xyz + r * 16) + q, x[q]);
     __syncthreads();
     if (act) {
       const Res5 M2 = unpack5(s_xyz + r * 16);

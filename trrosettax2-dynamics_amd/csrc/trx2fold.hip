@@ -139,6 +139,7 @@ struct trx2_ctx {
   int step_dyn_floor[2] = {0, 0};  // ... and the most the torsion role needs of it (its staged history at 128 / 256 residues)
   int step_static[2] = {0, 0};     // static LDS of the two fused step kernels
   int step2_static = 0;            // ... and of the low-register instantiation (k_step<1, 256, 256, true>)
+  int pair_static = 32 * 1024;     // static LDS of a pair-kernel workgroup
   int lds_total = 160 * 1024;      // LDS of a CU
   std::vector<hipEvent_t> prof_ev;
   double prof_pair_ms = 0, prof_step_ms = 0; int prof_n = 0;
@@ -252,6 +253,11 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
       ctx->step_dyn_floor[k] = hist[k];
       ctx->step_static[k] = (int)fa.sharedSizeBytes;
       ok = hipFuncSetAttribute(fstep[k], hipFuncAttributeMaxDynamicSharedMemorySize, dyn) == hipSuccess;
+    }
+    if (ok) {
+      hipFuncAttributes fp;
+      ok = hipFuncGetAttributes(&fp, (const void*)k_pair<64, FAM_ALL>) == hipSuccess;
+      if (ok) ctx->pair_static = (int)fp.sharedSizeBytes;
     }
     // the low-register instantiation (launches of more than 256 slots, chains of 129-256 residues): two workgroups per CU
     if (ok) {
@@ -959,19 +965,19 @@ static int ensure_outputs(trx2_ctx* ctx, size_t N, bool with_tors0) {
 static int step_dyn_budget(const trx2_ctx* ctx, int k, int L) {
   static const int env = getenv("TRX2_STEP_LDS_RESERVE") ? atoi(getenv("TRX2_STEP_LDS_RESERVE")) : -1;  // A/B timing only
   const bool shared = g_live_contexts.load() > 1;  // a second lane (a context of its own) or another chain's context in this process
-  const int reserve = env >= 0 ? env : (shared ? 58 * 1024 : 0);
+  const int reserve = env >= 0 ? env : (shared ? 2 * ctx->pair_static + 1024 : 0);   // two workgroups of the other stream's pair kernel
   return std::max(HIST_LDS_BYTES(L), ctx->step_dyn_max[k] - reserve);
 }
 // A fold on more than 256 slots launches more step workgroups than the chip has CUs, and the fused kernel's 256 + 106 registers
-// keep them at one per CU (640 slots: 2.5 rounds, 55 us).  Chains of 129-256 residues whose torsion-role history leaves room
-// then fold on the low-register instantiation -- the same arithmetic, bit for bit (tests), one stored pair at a time in the
-// Cartesian role, 256 registers -- with no more dynamic LDS than lets two workgroups share a CU.  Decided once per fold, by the
+// keep them at one per CU (640 slots: 2.5 rounds, 55 us).  Chains of 129-256 residues then fold on the low-register
+// instantiation -- the same arithmetic, bit for bit (tests), one stored pair at a time in the Cartesian role, 256 registers, the
+// role's arrays in dynamic LDS (9 KB static instead of 35) -- with no more dynamic LDS than lets two workgroups share a CU.  Decided once per fold, by the
 // slots it starts with (the tail compaction shrinks the launches, not the choice).  TRX2_STEP_ONE_PER_CU=1 (read per fold): never
 // (A/B timing, and the test that compares the two instantiations bit for bit).
 static bool step_two_per_cu(const trx2_ctx* ctx, int L, int slots, int* dyn_cap) {
   if (getenv("TRX2_STEP_ONE_PER_CU") != nullptr || slots <= 256 || L <= 128 || L > CHAIN_THREADS) return false;
   const int cap = (ctx->lds_total - 2 * ctx->step2_static) / 2;
-  if ((int)HIST_LDS_BYTES(L) > cap) return false;
+  if ((int)HIST_LDS_BYTES(L) > cap || (int)CART_ARRAYS_BYTES(L) > cap) return false;
   *dyn_cap = cap;
   return true;
 }
@@ -1055,17 +1061,20 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
         const dim3 g2(2 * B), b1(CHAIN_THREADS), b2(2 * CHAIN_THREADS);
         // dynamic LDS of the launch: the larger of the two roles' staged histories
         const int k = L <= 128 ? 0 : 1;
-        size_t dyn = HIST_LDS_BYTES(L);
+        // dynamic LDS of the launch: the larger of the torsion role's staged history and the Cartesian role's staged pairs (behind
+        // its own arrays in the low-register instantiation)
+        const size_t arrays = two_per_cu ? CART_ARRAYS_BYTES(L) : 0;
+        size_t dyn = L <= CHAIN_THREADS ? HIST_LDS_BYTES(L) : 0;
         if (L <= CHAIN_THREADS) {
-          const int budget = two_per_cu ? two_cap : step_dyn_budget(ctx, k, L);
-          cc.hist_lds = (int)std::min<size_t>(LBM, (size_t)budget / CART_HIST_BYTES(L));
+          const int budget = (two_per_cu ? two_cap : step_dyn_budget(ctx, k, L)) - (int)arrays;
+          cc.hist_lds = budget > 0 ? (int)std::min<size_t>(LBM, (size_t)budget / CART_HIST_BYTES(L)) : 0;
           if (const char* e = getenv("TRX2_CART_HIST_LDS")) cc.hist_lds = std::min(cc.hist_lds, std::max(0, atoi(e)));  // A/B and debugging only
-          dyn = std::max(dyn, cc.hist_lds * CART_HIST_BYTES(L));
+          dyn = std::max(dyn, arrays + cc.hist_lds * CART_HIST_BYTES(L));
         }
         if (L <= 128) hipLaunchKernelGGL((k_step<1, 128, 128>), g2, dim3(128), dyn, ctx->stream, ca, cc);
         else if (two_per_cu) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS, true>), g2, b1, dyn, ctx->stream, ca, cc);
         else if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS>), g2, b1, dyn, ctx->stream, ca, cc);
-        else hipLaunchKernelGGL((k_step<1, 2 * CHAIN_THREADS, 2 * CHAIN_THREADS>), g2, b2, 0, ctx->stream, ca, cc);
+        else hipLaunchKernelGGL((k_step<1, 2 * CHAIN_THREADS, 2 * CHAIN_THREADS>), g2, b2, dyn, ctx->stream, ca, cc);
       } else
         launch_chain_args(ctx, B, ca);
       if (samp) { (void)hipEventRecord(ctx->prof_ev[3 * prof_used + 2], ctx->stream); prof_used++; }
