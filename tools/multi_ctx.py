@@ -8,6 +8,7 @@ T = importlib.import_module("trrosettax2-dynamics_amd"); S = importlib.import_mo
 CFG = {2: (150, 64, False), 3: (150, 64, True), 4: (400, 32, True)}
 cfg, n, K = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 L, B, orient = CFG[cfg]
+B = int(os.environ.get("MULTI_B", B))   # MULTI_B: decoys per call instead of the config's
 runs = T.protocol.build_runs(L, 2)
 m = S.make_map(L, seed=L)
 ctxs = []
