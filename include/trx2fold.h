@@ -53,7 +53,7 @@ void trx2_ctx_destroy(trx2_ctx* ctx);
  * (utils_trX2dy/utils.py:501-503).  Every decoy keeps its identity (seed, decoy0 + index); results equal those of folding the
  * two halves as separate batches.  lanes = 1 (default) restores one stream.  Measured on MI355X, round 3 (one call of 64 decoys,
  * L=150): two lanes 404 against 344 decoys/s with distances only; two CHAINS of 64 on their own contexts (two streams already)
- * fold faster with one lane each (637 against 495), L=400 with 32 decoys 90 against 78.  GPU_MAX_HW_QUEUES=8 (HIP runtime) changes
+ * fold faster with one lane each (814 decoys/s at the end of the round; 637 against 495 when compared), L=400 with 32 decoys 90 against 78.  GPU_MAX_HW_QUEUES=8 (HIP runtime) changes
  * nothing at two or three concurrent streams and costs 16 % at four (2 chains x 2 lanes): the library neither needs nor sets it;
  * keep a process at two to three folding streams (pipeline.run_single and fold.fold_arrays choose the lanes accordingly). */
 int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes);
@@ -63,8 +63,10 @@ int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes);
  * decoys; with fewer slots than decoys the slots stay busy until the queue is empty.  The reference's counterpart is its
  * process pool (ThreadPoolExecutor over `python folding.py` children, utils_trX2dy/utils.py:501-503), which also starts the next
  * decoy when a worker frees up.  A decoy is identified by (seed, decoy0 + index) and its results do not depend on the slot that
- * folded it, on `slots`, or on the order of completion.  trx2_last_fold_slot_efficiency: sum of evaluations over the decoys of
- * the last fold / (launch pairs x slots). */
+ * folded it, on `slots`, or on the order of completion.  (A fold that starts on more than 256 slots steps chains of 129-256
+ * residues with a low-register instantiation of the step kernel, two workgroups per CU: the same operations in the same order,
+ * tested bit for bit.)  How many slots: with the kernels of round 3, as many as the job offers up to ~960 per lane
+ * (INTEGRATION.md).  trx2_last_fold_slot_efficiency: sum of evaluations over the decoys of the last fold / (launch pairs x slots). */
 int trx2_ctx_set_pool(trx2_ctx* ctx, int slots);
 /* Tail of a fold.  Once the queue is empty the slots retire one by one, but a launch over several decoy groups (more than 64 slots)
  * keeps its full length while every group still holds a live decoy.  mode 1 (default): whenever the live decoys fit into one group
