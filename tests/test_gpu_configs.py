@@ -499,7 +499,7 @@ def test_bench_pooled_shape_two_lanes_192_slots():
 
 @pytest.mark.parametrize("L,orient", [(130, True), (150, True), (200, False), (256, True)])
 def test_low_register_step_kernel_is_the_same_arithmetic(L, orient):
-    """Folds that start on more than 256 slots run the fused step kernel's low-register instantiation (two workgroups per CU; chains
+    """Folds that start on 160 slots or more run the fused step kernel's low-register instantiation (two workgroups per CU; chains
     of 129-256 residues): same operations in the same order, so 400 evaluations of 600
     decoys (300 slots per lane) -- a short torsion run, the Cartesian run, a torsion run again, from near the target -- must come out
     bit for bit as with TRX2_STEP_ONE_PER_CU=1 (the ordinary instantiation; read per fold): coordinates, energies, counts."""

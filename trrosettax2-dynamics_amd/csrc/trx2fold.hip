@@ -968,14 +968,16 @@ static int step_dyn_budget(const trx2_ctx* ctx, int k, int L) {
   const int reserve = env >= 0 ? env : (shared ? 2 * ctx->pair_static + 1024 : 0);   // two workgroups of the other stream's pair kernel
   return std::max(HIST_LDS_BYTES(L), ctx->step_dyn_max[k] - reserve);
 }
-// A fold on more than 256 slots launches more step workgroups than the chip has CUs, and the fused kernel's 256 + 106 registers
-// keep them at one per CU (640 slots: 2.5 rounds, 55 us).  Chains of 129-256 residues then fold on the low-register
+// A fold on many slots launches more step workgroups (of both lanes) than the chip has CUs, and the fused kernel's 256 + 106
+// registers keep them at one per CU (640 slots: 2.5 rounds, 55 us).  Chains of 129-256 residues then fold on the low-register
 // instantiation -- the same arithmetic, bit for bit (tests), one stored pair at a time in the Cartesian role, 256 registers, the
 // role's arrays in dynamic LDS (9 KB static instead of 35) -- with no more dynamic LDS than lets two workgroups share a CU.  Decided once per fold, by the
 // slots it starts with (the tail compaction shrinks the launches, not the choice).  TRX2_STEP_ONE_PER_CU=1 (read per fold): never
 // (A/B timing, and the test that compares the two instantiations bit for bit).
 static bool step_two_per_cu(const trx2_ctx* ctx, int L, int slots, int* dyn_cap) {
-  if (getenv("TRX2_STEP_ONE_PER_CU") != nullptr || slots <= 256 || L <= 128 || L > CHAIN_THREADS) return false;
+  int min_slots = 160;   // measured crossover (tools/pool_sweep.py, 1280 decoys at L=150: +2 % at 160 slots per lane, +5 % at 192, +11 % at 256, -3 % at 32)
+  if (const char* e = getenv("TRX2_STEP_LOWREG_MIN")) min_slots = atoi(e);   // A/B timing only
+  if (getenv("TRX2_STEP_ONE_PER_CU") != nullptr || slots < min_slots || L <= 128 || L > CHAIN_THREADS) return false;
   const int cap = (ctx->lds_total - 2 * ctx->step2_static) / 2;
   if ((int)HIST_LDS_BYTES(L) > cap || (int)CART_ARRAYS_BYTES(L) > cap) return false;
   *dyn_cap = cap;
