@@ -63,8 +63,8 @@ int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes);
  * decoys; with fewer slots than decoys the slots stay busy until the queue is empty.  The reference's counterpart is its
  * process pool (ThreadPoolExecutor over `python folding.py` children, utils_trX2dy/utils.py:501-503), which also starts the next
  * decoy when a worker frees up.  A decoy is identified by (seed, decoy0 + index) and its results do not depend on the slot that
- * folded it, on `slots`, or on the order of completion.  (A fold that starts on 160 slots or more steps chains of 129-256
- * residues with a low-register instantiation of the step kernel, two workgroups per CU: the same operations in the same order,
+ * folded it, on `slots`, or on the order of completion.  (A fold that starts on 160 slots or more -- 128 for chains of up to 128 residues -- steps
+ * with a low-register instantiation of the step kernel, eight waves per CU instead of four: the same operations in the same order,
  * tested bit for bit.)  How many slots: with the kernels of round 3, as many as the job offers up to ~960 per lane
  * (INTEGRATION.md).  trx2_last_fold_slot_efficiency: sum of evaluations over the decoys of the last fold / (launch pairs x slots). */
 int trx2_ctx_set_pool(trx2_ctx* ctx, int slots);

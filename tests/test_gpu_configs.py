@@ -497,17 +497,17 @@ def test_bench_pooled_shape_two_lanes_192_slots():
         ctx.close(); ref.close()
 
 
-@pytest.mark.parametrize("L,orient", [(130, True), (150, True), (200, False), (256, True)])
+@pytest.mark.parametrize("L,orient", [(64, True), (128, False), (130, True), (150, True), (200, False), (256, True)])
 def test_low_register_step_kernel_is_the_same_arithmetic(L, orient):
-    """Folds that start on 160 slots or more run the fused step kernel's low-register instantiation (two workgroups per CU; chains
-    of 129-256 residues): same operations in the same order, so 400 evaluations of 600
-    decoys (300 slots per lane) -- a short torsion run, the Cartesian run, a torsion run again, from near the target -- must come out
+    """Folds that start on many slots (160 per lane; 320 for chains of up to 128 residues) run the fused step kernel's low-register instantiation (eight waves per CU instead of four;
+    chains of up to 256 residues): same operations in the same order, so 400 evaluations of 700
+    decoys (350 slots per lane) -- a short torsion run, the Cartesian run, a torsion run again, from near the target -- must come out
     bit for bit as with TRX2_STEP_ONE_PER_CU=1 (the ordinary instantiation; read per fold): coordinates, energies, counts."""
     m = S.make_map(L, seed=L)
     full = T.protocol.build_runs(L, 2)
     runs = [dict(full[5], max_iter=40), dict(full[8], max_iter=150), dict(full[5], max_iter=40)]
     assert runs[1]["cartesian"] == 1 and not runs[0]["precheck"]
-    t0 = near_starts(m, 600, 11)
+    t0 = near_starts(m, 700, 11)
     out = {}
     old = os.environ.get("TRX2_STEP_ONE_PER_CU")
     try:
@@ -519,7 +519,7 @@ def test_low_register_step_kernel_is_the_same_arithmetic(L, orient):
             c = T.Context(0, lanes=2)
             try:
                 c.set_map(m["dist"], *chans(m, orient), seq=m["seq"])
-                out[one] = c.fold_batch(600, runs, tors0=t0, max_evals=400)
+                out[one] = c.fold_batch(700, runs, tors0=t0, max_evals=400)
             finally:
                 c.close()
     finally:

@@ -1828,7 +1828,7 @@ __global__ __launch_bounds__(TN) void k_chain(ChainArgs A) {
   chain_body<RPT, TN>(A, blockIdx.x, s_runs, s_gl);
 }
 template <int RPT, int TN, int NT, bool LOWREG = false>
-__global__ __launch_bounds__(NT, (LOWREG ? 2 : 1)) void k_step(ChainArgs A, CartArgs C) {
+__global__ __launch_bounds__(NT, (LOWREG ? 2 : 1)) void k_step(ChainArgs A, CartArgs C) {   // (HIP: waves per SIMD) LOWREG: two, 256 registers
   __shared__ int s_runs[STEP_RUNS_INTS];
   __shared__ GramLds<(RPT == 1) ? TN : 16> s_gl;   // either role's (a workgroup is in one)
   // the Cartesian role first: its workgroups are the slower ones, and the launch ends with the last of them

@@ -138,7 +138,7 @@ struct trx2_ctx {
   int step_dyn_max[2] = {0, 0};  // dynamic LDS the fused step kernels may ask for (L <= 128 | L <= 256): 160 KB - their static LDS
   int step_dyn_floor[2] = {0, 0};  // ... and the most the torsion role needs of it (its staged history at 128 / 256 residues)
   int step_static[2] = {0, 0};     // static LDS of the two fused step kernels
-  int step2_static = 0;            // ... and of the low-register instantiation (k_step<1, 256, 256, true>)
+  int step2_static[2] = {0, 0};    // ... and of their low-register instantiations (k_step<1, NT, NT, true>)
   int pair_static = 32 * 1024;     // static LDS of a pair-kernel workgroup
   int lds_total = 160 * 1024;      // LDS of a CU
   std::vector<hipEvent_t> prof_ev;
@@ -259,15 +259,16 @@ extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
       ok = hipFuncGetAttributes(&fp, (const void*)k_pair<64, FAM_ALL>) == hipSuccess;
       if (ok) ctx->pair_static = (int)fp.sharedSizeBytes;
     }
-    // the low-register instantiation (launches of more than 256 slots, chains of 129-256 residues): two workgroups per CU
-    if (ok) {
-      hipFuncAttributes fa;
-      const void* f2 = (const void*)k_step<1, CHAIN_THREADS, CHAIN_THREADS, true>;
-      ok = hipFuncGetAttributes(&fa, f2) == hipSuccess;
-      if (ok) {
-        ctx->lds_total = lds_max;
-        ctx->step2_static = (int)fa.sharedSizeBytes;
-        ok = hipFuncSetAttribute(f2, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max - (int)fa.sharedSizeBytes) == hipSuccess;
+    // the low-register instantiations (folds on many slots): two workgroups of 256 threads per CU, four of 128
+    {
+      const void* f2[2] = {(const void*)k_step<1, 128, 128, true>, (const void*)k_step<1, CHAIN_THREADS, CHAIN_THREADS, true>};
+      ctx->lds_total = lds_max;
+      for (int k = 0; k < 2 && ok; k++) {
+        hipFuncAttributes fa;
+        ok = hipFuncGetAttributes(&fa, f2[k]) == hipSuccess;
+        if (!ok) break;
+        ctx->step2_static[k] = (int)fa.sharedSizeBytes;
+        ok = hipFuncSetAttribute(f2[k], hipFuncAttributeMaxDynamicSharedMemorySize, lds_max - (int)fa.sharedSizeBytes) == hipSuccess;
       }
     }
     if (!ok) {
@@ -975,10 +976,13 @@ static int step_dyn_budget(const trx2_ctx* ctx, int k, int L) {
 // slots it starts with (the tail compaction shrinks the launches, not the choice).  TRX2_STEP_ONE_PER_CU=1 (read per fold): never
 // (A/B timing, and the test that compares the two instantiations bit for bit).
 static bool step_two_per_cu(const trx2_ctx* ctx, int L, int slots, int* dyn_cap) {
-  int min_slots = 160;   // measured crossover (tools/pool_sweep.py, 1280 decoys at L=150: +2 % at 160 slots per lane, +5 % at 192, +11 % at 256, -3 % at 32)
+  // measured crossovers (tools/pool_sweep.py, 1280 decoys): chains of 129-256 residues +2 % at 160 slots per lane, +5 % at 192,
+  // +11 % at 256, -3 % at 32; L=90: +1..3 % at 128, +8 % at 192, +19 % at 320, +30 % at 640, -7 % at 64 with distances only
+  int min_slots = L <= 128 ? 128 : 160;
   if (const char* e = getenv("TRX2_STEP_LOWREG_MIN")) min_slots = atoi(e);   // A/B timing only
-  if (getenv("TRX2_STEP_ONE_PER_CU") != nullptr || slots < min_slots || L <= 128 || L > CHAIN_THREADS) return false;
-  const int cap = (ctx->lds_total - 2 * ctx->step2_static) / 2;
+  if (getenv("TRX2_STEP_ONE_PER_CU") != nullptr || slots < min_slots || L > CHAIN_THREADS) return false;
+  const int k = L <= 128 ? 0 : 1, n = L <= 128 ? 4 : 2;   // workgroups per CU: eight waves either way
+  const int cap = (ctx->lds_total - n * ctx->step2_static[k]) / n / 16 * 16;
   if ((int)HIST_LDS_BYTES(L) > cap || (int)CART_ARRAYS_BYTES(L) > cap) return false;
   *dyn_cap = cap;
   return true;
@@ -1073,7 +1077,8 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
           if (const char* e = getenv("TRX2_CART_HIST_LDS")) cc.hist_lds = std::min(cc.hist_lds, std::max(0, atoi(e)));  // A/B and debugging only
           dyn = std::max(dyn, arrays + cc.hist_lds * CART_HIST_BYTES(L));
         }
-        if (L <= 128) hipLaunchKernelGGL((k_step<1, 128, 128>), g2, dim3(128), dyn, ctx->stream, ca, cc);
+        if (L <= 128 && two_per_cu) hipLaunchKernelGGL((k_step<1, 128, 128, true>), g2, dim3(128), dyn, ctx->stream, ca, cc);
+        else if (L <= 128) hipLaunchKernelGGL((k_step<1, 128, 128>), g2, dim3(128), dyn, ctx->stream, ca, cc);
         else if (two_per_cu) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS, true>), g2, b1, dyn, ctx->stream, ca, cc);
         else if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS>), g2, b1, dyn, ctx->stream, ca, cc);
         else hipLaunchKernelGGL((k_step<1, 2 * CHAIN_THREADS, 2 * CHAIN_THREADS>), g2, b2, dyn, ctx->stream, ca, cc);
