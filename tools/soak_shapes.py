@@ -1,13 +1,14 @@
 """Soak of the fold entry point over random shapes: chain lengths in every kernel class (<= 128, <= 256, <= 512 residues, beyond),
 batch sizes, lanes, slot pools, tail-compaction modes, evaluation budgets, with and without the angle channels.  Every fold must end
 with status 0 (or 2 = budget spent when one was set), finite coordinates and energies, and repeat bit for bit.
-usage: soak_shapes.py <repo> [n = 40] [seed = 1]"""
+usage: soak_shapes.py <repo> [n = 40] [seed = 1] [big: batches of 260-700 decoys for chains of up to 256 residues]"""
 import importlib, sys, time
 import numpy as np
 sys.path.insert(0, sys.argv[1])
 T = importlib.import_module("trrosettax2-dynamics_amd"); S = importlib.import_module("trrosettax2-dynamics_amd.synth")
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 rng = np.random.default_rng(int(sys.argv[3]) if len(sys.argv) > 3 else 1)
+big = len(sys.argv) > 4 and sys.argv[4] == "big"
 bad = 0
 t_all = time.perf_counter()
 for it in range(n):
@@ -16,6 +17,8 @@ for it in range(n):
     orient = bool(rng.integers(0, 2))
     lanes = int(rng.integers(1, 3))
     B = int(rng.integers(1, 81)) if L <= 256 else int(rng.integers(1, 25))
+    if big and L <= 256:
+        B = int(rng.integers(260, 700))     # folds that start on enough slots for the low-register step instantiation
     pool = 0 if rng.random() < 0.5 else int(rng.integers(1, B + 1))
     mode = int(rng.integers(0, 3))
     budget = 0 if (rng.random() < 0.4 and L <= 300) else int(rng.integers(20, 400))
