@@ -61,7 +61,7 @@ MAX_SLOTS = 640  # decoy slots per lane of the pooled leg = every decoy of its q
                  # tools/pool_sweep.py, round 3: 1280 decoys on 2 x 192 / 320 / 640 slots -> 1121 / 1425 / 1675 decoys/s)
 POOLED_QUEUE = 1280  # decoys of the pooled_queue leg (fixed: the leg does not depend on --steps)
 LEG_QUEUE = 320      # decoys of the in_flight_B / single_stream legs
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
 KERNEL_SOURCES = {"k_pair": ("kernel_pair.h", "trx2_device.h"), "k_step": ("kernel_step.h", "trx2_device.h")}
 
 
@@ -198,26 +198,36 @@ def sampled_fold(ctx, B, runs, seed, decoy0):
         ctx.set_profiling(0)
 
 
-def e2e_leg(pipe_mod, synth, L, init_num, seed=7, candidates=1):
+def e2e_leg(pipe_mod, synth, L, init_num, seed=7, candidates=1, real=False, nmax=300):
     """The job the reference runs (run_inference.py:16-143,280-337; VERDICT r2 missing 2): both models of one target end to end --
     init_num initial decoys per model as one batch, the best one fed back, then ONE decoy per iteration (fold + feedback on the
     resident distograms) until the cumulative array moves by < 0.01 or Nmax = 300 (the CLI default) -- every decoy written as a
-    PDB file, final renaming included.  Synthetic pair of maps (seeds L and L + 1).  decoys/sec = files written / wall."""
+    PDB file, final renaming included.  Synthetic pair of maps (seeds L and L + 1), or with real=True the reference's own example
+    (tests/golden/seq_{NMR,Xray}.npz, L=90: the only real distograms there are).  decoys/sec = files written / wall.  Per chain:
+    iterations run, whether the convergence exit (max |tmp_new - tmp_old| < 0.01, run_inference.py:133-137) was taken, and the
+    trace of that measure (first five, the minimum, the last)."""
     work = tempfile.mkdtemp(prefix="trx2_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         name = "t"
         fasta = os.path.join(work, name + ".fasta")
-        maps = [synth.make_map(L, seed=L + c) for c in range(2)]
+        if real:
+            gd = os.path.join(ROOT, "tests", "golden")
+            seq = "".join(l.strip() for l in open(os.path.join(gd, "seq.fasta")) if not l.startswith(">"))
+            paths = [os.path.join(gd, "seq_NMR.npz"), os.path.join(gd, "seq_Xray.npz")]
+            L = len(seq)
+        else:
+            maps = [synth.make_map(L, seed=L + c) for c in range(2)]
+            seq = maps[0]["seq"]
+            paths = []
+            for tag, m in zip(("NMR", "Xray"), maps):
+                q = os.path.join(work, f"{name}_{tag}.npz")
+                np.savez(q, dist=m["dist"], omega=m["omega"], theta=m["theta"], phi=m["phi"])
+                paths.append(q)
         with open(fasta, "w") as f:
-            f.write(f">{name}\n{maps[0]['seq']}\n")
-        paths = []
-        for tag, m in zip(("NMR", "Xray"), maps):
-            q = os.path.join(work, f"{name}_{tag}.npz")
-            np.savez(q, dist=m["dist"], omega=m["omega"], theta=m["theta"], phi=m["phi"])
-            paths.append(q)
+            f.write(f">{name}\n{seq}\n")
         phases = {}
         t0 = time.perf_counter()
-        n_out = pipe_mod.run_single(name, fasta, os.path.join(work, "out"), init_num=init_num, Nmax=300, angle=True, mult_two_models=True,
+        n_out = pipe_mod.run_single(name, fasta, os.path.join(work, "out"), init_num=init_num, Nmax=nmax, angle=True, mult_two_models=True,
                                     npz_nmr=paths[0], npz_xray=paths[1], device=0, seed=seed, phase_times=phases, candidates=candidates)
         wall = time.perf_counter() - t0
         n_files = len([f for f in os.listdir(os.path.join(work, "out", name, "pred_pdb")) if f.endswith(".pdb")])
@@ -225,18 +235,48 @@ def e2e_leg(pipe_mod, synth, L, init_num, seed=7, candidates=1):
         n_iter = sum(v["iterations"] for v in it.values())
         t_init = max(v["initial_s"] for v in it.values())           # the two chains run concurrently
         t_iter = max(v["iteration_s"] for v in it.values())
-        return {"workload": f"run_inference end to end: L={L}, init_num={init_num} per model, two models (synthetic maps seed {L}, {L + 1}), all channels, "
-                            "Nmax=300, PDB files written" + ("" if candidates == 1 else f"; EXTENSION (off by default): {candidates} decoys folded and written per "
+
+        def trace(v):
+            d = v.get("tmp_change", [])
+            return {"iterations": v["iterations"], "converged": bool(v.get("converged")), "first": [round(x, 4) for x in d[:5]],
+                    "min": round(min(d), 4) if d else None, "last": round(d[-1], 4) if d else None}
+        src = "the reference's example maps tests/golden/seq_{NMR,Xray}.npz" if real else f"synthetic maps seed {L}, {L + 1}"
+        return {"workload": f"run_inference end to end: L={L}, init_num={init_num} per model, two models ({src}), all channels, "
+                            f"Nmax={nmax}, default protocol (--fastrelax), PDB files written" + ("" if candidates == 1 else f"; EXTENSION (off by default): {candidates} decoys folded and written per "
                             "feedback iteration, candidate 0 fed back"), "value": n_out / wall, "unit": "decoys/sec", "decoys_written": n_out, "pdb_files": n_files,
                 "wall_s": wall, "initial_phase_s": t_init, "iteration_phase_s": t_iter, "iterations": {k: v["iterations"] for k, v in it.items()},
+                "convergence": {k: trace(v) for k, v in it.items()},
                 "ms_per_iteration": 1e3 * sum(v["iteration_s"] for v in it.values()) / max(n_iter, 1),
                 "ms_per_iteration_fold": 1e3 * sum(v["iteration_fold_s"] for v in it.values()) / max(n_iter, 1),
-                "note": "chains (models) run concurrently on two streams; within a chain the iterations are sequential single-decoy folds"}
+                "note": "chains (models) run concurrently; within a chain the iterations are sequential single-decoy folds"}
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
 
-def e2e_batch_leg(pipe_mod, synth, L, n_targets=4, nmax=80, seed=3):
+def cpu_e2e_baseline(synth, L, init_num, iterations, runs, n_folds=4):
+    """CPU figure for the e2e job: the job is init_num initial decoys per model, then `iterations` SEQUENTIAL
+    single-decoy folds per model (run_inference.py:97-139) -- on a CPU a chain's iteration cannot use more than one core of this
+    port, so the job's wall is (initial batch over the cores) + iterations x (seconds of one fold).  Measured here: `n_folds`
+    oracle folds of the all-channel L-residue map, one per thread; DERIVED (stated, not measured end to end): the job's rate."""
+    from oracle import oracle as O
+    m = synth.make_map(L, seed=L)
+    Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"])
+    cores = O.usable_cores()
+    nt = max(1, min(n_folds, cores))
+    t0 = time.time()
+    O.fold_batch(Tb, np.stack([O.random_torsions(L, 777, d) for d in range(nt)]), runs, nthreads=nt)
+    t_fold = time.time() - t0                                     # nt folds side by side: the seconds of one (the slowest)
+    n_chain = 2
+    t_init = t_fold * -(-init_num * n_chain // cores)            # initial decoys of both models over the usable cores
+    wall = t_init + iterations * t_fold                           # the two chains side by side on two cores
+    n = n_chain * (init_num + iterations)
+    return {"value": n / wall, "unit": "decoys/sec", "kind": "port", "cores": cores,
+            "seconds_per_single_decoy_fold": t_fold, "sample": f"{nt} oracle folds (L={L}, all channels, default protocol) on {nt} threads, {t_fold:.1f} s",
+            "derivation": f"DERIVED, not run end to end: {n} decoys / ({t_init:.1f} s initial batches + {iterations} sequential iterations x {t_fold:.2f} s); "
+                          "a chain's iterations are sequential, so more cores do not shorten them"}
+
+
+def e2e_batch_leg(pipe_mod, synth, L, n_targets=4, nmax=80, seed=3, in_flight=(1, 2)):
     """Batch mode of run_inference.py (:339-348) on ONE GPU: n_targets targets (the same synthetic pair of maps under different names),
     init_num=10, both models, Nmax shortened to `nmax` -- one target after the other as the reference's loop does, and two at a time
     (pipeline.run_batch's default: four chains on four streams; the files are byte-identical either way, tests/test_gpu_boundary.py)."""
@@ -255,7 +295,7 @@ def e2e_batch_leg(pipe_mod, synth, L, n_targets=4, nmax=80, seed=3):
             with open(os.path.join(fdir, nm + ".fasta"), "w") as f:
                 f.write(f">{nm}\n{maps[0]['seq']}\n")
         out = {"workload": f"run_inference batch mode on one GPU: {n_targets} targets of L={L}, init_num=10, two models, all channels, Nmax={nmax}, PDB files written"}
-        for k in (1, 2):
+        for k in in_flight:
             save = os.path.join(work, f"out{k}")
             t0 = time.perf_counter()
             res = pipe_mod.run_batch(names, fdir, save, targets_in_flight=k, init_num=10, Nmax=nmax, angle=True, mult_two_models=True, seed=seed,
@@ -263,6 +303,7 @@ def e2e_batch_leg(pipe_mod, synth, L, n_targets=4, nmax=80, seed=3):
             el = time.perf_counter() - t0
             out[f"targets_in_flight_{k}"] = {"value": res["decoys"] / el, "unit": "decoys/sec", "decoys_written": res["decoys"], "wall_s": el, "failed": res["failed"]}
             shutil.rmtree(save, ignore_errors=True)
+        out["best"] = max((out[f"targets_in_flight_{k}"] for k in in_flight), key=lambda r: r["value"])
         return out
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -306,7 +347,7 @@ def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, wit
 
     def fold(k, i):
         it = mine[k]
-        return ctxs[k].fold_batch(it.n, T.protocol.build_runs(it.L, 2), seed=it.L, decoy0=i * B + it.decoy0)
+        return ctxs[k].fold_batch(it.n, T.protocol.build_runs(it.L, 2, fastrelax=True), seed=it.L, decoy0=i * B + it.decoy0)
 
     def step(i):
         with ThreadPoolExecutor(max_workers=3) as ex:
@@ -341,7 +382,7 @@ def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, wit
             "metric": "decoys/sec", "value": args.steps * total / elapsed, "unit": "decoys/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["name"], "decoys_per_step": total, "protocol": "mode 2, full staged minimisation",
+            "config": {"workload": cfg["name"], "decoys_per_step": total, "protocol": "the reference's default: -m 2 --fastrelax",
                        "parallelism": f"{len(items)} targets -> {sum(len(p) for p in sched.lpt_assign(items, world))} items over {world} rank(s), "
                                       "no collective on the data path",
                        "items_rank0": [(i.target, i.decoy0, i.n) for i in mine]},
@@ -356,7 +397,7 @@ def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, wit
             out["roofline"]["kernel"] += f" of target {it.target}"
         if with_cpu:
             L0 = min(cfg["targets"])
-            out["cpu_baseline"] = cpu_baseline(synth.make_map(L0, seed=L0), dict(L=L0, orient=True), T.protocol.build_runs(L0, 2))
+            out["cpu_baseline"] = cpu_baseline(synth.make_map(L0, seed=L0), dict(L=L0, orient=True), T.protocol.build_runs(L0, 2, fastrelax=True))
             out["cpu_baseline"]["sample"] += f" (the L={L0} target only)"
     for c in ctxs:
         c.close()
@@ -369,7 +410,10 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
     n_chains = cfg.get("chains", 1)
     ms_ = [synth.make_map(L, seed=L + c) for c in range(n_chains)]
     m = ms_[0]
-    runs = T.protocol.build_runs(L, 2)
+    # the reference's DEFAULT protocol: mode 2 with --fastrelax on (folding/utils_ros/arguments.py:12,24-25; run_inference.py:295 never
+    # disables it) = staged minimisation + the backbone-visible part of the full-atom refinement (protocol.relax_runs)
+    runs = T.protocol.build_runs(L, 2, fastrelax=True)
+    runs_norelax = T.protocol.build_runs(L, 2)
     # the library's defaults for a call of B decoys (fold.fold_arrays): two lanes, unless two chains already occupy two streams
     # (pipeline.run_single); one slot per decoy; default tail compaction
     lanes = 2 if n_chains == 1 else 1
@@ -378,11 +422,11 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
         c_.set_map(m_["dist"], *([m_["omega"], m_["theta"], m_["phi"]] if cfg["orient"] else []), seq=m_["seq"])
     ctx = ctxs[0]
 
-    def step(i, n=B):
+    def step(i, n=B, runs_=None):
         # distinct decoys for every step, rank and chain (timed steps use indices 0.., warm-up steps 900..); the chains of a
         # step are independent (run_inference.py:310-318) and run concurrently, one context = one stream each
         def one(c):
-            return ctxs[c].fold_batch(n, runs, seed=150 + c, decoy0=((rank * 1000 + i) * B))
+            return ctxs[c].fold_batch(n, runs_ or runs, seed=150 + c, decoy0=((rank * 1000 + i) * B))
         if n_chains == 1:
             return [one(0)]
         with ThreadPoolExecutor(max_workers=n_chains) as ex:
@@ -428,6 +472,16 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
             return {"value": n_queue * n_chains / e1, "unit": "decoys/sec", "seconds": e1, "workload": note,
                     "pair_launches": sum(r["launches"] for r in rs) / n_chains, "slot_efficiency": float(np.mean([r["slot_efficiency"] for r in rs])),
                     "all_decoys_converged": bool(all(np.all(r["status"] == 0) for r in rs))}, rs
+        # round 3's `value`: the same calls with --no-fastrelax (the protocol every earlier round benched)
+        kk = max(1, min(5, steps))
+        step(899, B, runs_norelax)
+        t1 = time.perf_counter()
+        rs_nr = [r for i in range(kk) for r in step(800 + i, B, runs_norelax)]
+        e1 = time.perf_counter() - t1
+        legs["no_fastrelax"] = {"value": kk * B * n_chains / e1, "unit": "decoys/sec", "steps": kk, "ms_per_step": 1e3 * e1 / kk,
+                                "workload": "the same calls with --no-fastrelax: mode 2 without the relax stage (what rounds 1-3 reported as `value`)",
+                                "evals_per_decoy_median": float(np.median(np.concatenate([r["n_evals"] for r in rs_nr]))),
+                                "all_decoys_converged": bool(all(np.all(r["status"] == 0) for r in rs_nr))}
         if lanes == 2:
             legs["pooled_queue"], rs_pool = leg(2, MAX_SLOTS, POOLED_QUEUE, f"ONE call over a queue of {POOLED_QUEUE} decoys of the same map on 2 lanes x {MAX_SLOTS} "
                                                 f"decoy slots, the library's slot policy (round 2's headline mode ran the same queue on 2 x 192 slots)")
@@ -449,7 +503,9 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
             "metric": "decoys/sec", "value": world * steps * B * n_chains / elapsed, "unit": "decoys/sec",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": cfg["name"], "L": L, "decoys_per_step": B * n_chains, "protocol": "mode 2, full staged minimisation",
+            "config": {"workload": cfg["name"], "L": L, "decoys_per_step": B * n_chains,
+                       "protocol": "the reference's default: -m 2 --fastrelax (staged minimisation + the backbone-visible part of the full-atom "
+                                   f"refinement, {len(runs)} minimiser runs); the no_fastrelax leg carries the {len(runs_norelax)}-run protocol of rounds 1-3",
                        "call": f"one trx2_fold_batch of {B} decoys per chain and step, library defaults: {lanes} lane(s) "
                                f"({b_lane} decoys per launch), one slot per decoy, default tail compaction",
                        "parallelism": f"calls sharded over {world} rank(s), no collective on the data path"},
@@ -494,6 +550,7 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the pooled-queue / B-in-flight / single-stream legs (profiling: every launch in the trace then belongs to `value`'s calls)")
     ap.add_argument("--no-sub-records", action="store_true", help="skip the config 3 / 4 sub-records (N=1) and the batch-mode record (N>1)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run_inference leg (N=1, config 2)")
+    ap.add_argument("--all-e2e", action="store_true", help="also run the init_num=64 and --candidates 8 end-to-end legs (another ~2 minutes)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -530,9 +587,16 @@ def main():
             import contextlib
             import io
             with contextlib.redirect_stdout(io.StringIO()):     # the pipeline prints the reference's progress lines
-                out["e2e"] = {f"init_num_{n}": e2e_leg(pipe_mod, synth, cfg["L"], n) for n in (10, 64)}
-                out["e2e"]["init_num_10_candidates_8"] = e2e_leg(pipe_mod, synth, cfg["L"], 10, candidates=8)
+                # BASELINE.json's metric is quoted at init_num=10: that job, on the synthetic L=150 pair and on the reference's own example
+                out["e2e"] = {"init_num_10": e2e_leg(pipe_mod, synth, cfg["L"], 10),
+                              "example_L90_init_num_10": e2e_leg(pipe_mod, synth, 90, 10, real=True)}
+                if args.all_e2e:
+                    out["e2e"]["init_num_64"] = e2e_leg(pipe_mod, synth, cfg["L"], 64)
+                    out["e2e"]["init_num_10_candidates_8"] = e2e_leg(pipe_mod, synth, cfg["L"], 10, candidates=8)
                 out["e2e"]["batch_mode_one_gpu"] = e2e_batch_leg(pipe_mod, synth, cfg["L"])
+            if with_cpu:
+                its = max(out["e2e"]["init_num_10"]["iterations"].values())
+                out["e2e"]["cpu_baseline"] = cpu_e2e_baseline(synth, cfg["L"], 10, its, T.protocol.build_runs(cfg["L"], 2, fastrelax=True))
         if args.config == 2 and not args.no_sub_records:
             if world == 1:
                 # the other single-GPU configs of BASELINE.json, shorter legs of the same measurement
@@ -553,6 +617,22 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        # Short numeric copies of the other records inside `config` (the driver's parsed record keeps `config` whole): the job
+        # BASELINE.json's metric names (init_num=10, end to end), the pooled queue, the other single-GPU configs.  decoys/sec each.
+        def num(*path):
+            d = out
+            for k in path:
+                d = d.get(k) if isinstance(d, dict) else None
+                if d is None:
+                    return None
+            return round(float(d), 2)
+        for key, path in (("e2e_init10", ("e2e", "init_num_10", "value")), ("e2e_example_L90_init10", ("e2e", "example_L90_init_num_10", "value")),
+                          ("e2e_cpu_init10", ("e2e", "cpu_baseline", "value")), ("batch_mode_one_gpu", ("e2e", "batch_mode_one_gpu", "best", "value")),
+                          ("pooled_1280", ("pooled_queue", "value")), ("no_fastrelax", ("no_fastrelax", "value")),
+                          ("c3", ("sub_records", "config3", "value")), ("c4", ("sub_records", "config4", "value"))):
+            v = num(*path)
+            if v is not None:
+                out["config"][key] = v
         print(json.dumps(out))
 
 

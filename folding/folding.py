@@ -2,7 +2,8 @@
 """Command-line shim with the flags of the reference's fold script (/root/reference/folding/folding.py +
 folding/utils_ros/arguments.py:5-25):  python ./folding/folding.py -NPZ x.npz -FASTA s.fasta -OUT o.pdb [-m 2]
 [-r no-idp] [--orient|--no-orient] [--fastrelax|--no-fastrelax] [-pd P] ...   One decoy, folded on the GPU; exit code 0
-on success.  --fastrelax is accepted and ignored (no full-atom stage); there is no CPU fallback."""
+on success.  --fastrelax (the default, as in the reference) appends the backbone-visible part of the full-atom refinement
+(protocol.relax_runs; no side chains: DESIGN.md section 2), --no-fastrelax skips it; there is no CPU fallback."""
 import argparse
 import importlib
 import os

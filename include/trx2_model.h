@@ -163,7 +163,8 @@ enum {
 #ifndef TRX2_RAMA_GUARD_OFFSET
 #define TRX2_RAMA_GUARD_OFFSET 0.0
 #endif
-#define TRX2_MAX_RUNS 48
+/* mode 0 with the relax stage is the longest protocol: 32 + 21 = 53 runs (protocol.build_runs) */
+#define TRX2_MAX_RUNS 64
 
 /* ---- backbone-visible part of the full-atom refinement (folding/folding.py:200-268; "a11-lite") ----------------------
  * The reference ends every decoy with FastRelax x 2 on ref2015_cart + atom_pair 5 / dihedral 1 / angle 1 (folding.py:202-205)

@@ -56,3 +56,17 @@ def test_protocol_mode2_matches_reference_script():
     assert long[8]["cartesian"] == 0 and long[8]["w"][6] == 0.0 and long[8]["w"][:6] == P.SF_CART[:6]
     assert all(r["w"] == P.SF1 and r["precheck"] == 1 and r["skip_to"] == 14 for r in runs[9:])
     assert [(r["sep_lo"], r["sep_hi"]) for r in P.build_runs(90, 0)[5:8]] == [(1, 12)] * 3
+
+
+def test_every_mode_with_the_relax_stage_fits_the_protocol_table():
+    """-m 0 --fastrelax is 32 + 21 = 53 runs; TRX2_MAX_RUNS (include/trx2_model.h) must hold the longest protocol, the
+    Python mirror of the constant must agree with the header, and the default options select the relax stage (arguments.py:24-25)."""
+    pkg = importlib.import_module("trrosettax2-dynamics_amd")
+    P, FO = pkg.protocol, importlib.import_module("trrosettax2-dynamics_amd.fold")
+    hdr = open(os.path.join(ROOT, "include", "trx2_model.h")).read()
+    assert int(re.search(r"#define TRX2_MAX_RUNS (\d+)", hdr).group(1)) == P.MAX_RUNS
+    n = {mode: len(P.build_runs(90, mode, fastrelax=True)) for mode in (0, 1, 2, 3)}
+    assert n == {0: 53, 1: 44, 2: 35, 3: 44} and max(n.values()) <= P.MAX_RUNS
+    assert FO.relax_lite(FO.parse_options("-m 2 --orient -r no-idp")) and not FO.relax_lite(FO.parse_options("--no-fastrelax"))
+    relax = P.build_runs(90, 2, fastrelax=True)[14:]
+    assert [r["pair_filter"] for r in relax] == [2] * 12 + [3] * 9 and sum(r["cartesian"] for r in relax) == 13

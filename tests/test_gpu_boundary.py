@@ -186,7 +186,7 @@ def test_abi_error_paths_fail_loudly(golden_dir, seq):
         with pytest.raises(RuntimeError, match="bad arguments"):
             c.fold_batch(0, runs)
         with pytest.raises(RuntimeError, match="bad arguments"):
-            c.fold_batch(2, runs * 4)                      # more than TRX2_MAX_RUNS
+            c.fold_batch(2, runs * 5)                      # 70 runs: more than TRX2_MAX_RUNS = 64
         c2 = T.Context(0)
         try:
             c2.set_map(z["dist"], seq=seq)

@@ -66,9 +66,13 @@ def test_cartesian_run_tracks_oracle_over_a_short_horizon(ctx, golden_dir, seq):
     assert dmax <= 1.5 * omax + 0.02, (dmax, omax)
 
 
+# relax: the default protocol (--fastrelax, the reference's default) -- measured on 1024 decoys per map (profiles/r03_outcome_n1024.txt):
+# X-ray median 0.480 A, 58 % within 0.5 A, 83 % within 1 A; NMR 0.746 A, 6 % / 86 %; NO peptide twisted beyond 60 degrees in either map
+# (5 % / 9 % without the stage).  plain: --no-fastrelax (rounds 1-3's protocol), thresholds as before.
+@pytest.mark.parametrize("relax", [True, False], ids=["fastrelax", "no-fastrelax"])
 @pytest.mark.parametrize("tag,refs,med_max,trap_max,f05_min,f10_min", [("Xray", ("conf_1_1", "conf_1_2"), 0.75, 0.11, 0.40, 0.74),
                                                                          ("NMR", ("conf_2_1", "conf_2_2"), 0.90, 0.08, 0.0, 0.74)])
-def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med_max, trap_max, f05_min, f10_min):
+def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med_max, trap_max, f05_min, f10_min, relax):
     """Mode-2 protocol with the Cartesian run on (the default for L <= 512): OUTCOME parity with the reference's PyRosetta decoys
     (the energy model itself is unpinned, DESIGN.md section 2, so this is the only anchor it has).
     Thresholds = measured + margin, not slack.  Measured on 1024 decoys per map
@@ -86,8 +90,10 @@ def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med
     ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
     dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
     B = 256  # mirror trapping is decided by the random start (3-6 % of starts): a rate needs a large batch
-    runs = P.build_runs(90, 2)
+    runs = P.build_runs(90, 2, fastrelax=relax)
     assert any(q["cartesian"] for q in runs)
+    if relax and tag == "Xray":
+        f05_min = 0.46            # measured 58 % of 1024 (sampling sd of a fraction at n = 256: 3 %)
     r = ctx.fold_batch(B, runs, seed=4242)
     assert np.all(r["status"] == 0) and np.all(np.isfinite(r["xyz"]))
     best = np.array([min(kabsch_rmsd(r["xyz"][i, :, 1], dec[k][:, 1]) for k in refs) for i in range(B)])
@@ -107,7 +113,9 @@ def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med
     assert len(far) <= trap_max * B, (len(far), B)
     assert n_mirror >= 0.7 * len(far) - 1, (n_mirror, len(far))
     assert bond_sd < 0.02 and 1.5 < ang_sd < 4.5
-    assert twisted <= 0.25 * B
+    # twisted peptides: none with the relax stage (measured 0 of 1024 per map; the reference's eight decoys hold one cis peptide and
+    # none twisted); without it 4-11 % (deviation 2): measured + margin each
+    assert twisted <= (0.02 if relax else 0.15) * B, twisted
 
 
 def test_cartesian_run_on_a_chain_longer_than_256(ctx):

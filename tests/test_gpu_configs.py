@@ -365,7 +365,12 @@ def test_tail_compaction_moves_the_survivors_and_changes_nothing(golden_dir, seq
               f"seconds {out[0]['seconds']:.3f} / {out[2]['seconds']:.3f} / {out[1]['seconds']:.3f}; decoys unchanged within 0.5 A with the new split: {same:.2f}")
         assert abs(np.median(out[1]["n_evals"]) - np.median(out[0]["n_evals"])) <= 0.1 * np.median(out[0]["n_evals"])
         same_distribution(out[0]["f"], out[1]["f"])
-        assert same >= 0.3
+        # The guard against a compaction that corrupts moved slots is the BITWISE check of mode 2 above (same moves, split kept).
+        # Mode 1 changes the order of additions from the first shape change on, so only what retired before it is bit-identical:
+        # the launches shrink when the live decoys fit one group (<= 64 of 100), i.e. at least 36 decoys had reported by then.
+        same_bits = sum(np.array_equal(out[1]["xyz"][i], out[0]["xyz"][i]) for i in range(100))
+        print(f"   decoys bit-identical with and without the new split: {same_bits} of 100 (>= 36 retire before the first shape change)")
+        assert same_bits >= 36 and same >= 0.3
         # below one group the group itself halves (64 -> 32 -> .. decoys per wave, coordinates laid out anew): a batch of 48
         a, b = {}, {}
         for mode, dst in ((0, a), (1, b)):
@@ -374,7 +379,8 @@ def test_tail_compaction_moves_the_survivors_and_changes_nothing(golden_dir, seq
             assert np.all(dst["status"] == 0) and np.all(np.isfinite(dst["xyz"]))
         same48 = np.mean(np.sqrt(((a["xyz"] - b["xyz"]) ** 2).sum(-1)).max(axis=(1, 2)) < 0.5)
         print(f"48 decoys: slot efficiency {a['slot_efficiency']:.3f} -> {b['slot_efficiency']:.3f}, seconds {a['seconds']:.3f} -> {b['seconds']:.3f}, unchanged within 0.5 A: {same48:.2f}")
-        assert b["slot_efficiency"] > a["slot_efficiency"] + 0.05 and same48 >= 0.3
+        bits48 = sum(np.array_equal(a["xyz"][i], b["xyz"][i]) for i in range(48))   # the wave halves at <= 32 live decoys: >= 16 had reported
+        assert b["slot_efficiency"] > a["slot_efficiency"] + 0.05 and same48 >= 0.3 and bits48 >= 16, (same48, bits48)
         same_distribution(a["f"], b["f"])
         assert abs(np.median(b["n_evals"]) - np.median(a["n_evals"])) <= 0.1 * np.median(a["n_evals"])
         # the fold leaves the full batch's launch shape behind: a pair-kernel replay of all 100 slots (what bench.py's roofline
@@ -499,7 +505,7 @@ def test_bench_pooled_shape_two_lanes_192_slots():
 
 @pytest.mark.parametrize("L,orient", [(64, True), (128, False), (130, True), (150, True), (200, False), (256, True)])
 def test_low_register_step_kernel_is_the_same_arithmetic(L, orient):
-    """Folds that start on many slots (160 per lane; 320 for chains of up to 128 residues) run the fused step kernel's low-register instantiation (eight waves per CU instead of four;
+    """Folds that start on many slots (160 per lane; 128 for chains of up to 128 residues) run the fused step kernel's low-register instantiation (eight waves per CU instead of four;
     chains of up to 256 residues): same operations in the same order, so 400 evaluations of 700
     decoys (350 slots per lane) -- a short torsion run, the Cartesian run, a torsion run again, from near the target -- must come out
     bit for bit as with TRX2_STEP_ONE_PER_CU=1 (the ordinary instantiation; read per fold): coordinates, energies, counts."""

@@ -122,7 +122,7 @@ __device__ unsigned long long g_stamp[32];
 #define PAIR_ROW_B_BITS 0x3ffu /* partner index in a row entry: L <= 1024 */
 
 // Row lists (once per map and per feedback step, after k_pack_masks): row a keeps, in ascending order, every partner b != a
-// whose packed mask byte has any bit -- a selected restraint of (a,b) or of (b,a).  One workgroup per row, order-preserving
+// whose packed mask byte -- or either relax-stage mask -- has any bit: a selected restraint of (a,b) or of (b,a).  One workgroup per row, order-preserving
 // compaction by wave ballots.  Fixed row stride L: no prefix sum over rows.
 __global__ __launch_bounds__(256) void k_build_rows(int L, const unsigned char* __restrict__ mask, const unsigned char* __restrict__ mask_odr,
                                                      const unsigned char* __restrict__ mask_r1, const unsigned char* __restrict__ mask_r2,
@@ -138,9 +138,12 @@ __global__ __launch_bounds__(256) void k_build_rows(int L, const unsigned char* 
     if (b < L && b != a) {
       m = mask[(size_t)a * L + b];
       mo = mask_odr ? mask_odr[(size_t)a * L + b] : m;
-      mr = (unsigned)mask_r1[(size_t)a * L + b] | ((unsigned)mask_r2[(size_t)a * L + b] << 8);   // subsets of m
+      mr = (unsigned)mask_r1[(size_t)a * L + b] | ((unsigned)mask_r2[(size_t)a * L + b] << 8);
     }
-    const bool keep = m != 0;
+    // The relax re-selections are made from ALL generated restraints (add_rst(.., nogly=True), utils_ros.py:713-717), not from the
+    // selection at the map's PCUT: with -pd above 0.15 they hold pairs that `m` does not.  Such an entry costs the
+    // other stages nothing: the visit takes its mask from the run's filter.
+    const bool keep = (m | mr) != 0;
     const unsigned long long bal = __ballot(keep);
     const int pre = __popcll(bal & ((1ull << lane) - 1ull));
     if (lane == 0) s_w[wave] = __popcll(bal);

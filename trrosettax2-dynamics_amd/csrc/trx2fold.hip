@@ -188,7 +188,9 @@ static std::atomic<int> g_live_contexts{0};  // contexts alive in this process (
 struct StreamPool { hipStream_t s[TRX2_POOL_STREAMS] = {nullptr, nullptr, nullptr, nullptr}; int use[TRX2_POOL_STREAMS] = {0, 0, 0, 0}; bool ready = false; };
 static std::mutex g_pool_mutex;
 static std::map<int, StreamPool> g_pools;
-static hipStream_t pool_acquire(int device) {
+// avoid: a stream the caller must not share (a second lane takes any stream but its parent's: after contexts have come and gone
+// the least-used stream can be the parent's own, and two lanes on one stream serialise -- ADVICE r3)
+static hipStream_t pool_acquire(int device, hipStream_t avoid = nullptr) {
   std::lock_guard<std::mutex> lk(g_pool_mutex);
   StreamPool& P = g_pools[device];
   if (!P.ready) {
@@ -199,10 +201,18 @@ static hipStream_t pool_acquire(int device) {
       }
     P.ready = true;
   }
-  int best = 0;
-  for (int k = 1; k < TRX2_POOL_STREAMS; k++) if (P.use[k] < P.use[best]) best = k;
+  int best = -1;
+  for (int k = 0; k < TRX2_POOL_STREAMS; k++) if (P.s[k] != avoid && (best < 0 || P.use[k] < P.use[best])) best = k;
   P.use[best]++;
   return P.s[best];
+}
+// contexts that hold this stream (more than one: their launches interleave on it -- no stream capture then)
+static int pool_use_count(int device, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_pool_mutex);
+  auto it = g_pools.find(device);
+  if (it == g_pools.end()) return 0;
+  for (int k = 0; k < TRX2_POOL_STREAMS; k++) if (it->second.s[k] == st) return it->second.use[k];
+  return 0;
 }
 static void pool_release(int device, hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_pool_mutex);
@@ -213,13 +223,15 @@ static void pool_release(int device, hipStream_t st) {
 
 extern "C" int trx2_abi_version(void) { return 1; }
 
-extern "C" int trx2_ctx_create(int device, trx2_ctx** out) {
+static int ctx_create_impl(int device, trx2_ctx** out, hipStream_t avoid_stream);
+extern "C" int trx2_ctx_create(int device, trx2_ctx** out) { return ctx_create_impl(device, out, nullptr); }
+static int ctx_create_impl(int device, trx2_ctx** out, hipStream_t avoid_stream) {
   if (!out) return 1;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return 2;
   trx2_ctx* ctx = new trx2_ctx();
   ctx->device = device;
-  if (hipSetDevice(device) != hipSuccess || (ctx->stream = pool_acquire(device)) == nullptr) {
+  if (hipSetDevice(device) != hipSuccess || (ctx->stream = pool_acquire(device, avoid_stream)) == nullptr) {
     delete ctx;
     return 3;
   }
@@ -401,7 +413,7 @@ extern "C" int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes) {
   if (lanes != 1 && lanes != 2) { ctx->err = "trx2_ctx_set_lanes: 1 or 2"; return 1; }
   if (lanes == 2 && !ctx->child) {
     trx2_ctx* k = nullptr;
-    if (trx2_ctx_create(ctx->device, &k) != 0) { ctx->err = "trx2_ctx_set_lanes: cannot create the second lane"; return 1; }
+    if (ctx_create_impl(ctx->device, &k, ctx->stream) != 0) { ctx->err = "trx2_ctx_set_lanes: cannot create the second lane"; return 1; }
     k->borrows_map = true;
     k->pool = ctx->pool;
     k->compact = ctx->compact;
@@ -993,7 +1005,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
                      double* f_final, int* status, int* n_evals, int* n_iters) {
   if (!ctx) return 1;
   if (!ctx->L) { ctx->err = "trx2_fold_batch: no map set"; return 1; }
-  if (N < 1 || !runs || nruns < 1 || nruns > TRX2_MAX_RUNS) { ctx->err = "trx2_fold_batch: bad arguments"; return 1; }
+  if (N < 1 || !runs || nruns < 1 || nruns > TRX2_MAX_RUNS) { ctx->err = "trx2_fold_batch: bad arguments (need B >= 1 decoys and 1 .. " + std::to_string(TRX2_MAX_RUNS) + " runs)"; return 1; }
   bool has_cart = false, has_filter = false;
   for (int i = 0; i < nruns; i++) {
     has_cart |= runs[i].cartesian != 0; has_filter |= runs[i].pair_filter == TRX2_FILTER_ODR;
@@ -1092,7 +1104,8 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   // once per (batch shape, protocol length, buffers) and replay it -- 128 launches become one hipGraphLaunch.  Measured on
   // MI355X it changes nothing (the loop is not launch-bound: profiles/README.md), so direct launches stay the default and
   // TRX2_GRAPH=1 opts in.
-  static const bool no_graph = getenv("TRX2_GRAPH") == nullptr;
+  // (never on a pool stream another context holds too: its launches from another host thread would land inside the capture)
+  const bool no_graph = getenv("TRX2_GRAPH") == nullptr || pool_use_count(ctx->device, ctx->stream) > 1;
   if (!no_graph) {
     const long key[8] = {B, nruns, max_evals, has_cart ? 1 : 0, (long)L * 4096 + N, (long)(seed ^ ((uint64_t)decoy0 << 40) ^ (tors0 ? 1 : 0)), (long)ctx->plan_cur * 128 + ctx->BW, ctx->alloc_epoch};
     if (!ctx->gexec || memcmp(key, ctx->g_key, sizeof key) != 0) {

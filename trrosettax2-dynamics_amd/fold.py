@@ -9,9 +9,10 @@ Differences from the reference, all deliberate:
   D  failed folds raise RuntimeError (FoldError) instead of passing silently (utils.py:498 runs subprocess.run unchecked); the
      decoys of the batch that did fold are written first, the failed ones get no file
   D  start torsions come from an explicit seed (the reference never seeds `random`, utils_ros.py:677)
-  D  there is no full-atom stage (folding.py:200-268: side chains, ref2015_cart, idealize).  Its backbone-visible part -- the two
-     restraint re-selections without glycine pairs and the re-weighted score through the FastRelax ramps (protocol.relax_runs)
-     -- runs when --fastrelax is given AND TRX2_FASTRELAX_LITE=1 is set (off by default: measured effect DESIGN.md section 2)
+  D  there is no full-atom model (folding.py:200-268: side chains, ref2015_cart, idealize).  What a backbone sees of that stage
+     -- the two restraint re-selections without glycine pairs and the re-weighted score through the FastRelax ramps
+     (protocol.relax_runs) -- runs under --fastrelax, which is the DEFAULT as in the reference (arguments.py:24-25;
+     run_inference.py:295 never disables it); --no-fastrelax skips it (measured effect: DESIGN.md section 2)
 """
 import argparse
 import os
@@ -55,8 +56,8 @@ def parse_options(options):
 
 
 def relax_lite(args):
-    """the backbone-visible part of the full-atom stage: on only when the reference's flag is on AND the opt-in switch is set"""
-    return bool(args.fastrelax) and os.environ.get("TRX2_FASTRELAX_LITE", "0") == "1"
+    """the backbone-visible part of the full-atom stage follows the reference's flag: on unless --no-fastrelax (arguments.py:24-25)"""
+    return bool(args.fastrelax)
 
 
 def _unquote(p):

@@ -22,7 +22,7 @@ import numpy as np
 
 from . import sched
 from .feedback import calculate_reliability_score, feedback_labels
-from .fold import close_contexts, fold_arrays_to_pdb, fold_resident_to_pdb, get_context
+from .fold import FoldError, close_contexts, fold_arrays_to_pdb, fold_resident_to_pdb, get_context
 from .pdbio import as_read_from_pdb, read_backbone, read_fasta
 
 
@@ -54,11 +54,12 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     Returns the number of iteration files (K per iteration).  Needs the resident feedback path.
 
     timing: a dict that receives initial_s (initial batch: table build, fold, files, ranking), iteration_s (everything after),
-    iteration_fold_s (the single-decoy folds alone) and iterations -- bench.py's e2e leg."""
+    iteration_fold_s (the single-decoy folds alone), iterations, tmp_change (the convergence measure after every iteration: max
+    |tmp_new - tmp_old|, run_inference.py:133) and converged (the chain took the < 0.01 exit) -- bench.py's e2e legs."""
     import time
     os.makedirs(processed_npz_dir, exist_ok=True)
     t_start = time.perf_counter()
-    tm = dict(initial_s=0.0, iteration_s=0.0, iteration_fold_s=0.0, iterations=0)
+    tm = dict(initial_s=0.0, iteration_s=0.0, iteration_fold_s=0.0, iterations=0, tmp_change=[], converged=False)
 
     def done(iter_n):
         tm["iterations"] = iter_n - begin_num
@@ -115,13 +116,27 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
             print(f"Start generating structure {iter_n}")
             t_f = time.perf_counter()
             first = begin_num + (iter_n - begin_num - 1) * K + 1      # K = 1: iter_n
-            r = fold_resident_to_pdb(ctx, seq, pred_pdb_dir, [f"{pdb_name}{first + c}.pdb" for c in range(K)], tta_opt,
-                                     seed=None if seed is None else seed + iter_n)
+            try:
+                r = fold_resident_to_pdb(ctx, seq, pred_pdb_dir, [f"{pdb_name}{first + c}.pdb" for c in range(K)], tta_opt,
+                                         seed=None if seed is None else seed + iter_n)
+            except FoldError as e:
+                # Only candidate 0 is fed back: a diverged EXTRA candidate must not end a chain that K = 1 would have continued
+                # (ADVICE r3).  Its file slot is filled with a copy of candidate 0, so that the numbering every later stage
+                # relies on (K files per iteration) holds; the failure is reported.  Candidate 0 itself failing ends the chain.
+                if 0 in e.bad:
+                    raise
+                r = e.result
+                for c in e.bad:
+                    shutil.copyfile(os.path.join(pred_pdb_dir, f"{pdb_name}{first}.pdb"), os.path.join(pred_pdb_dir, f"{pdb_name}{first + c}.pdb"))
+                print(f"warning: candidates {list(e.bad)} of iteration {iter_n} failed to fold; their files repeat candidate 0")
             tm["iteration_fold_s"] += time.perf_counter() - t_f
             print("Done generating structure", iter_n)
             if iter_n - begin_num >= Nmax:
                 break
-            if step(r["xyz"][0], iter_n + 1) < 0.01:
+            delta = step(r["xyz"][0], iter_n + 1)
+            tm["tmp_change"].append(float(delta))                  # max |tmp_new - tmp_old|: the reference's convergence measure
+            if delta < 0.01:
+                tm["converged"] = True
                 break
         done(iter_n)
         return begin_num + (iter_n - begin_num) * K

@@ -24,6 +24,7 @@ MAX_ITER = 1000      # folding.py:92,95,101
 MAX_ITER_VDW = 500   # folding.py:98
 N_REPEAT = 3         # folding.py:104
 N_DECLASH = 5        # utils_ros.py:700
+MAX_RUNS = 64        # include/trx2_model.h TRX2_MAX_RUNS (the protocol table lives in the step kernel's LDS)
 
 
 def _run(w, max_iter, sep_lo, sep_hi, precheck=0, skip_to=0, cartesian=0, pair_filter=0, tol=0.0):
@@ -114,4 +115,6 @@ def build_runs(L, mode=2, cartesian_stage=None, fastrelax=False):
         _declash(runs, SF1, MAX_ITER, lo, hi, pair_filter=flt)    # remove_clash(sf_vdw, min_mover1, pose)
     if fastrelax:
         runs += relax_runs(L, cartesian_stage)
+    if len(runs) > MAX_RUNS:   # mode 0 with the relax stage is the longest: 32 + 21 = 53
+        raise ValueError(f"protocol of {len(runs)} runs exceeds TRX2_MAX_RUNS = {MAX_RUNS} (include/trx2_model.h)")
     return runs
