@@ -276,10 +276,12 @@ def cpu_e2e_baseline(synth, L, init_num, iterations, runs, n_folds=4):
                           "a chain's iterations are sequential, so more cores do not shorten them"}
 
 
-def e2e_batch_leg(pipe_mod, synth, L, n_targets=4, nmax=80, seed=3, in_flight=(1, 2)):
+def e2e_batch_leg(pipe_mod, synth, L, n_targets=8, nmax=80, seed=3, in_flight=(8,)):
     """Batch mode of run_inference.py (:339-348) on ONE GPU: n_targets targets (the same synthetic pair of maps under different names),
-    init_num=10, both models, Nmax shortened to `nmax` -- one target after the other as the reference's loop does, and two at a time
-    (pipeline.run_batch's default: four chains on four streams; the files are byte-identical either way, tests/test_gpu_boundary.py)."""
+    init_num=10, both models, Nmax shortened to `nmax`, `in_flight` targets at a time (pipeline.run_batch's default: eight = sixteen
+    chains whose single-decoy folds share launch pairs, csrc/launch_engine.h; the files are byte-identical to one target after the
+    other with every fold launching for itself: tests/test_gpu_shared_launch.py).  Round 3 (four streams, two targets in flight):
+    64 decoys/s without the relax stage, 41.5 with it (profiles/README.md, round 4)."""
     work = tempfile.mkdtemp(prefix="trx2_e2eb_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         maps = [synth.make_map(L, seed=L + c) for c in range(2)]

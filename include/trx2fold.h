@@ -80,6 +80,20 @@ int trx2_ctx_set_pool(trx2_ctx* ctx, int slots);
  * Environment (A/B timing and tests only): TRX2_NSPLIT=n cuts every row into n slices whatever the shape; TRX2_ROW_TARGET=t sets
  * the plan's target of list entries per slice and partner residue of a wave step (default 18). */
 int trx2_ctx_set_tail_compaction(trx2_ctx* ctx, int mode);
+/* Shared launches (process-wide; default on, TRX2_SHARED_LAUNCH=0 turns them off, TRX2_ENGINE_STREAMS=1..3 sets the engines per device,
+ * default 2).  A fold of ONE decoy -- every feedback iteration of run_inference.py:97-139 is one -- leaves the chip idle: a launch pair
+ * of ~24 us on a few workgroups, thousands of them in sequence.  With shared launches such a fold does not launch for itself: it hands
+ * its argument blocks (its own map's tables, row lists and row plan; its own state and buffers) to an engine thread of the library,
+ * whose launch pairs step the single-decoy folds of ALL contexts that are folding at that moment (k_pair_multi: blockIdx.z = fold,
+ * k_step_multi: blockIdx.y = fold), and sleeps until its decoy has reported.  The caller's side does not change -- one host thread
+ * per chain calling trx2_fold_batch, as pipeline.run_batch does for the chains of run_inference.py:339-348's targets -- and neither do
+ * the results: a fold's arithmetic does not depend on what shares its launches (bit-identical to mode 0: tests).  The reference's
+ * counterpart is its process pool over `python folding.py` children (utils_trX2dy/utils.py:501-503).
+ * mode 1 on, 0 off, -1 back to the environment's choice. */
+int trx2_set_shared_launches(int mode);
+/* measurement helper: out[5] = chunks of launch pairs the device's engines enqueued, folds x chunks (ratio: folds per launch), folds
+ * completed, seconds their host threads spent enqueuing, seconds they waited for the GPU */
+int trx2_shared_launch_stats(int device, double* out);
 int trx2_last_fold_slot_efficiency(trx2_ctx* ctx, double* eff);
 const char* trx2_last_error(const trx2_ctx* ctx);
 

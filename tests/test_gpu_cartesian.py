@@ -112,7 +112,11 @@ def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med
     assert (best <= 0.5).mean() >= f05_min and (best <= 1.0).mean() >= f10_min, ((best <= 0.5).mean(), (best <= 1.0).mean())
     assert len(far) <= trap_max * B, (len(far), B)
     assert n_mirror >= 0.7 * len(far) - 1, (n_mirror, len(far))
-    assert bond_sd < 0.02 and 1.5 < ang_sd < 4.5
+    # Geometry spread.  --no-fastrelax: where the reference's decoys are (CA-C sd 0.011 A, N-CA-C sd 2.4 deg: the bonded term's
+    # calibration, trx2_model.h).  With the relax stage the LAST run is a Cartesian minimisation WITHOUT restraints (folding.py:257-263)
+    # under ref2015_cart's cart_bonded weight 0.5: nothing strains the backbone any more -- the reference's full-atom terms, which
+    # do, do not exist here -- and the geometry returns to ideal (measured sd 0.0003 A / 0.2 deg): documented deviation, DESIGN.md.
+    assert bond_sd < 0.02 and ang_sd < 4.5 and (relax or ang_sd > 1.5), (bond_sd, ang_sd)
     # twisted peptides: none with the relax stage (measured 0 of 1024 per map; the reference's eight decoys hold one cis peptide and
     # none twisted); without it 4-11 % (deviation 2): measured + margin each
     assert twisted <= (0.02 if relax else 0.15) * B, twisted

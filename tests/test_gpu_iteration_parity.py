@@ -38,10 +38,13 @@ def fold_stats(ctx, ref, target, others, seed):
     return r, d_t, d_o
 
 
-# measured on MI355X, 256 decoys per map and stage, seeds as below (profiles/r04_iteration_parity.txt):
-#   tag   stage  median to the decoy of that map   <= 1 A    > 3 A
-LIMITS = {("NMR", 1): dict(med=1.25, f10=0.20, far=0.10), ("NMR", 2): dict(med=1.25, f10=0.20, far=0.10),
-          ("Xray", 1): dict(med=1.00, f10=0.45, far=0.12), ("Xray", 2): dict(med=1.00, f10=0.45, far=0.12)}
+# Measured on MI355X, 256 decoys per map and stage, seeds as below (profiles/r04_iteration_parity.txt): C-alpha RMSD to the reference's
+# decoy of that map -- NMR stage 1 median 1.15 A (quartiles 1.07-1.22), X-ray stage 1 0.82 A (0.44-1.23), X-ray stage 2 0.76 A
+# (0.54-1.26).  The reference's own decoys of one map differ by 0.81-1.51 A (NMR) and 0.34-0.72 A (X-ray) among themselves
+# (SURVEY.md section 4): these folds sit inside the NMR spread and at the upper end of the X-ray one.  Limits = measured + margin
+# (sampling error of a median at n = 256: ~0.03 A on the unimodal NMR map, ~0.1 A on the bimodal X-ray map).
+LIMITS = {("NMR", 1): dict(med=1.25, f15=0.85, far=0.08), ("NMR", 2): dict(med=1.35, f15=0.80, far=0.08),
+          ("Xray", 1): dict(med=0.97, f15=0.80, far=0.11), ("Xray", 2): dict(med=0.92, f15=0.80, far=0.11)}
 
 
 @pytest.mark.parametrize("tag", ["NMR", "Xray"])
@@ -66,12 +69,12 @@ def test_folds_of_the_fed_back_maps_reach_the_reference_iteration_decoys(golden_
             r, d_t, d_o = fold_stats(ctx, ref, target, (i0, i1), seed=7000 + 10 * stage)
             lim = LIMITS[(tag, stage)]
             far = d_t > 3.0
-            rows.append((stage, target, np.median(d_t), np.percentile(d_t, 25), np.percentile(d_t, 75), (d_t <= 0.5).mean(), (d_t <= 1.0).mean(), far.mean(),
+            rows.append((stage, target, np.median(d_t), np.percentile(d_t, 25), np.percentile(d_t, 75), 100 * (d_t <= 1.0).mean(), 100 * (d_t <= 1.5).mean(), 100 * far.mean(),
                          np.median(d_o[i0]), np.median(d_o[i1]), int(np.median(r["n_evals"]))))
-            print("\n%s stage %d -> %s: median %.3f A (quartiles %.2f-%.2f), <=0.5 A %.0f %%, <=1 A %.0f %%, >3 A %.1f %%; to initial0 / initial1 of the map: %.2f / %.2f; evaluations %d"
+            print("\n%s stage %d -> %s: median %.3f A (quartiles %.2f-%.2f), <=1 A %.0f %%, <=1.5 A %.0f %%, >3 A %.1f %%; to initial0 / initial1 of the map: %.2f / %.2f; evaluations %d"
                   % ((tag,) + rows[-1]))
             assert np.median(d_t) <= lim["med"], np.sort(d_t)[::16]
-            assert (d_t <= 1.0).mean() >= lim["f10"] and far.mean() <= lim["far"], ((d_t <= 1.0).mean(), far.mean())
+            assert (d_t <= 1.5).mean() >= lim["f15"] and far.mean() <= lim["far"], ((d_t <= 1.5).mean(), far.mean())
             # no twisted peptides with the relax stage on (the reference's decoys: |omega| 177.6 deg mean, one cis in eight)
             dw = np.degrees(np.abs((r["tors"][:, :-1, 2] % (2 * np.pi)) - np.pi))
             assert (dw.max(1) > 60).mean() <= 0.03, (dw.max(1) > 60).mean()

@@ -1,0 +1,94 @@
+"""GPU: shared launches (csrc/launch_engine.h, trx2_set_shared_launches).  The single-decoy folds of many
+contexts -- the iteration phase of run_inference.py:97-139, one chain per (target, model) -- advance in ONE (pair, step) launch
+pair per evaluation instead of one pair per chain.  A fold's arithmetic must not depend on what shares its launches: every
+result bit for bit the fold's own launches', at mixed chain lengths (all three step-kernel classes) and mixed channel sets
+(both pair-kernel instantiations), with folds joining and leaving the launches at different times."""
+import importlib
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  -- before libtrx2fold.so (see test_gpu_boundary.py)
+
+pytestmark = pytest.mark.gpu
+
+T = importlib.import_module("trrosettax2-dynamics_amd")
+L_ = importlib.import_module("trrosettax2-dynamics_amd._lib")
+S = importlib.import_module("trrosettax2-dynamics_amd.synth")
+PL = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
+KEYS = ("xyz", "tors", "e_terms", "f", "status", "n_evals", "n_iters")
+
+
+@pytest.fixture(autouse=True)
+def restore_mode():
+    yield
+    L_.set_shared_launches(-1)
+
+
+def test_shared_launches_are_bitwise_the_folds_own(golden_dir, seq):
+    real = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
+    cases = [("real90", dict(dist=real["dist"], omega=real["omega"], theta=real["theta"], phi=real["phi"], seq=seq), True, 0),
+             ("L150", S.make_map(150, seed=150), True, 900), ("L150d", S.make_map(150, seed=151), False, 900),
+             ("L120", S.make_map(120, seed=120, n_moves=150), True, 700), ("L300", S.make_map(300, seed=300, n_moves=150), True, 500)]
+    ctxs = []
+    try:
+        for name, m, orient, cap in cases:
+            for rep in range(2):                       # two contexts per map: ten folds share the launches
+                c = T.Context(0)
+                c.set_map(m["dist"], *([m["omega"], m["theta"], m["phi"]] if orient else []), seq=m["seq"])
+                ctxs.append((name, len(m["seq"]), cap, rep, c))
+        out = {}
+        for mode in (0, 1):
+            L_.set_shared_launches(mode)
+            res = [None] * len(ctxs)
+
+            def work(i):
+                name, L, cap, rep, c = ctxs[i]
+                rs = []
+                for it in range(2):                    # two folds in a row per context: joins and leaves at different times
+                    rs.append(c.fold_batch(1, T.protocol.build_runs(L, 2, fastrelax=True), seed=40 + i, decoy0=it, max_evals=cap))
+                res[i] = rs
+
+            if mode == 0:
+                for i in range(len(ctxs)):
+                    work(i)
+            else:
+                th = [threading.Thread(target=work, args=(i,)) for i in range(len(ctxs))]
+                [t.start() for t in th]
+                [t.join() for t in th]
+            assert all(r is not None for r in res)
+            out[mode] = res
+        for i, (name, L, cap, rep, c) in enumerate(ctxs):
+            for it in range(2):
+                a, b = out[0][i][it], out[1][i][it]
+                assert np.all(np.isfinite(a["xyz"])) and (cap > 0 or a["status"][0] == 0)
+                for k in KEYS:
+                    assert np.array_equal(a[k], b[k]), (name, rep, it, k)
+        ev = [int(out[1][i][1]["n_evals"][0]) for i in range(len(ctxs))]
+        print("\nshared launches: %d folds on %d contexts bit for bit equal to their own launches; evaluations of the second folds %s" % (2 * len(ctxs), len(ctxs), ev))
+    finally:
+        for *_, c in ctxs:
+            c.close()
+
+
+def test_batch_mode_files_do_not_depend_on_shared_launches(golden_dir, tmp_path):
+    """run_inference's batch mode (pipeline.run_batch), three targets x two models: every PDB byte for byte the same whether the
+    chains' single-decoy folds share launches (all six chains in flight) or every fold launches for itself, one target at a time."""
+    import shutil
+    fdir = tmp_path / "fasta"
+    fdir.mkdir()
+    names = ["ta", "tb", "tc"]
+    for n in names:
+        shutil.copyfile(os.path.join(golden_dir, "seq.fasta"), fdir / f"{n}.fasta")
+    kw = dict(init_num=2, Nmax=4, angle=True, mult_two_models=True, seed=5,
+              npz_nmr=os.path.join(golden_dir, "seq_NMR.npz"), npz_xray=os.path.join(golden_dir, "seq_Xray.npz"))
+    out = {}
+    for mode, inflight in ((0, 1), (1, 3)):
+        L_.set_shared_launches(mode)
+        save = str(tmp_path / f"out{mode}")
+        res = PL.run_batch(names, str(fdir), save, targets_in_flight=inflight, **kw)
+        assert res["failed"] == 0 and res["decoys"] == 3 * (2 * 2 + 2 * 4), res
+        out[mode] = {(n, f): open(os.path.join(save, n, "pred_pdb", f), "rb").read() for n in names for f in sorted(os.listdir(os.path.join(save, n, "pred_pdb")))}
+    assert out[0].keys() == out[1].keys() and len(out[0]) == 36
+    assert all(out[0][k] == out[1][k] for k in out[0])

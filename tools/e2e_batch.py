@@ -24,7 +24,7 @@ try:
                                npz_nmr=paths[0], npz_xray=paths[1])
         el = time.perf_counter() - t0
         print(json.dumps(dict(L=L, targets=n, Nmax=nmax, targets_in_flight=k, decoys=res["decoys"], failed=res["failed"], seconds=round(el, 2),
-                              decoys_per_sec=round(res["decoys"] / el, 1))), flush=True)
+                              decoys_per_sec=round(res["decoys"] / el, 1), engines=importlib.import_module("trrosettax2-dynamics_amd._lib").shared_launch_stats(0))), flush=True)
         shutil.rmtree(save, ignore_errors=True)
 finally:
     shutil.rmtree(work, ignore_errors=True)

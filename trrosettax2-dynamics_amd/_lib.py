@@ -94,6 +94,8 @@ def load():
     L.trx2_last_fold_stats.argtypes = [vp, dp, ip]
     L.trx2_ctx_set_pool.argtypes = [vp, C.c_int]
     L.trx2_ctx_set_tail_compaction.argtypes = [vp, C.c_int]
+    L.trx2_set_shared_launches.argtypes = [C.c_int]
+    L.trx2_shared_launch_stats.argtypes = [C.c_int, dp]
     L.trx2_last_fold_slot_efficiency.argtypes = [vp, dp]
     L.trx2_ctx_set_profiling.argtypes = [vp, C.c_int]
     L.trx2_last_fold_kernel_times.argtypes = [vp, dp, dp, ip]
@@ -104,6 +106,20 @@ def load():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def shared_launch_stats(device=0):
+    """-> dict(chunks, folds_per_launch, folds, enqueue_s, wait_s) of the device's launch engines (trx2_shared_launch_stats)"""
+    v = (C.c_double * 5)()
+    load().trx2_shared_launch_stats(int(device), v)
+    return dict(chunks=v[0], folds_per_launch=(v[1] / v[0] if v[0] else 0.0), folds=v[2], enqueue_s=v[3], wait_s=v[4])
+
+
+def set_shared_launches(mode):
+    """trx2_set_shared_launches: 1 = single-decoy folds of all contexts share launch pairs (default), 0 = every fold launches for
+    itself, -1 = back to the environment's choice (TRX2_SHARED_LAUNCH)"""
+    if load().trx2_set_shared_launches(int(mode)) != 0:
+        raise ValueError("mode must be -1, 0 or 1")
 
 
 class Context:

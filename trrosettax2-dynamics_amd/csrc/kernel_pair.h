@@ -19,6 +19,7 @@
 
 struct PairArgs {
   int L, B, Bpad;
+  int n_items;                // work items of this map's row plan (shared launches: the grid is the longest plan's, the rest exit)
   const uint2* items;         // work items of a launch, one workgroup each (row plan): x = row a | slice << 10 | slices of that row << 14,
                               // y = first entry of the slice in the row's list | one past its last << 16 (a row has < 1024 entries)
   int kd;       // knots of the distance spline: TRX2_KD, or TRX2_KD_AF2 for gen_rst_af2 tables
@@ -102,7 +103,7 @@ __device__ __forceinline__ float hbond_dev(f3 N, f3 H, f3 O, f3 C, float s, f3& 
 #ifdef TRX2_STAMP
 __device__ unsigned long long g_stamp[32];
 #define STAMP_DECL unsigned long long st_acc[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long st_prev = 0; \
-  const bool st_on = (blockIdx.x == gridDim.x / 2 && blockIdx.z == 0 && (threadIdx.x >> 6) == 0); \
+  const bool st_on = (bx == gridDim.x / 2 && grp == 0 && (threadIdx.x >> 6) == 0); \
   if (st_on) { __builtin_amdgcn_s_waitcnt(0); st_prev = __builtin_amdgcn_s_memtime(); }
 #define STAMP(k) if (st_on) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
   __builtin_amdgcn_s_waitcnt(0); st_acc[k] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); }
@@ -167,15 +168,16 @@ __global__ __launch_bounds__(256) void k_build_rows(int L, const unsigned char* 
 // per wave (WRITE_SIZE 19.5 MB against 0.8 MB of records, profiles/r03_traffic.json) for no gain in time (32.5 against 31.9 us).
 template <int BW, int FAM>
 constexpr int pair_min_waves() { return (FAM & FAM_ANG) ? ((BW == 64 || BW == 1) ? PAIR_MIN_WAVES : 2) : PAIR_MIN_WAVES_DIST; }
+// The kernel's body: work item `bx` of the row plan, decoy group `grp` of the map and batch that A describes.
 template <int BW, int FAM>
-__global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_pair(PairArgs A) {
+__device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, const int grp) {
   constexpr int PW = 64 / BW;
   const int L = A.L;
   // Work item = (row a, slice, slices of that row): rows are cut into a number of slices that follows their list length (the
   // row plan, host side), so that no workgroup walks a list twice as long as the others' (rows hold 20 .. 140 partners)
-  const uint2 item2 = A.items[blockIdx.x];
+  const uint2 item2 = A.items[bx];
   const unsigned item = item2.x;
-  const int a = (int)(item & PAIR_ROW_B_BITS), split = (int)((item >> 10) & 15u), nsl = (int)(item >> 14), grp = blockIdx.z;
+  const int a = (int)(item & PAIR_ROW_B_BITS), split = (int)((item >> 10) & 15u), nsl = (int)(item >> 14);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int d = lane % BW, h = lane / BW;
   const int dec = grp * BW + d;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_p
   // One evaluation = one sequence number.  Kept in device memory (not a kernel argument) so that a chunk of
   // (pair, step) launches is a STATIC graph that can be replayed.  The step kernel of this evaluation starts after this
   // kernel has finished (same stream), so every one of its workgroups reads the same, final value.
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && A.seq_ctr) *A.seq_ctr += 1;
+  if (bx == 0 && grp == 0 && threadIdx.x == 0 && A.seq_ctr) *A.seq_ctr += 1;
   // this lane's weights and residue a: requested first, so that their latency (they were written by the step kernel on
   // other CUs a moment ago) runs under the LDS fill and its barrier instead of after it
   const float4* wp = reinterpret_cast<const float4*>(A.wcur + (size_t)decc * 8);
@@ -489,4 +491,31 @@ __global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_p
   }
   STAMP(12)  // epilogue: LDS image, barrier, column sums, stores
   STAMP_FLUSH
+}
+template <int BW, int FAM>
+__global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_pair(PairArgs A) {
+  pair_body<BW, FAM>(A, blockIdx.x, (int)blockIdx.z);
+}
+// Shared launch (trx2fold.hip: LaunchEngine): ONE launch evaluates the pair terms of several independent folds, each on its own
+// map -- blockIdx.z picks the fold, whose argument block (tables, row lists, row plan, coordinates, records, chain length) is read
+// from device memory instead of the kernel arguments.  A fold here is one decoy group (the iteration phase of run_inference.py
+// folds one decoy per map and iteration, run_inference.py:97-139: a single-decoy launch leaves the chip idle, and four streams
+// are all the hardware queues there are).  The body is the same: a fold's arithmetic does not depend on what shares its launch.
+// an argument block from device memory through the CONSTANT address space: scalar loads into SGPRs, exactly what the kernel
+// arguments of the single-fold kernels are (the blocks are uploaded before the launch and never written during it)
+template <class T>
+__device__ __forceinline__ T load_args(const T* p) {
+  static_assert(sizeof(T) % 4 == 0, "argument blocks are copied word by word");
+  typedef __attribute__((address_space(4))) const unsigned* cword;
+  const cword src = (cword)(unsigned long long)p;
+  union U { T t; unsigned w[sizeof(T) / 4]; __device__ U() {} } u;
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; i++) u.w[i] = src[i];
+  return u.t;
+}
+template <int BW, int FAM>
+__global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_pair_multi(const PairArgs* AA) {
+  const PairArgs A = load_args(AA + blockIdx.z);
+  if ((int)blockIdx.x >= A.n_items) return;
+  pair_body<BW, FAM>(A, blockIdx.x, 0);
 }

@@ -1840,6 +1840,30 @@ __global__ __launch_bounds__(NT, (LOWREG ? 2 : 1)) void k_step(ChainArgs A, Cart
   }
 }
 
+// Shared launch (trx2fold.hip: LaunchEngine): blockIdx.y picks one of several independent folds, each with its own argument blocks
+// in device memory (its map's per-residue constants, its own state, vectors, records and protocol table); blockIdx.x is the
+// (role, slot) index within that fold, as in k_step.  Folds with fewer slots than the launch's widest leave at once.
+template <int RPT, int TN, int NT, bool LOWREG = false>
+__global__ __launch_bounds__(NT, (LOWREG ? 2 : 1)) void k_step_multi(const ChainArgs* AA, const CartArgs* CC) {
+  __shared__ int s_runs[STEP_RUNS_INTS];
+  __shared__ GramLds<(RPT == 1) ? TN : 16> s_gl;
+  static_assert(RPT == 1 && TN == NT, "shared launches serve the one-residue-per-thread instantiations");
+  const ChainArgs A = load_args(AA + blockIdx.y);
+  const int nB = A.B;
+  if ((int)blockIdx.x >= 2 * nB) return;
+  if ((int)blockIdx.x >= nB) {
+    chain_body<RPT, TN>(A, (int)blockIdx.x - nB, s_runs, s_gl);
+  } else {
+    const CartArgs C = load_args(CC + blockIdx.y);
+    cart_body<NT, LOWREG>(C, (int)blockIdx.x, s_runs, s_gl);
+  }
+}
+// one pass over the folds of a shared launch: each fold's count of retired slots, gathered for ONE copy to the host
+__global__ void k_gather_done(int n, const int* const* done, int* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = *done[i];
+}
+
 // ---- Tail of a fold: once the queue is empty the slots retire one by one, but a pair-kernel wave costs the same while ANY of its
 // 64 decoys is alive, and a batch of several decoy groups keeps all of them partly alive almost to the end.  When no more than
 // one group's worth of decoys is left, the survivors are moved into group 0 and the launches shrink to one group.

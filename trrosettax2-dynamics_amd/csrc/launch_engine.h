@@ -1,0 +1,273 @@
+// launch_engine.h -- shared launches: many independent single-group folds advance in ONE (pair, step) launch pair -- included by
+// trx2fold.hip (host side only; the kernels are k_pair_multi / k_step_multi / k_gather_done).
+//
+// Why.  The product of run_inference.py is its ITERATION phase: per chain (target x model) a sequence of single-decoy folds,
+// each on the map the previous decoy re-weighted (run_inference.py:97-139).  A single-decoy evaluation is a launch pair of ~24 us
+// that occupies a few hundred of the chip's 1024 SIMDs for a fraction of that time, a chain's folds depend on each other, and HIP
+// gives a process four hardware queues: four chains on four streams was the ceiling (3.6 x one chain, round 3).  The chains of a
+// batch job (run_inference.py:339-348: `for name in names`, two models each) are independent, so here their evaluations SHARE
+// launches: a fold that qualifies hands its argument blocks to an engine and sleeps; the engine's host thread launches, for all
+// folds it holds, one k_pair_multi (blockIdx.z = fold) and one k_step_multi (blockIdx.y = fold) per evaluation, and wakes a fold
+// when its decoys have reported.  Each fold keeps its own context -- map, tables, row plan, state, buffers -- and its arithmetic
+// does not depend on what shares its launches: results are bit-identical to the fold's own launches (tests).
+//
+// Shape.  One engine = one stream + one host thread; TRX2_ENGINE_STREAMS engines per device (default 2: the pair kernel of one
+// engine's folds overlaps the step kernel of the other's, as two lanes of one fold do).  The host loop keeps TWO chunks of
+// ENGINE_CHUNK launch pairs in flight: chunk k is enqueued before chunk k-1 is waited for, so the GPU never idles on the host.  A
+// fold found finished after chunk k-1 is still named in chunk k (already enqueued; its workgroups leave at once: PH_DONE), so it
+// is released when chunk k has completed -- no launch in flight ever refers to buffers whose owner has been woken.  Folds join
+// at chunk boundaries; their start-up work (on their own stream) is ordered before the chunk by an event.
+#pragma once
+#include <condition_variable>
+
+#define ENGINE_MAX_JOBS 96
+#define ENGINE_CHUNK 16
+
+struct EngineJob {
+  // filled by the submitting fold
+  PairArgs pa; ChainArgs ca; CartArgs cc;
+  int cls = 1;            // step kernel: 0 chains of <= 128 residues (128 threads), 1 <= 256, 2 <= 512
+  int fam_all = 1;        // pair kernel: all channels | distances only
+  int bw = 1;             // decoys per wave of the pair kernel (one decoy group per fold)
+  int B = 1;              // slots
+  int n_items = 0;        // workgroups of the fold's row plan
+  size_t dyn = 0;         // dynamic LDS its step workgroups need
+  const int* done_count = nullptr;  // device: slots retired
+  hipEvent_t ready = nullptr;       // recorded on the fold's own stream behind its start-up work
+  long cap = 0;           // launch pairs after which the fold is given up
+  // engine side
+  unsigned long long id = 0;
+  long launches = 0;
+  int done = 0;           // last observed count of retired slots
+  int state = 0;          // 0 queued, 1 active, 2 draining, 3 released
+  long drain_chunk = -1;
+  std::string err;
+};
+
+struct LaunchEngine {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::vector<EngineJob*> queued, active, draining;
+  unsigned long long next_id = 1;
+  bool started = false, broken = false;
+  std::string broken_why;
+  // device argument arrays (one set: uploads are ordered on the engine's stream) and pinned staging (ring of 3)
+  char* d_args = nullptr; char* h_args[3] = {nullptr, nullptr, nullptr};
+  int* d_flags = nullptr; int* h_flags[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  // statistics (trx2_shared_launch_stats): chunks enqueued, sum over chunks of the folds they held, folds completed, seconds the
+  // host thread spent enqueuing / waiting for a chunk
+  double st_chunks = 0, st_jobs = 0, st_done = 0, st_enqueue_s = 0, st_wait_s = 0;
+  size_t load() { return queued.size() + active.size(); }
+};
+
+static const size_t ENG_OFF_PA = 0;
+static const size_t ENG_OFF_CA = ENG_OFF_PA + sizeof(PairArgs) * ENGINE_MAX_JOBS;
+static const size_t ENG_OFF_CC = ENG_OFF_CA + sizeof(ChainArgs) * ENGINE_MAX_JOBS;
+static const size_t ENG_OFF_DP = ENG_OFF_CC + sizeof(CartArgs) * ENGINE_MAX_JOBS;
+static const size_t ENG_ARGS_BYTES = ENG_OFF_DP + sizeof(int*) * ENGINE_MAX_JOBS;
+
+static int g_engine_mode = -1;   // -1: TRX2_SHARED_LAUNCH decides (default on); 0 / 1: trx2_set_shared_launches
+static std::mutex g_engine_mutex;
+static std::map<int, std::vector<LaunchEngine*>> g_engines;   // per device; never destroyed (their threads outlive every context)
+
+static bool engine_enabled() {
+  if (g_engine_mode >= 0) return g_engine_mode != 0;
+  static const bool env_on = !(getenv("TRX2_SHARED_LAUNCH") && atoi(getenv("TRX2_SHARED_LAUNCH")) == 0);
+  return env_on;
+}
+
+template <int BW>
+static void engine_launch_pair(bool fam_all, dim3 grid, hipStream_t st, const PairArgs* a) {
+  if (fam_all) hipLaunchKernelGGL((k_pair_multi<BW, FAM_ALL>), grid, dim3(PAIR_THREADS), 0, st, a);
+  else hipLaunchKernelGGL((k_pair_multi<BW, FAM_DIST | FAM_VDW>), grid, dim3(PAIR_THREADS), 0, st, a);
+}
+static void engine_launch_step(int cls, dim3 grid, size_t dyn, hipStream_t st, const ChainArgs* a, const CartArgs* c) {
+  if (cls == 0) hipLaunchKernelGGL((k_step_multi<1, 128, 128>), grid, dim3(128), dyn, st, a, c);
+  else if (cls == 1) hipLaunchKernelGGL((k_step_multi<1, CHAIN_THREADS, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), dyn, st, a, c);
+  else hipLaunchKernelGGL((k_step_multi<1, 2 * CHAIN_THREADS, 2 * CHAIN_THREADS>), grid, dim3(2 * CHAIN_THREADS), dyn, st, a, c);
+}
+
+// launch class of a job: folds of one class share a launch pair (same instantiations); a chunk launches every class it holds
+static int engine_class(const EngineJob* j) { return j->cls * 2 + j->fam_all; }
+
+static void engine_fail(LaunchEngine* E, const std::string& why) {   // (mu held) a HIP error on the engine's stream: every fold it holds fails loudly
+  E->broken = true; E->broken_why = why;
+  for (auto* v : {&E->queued, &E->active, &E->draining})
+    for (EngineJob* j : *v) { j->err = "shared launches: " + why; j->state = 3; }
+  E->queued.clear(); E->active.clear(); E->draining.clear();
+  E->cv_done.notify_all();
+}
+
+static void engine_main(LaunchEngine* E) {
+  if (hipSetDevice(E->device) != hipSuccess) { std::lock_guard<std::mutex> lk(E->mu); engine_fail(E, "hipSetDevice failed in the engine thread"); return; }
+  struct Chunk { std::vector<EngineJob*> jobs; bool valid = false; } ch[2];
+  std::vector<unsigned long long> uploaded;   // ids of the jobs the device arrays describe, in order
+  long k = 0;
+  int ring = 0;
+  auto chk = [&](hipError_t e, const char* what) {
+    if (e == hipSuccess) return true;
+    std::lock_guard<std::mutex> lk(E->mu);
+    engine_fail(E, std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+  };
+  while (true) {
+    Chunk& C = ch[k & 1];
+    Chunk& Pv = ch[(k + 1) & 1];
+    {
+      std::unique_lock<std::mutex> lk(E->mu);
+      E->cv_work.wait(lk, [&] { return E->broken || !E->queued.empty() || !E->active.empty() || Pv.valid; });
+      if (E->broken) return;
+      for (EngineJob* j : E->queued) { j->state = 1; E->active.push_back(j); }
+      std::vector<EngineJob*> fresh;
+      fresh.swap(E->queued);
+      C.jobs = E->active;
+      lk.unlock();
+      for (EngineJob* j : fresh)   // the fold's start-up work (its own stream) comes before the first launch that steps it
+        if (!chk(hipStreamWaitEvent(E->stream, j->ready, 0), "hipStreamWaitEvent")) return;
+    }
+    C.valid = !C.jobs.empty();
+    const auto t_enq = std::chrono::steady_clock::now();
+    if (C.valid) {
+      std::stable_sort(C.jobs.begin(), C.jobs.end(), [](const EngineJob* a, const EngineJob* b) { return engine_class(a) < engine_class(b); });
+      const int n = (int)C.jobs.size();
+      bool same = uploaded.size() == (size_t)n;
+      for (int i = 0; same && i < n; i++) same = uploaded[(size_t)i] == C.jobs[(size_t)i]->id;
+      if (!same) {
+        char* h = E->h_args[ring];
+        ring = (ring + 1) % 3;
+        for (int i = 0; i < n; i++) {
+          const EngineJob* j = C.jobs[(size_t)i];
+          memcpy(h + ENG_OFF_PA + sizeof(PairArgs) * i, &j->pa, sizeof(PairArgs));
+          memcpy(h + ENG_OFF_CA + sizeof(ChainArgs) * i, &j->ca, sizeof(ChainArgs));
+          memcpy(h + ENG_OFF_CC + sizeof(CartArgs) * i, &j->cc, sizeof(CartArgs));
+          memcpy(h + ENG_OFF_DP + sizeof(int*) * i, &j->done_count, sizeof(int*));
+        }
+        // one copy of the whole block (60 KB at most; the arrays of the previous chunk are read by kernels that come before it on this stream)
+        if (!chk(hipMemcpyAsync(E->d_args, h, ENG_ARGS_BYTES, hipMemcpyHostToDevice, E->stream), "hipMemcpyAsync(args)")) return;
+        uploaded.resize((size_t)n);
+        for (int i = 0; i < n; i++) uploaded[(size_t)i] = C.jobs[(size_t)i]->id;
+      }
+      const PairArgs* dpa = (const PairArgs*)(E->d_args + ENG_OFF_PA);
+      const ChainArgs* dca = (const ChainArgs*)(E->d_args + ENG_OFF_CA);
+      const CartArgs* dcc = (const CartArgs*)(E->d_args + ENG_OFF_CC);
+      struct Grp { int lo, n, items, maxB, cls, fam, bw; size_t dyn; };
+      std::vector<Grp> groups;
+      for (int i = 0; i < n;) {
+        Grp g{i, 0, 0, 0, C.jobs[(size_t)i]->cls, C.jobs[(size_t)i]->fam_all, C.jobs[(size_t)i]->bw, 0};
+        while (i < n && engine_class(C.jobs[(size_t)i]) == engine_class(C.jobs[(size_t)g.lo])) {
+          const EngineJob* j = C.jobs[(size_t)i];
+          g.items = std::max(g.items, j->n_items); g.maxB = std::max(g.maxB, j->B); g.dyn = std::max(g.dyn, j->dyn);
+          g.n++; i++;
+        }
+        groups.push_back(g);
+      }
+      for (int it = 0; it < ENGINE_CHUNK; it++)
+        for (const Grp& g : groups) {
+          engine_launch_pair<1>(g.fam != 0, dim3((unsigned)g.items, 1, (unsigned)g.n), E->stream, dpa + g.lo);
+          engine_launch_step(g.cls, dim3((unsigned)(2 * g.maxB), (unsigned)g.n), g.dyn, E->stream, dca + g.lo, dcc + g.lo);
+        }
+      hipLaunchKernelGGL(k_gather_done, dim3(1), dim3(ENGINE_MAX_JOBS), 0, E->stream, n, (const int* const*)(E->d_args + ENG_OFF_DP), E->d_flags);
+      if (!chk(hipGetLastError(), "shared launch")) return;
+      if (!chk(hipMemcpyAsync(E->h_flags[k & 1], E->d_flags, sizeof(int) * n, hipMemcpyDeviceToHost, E->stream), "hipMemcpyAsync(flags)")) return;
+      if (!chk(hipEventRecord(E->ev[k & 1], E->stream), "hipEventRecord")) return;
+      E->st_chunks += 1; E->st_jobs += n;
+    }
+    const auto t_wait = std::chrono::steady_clock::now();
+    E->st_enqueue_s += std::chrono::duration<double>(t_wait - t_enq).count();
+    if (Pv.valid) {
+      if (!chk(hipEventSynchronize(E->ev[(k + 1) & 1]), "hipEventSynchronize")) return;
+      E->st_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
+      std::lock_guard<std::mutex> lk(E->mu);
+      bool woke = false;
+      for (size_t i = 0; i < E->draining.size();) {   // named in no launch that is still in flight: the owner may have its buffers back
+        EngineJob* j = E->draining[i];
+        if (j->drain_chunk <= k - 1) { j->state = 3; E->draining.erase(E->draining.begin() + (long)i); woke = true; }
+        else i++;
+      }
+      const int* fl = E->h_flags[(k + 1) & 1];
+      for (size_t i = 0; i < Pv.jobs.size(); i++) {
+        EngineJob* j = Pv.jobs[i];
+        if (j->state != 1) continue;
+        j->launches += ENGINE_CHUNK;
+        j->done = fl[i];
+        if (j->done >= j->B || j->launches >= j->cap) {
+          E->active.erase(std::find(E->active.begin(), E->active.end(), j));
+          const bool in_next = C.valid && std::find(C.jobs.begin(), C.jobs.end(), j) != C.jobs.end();
+          if (in_next) { j->state = 2; j->drain_chunk = k; E->draining.push_back(j); }
+          else { j->state = 3; woke = true; }
+          E->st_done += 1;
+        }
+      }
+      Pv.valid = false;
+      if (woke) E->cv_done.notify_all();
+    }
+    k++;
+  }
+}
+
+static bool engine_start(LaunchEngine* E) {   // (g_engine_mutex held)
+  if (hipSetDevice(E->device) != hipSuccess) return false;
+  // a stream of its own out of the library's four (pool_acquire), marked so that contexts avoid it while others are free
+  E->stream = pool_acquire(E->device, nullptr, 1000);
+  if (!E->stream) return false;
+  bool ok = hipMalloc((void**)&E->d_args, ENG_ARGS_BYTES) == hipSuccess && hipMalloc((void**)&E->d_flags, sizeof(int) * ENGINE_MAX_JOBS) == hipSuccess;
+  for (int i = 0; i < 3 && ok; i++) ok = hipHostMalloc((void**)&E->h_args[i], ENG_ARGS_BYTES) == hipSuccess;
+  for (int i = 0; i < 2 && ok; i++) ok = hipHostMalloc((void**)&E->h_flags[i], sizeof(int) * ENGINE_MAX_JOBS) == hipSuccess && hipEventCreateWithFlags(&E->ev[i], hipEventDisableTiming) == hipSuccess;
+  if (ok) {
+    int lds_max = 0;
+    if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, E->device) != hipSuccess || lds_max <= 0) lds_max = 65536;
+    if (lds_max > 160 * 1024) lds_max = 160 * 1024;
+    const void* f[2] = {(const void*)k_step_multi<1, 128, 128>, (const void*)k_step_multi<1, CHAIN_THREADS, CHAIN_THREADS>};
+    for (int q = 0; q < 2 && ok; q++) {
+      hipFuncAttributes fa;
+      ok = hipFuncGetAttributes(&fa, f[q]) == hipSuccess &&
+           hipFuncSetAttribute(f[q], hipFuncAttributeMaxDynamicSharedMemorySize, lds_max - (int)fa.sharedSizeBytes) == hipSuccess;
+    }
+  }
+  if (!ok) return false;
+  std::thread(engine_main, E).detach();
+  E->started = true;
+  return true;
+}
+
+// the least loaded engine of the device (created on first use); nullptr: shared launches are not available -> the fold launches itself
+static LaunchEngine* engine_pick(int device) {
+  std::lock_guard<std::mutex> lk(g_engine_mutex);
+  std::vector<LaunchEngine*>& v = g_engines[device];
+  if (v.empty()) {
+    int n = 2;
+    if (const char* e = getenv("TRX2_ENGINE_STREAMS")) n = std::max(1, std::min(3, atoi(e)));
+    for (int i = 0; i < n; i++) {
+      LaunchEngine* E = new LaunchEngine();
+      E->device = device;
+      if (!engine_start(E)) { E->broken = true; E->broken_why = "could not start"; }
+      v.push_back(E);
+    }
+  }
+  LaunchEngine* best = nullptr;
+  size_t best_load = 0;
+  for (LaunchEngine* E : v) {
+    std::lock_guard<std::mutex> l2(E->mu);
+    if (E->broken || !E->started) continue;
+    const size_t ld = E->load();
+    if (ld >= ENGINE_MAX_JOBS) continue;
+    if (!best || ld < best_load) { best = E; best_load = ld; }
+  }
+  return best;
+}
+
+// Hands a prepared fold to an engine and sleeps until its decoys have reported (or its launch cap is reached).  0: done (job->done,
+// job->launches are set); 1: error (job->err).
+static int engine_run(LaunchEngine* E, EngineJob* job) {
+  std::unique_lock<std::mutex> lk(E->mu);
+  if (E->broken) { job->err = "shared launches: " + E->broken_why; return 1; }
+  job->id = E->next_id++;
+  job->state = 0;
+  E->queued.push_back(job);
+  E->cv_work.notify_one();
+  E->cv_done.wait(lk, [&] { return job->state == 3; });
+  return job->err.empty() ? 0 : 1;
+}

@@ -126,6 +126,7 @@ struct trx2_ctx {
   long alloc_epoch = 0;
   trx2_run* runs = nullptr;
   int* h_done = nullptr;  // pinned
+  hipEvent_t ev_ready = nullptr;  // shared launches: recorded on this context's stream when a fold's start-up work is enqueued
   double last_seconds = 0; int last_launches = 0; double last_slot_eff = 0;
   // slot pool (trx2_ctx_set_pool): a fold of N decoys runs on min(N, pool) slots; a slot whose decoy has reported takes the next
   // one of the queue on the device.  0 = one slot per decoy.
@@ -190,7 +191,7 @@ static std::mutex g_pool_mutex;
 static std::map<int, StreamPool> g_pools;
 // avoid: a stream the caller must not share (a second lane takes any stream but its parent's: after contexts have come and gone
 // the least-used stream can be the parent's own, and two lanes on one stream serialise -- ADVICE r3)
-static hipStream_t pool_acquire(int device, hipStream_t avoid = nullptr) {
+static hipStream_t pool_acquire(int device, hipStream_t avoid = nullptr, int weight = 1) {   // weight: a launch engine's stream counts as heavily used
   std::lock_guard<std::mutex> lk(g_pool_mutex);
   StreamPool& P = g_pools[device];
   if (!P.ready) {
@@ -203,7 +204,7 @@ static hipStream_t pool_acquire(int device, hipStream_t avoid = nullptr) {
   }
   int best = -1;
   for (int k = 0; k < TRX2_POOL_STREAMS; k++) if (P.s[k] != avoid && (best < 0 || P.use[k] < P.use[best])) best = k;
-  P.use[best]++;
+  P.use[best] += weight;
   return P.s[best];
 }
 // contexts that hold this stream (more than one: their launches interleave on it -- no stream capture then)
@@ -435,6 +436,7 @@ extern "C" void trx2_ctx_destroy(trx2_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
   for (auto& e : ctx->prof_ev) (void)hipEventDestroy(e);
+  if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
   free_map(ctx);
   free_batch(ctx);
   if (ctx->fb_buf) (void)hipFree(ctx->fb_buf);
@@ -820,7 +822,7 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
 
 static PairArgs pair_args(trx2_ctx* c, int B) {
   PairArgs P;
-  P.L = c->L; P.B = B; P.Bpad = c->Bpad; P.items = c->plans[(size_t)c->plan_cur].items;
+  P.L = c->L; P.B = B; P.Bpad = c->Bpad; P.items = c->plans[(size_t)c->plan_cur].items; P.n_items = c->plans[(size_t)c->plan_cur].n_items;
   P.xyzT = c->xyzT; P.Td = c->Td; P.To = c->To; P.Tt = c->Tt; P.Tp = c->Tp;
   P.rows = c->rows; P.row_cnt = c->row_cnt; P.rows_rx = c->rows_rx; P.has_odr = c->mask_odr != nullptr;
   P.knots = c->knots_f; P.wcur = c->wcur; P.FA = c->FA; P.seq_ctr = c->seq_ctr;
@@ -1000,6 +1002,8 @@ static bool step_two_per_cu(const trx2_ctx* ctx, int L, int slots, int* dyn_cap)
   return true;
 }
 
+#include "launch_engine.h"
+
 static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint64_t seed, uint32_t decoy0,
                      const float* tors0, int max_evals, float* tors_out, float* xyz_out, double* e_terms,
                      double* f_final, int* status, int* n_evals, int* n_iters) {
@@ -1065,6 +1069,20 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   };
   int two_cap = 0;
   const bool two_per_cu = has_cart && step_two_per_cu(ctx, L, B0, &two_cap);
+  // dynamic LDS of a step launch: the larger of the torsion role's staged history and the Cartesian role's staged pairs (behind its
+  // own arrays in the low-register instantiation); sets how many stored pairs the Cartesian role stages
+  auto step_lds = [&](CartArgs& cc) -> size_t {
+    const int k = L <= 128 ? 0 : 1;
+    const size_t arrays = two_per_cu ? CART_ARRAYS_BYTES(L) : 0;
+    size_t dyn = L <= CHAIN_THREADS ? HIST_LDS_BYTES(L) : 0;
+    if (L <= CHAIN_THREADS) {
+      const int budget = (two_per_cu ? two_cap : step_dyn_budget(ctx, k, L)) - (int)arrays;
+      cc.hist_lds = budget > 0 ? (int)std::min<size_t>(LBM, (size_t)budget / CART_HIST_BYTES(L)) : 0;
+      if (const char* e = getenv("TRX2_CART_HIST_LDS")) cc.hist_lds = std::min(cc.hist_lds, std::max(0, atoi(e)));  // A/B and debugging only
+      dyn = std::max(dyn, arrays + cc.hist_lds * CART_HIST_BYTES(L));
+    }
+    return dyn;
+  };
   auto enqueue_chunk = [&]() -> int {  // non-zero: a pair launch was refused; nothing was launched after it
     for (int i = 0; i < chunk; i++) {
       const bool samp = pe > 0 && (i % pe) == 0 && (size_t)(3 * prof_used + 2) < ctx->prof_ev.size();
@@ -1077,18 +1095,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
         // fused launch: workgroups of 256 (512 for 256 < L <= 512) threads, one residue per thread in the Cartesian role
         CartArgs cc = cart_args(ctx, B, nruns, max_evals);
         const dim3 g2(2 * B), b1(CHAIN_THREADS), b2(2 * CHAIN_THREADS);
-        // dynamic LDS of the launch: the larger of the two roles' staged histories
-        const int k = L <= 128 ? 0 : 1;
-        // dynamic LDS of the launch: the larger of the torsion role's staged history and the Cartesian role's staged pairs (behind
-        // its own arrays in the low-register instantiation)
-        const size_t arrays = two_per_cu ? CART_ARRAYS_BYTES(L) : 0;
-        size_t dyn = L <= CHAIN_THREADS ? HIST_LDS_BYTES(L) : 0;
-        if (L <= CHAIN_THREADS) {
-          const int budget = (two_per_cu ? two_cap : step_dyn_budget(ctx, k, L)) - (int)arrays;
-          cc.hist_lds = budget > 0 ? (int)std::min<size_t>(LBM, (size_t)budget / CART_HIST_BYTES(L)) : 0;
-          if (const char* e = getenv("TRX2_CART_HIST_LDS")) cc.hist_lds = std::min(cc.hist_lds, std::max(0, atoi(e)));  // A/B and debugging only
-          dyn = std::max(dyn, arrays + cc.hist_lds * CART_HIST_BYTES(L));
-        }
+        const size_t dyn = step_lds(cc);
         if (L <= 128 && two_per_cu) hipLaunchKernelGGL((k_step<1, 128, 128, true>), g2, dim3(128), dyn, ctx->stream, ca, cc);
         else if (L <= 128) hipLaunchKernelGGL((k_step<1, 128, 128>), g2, dim3(128), dyn, ctx->stream, ca, cc);
         else if (two_per_cu) hipLaunchKernelGGL((k_step<1, CHAIN_THREADS, CHAIN_THREADS, true>), g2, b1, dyn, ctx->stream, ca, cc);
@@ -1100,13 +1107,40 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
     }
     return 0;
   };
+  // Shared launches (launch_engine.h): a single-decoy fold -- every feedback iteration of run_inference.py is one -- does not launch
+  // for itself; it hands its argument blocks to an engine whose launch pairs step the folds of many contexts at once, and sleeps.
+  bool via_engine = false;
+  if (B == 1 && N == 1 && has_cart && L <= 2 * CHAIN_THREADS && pe == 0 && getenv("TRX2_GRAPH") == nullptr && engine_enabled()) {
+    if (LaunchEngine* E = engine_pick(ctx->device)) {
+      EngineJob job;
+      job.pa = pair_args(ctx, B);
+      job.ca = chain_args(ctx, B, MODE_STEP, nruns, max_evals);
+      pool_args(job.ca);
+      job.cc = cart_args(ctx, B, nruns, max_evals);
+      job.dyn = step_lds(job.cc);
+      job.cls = L <= 128 ? 0 : (L <= CHAIN_THREADS ? 1 : 2);
+      job.fam_all = ctx->use_orient ? 1 : 0;
+      job.bw = ctx->BW; job.B = B; job.n_items = job.pa.n_items; job.done_count = ctx->done_count; job.cap = cap;
+      const RowPlan& rp = ctx->plans[(size_t)ctx->plan_cur];
+      if (ctx->BW != 1 || rp.epoch != ctx->rows_epoch || rp.pw != 64 || (size_t)rp.ns_max * B * L > ctx->fa_cap) {
+        ctx->err = "internal: shared launch shape does not fit the batch buffers or its row plan"; return 1;
+      }
+      if (!ctx->ev_ready) HIPCHK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(ctx->ev_ready, ctx->stream));
+      job.ready = ctx->ev_ready;
+      if (engine_run(E, &job)) { ctx->err = job.err; return 1; }
+      launches = (int)job.launches; slot_launches = (double)job.launches * B;
+      *ctx->h_done = job.done;
+      via_engine = true;
+    }
+  }
   // The chunk is a static graph (its only per-evaluation input, the sequence number, lives in device memory): capture it
   // once per (batch shape, protocol length, buffers) and replay it -- 128 launches become one hipGraphLaunch.  Measured on
   // MI355X it changes nothing (the loop is not launch-bound: profiles/README.md), so direct launches stay the default and
   // TRX2_GRAPH=1 opts in.
   // (never on a pool stream another context holds too: its launches from another host thread would land inside the capture)
   const bool no_graph = getenv("TRX2_GRAPH") == nullptr || pool_use_count(ctx->device, ctx->stream) > 1;
-  if (!no_graph) {
+  if (!no_graph && !via_engine) {
     const long key[8] = {B, nruns, max_evals, has_cart ? 1 : 0, (long)L * 4096 + N, (long)(seed ^ ((uint64_t)decoy0 << 40) ^ (tors0 ? 1 : 0)), (long)ctx->plan_cur * 128 + ctx->BW, ctx->alloc_epoch};
     if (!ctx->gexec || memcmp(key, ctx->g_key, sizeof key) != 0) {
       if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
@@ -1120,7 +1154,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
       memcpy(ctx->g_key, key, sizeof key);
     }
   }
-  while (true) {
+  while (!via_engine) {
     if (no_graph) {
       if (enqueue_chunk()) { (void)hipStreamSynchronize(ctx->stream); return 1; }  // ctx->err says which shape was refused
     } else HIPCHK(hipGraphLaunch(ctx->gexec, ctx->stream));
@@ -1199,6 +1233,28 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   ctx->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   ctx->last_launches = launches;
   ctx->last_slot_eff = evals / slot_launches;
+  return 0;
+}
+
+// process-wide switch of the shared launches (include/trx2fold.h); takes effect for the folds that start after it
+extern "C" int trx2_set_shared_launches(int mode) {
+  if (mode < -1 || mode > 1) return 1;
+  g_engine_mode = mode;
+  return 0;
+}
+
+// out[5] summed over the device's engines: chunks of ENGINE_CHUNK launch pairs enqueued, folds x chunks (their ratio = folds per
+// launch), folds completed, seconds the engine threads spent enqueuing, seconds they waited for the GPU
+extern "C" int trx2_shared_launch_stats(int device, double* out) {
+  if (!out) return 1;
+  for (int i = 0; i < 5; i++) out[i] = 0;
+  std::lock_guard<std::mutex> lk(g_engine_mutex);
+  auto it = g_engines.find(device);
+  if (it == g_engines.end()) return 0;
+  for (LaunchEngine* E : it->second) {
+    std::lock_guard<std::mutex> l2(E->mu);
+    out[0] += E->st_chunks; out[1] += E->st_jobs; out[2] += E->st_done; out[3] += E->st_enqueue_s; out[4] += E->st_wait_s;
+  }
   return 0;
 }
 

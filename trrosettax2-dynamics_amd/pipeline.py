@@ -265,38 +265,41 @@ def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mu
     return n_out
 
 
-def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, run=None, targets_in_flight=None, **kw):
+def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, run=None, targets_in_flight=None, store=None, **kw):
     """Batch mode (run_inference.py:339-348: `for name in names: run_single(...)`) sharded over ranks, one process per GPU.
 
-    Targets are independent, so there is no data-path collective: every rank derives the same longest-processing-time-first
-    plan (cost = decoys x L^2, sched.lpt_assign) from the name list and runs ITS targets on ITS device.  A target is not split:
-    its iteration loop is sequential and the choice of the best initial decoy needs all of them (run_inference.py:60-73).
-    A failing target is recorded and the rest of the list still runs (the reference's loop dies at the first exception);
-    the summary -- gathered with all_gather_object, the only communication -- carries the failures and the caller turns
-    them into a non-zero exit code.  `run` stands in for run_single in the CPU tests.
+    Targets are independent, so there is no data-path collective.  Every rank orders the name list longest first by the modelled
+    seconds of a target (sched.MODEL: initial batches + sequential single-decoy iterations; latency-bound, not n L^2) and PULLS
+    the next target from a shared counter when one of its worker threads is free (sched.DynamicQueue on a TCPStore: one atomic
+    integer add per target).  How long a target takes cannot be known beforehand -- its chains stop when their maps converge (53-64
+    iterations on the reference's example) or at Nmax = 300 -- so a static plan straggles; the queue does not.
+    A target is not split: its iteration loop is sequential and the choice of the best initial decoy needs all of them
+    (run_inference.py:60-73).  A failing target is recorded and the rest of the list still runs (the reference's loop dies at the
+    first exception); the summary -- gathered with all_gather_object -- carries the failures and the caller turns them into a
+    non-zero exit code.  `run` stands in for run_single in the CPU tests; `store` for the TCPStore (default: sched.queue_store).
 
-    targets_in_flight: a rank's targets are folded that many at a time on host threads (default: as many as keep FOUR chains in
-    flight -- two targets with both models, four with one).  A chain's iteration phase folds one decoy at a time and leaves the
-    chip idle; four single-decoy chains on four streams run at 26.4 us per evaluation each against 23.8 alone (3.6 x the
-    throughput of one), more than four streams lose (profiles/README.md, round 3).  A target's files do not depend on what folds
-    beside it: its decoys are identified by (seed, index), its contexts are its threads' own."""
+    targets_in_flight: a rank's targets are folded that many at a time on host threads (default: as many as keep SIXTEEN chains in
+    flight -- eight targets with both models).  A chain's iteration phase folds one decoy at a time and leaves the chip idle;
+    with shared launches (csrc/launch_engine.h, the library's default) the single-decoy folds of all chains in flight advance in
+    one launch pair per evaluation, which costs about what one chain's launch pair costs (round 3, without them: four chains on
+    four streams were the ceiling, 3.6 x one chain).  A target's files do not depend on what folds beside it: its decoys are
+    identified by (seed, index), its contexts are its threads' own, and a fold's arithmetic does not depend on what shares its
+    launches (tests/test_gpu_shared_launch.py)."""
     import time
     run = run or run_single
     n_chain = 2 if kw.get("mult_two_models", True) else 1
     init_num = kw.get("init_num", 10)
     fasta = {n: os.path.join(fasta_dir, n + ".fasta") for n in names}
-    # Cost of a target = its initial batch + its feedback iterations.  The iterations are SEQUENTIAL single-decoy folds
-    # (run_inference.py:75-139) and dominate a target's wall time: one of them costs about as much time as ITER_DECOYS decoys
-    # of a batch (a fold is latency-bound: 37 ms for 1 decoy against 230 ms for 64 at L=150, DESIGN.md section 5), and a chain
-    # runs ITER_EST of them before its convergence test fires (2-20 on the maps seen so far), never more than Nmax.
-    ITER_DECOYS, ITER_EST = 10, 10
-    n_eff = init_num * n_chain + n_chain * min(int(kw.get("Nmax", 300)), ITER_EST) * ITER_DECOYS
-    items = [sched.Item(n, "all", len(read_fasta(fasta[n])), 0, n_eff) for n in names]
-    mine = sched.lpt_assign(items, world, min_block=1 << 30)[rank]   # min_block: never split a target
+    # Order of the queue: modelled seconds of a target, longest first.  ITER_EST stands in for the unknowable iteration count
+    # (the convergence test fired after 53-64 iterations on the reference's example; never more than Nmax).
+    ITER_EST = 60
+    items = [sched.Item(n, "all", len(read_fasta(fasta[n])), 0, init_num * n_chain, iterations=min(int(kw.get("Nmax", 300)), ITER_EST)) for n in names]
+    items.sort(key=lambda it: (-it.cost, it.target))
     group = sched.summary_group(dist)                                # created up front: new_group is itself a collective
+    queue = sched.DynamicQueue(len(items), store if store is not None else (sched.queue_store(dist) if world > 1 else None))
     local = dict(decoys=0, seconds=0.0, failed=0, targets=[], errors=[])
     if targets_in_flight is None:
-        targets_in_flight = 4 // n_chain
+        targets_in_flight = 16 // n_chain
     lock = threading.Lock()
     t_all = time.perf_counter()
 
@@ -313,12 +316,20 @@ def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, 
         finally:
             close_contexts()    # this worker thread's cached context (the one-model path folds on the calling thread)
 
-    if targets_in_flight <= 1 or len(mine) <= 1:
-        for it in mine:
-            one(it)
-    else:   # longest first, as the plan orders them: the short ones fill in behind
-        with ThreadPoolExecutor(max_workers=int(targets_in_flight)) as ex:
-            list(ex.map(one, mine))
+    def worker():
+        while True:
+            i = queue.next()
+            if i is None:
+                return
+            one(items[i])
+
+    n_workers = max(1, min(int(targets_in_flight), len(items)))
+    if n_workers == 1:
+        worker()
+    else:
+        with ThreadPoolExecutor(max_workers=n_workers) as ex:
+            for f in [ex.submit(worker) for _ in range(n_workers)]:
+                f.result()
     local["seconds"] = time.perf_counter() - t_all
     per = sched.gather_stats(local, dist, group)   # gloo, 24 h timeout: ranks arrive as they finish
     return dict(decoys=sum(p["decoys"] for p in per), seconds=max(p["seconds"] for p in per), failed=sum(p["failed"] for p in per),
