@@ -110,11 +110,14 @@ def cpu_baseline(m, cfg, runs, budget_s=10.0):
     _, _, st, used = O.fold_batch(Tb, np.stack([O.random_torsions(L, 12345, 100 + d) for d in range(nb)]), runs, nthreads=cores)
     el2 = time.time() - t0
     # BASELINE.md section 3 / SURVEY.md 8d: the PyRosetta leg is timed only where `import pyrosetta` succeeds; say which
+    pyro_leg = None
     try:
         importlib.import_module("pyrosetta")
-        pyro, pyro_note = True, "pyrosetta is importable on this host, but no PyRosetta driver ships with this build: the port is the baseline"
+        pyro, pyro_note = True, "pyrosetta is importable on this host: the build's own driver (tools/pyrosetta_driver.py) was timed, see pyrosetta_leg"
+        pyro_leg = pyrosetta_leg(cores)
     except Exception as e:  # noqa: BLE001 -- ModuleNotFoundError on every host seen so far
-        pyro, pyro_note = False, f"PyRosetta unavailable ({type(e).__name__}); CPU baseline = the build's own C restatement (kind: port)"
+        pyro, pyro_note = False, (f"PyRosetta unavailable ({type(e).__name__}); CPU baseline = the build's own C restatement (kind: port); the build's own "
+                                  "PyRosetta driver (tools/pyrosetta_driver.py) runs when a host has it")
     host = os.cpu_count() or used
     return dict(value=nb / el2, unit="decoys/sec", cores=used, kind="port",
                 sample=f"{nb} decoys of the same map and protocol, oracle/trx2_oracle.c (gcc -O3 -march=native -fopenmp), "
@@ -123,7 +126,39 @@ def cpu_baseline(m, cfg, runs, budget_s=10.0):
                 all_core_extrapolation={"value": nb / el2 * host / max(used, 1), "unit": "decoys/sec", "cores": host,
                                         "note": "NOT measured: the usable-core figure scaled linearly to every core the host reports "
                                                 "(decoys are independent; an upper bound for this port)"},
-                pyrosetta_available=pyro, pyrosetta_note=pyro_note)
+                pyrosetta_available=pyro, pyrosetta_note=pyro_note, pyrosetta_leg=pyro_leg)
+
+
+def pyrosetta_leg(cores, budget_s=120.0):
+    """Only where PyRosetta is importable: the build's own driver (tools/pyrosetta_driver.py, the reference's protocol) on the
+    reference's L=90 example map, one process per usable core (at most 16), with and without the full-atom stage.  decoys/sec =
+    processes / wall of the slowest.  The restraint tables come from the GPU library (the same tables the GPU folds use)."""
+    import subprocess
+    T = importlib.import_module("trrosettax2-dynamics_amd")
+    drv = importlib.import_module("tools.pyrosetta_driver") if os.path.isdir(os.path.join(ROOT, "tools")) else None
+    gd = os.path.join(ROOT, "tests", "golden")
+    seq = "".join(l.strip() for l in open(os.path.join(gd, "seq.fasta")) if not l.startswith(">"))
+    m = np.load(os.path.join(gd, "seq_NMR.npz"))
+    work = tempfile.mkdtemp(prefix="trx2_pyr_")
+    try:
+        ctx = T.Context(0)
+        ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+        tables = os.path.join(work, "tables.npz")
+        drv.dump_tables(ctx, seq, tables)
+        ctx.close()
+        n = max(1, min(16, cores))
+        out = {}
+        for tag, extra in (("no_fastrelax", ["--no-fastrelax"]), ("default", [])):
+            t0 = time.time()
+            procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "pyrosetta_driver.py"), "--tables", tables, "--fasta", os.path.join(gd, "seq.fasta"),
+                                       "--out", os.path.join(work, f"{tag}{i}.pdb"), "--seed", str(i)] + extra, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for i in range(n)]
+            ok = sum(p.wait(timeout=budget_s * 10) == 0 for p in procs)
+            el = time.time() - t0
+            out[tag] = {"value": ok / el, "unit": "decoys/sec", "cores": n, "kind": "pyrosetta", "processes_ok": ok, "seconds": el,
+                        "sample": f"{n} decoys of the L=90 example map, one PyRosetta process each"}
+        return out
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def traffic_record(config, decoys_per_launch, kernel="k_pair"):
@@ -406,6 +441,61 @@ def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, wit
     return out
 
 
+def multi_gpu_plan(T, synth, local_rank, one_gpu_seconds):
+    """What 2 / 4 / 8 ranks would make of BASELINE config 5 (eight targets, L = 100 .. 400, 32 decoys each), PREDICTED from seconds
+    measured on this one GPU -- no multi-GPU node has been available to anyone in four rounds: every figure here is marked unmeasured.
+    Each item is timed folding ALONE (one context, one lane, default protocol); the prediction is list scheduling longest-first, what
+    sched.DynamicQueue / lpt_assign do.  Stated beside it: the bound (a job is never shorter than its longest item: the L=400
+    target), the same with the long items split into decoy blocks where sched.lpt_assign's model says a split pays, and the fit of
+    the seconds model (sched.CostModel) to these samples.  one_gpu_seconds: the same eight items on ONE GPU three at a time
+    (bench.py --config 5's way, measured by the caller) -- the denominator of the speed-up a scaling run would report."""
+    sched = importlib.import_module("trrosettax2-dynamics_amd.sched")
+    cfg = CONFIGS[5]
+    B = cfg["B"]
+    solo, samples = {}, []
+    for L in cfg["targets"]:
+        m = synth.make_map(L, seed=L)
+        c = T.Context(local_rank)
+        try:
+            c.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=m["seq"])
+            runs = T.protocol.build_runs(L, 2, fastrelax=True)
+            for n in (B, B // 2):
+                c.fold_batch(n, runs, seed=L, decoy0=10 ** 6, max_evals=2)     # buffers of this shape
+                t0 = time.perf_counter()
+                c.fold_batch(n, runs, seed=L, decoy0=0)
+                samples.append((L, n, time.perf_counter() - t0))
+            solo[L] = samples[-2][2]
+        finally:
+            c.close()
+    half = {L: t for (L, n, t) in samples if n == B // 2}
+    fit = sched.CostModel.fit(samples)
+    serial = sum(solo.values())
+    out = {"unmeasured": True, "note": "PREDICTION from single-GPU timings; no multi-GPU run has been observed (SCALE_r01..r03 skipped)",
+           "workload": cfg["name"], "item_seconds_alone": {f"L{L}": round(t, 4) for L, t in solo.items()},
+           "half_block_seconds_alone": {f"L{L}": round(t, 4) for L, t in half.items()},
+           "one_gpu_seconds_serial": serial, "one_gpu_seconds_three_in_flight": one_gpu_seconds,
+           "cost_model": {"form": "seconds(L, n) = c0 + c1 L + n (c2 L + c3 L^2)", "shipped": [sched.MODEL.c0, sched.MODEL.c1, sched.MODEL.c2, sched.MODEL.c3],
+                          "shipped_rel_error_max": float(np.max(np.abs(sched.MODEL.rel_errors(samples)))),
+                          "refit": [fit.c0, fit.c1, fit.c2, fit.c3], "refit_rel_error_max": float(np.max(np.abs(fit.rel_errors(samples))))},
+           "predicted": {}}
+    for N in (2, 4, 8):
+        mk, _ = sched.predict_makespan(list(solo.values()), N)
+        # with decoy-block splits where the model says they pay: measured half-block seconds for the halves
+        items = sched.make_items([(f"L{L}", L) for L in cfg["targets"]], chains=("NMR",), init_num=B)
+        plan = sched.lpt_assign(items, N)
+        secs = []
+        for its in plan:
+            secs.append(sum(solo[it.L] if it.n == B else half[it.L] if it.n == B // 2 else solo[it.L] * sched.MODEL.call_seconds(it.L, it.n) / sched.MODEL.call_seconds(it.L, B) for it in its))
+        out["predicted"][str(N)] = {"makespan_s": mk, "speedup_vs_serial": serial / mk, "speedup_vs_three_in_flight": (one_gpu_seconds / mk) if one_gpu_seconds else None,
+                                    "with_block_splits": {"items": sum(len(p) for p in plan), "makespan_s": max(secs), "speedup_vs_serial": serial / max(secs),
+                                                          "speedup_vs_three_in_flight": (one_gpu_seconds / max(secs)) if one_gpu_seconds else None}}
+    out["bound"] = {"longest_item_s": max(solo.values()), "max_speedup_vs_serial_without_splits": serial / max(solo.values()),
+                    "north_star_target": ">= 6 x at 8 GPUs in batch mode",
+                    "reading": "a call is latency-bound: the job cannot end before its L=400 target does; splitting that target's decoys helps as far as a half block "
+                               "is quicker than a whole one (measured above); beyond that only more targets than GPUs raise the ratio"}
+    return out
+
+
 def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, forced, steps, warmup, full):
     """one target (configs 2, 3, 4): every step is ONE call of B decoys per chain on every rank.  full: legs"""
     L, B = cfg["L"], cfg["B"]
@@ -607,6 +697,11 @@ def main():
                     r, _, _ = single_target(args, CONFIGS[c], c, T, synth, rank, local_rank, world, dist, forced, max(1, min(5, args.steps)), 1, False)
                     sub[f"config{c}"] = compact(r)
                 out["sub_records"] = sub
+                # config 5 on this one GPU (three items in flight), and what 2 / 4 / 8 ranks would make of it (prediction, unmeasured)
+                a5 = argparse.Namespace(steps=1, warmup=1)
+                bm = multi_target(a5, CONFIGS[5], T, synth, rank, local_rank, world, dist, forced, False)
+                out["sub_records"]["config5_one_gpu"] = {"value": bm["value"], "unit": bm["unit"], "ms_per_step": bm["ms_per_step"], "workload": bm["config"]["workload"]}
+                out["multi_gpu_plan"] = multi_gpu_plan(T, synth, local_rank, bm["ms_per_step"] * 1e-3)
             else:
                 # the north star's multi-GPU mode: independent targets sharded over the ranks (config 5, strong scaling)
                 a5 = argparse.Namespace(steps=1, warmup=0)
@@ -631,7 +726,8 @@ def main():
         for key, path in (("e2e_init10", ("e2e", "init_num_10", "value")), ("e2e_example_L90_init10", ("e2e", "example_L90_init_num_10", "value")),
                           ("e2e_cpu_init10", ("e2e", "cpu_baseline", "value")), ("batch_mode_one_gpu", ("e2e", "batch_mode_one_gpu", "best", "value")),
                           ("pooled_1280", ("pooled_queue", "value")), ("no_fastrelax", ("no_fastrelax", "value")),
-                          ("c3", ("sub_records", "config3", "value")), ("c4", ("sub_records", "config4", "value"))):
+                          ("c3", ("sub_records", "config3", "value")), ("c4", ("sub_records", "config4", "value")), ("c5_one_gpu", ("sub_records", "config5_one_gpu", "value")),
+                          ("predicted_speedup_8gpu_unmeasured", ("multi_gpu_plan", "predicted", "8", "with_block_splits", "speedup_vs_three_in_flight"))):
             v = num(*path)
             if v is not None:
                 out["config"][key] = v

@@ -84,7 +84,7 @@ int trx2_ctx_set_tail_compaction(trx2_ctx* ctx, int mode);
  * default 2).  A fold of ONE decoy -- every feedback iteration of run_inference.py:97-139 is one -- leaves the chip idle: a launch pair
  * of ~24 us on a few workgroups, thousands of them in sequence.  With shared launches such a fold does not launch for itself: it hands
  * its argument blocks (its own map's tables, row lists and row plan; its own state and buffers) to an engine thread of the library,
- * whose launch pairs step the single-decoy folds of ALL contexts that are folding at that moment (k_pair_multi: blockIdx.z = fold,
+ * whose launch pairs step the single-decoy folds of ALL contexts that are folding at that moment (k_pair1_multi: blockIdx.z = fold,
  * k_step_multi: blockIdx.y = fold), and sleeps until its decoy has reported.  The caller's side does not change -- one host thread
  * per chain calling trx2_fold_batch, as pipeline.run_batch does for the chains of run_inference.py:339-348's targets -- and neither do
  * the results: a fold's arithmetic does not depend on what shares its launches (bit-identical to mode 0: tests).  The reference's

@@ -94,6 +94,7 @@ def lib():
         L.orc_eval_cart.restype = C.c_double
         L.orc_eval_cart.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
         L.orc_extract_internal.argtypes = [C.c_int, vp, vp, vp]
+        L.orc_per_residue_terms.argtypes = [vp, vp, vp]
         L.orc_nerf_geom.argtypes = [C.c_int, vp, vp, vp]
         L.orc_uniform.restype = C.c_double
         L.orc_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
@@ -251,6 +252,14 @@ def eval_cart(tab, xyz, w, sep_lo=1, sep_hi=None, grad=True):
     e = np.zeros(NTERMS); gx = np.zeros_like(xyz) if grad else None
     f = lib().orc_eval_cart(tab.h, _p(xyz), _p(w), int(sep_lo), int(sep_hi if sep_hi is not None else tab.L), _p(e), _p(gx))
     return f, e, gx
+
+
+def per_residue_terms(tab, xyz):
+    """raw surrogate backbone terms split per residue on given coordinates -> [L, 5]: omega_bb, rama, hydrogen bonds, bonded, repulsion"""
+    xyz = np.ascontiguousarray(xyz, np.float64)
+    out = np.zeros((tab.L, 5))
+    lib().orc_per_residue_terms(tab.h, _p(xyz), _p(out))
+    return out
 
 
 def extract_internal(xyz):

@@ -169,8 +169,15 @@ __global__ __launch_bounds__(256) void k_build_rows(int L, const unsigned char* 
 template <int BW, int FAM>
 constexpr int pair_min_waves() { return (FAM & FAM_ANG) ? ((BW == 64 || BW == 1) ? PAIR_MIN_WAVES : 2) : PAIR_MIN_WAVES_DIST; }
 // The kernel's body: work item `bx` of the row plan, decoy group `grp` of the map and batch that A describes.
-template <int BW, int FAM>
+// NW = waves of the workgroup.  4 (PAIR_WAVES) for batches: the waves share a row's list and partner range.  1 for SINGLE-DECOY
+// folds (round 4): a lone decoy's row holds ~70 entries and its chain 90-400 partner residues, so four waves of 64 lanes each ran
+// a quarter full; one wave per row walks the list in 2-3 steps, needs no workgroup barrier, no LDS image of the partial sums and no
+// cross-wave reduction (the 24 sums leave the wave through DPP row rotations and v_readlane), and -- what matters when the
+// single-decoy folds of many chains share a launch (launch_engine.h) -- a launch holds a quarter of the waves.
+template <int BW, int FAM, int NW = PAIR_WAVES>
 __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, const int grp) {
+  static_assert(NW == PAIR_WAVES || (NW == 1 && BW == 1), "the one-wave workgroup serves single-decoy folds");
+  constexpr int NT = NW * 64;   // threads of the workgroup
   constexpr int PW = 64 / BW;
   const int L = A.L;
   // Work item = (row a, slice, slices of that row): rows are cut into a number of slices that follows their list length (the
@@ -186,7 +193,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
 
   STAMP_DECL
   __shared__ float s_kn[TRX2_KTOT_MAX];
-  __shared__ float s_red[PAIR_WAVES * 64 * RED_STRIDE];  // [wave][decoy][24 (+1 pad: bank-conflict-free)]
+  __shared__ float s_red[NW == 1 ? 1 : NW * 64 * RED_STRIDE];  // [wave][decoy][24 (+1 pad: bank-conflict-free)]; unused by a one-wave workgroup
   __shared__ unsigned s_ent[1024];                       // this workgroup's slice of row a's list (a row has < L <= 1024 entries)
   __shared__ unsigned short s_rx[1024];                  // ... and the entries' relax-stage masks
   // One evaluation = one sequence number.  Kept in device memory (not a kernel argument) so that a chunk of
@@ -200,16 +207,16 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
   const float4* xa = A.xyzT + ((size_t)(grp * L + a) * 5) * BW + d;
   const float4 q0 = xa[0], q1 = xa[BW], q2 = xa[2 * BW], q3 = xa[3 * BW], q4 = xa[4 * BW];
   const int kd = A.kd, ktot = kd + 2 * KO + KP;
-  for (int i = threadIdx.x; i < ktot; i += PAIR_THREADS) s_kn[i] = A.knots[i];
+  for (int i = threadIdx.x; i < ktot; i += NT) s_kn[i] = A.knots[i];
   // equal slices of the row's list: every workgroup of a row gets the same number of restraint visits.  The bounds come with the
   // work item (the host made the plan from the rows' lengths): reading the length here was one more dependent round trip in
   // front of the list itself.
   const int e_lo = (int)(item2.y & 0xffffu), e_hi = (int)(item2.y >> 16);
-  for (int i = e_lo + (int)threadIdx.x; i < e_hi; i += PAIR_THREADS) {
+  for (int i = e_lo + (int)threadIdx.x; i < e_hi; i += NT) {
     s_ent[i - e_lo] = A.rows[(size_t)a * L + i];
     s_rx[i - e_lo] = A.rows_rx[(size_t)a * L + i];
   }
-  __syncthreads();
+  if constexpr (NW == 1) wave_lds_sync(); else __syncthreads();
   const float* knd = s_kn;
   const float* kno = s_kn + kd;
   const float* knt = s_kn + kd + KO;
@@ -233,7 +240,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
   f3 gN = mk3(0, 0, 0), gCA = gN, gC = gN, gO = gN, gCB = gN, gH = gN;
   float e_d = 0, e_o = 0, e_t = 0, e_p = 0, e_v = 0, e_h = 0;
   const unsigned aL = (unsigned)a * (unsigned)L;
-  constexpr int VSTRIDE = PAIR_WAVES * PW;
+  constexpr int VSTRIDE = NW * PW;
   STAMP(0)  // prologue: knots and list slice to LDS, barrier, weights, residue a
 
   // ---- (i) restraint terms: the slice of the row's list, PW entries per wave step (lane = decoy, sub-lane h = entry).  The
@@ -465,20 +472,37 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
                                   : o == 2 ? __builtin_amdgcn_update_dpp(0, __float_as_int(vals[k]), 0x122, 0xF, 0xF, false)
                                   : o == 4 ? __builtin_amdgcn_update_dpp(0, __float_as_int(vals[k]), 0x124, 0xF, 0xF, false)
                                            : __builtin_amdgcn_update_dpp(0, __float_as_int(vals[k]), 0x128, 0xF, 0xF, false));
+    if constexpr (NW != 1) {
 #pragma unroll
     for (int o = (BW < 16 ? 16 : BW); o < 64; o <<= 1)
 #pragma unroll
       for (int k = 0; k < PR_REC; k++) vals[k] += __shfl_xor(vals[k], o, 64);
+    }
+    if constexpr (NW == 1) {
+      // (one wave, one decoy: BW == 1, so the loops above left every lane with the sum of its row of 16 lanes) the four rows by
+      // v_readlane in a fixed order; lane 0 stores the record
+      float tot[PR_REC];
+#pragma unroll
+      for (int k = 0; k < PR_REC; k++) tot[k] = (lane_value(vals[k], 0) + lane_value(vals[k], 16)) + (lane_value(vals[k], 32) + lane_value(vals[k], 48));
+      STAMP(13)
+      if (lane == 0 && live) {
+        float4* o = reinterpret_cast<float4*>(A.FA + (((size_t)split * A.B + dec) * L + a) * PR_REC);
+#pragma unroll
+        for (int q = 0; q < 6; q++) o[q] = make_float4(tot[q * 4], tot[q * 4 + 1], tot[q * 4 + 2], tot[q * 4 + 3]);
+      }
+    } else {
     if (h == 0) {
       float* s = s_red + ((size_t)wave * BW + d) * RED_STRIDE;
 #pragma unroll
       for (int k = 0; k < PR_REC; k++) s[k] = vals[k];
     }
+    }
   }
+  if constexpr (NW != 1) {
   STAMP(13)  // epilogue: sums over the sub-lanes, LDS image
   __syncthreads();
   STAMP(14)  // epilogue: barrier (the other waves of the workgroup)
-  for (int t = threadIdx.x; t < 6 * BW; t += PAIR_THREADS) {  // 6 quads per decoy = one 24-float record
+  for (int t = threadIdx.x; t < 6 * BW; t += NT) {  // 6 quads per decoy = one 24-float record
     const int dd = t / 6, q = t % 6;
     const int dc = grp * BW + dd;
     if (dc >= A.B) continue;
@@ -486,8 +510,9 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int sl = 0; sl < PAIR_WAVES; sl++) acc[i] += s_red[((size_t)sl * BW + dd) * RED_STRIDE + q * 4 + i];
+      for (int sl = 0; sl < NW; sl++) acc[i] += s_red[((size_t)sl * BW + dd) * RED_STRIDE + q * 4 + i];
     reinterpret_cast<float4*>(A.FA + (((size_t)split * A.B + dc) * L + a) * PR_REC)[q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  }
   }
   STAMP(12)  // epilogue: LDS image, barrier, column sums, stores
   STAMP_FLUSH
@@ -496,11 +521,16 @@ template <int BW, int FAM>
 __global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_pair(PairArgs A) {
   pair_body<BW, FAM>(A, blockIdx.x, (int)blockIdx.z);
 }
+// single-decoy folds: one wave per work item (row), 64-thread workgroups
+template <int FAM>
+__global__ __launch_bounds__(64, (pair_min_waves<1, FAM>())) void k_pair1(PairArgs A) {
+  pair_body<1, FAM, 1>(A, blockIdx.x, (int)blockIdx.z);
+}
 // Shared launch (trx2fold.hip: LaunchEngine): ONE launch evaluates the pair terms of several independent folds, each on its own
 // map -- blockIdx.z picks the fold, whose argument block (tables, row lists, row plan, coordinates, records, chain length) is read
-// from device memory instead of the kernel arguments.  A fold here is one decoy group (the iteration phase of run_inference.py
-// folds one decoy per map and iteration, run_inference.py:97-139: a single-decoy launch leaves the chip idle, and four streams
-// are all the hardware queues there are).  The body is the same: a fold's arithmetic does not depend on what shares its launch.
+// from device memory instead of the kernel arguments.  A fold here is one decoy (the iteration phase of run_inference.py folds
+// one decoy per map and iteration, run_inference.py:97-139: a single-decoy launch leaves the chip idle, and four streams are all
+// the hardware queues there are).  The body is k_pair1's: a fold's arithmetic does not depend on what shares its launch.
 // an argument block from device memory through the CONSTANT address space: scalar loads into SGPRs, exactly what the kernel
 // arguments of the single-fold kernels are (the blocks are uploaded before the launch and never written during it)
 template <class T>
@@ -513,9 +543,9 @@ __device__ __forceinline__ T load_args(const T* p) {
   for (unsigned i = 0; i < sizeof(T) / 4; i++) u.w[i] = src[i];
   return u.t;
 }
-template <int BW, int FAM>
-__global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_pair_multi(const PairArgs* AA) {
+template <int FAM>
+__global__ __launch_bounds__(64, (pair_min_waves<1, FAM>())) void k_pair1_multi(const PairArgs* AA) {
   const PairArgs A = load_args(AA + blockIdx.z);
   if ((int)blockIdx.x >= A.n_items) return;
-  pair_body<BW, FAM>(A, blockIdx.x, 0);
+  pair_body<1, FAM, 1>(A, blockIdx.x, 0);
 }

@@ -1,5 +1,5 @@
 // launch_engine.h -- shared launches: many independent single-group folds advance in ONE (pair, step) launch pair -- included by
-// trx2fold.hip (host side only; the kernels are k_pair_multi / k_step_multi / k_gather_done).
+// trx2fold.hip (host side only; the kernels are k_pair1_multi / k_step_multi / k_gather_done).
 //
 // Why.  The product of run_inference.py is its ITERATION phase: per chain (target x model) a sequence of single-decoy folds,
 // each on the map the previous decoy re-weighted (run_inference.py:97-139).  A single-decoy evaluation is a launch pair of ~24 us
@@ -7,7 +7,7 @@
 // gives a process four hardware queues: four chains on four streams was the ceiling (3.6 x one chain, round 3).  The chains of a
 // batch job (run_inference.py:339-348: `for name in names`, two models each) are independent, so here their evaluations SHARE
 // launches: a fold that qualifies hands its argument blocks to an engine and sleeps; the engine's host thread launches, for all
-// folds it holds, one k_pair_multi (blockIdx.z = fold) and one k_step_multi (blockIdx.y = fold) per evaluation, and wakes a fold
+// folds it holds, one k_pair1_multi (blockIdx.z = fold) and one k_step_multi (blockIdx.y = fold) per evaluation, and wakes a fold
 // when its decoys have reported.  Each fold keeps its own context -- map, tables, row plan, state, buffers -- and its arithmetic
 // does not depend on what shares its launches: results are bit-identical to the fold's own launches (tests).
 //
@@ -79,10 +79,9 @@ static bool engine_enabled() {
   return env_on;
 }
 
-template <int BW>
 static void engine_launch_pair(bool fam_all, dim3 grid, hipStream_t st, const PairArgs* a) {
-  if (fam_all) hipLaunchKernelGGL((k_pair_multi<BW, FAM_ALL>), grid, dim3(PAIR_THREADS), 0, st, a);
-  else hipLaunchKernelGGL((k_pair_multi<BW, FAM_DIST | FAM_VDW>), grid, dim3(PAIR_THREADS), 0, st, a);
+  if (fam_all) hipLaunchKernelGGL((k_pair1_multi<FAM_ALL>), grid, dim3(64), 0, st, a);
+  else hipLaunchKernelGGL((k_pair1_multi<FAM_DIST | FAM_VDW>), grid, dim3(64), 0, st, a);
 }
 static void engine_launch_step(int cls, dim3 grid, size_t dyn, hipStream_t st, const ChainArgs* a, const CartArgs* c) {
   if (cls == 0) hipLaunchKernelGGL((k_step_multi<1, 128, 128>), grid, dim3(128), dyn, st, a, c);
@@ -166,7 +165,7 @@ static void engine_main(LaunchEngine* E) {
       }
       for (int it = 0; it < ENGINE_CHUNK; it++)
         for (const Grp& g : groups) {
-          engine_launch_pair<1>(g.fam != 0, dim3((unsigned)g.items, 1, (unsigned)g.n), E->stream, dpa + g.lo);
+          engine_launch_pair(g.fam != 0, dim3((unsigned)g.items, 1, (unsigned)g.n), E->stream, dpa + g.lo);
           engine_launch_step(g.cls, dim3((unsigned)(2 * g.maxB), (unsigned)g.n), g.dyn, E->stream, dca + g.lo, dcc + g.lo);
         }
       hipLaunchKernelGGL(k_gather_done, dim3(1), dim3(ENGINE_MAX_JOBS), 0, E->stream, n, (const int* const*)(E->d_args + ENG_OFF_DP), E->d_flags);

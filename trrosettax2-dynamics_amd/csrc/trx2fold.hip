@@ -861,6 +861,13 @@ static int launch_pair(trx2_ctx* c, int B) {
 #define LAUNCH_PAIR(W)                                                                                       \
   if (c->use_orient) hipLaunchKernelGGL((k_pair<W, FAM_ALL>), grid, block, 0, c->stream, P);               \
   else hipLaunchKernelGGL((k_pair<W, FAM_DIST | FAM_VDW>), grid, block, 0, c->stream, P)
+  // a single decoy: one wave per row (k_pair1), unless TRX2_PAIR1_WG4=1 asks for the four-wave workgroups of rounds 1-3 (A/B timing)
+  static const bool pair1_wg4 = getenv("TRX2_PAIR1_WG4") != nullptr;
+  if (c->BW == 1 && !pair1_wg4) {
+    if (c->use_orient) hipLaunchKernelGGL((k_pair1<FAM_ALL>), grid, dim3(64), 0, c->stream, P);
+    else hipLaunchKernelGGL((k_pair1<FAM_DIST | FAM_VDW>), grid, dim3(64), 0, c->stream, P);
+    return 0;
+  }
   switch (c->BW) {
     case 64: LAUNCH_PAIR(64); break;
     case 32: LAUNCH_PAIR(32); break;

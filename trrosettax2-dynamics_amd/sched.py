@@ -21,10 +21,12 @@ from dataclasses import dataclass
 
 @dataclass(frozen=True)
 class CostModel:
-    c0: float = 0.012
-    c1: float = 6.6e-4
-    c2: float = 9.0e-6
-    c3: float = 1.5e-8
+    # fit of 30 calls on one MI355X, L = 90 .. 400, n = 1 .. 128, default protocol, all channels (profiles/r04_cost_model.json):
+    # median relative error 8.6 %, worst 27 % (what is left is the spread of the slowest decoy's evaluation count)
+    c0: float = 0.0301
+    c1: float = 3.42e-4
+    c2: float = 6.45e-6
+    c3: float = 1.87e-8
 
     def call_seconds(self, L, n):
         """one fold call: n decoys of an L-residue chain, all in flight, default protocol"""
