@@ -91,6 +91,15 @@ int trx2_ctx_set_tail_compaction(trx2_ctx* ctx, int mode);
  * counterpart is its process pool over `python folding.py` children (utils_trX2dy/utils.py:501-503).
  * mode 1 on, 0 off, -1 back to the environment's choice. */
 int trx2_set_shared_launches(int mode);
+/* Shape of the pair kernel for the context's SINGLE-decoy folds.  waves = 4 (default): one workgroup of four waves per row of the
+ * restraint lists -- the shortest evaluation while few folds are in flight (run_inference.py on one target: two chains).  waves = 1:
+ * one wave per row (k_pair1): a row's ~70 entries and the chain's partner residues in 2-3 steps of one wave, no workgroup barrier,
+ * the sums straight out of the wave -- a quarter of the waves per fold, which is what counts when the folds of MANY chains share
+ * launches (batch mode).  Measured on MI355X, L=150, all channels, default protocol: one target (two chains) 26.1 against 21.7
+ * decoys/s; sixteen targets in flight 97 against 109; 64 folds per launch 405 k against 619 k fold-evaluations/s.  The two shapes add a
+ * residue's terms in different orders: results differ by rounding, as between batches of different widths; within one shape a
+ * fold's result does not depend on what shares its launches.  pipeline.run_batch sets 1, everything else keeps 4. */
+int trx2_ctx_set_single_decoy_waves(trx2_ctx* ctx, int waves);
 /* measurement helper: out[5] = chunks of launch pairs the device's engines enqueued, folds x chunks (ratio: folds per launch), folds
  * completed, seconds their host threads spent enqueuing, seconds they waited for the GPU */
 int trx2_shared_launch_stats(int device, double* out);

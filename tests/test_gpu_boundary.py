@@ -75,9 +75,44 @@ def test_run_single_reproduces_the_example_layout(golden_dir, tmp_path):
     print("\nfile      vs same-provenance reference decoy / apo / holo (A)")
     for r in rows:
         print("  %-9s %5.2f %5.2f %5.2f" % r)
-    assert np.median([r[1] for r in rows]) < 2.0, rows
-    # summary.txt of the reference: best apo 3.018, best holo 3.931
+    # measured (round 4, default protocol): median 0.80 - 1.02 A over the 8 files (an 8-decoy median is good to +- 0.3 A, DESIGN.md
+    # section 2); 3-8 % of all starts end in the mirror-image topology (~12 A; the reference ranks them out by its reliability score):
+    # among 8 files at most one may, and then it IS the mirror image (closer to the mirrored reference decoy)
+    assert np.median([r[1] for r in rows]) < 1.35, rows
+    far = [r for r in rows if r[1] > 3.0]
+    assert len(far) <= 1, rows
+    for r in far:
+        xyz, _ = P.read_backbone(os.path.join(pdb_dir, r[0] + ".pdb"))
+        assert kabsch_rmsd(xyz[:, 1] * np.array([1.0, 1.0, -1.0]), dec[r[0]][:, 1]) < r[1], r
+    # summary.txt of the reference: best apo 3.018 (an X-ray-map decoy), best holo 3.931 (an NMR-map decoy); asserted on 32 decoys per
+    # map in the next test, printed here
     print("  best apo %.2f (reference 3.02)  best holo %.2f (reference 3.93)" % (min(r[2] for r in rows), min(r[3] for r in rows)))
+
+
+def test_example_run_reaches_the_reference_summary(golden_dir, tmp_path):
+    """The reference's committed accuracy summary (example/output/seq/summary.txt:1-2): best C-alpha RMSD to the apo state 3.018 A
+    (model seq3, an X-ray-map decoy), to the holo state 3.931 A (seq2, an NMR-map decoy), over its 8 decoys.  Here: the same job with
+    32 decoys per map (init_num=30 + 2 iterations), every file through the PDB writer and reader.  Asserted: the
+    best-of-run values sit in a band around the reference's (more decoys can only lower a minimum, by the run-to-run spread of
+    0.3-0.7 A; a model that cannot reach the states would sit above), and the two maps keep their roles -- the X-ray map's decoys are
+    the apo-like ones, the NMR map's the holo-like ones, as in the reference's run."""
+    save = str(tmp_path / "out")
+    n = PL.run_single("seq", os.path.join(golden_dir, "seq.fasta"), save, init_num=30, Nmax=2, angle=True, mult_two_models=True,
+                      npz_nmr=os.path.join(golden_dir, "seq_NMR.npz"), npz_xray=os.path.join(golden_dir, "seq_Xray.npz"), seed=23)
+    assert n == 64
+    pdb_dir = os.path.join(save, "seq", "pred_pdb")
+    dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    apo, holo = {1: [], 2: []}, {1: [], 2: []}
+    for f in sorted(os.listdir(pdb_dir)):
+        xyz, _ = P.read_backbone(os.path.join(pdb_dir, f))
+        m = int(f.split("_")[1])                       # conf_1_* = X-ray map, conf_2_* = NMR map initial decoys (+ the other chain's iterations)
+        apo[m].append(kabsch_rmsd(xyz[:, 1], dec["apo"][:, 1])); holo[m].append(kabsch_rmsd(xyz[:, 1], dec["holo"][:, 1]))
+    best_apo, best_holo = min(apo[1] + apo[2]), min(holo[1] + holo[2])
+    print("\n64 decoys: best apo %.2f (reference 3.02), best holo %.2f (reference 3.93); median apo / holo of conf_1_*: %.2f / %.2f, of conf_2_*: %.2f / %.2f"
+          % (best_apo, best_holo, np.median(apo[1]), np.median(holo[1]), np.median(apo[2]), np.median(holo[2])))
+    assert 2.55 <= best_apo <= 3.30 and 3.45 <= best_holo <= 4.25, (best_apo, best_holo)
+    # conf_1_* holds the 30 X-ray initial decoys + the 2 NMR iteration decoys, conf_2_* the reverse (run_inference.py:170-278)
+    assert np.median(apo[1]) < np.median(apo[2]) and np.median(holo[2]) < np.median(holo[1])
 
 
 def test_candidates_extension_writes_k_decoys_per_iteration(golden_dir, tmp_path):

@@ -26,7 +26,9 @@ def restore_mode():
     L_.set_shared_launches(-1)
 
 
-def test_shared_launches_are_bitwise_the_folds_own(golden_dir, seq):
+@pytest.mark.parametrize("waves", [4, 1], ids=["four-waves-per-row", "one-wave-per-row"])
+def test_shared_launches_are_bitwise_the_folds_own(golden_dir, seq, waves):
+    """both pair-kernel shapes of a single-decoy fold (Context.set_single_decoy_waves): the default, and the one batch mode sets"""
     real = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
     cases = [("real90", dict(dist=real["dist"], omega=real["omega"], theta=real["theta"], phi=real["phi"], seq=seq), True, 0),
              ("L150", S.make_map(150, seed=150), True, 900), ("L150d", S.make_map(150, seed=151), False, 900),
@@ -37,6 +39,7 @@ def test_shared_launches_are_bitwise_the_folds_own(golden_dir, seq):
             for rep in range(2):                       # two contexts per map: ten folds share the launches
                 c = T.Context(0)
                 c.set_map(m["dist"], *([m["omega"], m["theta"], m["phi"]] if orient else []), seq=m["seq"])
+                c.set_single_decoy_waves(waves)
                 ctxs.append((name, len(m["seq"]), cap, rep, c))
         out = {}
         for mode in (0, 1):

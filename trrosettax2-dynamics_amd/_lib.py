@@ -94,6 +94,7 @@ def load():
     L.trx2_last_fold_stats.argtypes = [vp, dp, ip]
     L.trx2_ctx_set_pool.argtypes = [vp, C.c_int]
     L.trx2_ctx_set_tail_compaction.argtypes = [vp, C.c_int]
+    L.trx2_ctx_set_single_decoy_waves.argtypes = [vp, C.c_int]
     L.trx2_set_shared_launches.argtypes = [C.c_int]
     L.trx2_shared_launch_stats.argtypes = [C.c_int, dp]
     L.trx2_last_fold_slot_efficiency.argtypes = [vp, dp]
@@ -336,6 +337,11 @@ class Context:
         """0 off, 1 (default) the last <= 64 live decoys of a wider batch move into one decoy group, 2 the same with the pair kernel's
         split kept (bitwise equal to 0): trx2_ctx_set_tail_compaction"""
         self._chk(self._l.trx2_ctx_set_tail_compaction(self._h, int(mode)), "trx2_ctx_set_tail_compaction")
+
+    def set_single_decoy_waves(self, waves):
+        """pair-kernel shape of this context's single-decoy folds: 4 (default, shortest evaluation) or 1 (one wave per row: the shape
+        for many chains sharing launches) -- trx2_ctx_set_single_decoy_waves"""
+        self._chk(self._l.trx2_ctx_set_single_decoy_waves(self._h, int(waves)), "trx2_ctx_set_single_decoy_waves")
 
     def set_profiling(self, every):
         """every > 0: bracket every `every`-th evaluation of the following folds by HIP events (trx2_ctx_set_profiling)"""

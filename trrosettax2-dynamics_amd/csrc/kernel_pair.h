@@ -207,6 +207,11 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
   const float4* xa = A.xyzT + ((size_t)(grp * L + a) * 5) * BW + d;
   const float4 q0 = xa[0], q1 = xa[BW], q2 = xa[2 * BW], q3 = xa[3 * BW], q4 = xa[4 * BW];
   const int kd = A.kd, ktot = kd + 2 * KO + KP;
+  // Every decoy of this decoy group has retired (its slot's "active" word is 0): nothing to evaluate and nobody reads the records --
+  // the launches a host chunk has queued behind a fold's last report, and the folds a shared launch still names while they drain
+  // (launch_engine.h), leave here instead of filling LDS and storing zeros.  The waves of a workgroup hold the same decoys: they
+  // all leave or all stay (no barrier is left waiting).
+  if (!__any((int)(live && w1.z != 0.0f))) return;
   for (int i = threadIdx.x; i < ktot; i += NT) s_kn[i] = A.knots[i];
   // equal slices of the row's list: every workgroup of a row gets the same number of restraint visits.  The bounds come with the
   // work item (the host made the plan from the rows' lengths): reading the length here was one more dependent round trip in
@@ -543,9 +548,33 @@ __device__ __forceinline__ T load_args(const T* p) {
   for (unsigned i = 0; i < sizeof(T) / 4; i++) u.w[i] = src[i];
   return u.t;
 }
-template <int FAM>
-__global__ __launch_bounds__(64, (pair_min_waves<1, FAM>())) void k_pair1_multi(const PairArgs* AA) {
+// (the four-wave workgroups of rounds 1-3 in a shared launch: TRX2_PAIR1_WG4=1, A/B timing)
+template <int BW, int FAM>
+__global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_pair_multi(const PairArgs* AA) {
   const PairArgs A = load_args(AA + blockIdx.z);
   if ((int)blockIdx.x >= A.n_items) return;
-  pair_body<1, FAM, 1>(A, blockIdx.x, 0);
+  pair_body<BW, FAM>(A, blockIdx.x, 0);
+}
+// Placement.  Both visits of a residue pair -- from row a and from row b -- read the same six spline segments, and a fold's rows
+// read the same coordinate records; the table lines a fold touches in one evaluation are ~2 MB, half of an XCD's L2.  Workgroups are
+// dealt round-robin over the eight XCDs (observed, never relied on for correctness: MI355X_MICROARCH.md, workgroup dispatch), whose
+// L2s do not share lines.  With eight or more folds in a launch (xcd_groups != 0) the 1-D grid is laid out so that ALL rows of a fold
+// carry the same block id modulo 8 -- one XCD, one L2: the second visit of a pair finds its segments there.  Measured at 14 folds
+// per launch (profiles/README.md, round 4): L2 hit rate 29 % and 51 MB fetched per launch with the rows spread over the XCDs.
+// With fewer folds a fold's rows stay spread: one XCD is an eighth of the chip.  The mapping changes no result.
+template <int FAM>
+__global__ __launch_bounds__(64, (pair_min_waves<1, FAM>())) void k_pair1_multi(const PairArgs* AA, int n_folds, int max_items, int xcd_groups) {
+  unsigned fold, item;
+  if (xcd_groups) {
+    const unsigned id = blockIdx.x, x = id & 7u, s = id >> 3;
+    fold = x + 8u * (s / (unsigned)max_items);
+    item = s % (unsigned)max_items;
+  } else {
+    fold = blockIdx.x / (unsigned)max_items;
+    item = blockIdx.x % (unsigned)max_items;
+  }
+  if ((int)fold >= n_folds) return;
+  const PairArgs A = load_args(AA + fold);
+  if ((int)item >= A.n_items) return;
+  pair_body<1, FAM, 1>(A, item, 0);
 }

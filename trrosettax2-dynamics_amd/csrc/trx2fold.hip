@@ -131,6 +131,9 @@ struct trx2_ctx {
   // slot pool (trx2_ctx_set_pool): a fold of N decoys runs on min(N, pool) slots; a slot whose decoy has reported takes the next
   // one of the queue on the device.  0 = one slot per decoy.
   int pool = 0;
+  // single-decoy folds: waves per row of the pair kernel -- 4 (default: the shortest evaluation when few folds are in flight) or 1
+  // (k_pair1: a quarter of the waves, the shape for MANY concurrent single-decoy folds sharing launches); trx2_ctx_set_single_decoy_waves
+  int pair1_waves = 4;
   int *slot_id = nullptr, *next_id = nullptr, *out_stat = nullptr;
   float4 *out_xyz = nullptr, *out_X = nullptr; double *out_e = nullptr, *out_f = nullptr; float* tors0_all = nullptr;
   size_t out_cap = 0, out_L = 0;  // decoys x residues the output arrays hold
@@ -417,6 +420,7 @@ extern "C" int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes) {
     if (ctx_create_impl(ctx->device, &k, ctx->stream) != 0) { ctx->err = "trx2_ctx_set_lanes: cannot create the second lane"; return 1; }
     k->borrows_map = true;
     k->pool = ctx->pool;
+    k->pair1_waves = ctx->pair1_waves;
     k->compact = ctx->compact;
     ctx->child = k;
     if (ctx->L) { HIPCHK(hipStreamSynchronize(ctx->stream)); lend_map(ctx); }
@@ -861,9 +865,8 @@ static int launch_pair(trx2_ctx* c, int B) {
 #define LAUNCH_PAIR(W)                                                                                       \
   if (c->use_orient) hipLaunchKernelGGL((k_pair<W, FAM_ALL>), grid, block, 0, c->stream, P);               \
   else hipLaunchKernelGGL((k_pair<W, FAM_DIST | FAM_VDW>), grid, block, 0, c->stream, P)
-  // a single decoy: one wave per row (k_pair1), unless TRX2_PAIR1_WG4=1 asks for the four-wave workgroups of rounds 1-3 (A/B timing)
-  static const bool pair1_wg4 = getenv("TRX2_PAIR1_WG4") != nullptr;
-  if (c->BW == 1 && !pair1_wg4) {
+  // a single decoy on a context set to one wave per row (trx2_ctx_set_single_decoy_waves): k_pair1
+  if (c->BW == 1 && c->pair1_waves == 1) {
     if (c->use_orient) hipLaunchKernelGGL((k_pair1<FAM_ALL>), grid, dim3(64), 0, c->stream, P);
     else hipLaunchKernelGGL((k_pair1<FAM_DIST | FAM_VDW>), grid, dim3(64), 0, c->stream, P);
     return 0;
@@ -1127,6 +1130,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
       job.dyn = step_lds(job.cc);
       job.cls = L <= 128 ? 0 : (L <= CHAIN_THREADS ? 1 : 2);
       job.fam_all = ctx->use_orient ? 1 : 0;
+      job.wave1 = ctx->pair1_waves == 1 ? 1 : 0;
       job.bw = ctx->BW; job.B = B; job.n_items = job.pa.n_items; job.done_count = ctx->done_count; job.cap = cap;
       const RowPlan& rp = ctx->plans[(size_t)ctx->plan_cur];
       if (ctx->BW != 1 || rp.epoch != ctx->rows_epoch || rp.pw != 64 || (size_t)rp.ns_max * B * L > ctx->fa_cap) {
@@ -1610,6 +1614,13 @@ extern "C" int trx2_ctx_set_tail_compaction(trx2_ctx* ctx, int mode) {
   return 0;
 }
 
+extern "C" int trx2_ctx_set_single_decoy_waves(trx2_ctx* ctx, int waves) {
+  if (!ctx) return 1;
+  if (waves != 1 && waves != 4) { ctx->err = "trx2_ctx_set_single_decoy_waves: 1 or 4"; return 1; }
+  ctx->pair1_waves = waves;
+  if (ctx->child) ctx->child->pair1_waves = waves;
+  return 0;
+}
 extern "C" int trx2_ctx_set_pool(trx2_ctx* ctx, int slots) {
   if (!ctx) return 1;
   if (slots < 0 || slots > 4096) { ctx->err = "trx2_ctx_set_pool: 0 (one slot per decoy) .. 4096 slots"; return 1; }

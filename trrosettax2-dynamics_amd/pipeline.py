@@ -28,7 +28,7 @@ from .pdbio import as_read_from_pdb, read_backbone, read_fasta
 
 def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz, fasta, N=10, Nmax=500, begin_num=0,
                          sigma=1.0, tta_opt="-m 2 -r no-idp --orient ", angle=True, device=0, seed=None, lanes=2,
-                         write_tmp_npz=False, device_feedback=True, timing=None, candidates=1):
+                         write_tmp_npz=False, device_feedback=True, timing=None, candidates=1, single_decoy_waves=4):
     """N initial decoys as one GPU batch -> best by reliability -> feedback -> one decoy per iteration until the
     cumulative `tmp` array moves by < 0.01 or Nmax iterations (run_inference.py:97-139).  Returns the last index.
 
@@ -52,6 +52,9 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     back.  The chain of maps is the reference's (up to the rounding a batch of another width brings); the ensemble holds K decoys
     per state of the maps instead of one, for ~1.3 x (K = 8) the time of an iteration: a single-decoy fold leaves the chip idle.
     Returns the number of iteration files (K per iteration).  Needs the resident feedback path.
+
+    single_decoy_waves: the pair kernel's shape for the iteration phase's single-decoy folds (Context.set_single_decoy_waves): 4 for a
+    job with few chains in flight, 1 when many chains share launches (run_batch passes 1).
 
     timing: a dict that receives initial_s (initial batch: table build, fold, files, ranking), iteration_s (everything after),
     iteration_fold_s (the single-decoy folds alone), iterations, tmp_change (the convergence measure after every iteration: max
@@ -100,6 +103,7 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     if resident:
         # The initial batch left its map in this thread's context.  From here on the distograms never leave the device.
         ctx = get_context(device, lanes)
+        ctx.set_single_decoy_waves(single_decoy_waves)
 
         def step(xyz_fold, k):
             # the decoy as the reference sees it -- through its PDB file -- without reading the file back
@@ -207,7 +211,7 @@ def flatten_and_rename(save_pdb_dir, num_conf1_others):
 
 
 def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mult_two_models=True, npz_nmr=None,
-               npz_xray=None, device=0, seed=None, keep_tmp_npz=False, phase_times=None, candidates=1):
+               npz_xray=None, device=0, seed=None, keep_tmp_npz=False, phase_times=None, candidates=1, single_decoy_waves=4):
     """run_inference.py:280-337 without the network front-end: expects the distograms to exist.
     phase_times: a dict that receives, per chain ("NMR" / "Xray"), generate_npz_and_pdb's timing record.
     candidates: decoys folded and written per feedback iteration (extension, default 1: generate_npz_and_pdb)."""
@@ -242,7 +246,7 @@ def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mu
                                     N=init_num, Nmax=Nmax, begin_num=0, angle=angle, tta_opt=tta_opt, device=device,
                                     seed=None if seed is None else seed + 100000 * len(tag),
                                     lanes=1 if len(maps) == 2 else 2,   # two chains already occupy two streams
-                                    write_tmp_npz=keep_tmp_npz, candidates=candidates,
+                                    write_tmp_npz=keep_tmp_npz, candidates=candidates, single_decoy_waves=single_decoy_waves,
                                     timing=None if phase_times is None else phase_times.setdefault(tag, {}))
 
     if len(maps) == 2:
@@ -286,6 +290,10 @@ def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, 
     identified by (seed, index), its contexts are its threads' own, and a fold's arithmetic does not depend on what shares its
     launches (tests/test_gpu_shared_launch.py)."""
     import time
+    if run is None:
+        # many chains in flight: the single-decoy folds run the one-wave-per-row pair kernel (include/trx2fold.h,
+        # trx2_ctx_set_single_decoy_waves); set for every target alike, whatever targets_in_flight is: files do not depend on it
+        kw.setdefault("single_decoy_waves", 1)
     run = run or run_single
     n_chain = 2 if kw.get("mult_two_models", True) else 1
     init_num = kw.get("init_num", 10)
