@@ -25,8 +25,9 @@ def main(argv=None):
     p.add_argument("--npz_nmr", type=str, default=None, help="precomputed NMR-model distogram (extension)")
     p.add_argument("--npz_xray", type=str, default=None, help="precomputed X-ray-model distogram (extension)")
     p.add_argument("--seed", type=int, default=None, help="seed of the random start torsions (extension)")
-    p.add_argument("--targets_in_flight", type=int, default=None, help="batch mode: targets a rank folds at a time (extension; default keeps four "
-                   "chains in flight: 2 targets with both models, 4 with one; 1 = one after the other as the reference does)")
+    p.add_argument("--targets_in_flight", type=int, default=None, help="batch mode: targets a rank folds at a time (extension; default keeps sixteen "
+                   "chains in flight, whose single-decoy folds share launches: 8 targets with both models, 16 with one; 1 = one after the other "
+                   "as the reference does; the files do not depend on it)")
     p.add_argument("--candidates", type=int, default=1, help="decoys folded and written per feedback iteration, candidate 0 fed back "
                    "(extension; 1 = the reference's chain)")
     p.add_argument("--keep_tmp_npz", action="store_true", help="write tmp_npz/{name}{k}.npz for every iteration as the reference does "
@@ -43,7 +44,8 @@ def main(argv=None):
               keep_tmp_npz=a.keep_tmp_npz, candidates=a.candidates)
     if a.name_lst:
         # run_inference.py:343-348, sharded over ranks when launched by torch.distributed.run (one process per GPU):
-        # targets are independent, the only communication is the final gather of the per-rank summaries
+        # targets are independent; ranks pull the next target from a shared counter (sched.DynamicQueue on a TCPStore) and the only
+        # collective is the final gather of the per-rank summaries
         names = [l.strip() for l in open(a.name_lst) if l.strip()]
         rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0")))
         dist = None

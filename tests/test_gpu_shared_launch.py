@@ -95,3 +95,46 @@ def test_batch_mode_files_do_not_depend_on_shared_launches(golden_dir, tmp_path)
         out[mode] = {(n, f): open(os.path.join(save, n, "pred_pdb", f), "rb").read() for n in names for f in sorted(os.listdir(os.path.join(save, n, "pred_pdb")))}
     assert out[0].keys() == out[1].keys() and len(out[0]) == 36
     assert all(out[0][k] == out[1][k] for k in out[0])
+
+
+def test_segment_cache_changes_no_bit(golden_dir, tmp_path):
+    """The pair kernel's segment cache (csrc/kernel_pair.h, PairArgs) serves a spline lookup from the decoy's own copy of the segment it
+    used last; the cached numbers are the table's, so every result must be bit for bit that of the gathers (TRX2_SEG_CACHE=0; the
+    switch is read once per process: two child processes).  Shapes: a batch of 40 on two lanes through tail compaction and wave
+    halving (all channels), 5 decoys of a distance-only map, a single decoy followed by a feedback step and another single decoy
+    (the tables change under the cache: its tags must have been reset)."""
+    import subprocess
+    import sys
+    code = r'''
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch
+T = importlib.import_module("trrosettax2-dynamics_amd")
+g = os.path.join(sys.argv[1], "tests", "golden")
+seq = "".join(l.strip() for l in open(os.path.join(g, "seq.fasta")) if not l.startswith(">"))
+m = np.load(os.path.join(g, "seq_NMR.npz"))
+runs = T.protocol.build_runs(90, 2, fastrelax=True)
+out = {}
+c = T.Context(0, lanes=2)
+c.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
+r = c.fold_batch(40, runs, seed=3); out["b40_xyz"], out["b40_f"], out["b40_ev"] = r["xyz"], r["f"], r["n_evals"]
+r = c.fold_batch(1, runs, seed=4); out["s1_xyz"], out["s1_ev"] = r["xyz"], r["n_evals"]
+out["delta"] = np.array(c.feedback_step(np.nan_to_num(np.load(os.path.join(g, "ref_decoys.npz"))["conf_2_1"]), seq))
+r = c.fold_batch(1, runs, seed=5); out["s2_xyz"], out["s2_ev"] = r["xyz"], r["n_evals"]
+c.set_map(m["dist"], seq=seq)
+r = c.fold_batch(5, T.protocol.build_runs(90, 2), seed=6); out["d5_xyz"], out["d5_f"] = r["xyz"], r["f"]
+c.close()
+np.savez(sys.argv[2], **out)
+'''
+    res = {}
+    for mode in ("1", "0"):
+        path = str(tmp_path / f"seg{mode}.npz")
+        env = dict(os.environ, TRX2_SEG_CACHE=mode)
+        p = subprocess.run([sys.executable, "-c", code, os.path.dirname(golden_dir.rstrip("/")).rsplit("/tests", 1)[0], path], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[mode] = dict(np.load(path))
+    assert res["1"].keys() == res["0"].keys()
+    for k in res["1"]:
+        assert np.array_equal(res["1"][k], res["0"][k]), k
+    assert np.all(np.isfinite(res["1"]["b40_xyz"])) and res["1"]["b40_ev"].min() > 500

@@ -9,7 +9,7 @@ CFG = {2: (150, 64, False, 1), 3: (150, 64, True, 2), 4: (400, 32, True, 1)}
 cfg, lanes, K = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 mode = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 L, B, orient, nch = CFG[cfg]
-runs = T.protocol.build_runs(L, 2, cartesian_stage=False if os.environ.get("PERCALL_NOCART") else None)   # PERCALL_NOCART=1: the Cartesian run in torsion space (A/B of the step launch)
+runs = T.protocol.build_runs(L, 2, cartesian_stage=False if os.environ.get("PERCALL_NOCART") else None, fastrelax=not os.environ.get("PERCALL_NORELAX"))   # PERCALL_NOCART=1: the Cartesian run in torsion space (A/B of the step launch)
 ctxs = []
 for c in range(nch):
     m = S.make_map(L, seed=L + c); x = T.Context(0, lanes=lanes)

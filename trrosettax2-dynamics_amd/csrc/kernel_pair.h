@@ -36,6 +36,16 @@ struct PairArgs {
   float* FA;                  // [slice][B][L][24] per (slice of the row, decoy, residue a): gradient on N CA C O CB H, then the raw energies
                               // dist omega theta phi vdw hb (PR_REC; the step kernel sums the slabs: sum_pair_records)
   int* seq_ctr;               // evaluation counter in device memory: bumped here, read by the step kernel that follows
+  // Segment cache (round 4; NULL: off).  A spline lookup reads ONE cubic segment -- two knots, 16 bytes -- out of a 19-137 MB table at
+  // an address that depends on the geometry: a dependent, uncoalesced gather that moves a 64-byte line for 16 bytes, six of them per
+  // all-channel visit.  Between two evaluations of a minimisation a pair seldom leaves its segment, so every (row entry, decoy) keeps
+  // the segments it used last: segc[a rowcap + e][NSEG] float4 (y0, y0'', y1, y1'') with their segment indices in
+  // segt (one byte each).  The block's address depends on the entry alone, so it is requested WITH residue b's coordinates -- the
+  // gather's round trip leaves the visit's dependent chain -- and a wave reads its lanes' blocks as one contiguous run.  A lookup whose
+  // segment index differs from the tag gathers from the table as before and refreshes the block.  The cached numbers ARE the
+  // table's: results are bit for bit those without the cache.  Valid as long as the tables are (the host resets the tags when they
+  // change); nothing in a block depends on which decoy used it last.  Single-decoy folds only (pair_body, SEGC).
+  float4* segc; uint2* segt; int rowcap;
 };
 
 // One spline evaluation in three stages, so that the lookups of all the terms of a visit can travel together: seek (ONE round of
@@ -169,14 +179,23 @@ __global__ __launch_bounds__(256) void k_build_rows(int L, const unsigned char* 
 template <int BW, int FAM>
 constexpr int pair_min_waves() { return (FAM & FAM_ANG) ? ((BW == 64 || BW == 1) ? PAIR_MIN_WAVES : 2) : PAIR_MIN_WAVES_DIST; }
 // The kernel's body: work item `bx` of the row plan, decoy group `grp` of the map and batch that A describes.
+// one spline segment: from the cache block when its tag matches the segment the geometry asks for, else from the table (miss = true)
+__device__ __forceinline__ void seg_fetch(bool use_c, unsigned tag, int idx, float4 c, const float2* row, float2& k0, float2& k1, bool& miss) {
+  if (use_c && tag == (unsigned)idx) { k0 = make_float2(c.x, c.y); k1 = make_float2(c.z, c.w); }
+  else { k0 = row[0]; k1 = row[1]; miss = use_c; }
+}
 // NW = waves of the workgroup.  4 (PAIR_WAVES) for batches: the waves share a row's list and partner range.  1 for SINGLE-DECOY
 // folds (round 4): a lone decoy's row holds ~70 entries and its chain 90-400 partner residues, so four waves of 64 lanes each ran
 // a quarter full; one wave per row walks the list in 2-3 steps, needs no workgroup barrier, no LDS image of the partial sums and no
 // cross-wave reduction (the 24 sums leave the wave through DPP row rotations and v_readlane), and -- what matters when the
 // single-decoy folds of many chains share a launch (launch_engine.h) -- a launch holds a quarter of the waves.
-template <int BW, int FAM, int NW = PAIR_WAVES>
+// SEGC: the instantiation that keeps a segment cache (PairArgs) -- single-decoy folds only (BW == 1).  With several decoys per wave
+// the lanes of a sub-lane look up the SAME pair's table row, a few cache lines for the whole wave, and a block per (entry, decoy)
+// would fetch sixteen times as much (measured: config 3 -26 % with it); with one decoy per wave every lane is another pair.
+template <int BW, int FAM, int NW = PAIR_WAVES, bool SEGC = false>
 __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, const int grp) {
   static_assert(NW == PAIR_WAVES || (NW == 1 && BW == 1), "the one-wave workgroup serves single-decoy folds");
+  static_assert(!SEGC || BW == 1, "the segment cache serves single-decoy folds");
   constexpr int NT = NW * 64;   // threads of the workgroup
   constexpr int PW = 64 / BW;
   const int L = A.L;
@@ -251,6 +270,7 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
   // ---- (i) restraint terms: the slice of the row's list, PW entries per wave step (lane = decoy, sub-lane h = entry).  The
   // pair, hence the table row, is the same for all decoys of a sub-lane.  Skipped outright while no decoy of the wave has a
   // restraint weight or an open separation window (the declash runs, folding.py:119: no restraints loaded yet).
+  constexpr bool use_c = SEGC;
   const bool want_rst = active && sep_hi > sep_lo && ((((FAM & FAM_DIST) != 0) && w_ap != 0.0f) || (((FAM & FAM_ANG) != 0) && (w_dih != 0.0f || w_ang != 0.0f)));
   if (__any((int)want_rst)) {
   // (Measured and not kept, profiles/README.md round 3: the visit as a lambda called from the loop -- the register allocation
@@ -265,6 +285,18 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
     // residue b's CA, N, CB: requested as soon as the entry is read, before its masks are examined
     const float4* xb = A.xyzT + (__umul24((unsigned)(grp * L + bc), 5u * BW) + (unsigned)d);
     const float4 r0 = xb[0], r1 = xb[BW], r2 = xb[2 * BW];
+    // ... and with them this (entry, decoy)'s segment-cache block (PairArgs): its address does not wait for the geometry
+    constexpr int NSEG = (FAM & FAM_ANG) ? 6 : 1;
+    const size_t ci = (size_t)a * (size_t)A.rowcap + (size_t)min(e, e_hi - 1);   // (one decoy: the block belongs to the row entry)
+    uint2 ctag = make_uint2(0xffffffffu, 0xffffffffu);
+    float4 cseg[NSEG];
+#pragma unroll
+    for (int q = 0; q < NSEG; q++) cseg[q] = make_float4(0, 0, 0, 0);
+    if constexpr (use_c) {
+      ctag = A.segt[ci];
+#pragma unroll
+      for (int q = 0; q < NSEG; q++) cseg[q] = A.segc[ci * NSEG + q];
+    }
     const int sep = abs(a - bc);
     unsigned m_ab = 0, m_ba = 0;
     if (want_rst && e < e_hi && sep >= sep_lo && sep < sep_hi) {
@@ -298,10 +330,10 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
     if (A.dist_ca) { ud = CAa - CAb; const float d2 = dot(ud, ud); idd = frsq(d2); dd = d2 * idd; }
     SplSeg sd;
     float2 kd0 = make_float2(0, 0), kd1_ = kd0;
+    bool miss_d = false, miss_a = false;
     if (on_d) {
       sd = spline_seek(knd, kd, dd < kd1 ? 0 : (dd < kd2 ? 1 : (dd < kd3 ? 2 : 3 + (int)((dd - kd3) * inv_d))), dd);
-      const float2* row = A.Td + __umul24(isym, (unsigned)kd) + sd.idx;
-      kd0 = row[0]; kd1_ = row[1];
+      seg_fetch(use_c, ctag.x & 0xffu, sd.idx, cseg[0], A.Td + __umul24(isym, (unsigned)kd) + sd.idx, kd0, kd1_, miss_d);
     }
     STAMP(3)  // dist: seek, fetch
     if constexpr ((FAM & FAM_ANG) != 0) {
@@ -329,7 +361,29 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
       const float2* r_t2 = A.Tt + __umul24(iba, (unsigned)KO) + g_t2.idx;
       const float2* r_p1 = A.Tp + __umul24(iab, (unsigned)KP) + g_p1.idx;
       const float2* r_p2 = A.Tp + __umul24(iba, (unsigned)KP) + g_p2.idx;
-      const float2 o0 = r_o[0], o1 = r_o[1], t10 = r_t1[0], t11 = r_t1[1], t20 = r_t2[0], t21 = r_t2[1], p10 = r_p1[0], p11 = r_p1[1], p20 = r_p2[0], p21 = r_p2[1];
+      float2 o0, o1, t10, t11, t20, t21, p10, p11, p20, p21;
+      if constexpr (!use_c) {   // (straight-line: the five gathers leave together)
+        o0 = r_o[0]; o1 = r_o[1]; t10 = r_t1[0]; t11 = r_t1[1]; t20 = r_t2[0]; t21 = r_t2[1]; p10 = r_p1[0]; p11 = r_p1[1]; p20 = r_p2[0]; p21 = r_p2[1];
+      } else {
+        constexpr int Q = NSEG > 1 ? 1 : 0;   // (NSEG == 6 here: the angular block exists only with FAM_ANG)
+        bool m1 = false, m2 = false, m3 = false, m4 = false, m5 = false;
+        seg_fetch(true, (ctag.x >> 8) & 0xffu, g_o.idx, cseg[1 * Q], r_o, o0, o1, m1);
+        seg_fetch(true, (ctag.x >> 16) & 0xffu, g_t1.idx, cseg[2 * Q], r_t1, t10, t11, m2);
+        seg_fetch(true, ctag.x >> 24, g_t2.idx, cseg[3 * Q], r_t2, t20, t21, m3);
+        seg_fetch(true, ctag.y & 0xffu, g_p1.idx, cseg[4 * Q], r_p1, p10, p11, m4);
+        seg_fetch(true, (ctag.y >> 8) & 0xffu, g_p2.idx, cseg[5 * Q], r_p2, p20, p21, m5);
+        if (m1 | m2 | m3 | m4 | m5) {   // refresh the block with the segments just gathered
+          miss_a = true;
+          float4* cb = A.segc + ci * NSEG;
+          if (m1) cb[1 * Q] = make_float4(o0.x, o0.y, o1.x, o1.y);
+          if (m2) cb[2 * Q] = make_float4(t10.x, t10.y, t11.x, t11.y);
+          if (m3) cb[3 * Q] = make_float4(t20.x, t20.y, t21.x, t21.y);
+          if (m4) cb[4 * Q] = make_float4(p10.x, p10.y, p11.x, p11.y);
+          if (m5) cb[5 * Q] = make_float4(p20.x, p20.y, p21.x, p21.y);
+          ctag.x = (ctag.x & 0xffu) | ((unsigned)g_o.idx << 8) | ((unsigned)g_t1.idx << 16) | ((unsigned)g_t2.idx << 24);
+          ctag.y = (ctag.y & 0xffff0000u) | (unsigned)g_p1.idx | ((unsigned)g_p2.idx << 8);
+        }
+      }
       STAMP(4)  // angles, five seeks, five fetches
       float ev, de;
       {  // omega: F = va, G = u, H = vb
@@ -378,6 +432,13 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
       if (first) e_d += ev;
       if (A.dist_ca) gCA = fma3(ud, w_ap * de * idd, gCA);
       else gCB = fma3(ud, w_ap * de * idd, gCB);
+    }
+    if constexpr (use_c) {
+      if (miss_d) {   // (only lanes with the term on and a real entry reach a fetch, so only they write)
+        A.segc[ci * NSEG] = make_float4(kd0.x, kd0.y, kd1_.x, kd1_.y);
+        ctag.x = (ctag.x & 0xffffff00u) | (unsigned)sd.idx;
+      }
+      if (miss_d | miss_a) A.segt[ci] = ctag;
     }
     STAMP(8)  // values, gradients
   }
@@ -526,10 +587,18 @@ template <int BW, int FAM>
 __global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_pair(PairArgs A) {
   pair_body<BW, FAM>(A, blockIdx.x, (int)blockIdx.z);
 }
-// single-decoy folds: one wave per work item (row), 64-thread workgroups
+// Single-decoy folds with the segment cache: 24 more live registers in the all-channel visit -- two waves per SIMD there (at three
+// the cache variants spill 70-90 registers: measured 1.5 x slower), three with distances only.
 template <int FAM>
-__global__ __launch_bounds__(64, (pair_min_waves<1, FAM>())) void k_pair1(PairArgs A) {
-  pair_body<1, FAM, 1>(A, blockIdx.x, (int)blockIdx.z);
+constexpr int pair_c_min_waves() { return (FAM & FAM_ANG) ? 2 : PAIR_MIN_WAVES_DIST; }
+template <int FAM>
+__global__ __launch_bounds__(PAIR_THREADS, (pair_c_min_waves<FAM>())) void k_pair_c(PairArgs A) {   // four waves per row
+  pair_body<1, FAM, PAIR_WAVES, true>(A, blockIdx.x, (int)blockIdx.z);
+}
+// ... one wave per work item (row), 64-thread workgroups
+template <int FAM, bool SEGC>
+__global__ __launch_bounds__(64, (SEGC ? pair_c_min_waves<FAM>() : pair_min_waves<1, FAM>())) void k_pair1(PairArgs A) {
+  pair_body<1, FAM, 1, SEGC>(A, blockIdx.x, (int)blockIdx.z);
 }
 // Shared launch (trx2fold.hip: LaunchEngine): ONE launch evaluates the pair terms of several independent folds, each on its own
 // map -- blockIdx.z picks the fold, whose argument block (tables, row lists, row plan, coordinates, records, chain length) is read
@@ -548,12 +617,12 @@ __device__ __forceinline__ T load_args(const T* p) {
   for (unsigned i = 0; i < sizeof(T) / 4; i++) u.w[i] = src[i];
   return u.t;
 }
-// (the four-wave workgroups of rounds 1-3 in a shared launch: TRX2_PAIR1_WG4=1, A/B timing)
-template <int BW, int FAM>
-__global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_pair_multi(const PairArgs* AA) {
+// the four-wave workgroups in a shared launch (contexts whose single-decoy folds keep four waves per row)
+template <int FAM, bool SEGC>
+__global__ __launch_bounds__(PAIR_THREADS, (SEGC ? pair_c_min_waves<FAM>() : pair_min_waves<1, FAM>())) void k_pair_multi(const PairArgs* AA) {
   const PairArgs A = load_args(AA + blockIdx.z);
   if ((int)blockIdx.x >= A.n_items) return;
-  pair_body<BW, FAM>(A, blockIdx.x, 0);
+  pair_body<1, FAM, PAIR_WAVES, SEGC>(A, blockIdx.x, 0);
 }
 // Placement.  Both visits of a residue pair -- from row a and from row b -- read the same six spline segments, and a fold's rows
 // read the same coordinate records; the table lines a fold touches in one evaluation are ~2 MB, half of an XCD's L2.  Workgroups are
@@ -562,8 +631,8 @@ __global__ __launch_bounds__(PAIR_THREADS, (pair_min_waves<BW, FAM>())) void k_p
 // carry the same block id modulo 8 -- one XCD, one L2: the second visit of a pair finds its segments there.  Measured at 14 folds
 // per launch (profiles/README.md, round 4): L2 hit rate 29 % and 51 MB fetched per launch with the rows spread over the XCDs.
 // With fewer folds a fold's rows stay spread: one XCD is an eighth of the chip.  The mapping changes no result.
-template <int FAM>
-__global__ __launch_bounds__(64, (pair_min_waves<1, FAM>())) void k_pair1_multi(const PairArgs* AA, int n_folds, int max_items, int xcd_groups) {
+template <int FAM, bool SEGC>
+__global__ __launch_bounds__(64, (SEGC ? pair_c_min_waves<FAM>() : pair_min_waves<1, FAM>())) void k_pair1_multi(const PairArgs* AA, int n_folds, int max_items, int xcd_groups) {
   unsigned fold, item;
   if (xcd_groups) {
     const unsigned id = blockIdx.x, x = id & 7u, s = id >> 3;
@@ -576,5 +645,5 @@ __global__ __launch_bounds__(64, (pair_min_waves<1, FAM>())) void k_pair1_multi(
   if ((int)fold >= n_folds) return;
   const PairArgs A = load_args(AA + fold);
   if ((int)item >= A.n_items) return;
-  pair_body<1, FAM, 1>(A, item, 0);
+  pair_body<1, FAM, 1, SEGC>(A, item, 0);
 }

@@ -28,6 +28,7 @@ struct EngineJob {
   PairArgs pa; ChainArgs ca; CartArgs cc;
   int cls = 1;            // step kernel: 0 chains of <= 128 residues (128 threads), 1 <= 256, 2 <= 512
   int fam_all = 1;        // pair kernel: all channels | distances only
+  int segc = 0;           // pair kernel: the instantiation with the segment cache
   int wave1 = 0;          // pair kernel: one wave per row (k_pair1_multi) | the four-wave workgroups (k_pair_multi<1>)
   int bw = 1;             // decoys per wave of the pair kernel (one decoy group per fold)
   int B = 1;              // slots
@@ -80,19 +81,21 @@ static bool engine_enabled() {
   return env_on;
 }
 
-static void engine_launch_pair(bool fam_all, bool wave1, int n_folds, int max_items, hipStream_t st, const PairArgs* a) {
+template <int FAM, bool SEGC>
+static void engine_launch_pair_t(bool wave1, int n_folds, int max_items, hipStream_t st, const PairArgs* a) {
   if (!wave1) {
-    const dim3 grid((unsigned)max_items, 1, (unsigned)n_folds);
-    if (fam_all) hipLaunchKernelGGL((k_pair_multi<1, FAM_ALL>), grid, dim3(PAIR_THREADS), 0, st, a);
-    else hipLaunchKernelGGL((k_pair_multi<1, FAM_DIST | FAM_VDW>), grid, dim3(PAIR_THREADS), 0, st, a);
+    hipLaunchKernelGGL((k_pair_multi<FAM, SEGC>), dim3((unsigned)max_items, 1, (unsigned)n_folds), dim3(PAIR_THREADS), 0, st, a);
     return;
   }
   // eight folds or more: every fold's rows on one XCD (kernel_pair.h, k_pair1_multi); TRX2_XCD_GROUPS=0 / 1 forces either layout (A/B timing)
   static const int env_x = getenv("TRX2_XCD_GROUPS") ? atoi(getenv("TRX2_XCD_GROUPS")) : -1;
   const int xg = env_x >= 0 ? (env_x != 0) : (n_folds >= 8);
   const unsigned blocks = xg ? 8u * (unsigned)((n_folds + 7) / 8) * (unsigned)max_items : (unsigned)n_folds * (unsigned)max_items;
-  if (fam_all) hipLaunchKernelGGL((k_pair1_multi<FAM_ALL>), dim3(blocks), dim3(64), 0, st, a, n_folds, max_items, xg);
-  else hipLaunchKernelGGL((k_pair1_multi<FAM_DIST | FAM_VDW>), dim3(blocks), dim3(64), 0, st, a, n_folds, max_items, xg);
+  hipLaunchKernelGGL((k_pair1_multi<FAM, SEGC>), dim3(blocks), dim3(64), 0, st, a, n_folds, max_items, xg);
+}
+static void engine_launch_pair(bool fam_all, bool wave1, bool segc, int n_folds, int max_items, hipStream_t st, const PairArgs* a) {
+  if (fam_all) { if (segc) engine_launch_pair_t<FAM_ALL, true>(wave1, n_folds, max_items, st, a); else engine_launch_pair_t<FAM_ALL, false>(wave1, n_folds, max_items, st, a); }
+  else { if (segc) engine_launch_pair_t<FAM_DIST | FAM_VDW, true>(wave1, n_folds, max_items, st, a); else engine_launch_pair_t<FAM_DIST | FAM_VDW, false>(wave1, n_folds, max_items, st, a); }
 }
 static void engine_launch_step(int cls, dim3 grid, size_t dyn, hipStream_t st, const ChainArgs* a, const CartArgs* c) {
   if (cls == 0) hipLaunchKernelGGL((k_step_multi<1, 128, 128>), grid, dim3(128), dyn, st, a, c);
@@ -101,7 +104,7 @@ static void engine_launch_step(int cls, dim3 grid, size_t dyn, hipStream_t st, c
 }
 
 // launch class of a job: folds of one class share a launch pair (same instantiations); a chunk launches every class it holds
-static int engine_class(const EngineJob* j) { return (j->cls * 2 + j->fam_all) * 2 + j->wave1; }
+static int engine_class(const EngineJob* j) { return ((j->cls * 2 + j->fam_all) * 2 + j->wave1) * 2 + j->segc; }
 
 static void engine_fail(LaunchEngine* E, const std::string& why) {   // (mu held) a HIP error on the engine's stream: every fold it holds fails loudly
   E->broken = true; E->broken_why = why;
@@ -163,10 +166,10 @@ static void engine_main(LaunchEngine* E) {
       const PairArgs* dpa = (const PairArgs*)(E->d_args + ENG_OFF_PA);
       const ChainArgs* dca = (const ChainArgs*)(E->d_args + ENG_OFF_CA);
       const CartArgs* dcc = (const CartArgs*)(E->d_args + ENG_OFF_CC);
-      struct Grp { int lo, n, items, maxB, cls, fam, wave1; size_t dyn; };
+      struct Grp { int lo, n, items, maxB, cls, fam, wave1, segc; size_t dyn; };
       std::vector<Grp> groups;
       for (int i = 0; i < n;) {
-        Grp g{i, 0, 0, 0, C.jobs[(size_t)i]->cls, C.jobs[(size_t)i]->fam_all, C.jobs[(size_t)i]->wave1, 0};
+        Grp g{i, 0, 0, 0, C.jobs[(size_t)i]->cls, C.jobs[(size_t)i]->fam_all, C.jobs[(size_t)i]->wave1, C.jobs[(size_t)i]->segc, 0};
         while (i < n && engine_class(C.jobs[(size_t)i]) == engine_class(C.jobs[(size_t)g.lo])) {
           const EngineJob* j = C.jobs[(size_t)i];
           g.items = std::max(g.items, j->n_items); g.maxB = std::max(g.maxB, j->B); g.dyn = std::max(g.dyn, j->dyn);
@@ -176,7 +179,7 @@ static void engine_main(LaunchEngine* E) {
       }
       for (int it = 0; it < ENGINE_CHUNK; it++)
         for (const Grp& g : groups) {
-          engine_launch_pair(g.fam != 0, g.wave1 != 0, g.n, g.items, E->stream, dpa + g.lo);
+          engine_launch_pair(g.fam != 0, g.wave1 != 0, g.segc != 0, g.n, g.items, E->stream, dpa + g.lo);
           engine_launch_step(g.cls, dim3((unsigned)(2 * g.maxB), (unsigned)g.n), g.dyn, E->stream, dca + g.lo, dcc + g.lo);
         }
       hipLaunchKernelGGL(k_gather_done, dim3(1), dim3(ENGINE_MAX_JOBS), 0, E->stream, n, (const int* const*)(E->d_args + ENG_OFF_DP), E->d_flags);

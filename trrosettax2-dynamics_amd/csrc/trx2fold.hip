@@ -114,6 +114,9 @@ struct trx2_ctx {
   float4 *X = nullptr, *G = nullptr, *D = nullptr, *XT = nullptr, *S = nullptr, *Y = nullptr;
   float4* P = nullptr; float4* xyzT = nullptr; float* wcur = nullptr; float4* geom = nullptr;
   float* FA = nullptr;
+  // segment cache of the pair kernel (kernel_pair.h, PairArgs): blocks + tags for Bpad x L x L (entry, decoy) places; tab_epoch counts
+  // table changes, seg_epoch is the one the tags were last reset for
+  float4* segc = nullptr; uint2* segt = nullptr; size_t seg_bytes = 0, seg_elems = 0; long tab_epoch = 0, seg_epoch = -1;
   double *e_last = nullptr, *f_last = nullptr;
   float* grad = nullptr; float* tors0 = nullptr;
   float4 *CX = nullptr, *CG = nullptr, *CD = nullptr, *CS = nullptr, *CY = nullptr;  // Cartesian runs (allocated on first use)
@@ -366,6 +369,9 @@ static void free_batch(trx2_ctx* c) {
   c->P = nullptr; c->xyzT = nullptr; c->geom = nullptr; c->wcur = nullptr; c->FA = nullptr;
   c->e_last = c->f_last = nullptr; c->grad = nullptr; c->tors0 = nullptr; c->done_count = nullptr; c->seq_ctr = nullptr; c->runs = nullptr;
   c->plan = nullptr; c->fa_cap = 0;
+  if (c->segc) (void)hipFree(c->segc);
+  if (c->segt) (void)hipFree(c->segt);
+  c->segc = nullptr; c->segt = nullptr; c->seg_bytes = c->seg_elems = 0; c->seg_epoch = -1;
   c->Bcap = c->Lcap = 0;
   c->alloc_epoch++;
   void* q[] = {c->CX, c->CG, c->CD, c->CS, c->CY, c->slot_id, c->next_id, c->out_stat, c->out_xyz, c->out_X, c->out_e, c->out_f, c->tors0_all};
@@ -406,7 +412,7 @@ static void lend_map(trx2_ctx* c) {
   k->Td = c->Td; k->To = c->To; k->Tt = c->Tt; k->Tp = c->Tp; k->pd = c->pd; k->po = c->po; k->pt = c->pt; k->pp = c->pp;
   k->gen = c->gen; k->sel = c->sel; k->mask2 = c->mask2; k->hasH = c->hasH; k->knots_f = c->knots_f; k->knots_d = c->knots_d;
   k->idr = c->idr; k->mask_odr = c->mask_odr; k->rst_kind = c->rst_kind; k->kd = c->kd; k->dist_ca = c->dist_ca;
-  k->rows = c->rows; k->row_cnt = c->row_cnt; k->h_row_cnt = c->h_row_cnt; k->rows_epoch++;
+  k->rows = c->rows; k->row_cnt = c->row_cnt; k->h_row_cnt = c->h_row_cnt; k->rows_epoch++; k->tab_epoch++;
   k->mask_r1 = c->mask_r1; k->mask_r2 = c->mask_r2; k->gly = c->gly; k->rows_rx = c->rows_rx;
   memcpy(k->knots_h, c->knots_h, sizeof c->knots_h);
   k->alloc_epoch++;
@@ -456,8 +462,8 @@ static int fetch_row_counts(trx2_ctx* ctx) {
   ctx->h_row_cnt.assign((size_t)ctx->L, 0);
   HIPCHK(hipMemcpyAsync(ctx->h_row_cnt.data(), ctx->row_cnt, sizeof(int) * (size_t)ctx->L, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
-  ctx->rows_epoch++;
-  if (ctx->child) { ctx->child->h_row_cnt = ctx->h_row_cnt; ctx->child->rows_epoch++; }
+  ctx->rows_epoch++; ctx->tab_epoch++;
+  if (ctx->child) { ctx->child->h_row_cnt = ctx->h_row_cnt; ctx->child->rows_epoch++; ctx->child->tab_epoch++; }
   return 0;
 }
 
@@ -729,6 +735,8 @@ extern "C" int trx2_override_table_rows(trx2_ctx* ctx, int channel, int n, const
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(ctx->stream));
   (void)hipFree(da); (void)hipFree(db); (void)hipFree(dy);
+  ctx->tab_epoch++;   // cached segments of the edited rows are stale
+  if (ctx->child) ctx->child->tab_epoch++;
   return 0;
 }
 
@@ -824,6 +832,34 @@ static int ensure_batch(trx2_ctx* ctx, int B) {
   return 0;
 }
 
+// Segment cache of the pair kernel (kernel_pair.h, PairArgs / SEGC) for SINGLE-decoy folds: one block of NSEG cubic segments + their
+// tags per row entry, rows at a fixed stride of L entries (2.3 MB at 150 residues with all channels, 16.6 MB at 400).  (Re)allocated
+// when the map outgrows it; the tags are reset whenever the tables have changed since (a new map, a feedback step, edited rows).
+// TRX2_SEG_CACHE=0 turns it off (A/B timing; results are bit-identical either way).
+static int ensure_seg_cache(trx2_ctx* ctx) {
+  static const bool off = getenv("TRX2_SEG_CACHE") && atoi(getenv("TRX2_SEG_CACHE")) == 0;
+  if (off || ctx->Bpad != 1) return 0;   // batches keep their gathers (the lanes of a wave share table rows there); seg_on() says which
+  const size_t L = (size_t)ctx->L, nseg = ctx->use_orient ? 6 : 1;
+  const size_t elems = L * L, bytes = elems * nseg * sizeof(float4);
+  if (bytes > ctx->seg_bytes || elems > ctx->seg_elems) {
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->segc) (void)hipFree(ctx->segc);
+    if (ctx->segt) (void)hipFree(ctx->segt);
+    ctx->segc = nullptr; ctx->segt = nullptr; ctx->seg_bytes = ctx->seg_elems = 0;
+    HIPCHK(hipMalloc((void**)&ctx->segc, bytes));
+    HIPCHK(hipMalloc((void**)&ctx->segt, elems * sizeof(uint2)));
+    ctx->seg_bytes = bytes; ctx->seg_elems = elems; ctx->seg_epoch = -1;
+    ctx->alloc_epoch++;
+  }
+  if (ctx->seg_epoch != ctx->tab_epoch) {   // 0xff in every tag byte: no segment has that index
+    HIPCHK(hipMemsetAsync(ctx->segt, 0xff, elems * sizeof(uint2), ctx->stream));
+    ctx->seg_epoch = ctx->tab_epoch;
+  }
+  return 0;
+}
+// the launch about to be made uses the cache: a single-decoy shape whose blocks and tags are in place for the current tables
+static bool seg_on(const trx2_ctx* c) { return c->BW == 1 && c->Bpad == 1 && c->segc && c->seg_epoch == c->tab_epoch && c->seg_elems >= (size_t)c->L * c->L; }
+
 static PairArgs pair_args(trx2_ctx* c, int B) {
   PairArgs P;
   P.L = c->L; P.B = B; P.Bpad = c->Bpad; P.items = c->plans[(size_t)c->plan_cur].items; P.n_items = c->plans[(size_t)c->plan_cur].n_items;
@@ -831,6 +867,8 @@ static PairArgs pair_args(trx2_ctx* c, int B) {
   P.rows = c->rows; P.row_cnt = c->row_cnt; P.rows_rx = c->rows_rx; P.has_odr = c->mask_odr != nullptr;
   P.knots = c->knots_f; P.wcur = c->wcur; P.FA = c->FA; P.seq_ctr = c->seq_ctr;
   P.kd = c->kd; P.dist_ca = c->dist_ca;
+  const bool sc = seg_on(c);
+  P.segc = sc ? c->segc : nullptr; P.segt = sc ? c->segt : nullptr; P.rowcap = c->L;
   return P;
 }
 static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_evals) {
@@ -865,10 +903,15 @@ static int launch_pair(trx2_ctx* c, int B) {
 #define LAUNCH_PAIR(W)                                                                                       \
   if (c->use_orient) hipLaunchKernelGGL((k_pair<W, FAM_ALL>), grid, block, 0, c->stream, P);               \
   else hipLaunchKernelGGL((k_pair<W, FAM_DIST | FAM_VDW>), grid, block, 0, c->stream, P)
-  // a single decoy on a context set to one wave per row (trx2_ctx_set_single_decoy_waves): k_pair1
-  if (c->BW == 1 && c->pair1_waves == 1) {
-    if (c->use_orient) hipLaunchKernelGGL((k_pair1<FAM_ALL>), grid, dim3(64), 0, c->stream, P);
-    else hipLaunchKernelGGL((k_pair1<FAM_DIST | FAM_VDW>), grid, dim3(64), 0, c->stream, P);
+  // a single decoy: one wave per row on a context set so (trx2_ctx_set_single_decoy_waves), with the segment cache where it is in place
+  if (c->BW == 1 && (c->pair1_waves == 1 || P.segc)) {
+    const bool ang = c->use_orient != 0;
+    if (c->pair1_waves == 1) {
+      if (P.segc) { if (ang) hipLaunchKernelGGL((k_pair1<FAM_ALL, true>), grid, dim3(64), 0, c->stream, P); else hipLaunchKernelGGL((k_pair1<FAM_DIST | FAM_VDW, true>), grid, dim3(64), 0, c->stream, P); }
+      else { if (ang) hipLaunchKernelGGL((k_pair1<FAM_ALL, false>), grid, dim3(64), 0, c->stream, P); else hipLaunchKernelGGL((k_pair1<FAM_DIST | FAM_VDW, false>), grid, dim3(64), 0, c->stream, P); }
+    } else {
+      if (ang) hipLaunchKernelGGL((k_pair_c<FAM_ALL>), grid, block, 0, c->stream, P); else hipLaunchKernelGGL((k_pair_c<FAM_DIST | FAM_VDW>), grid, block, 0, c->stream, P);
+    }
     return 0;
   }
   switch (c->BW) {
@@ -924,7 +967,7 @@ extern "C" int trx2_eval_batch(trx2_ctx* ctx, int B, const float* tors, const fl
   if (!ctx->L) { ctx->err = "trx2_eval_batch: no map set"; return 1; }
   if (B < 1 || !tors || !w) { ctx->err = "trx2_eval_batch: bad arguments"; return 1; }
   HIPCHK(hipSetDevice(ctx->device));
-  if (ensure_batch(ctx, B)) return 1;
+  if (ensure_batch(ctx, B) || ensure_seg_cache(ctx)) return 1;
   const int L = ctx->L;
   const size_t BL = (size_t)B * L;
   if (upload_single_run(ctx, w, sep_lo, sep_hi)) return 1;
@@ -1031,7 +1074,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   HIPCHK(hipSetDevice(ctx->device));
   const int B0 = (ctx->pool > 0 && ctx->pool < N) ? ctx->pool : N;   // slots
   int B = B0;   // shrinks by a decoy group at a time at the tail of the fold (below)
-  if (ensure_batch(ctx, B)) return 1;
+  if (ensure_batch(ctx, B) || ensure_seg_cache(ctx)) return 1;
   if (has_cart && ensure_cart(ctx, B)) return 1;
   if (ensure_outputs(ctx, (size_t)N, tors0 != nullptr)) return 1;
   // The launch shape of the full batch comes back when the fold ends, however it ends: the buffers are laid out for it, and
@@ -1131,6 +1174,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
       job.cls = L <= 128 ? 0 : (L <= CHAIN_THREADS ? 1 : 2);
       job.fam_all = ctx->use_orient ? 1 : 0;
       job.wave1 = ctx->pair1_waves == 1 ? 1 : 0;
+      job.segc = job.pa.segc ? 1 : 0;
       job.bw = ctx->BW; job.B = B; job.n_items = job.pa.n_items; job.done_count = ctx->done_count; job.cap = cap;
       const RowPlan& rp = ctx->plans[(size_t)ctx->plan_cur];
       if (ctx->BW != 1 || rp.epoch != ctx->rows_epoch || rp.pw != 64 || (size_t)rp.ns_max * B * L > ctx->fa_cap) {
