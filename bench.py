@@ -168,7 +168,8 @@ def traffic_record(config, decoys_per_launch, kernel="k_pair"):
     if not os.path.exists(TRAFFIC_FILE):
         return None
     rec = json.load(open(TRAFFIC_FILE))
-    if rec.get("kernel_src_sha", {}).get(kernel) != kernel_source_sha(kernel):
+    src = "k_step" if kernel.startswith("k_step") else "k_pair"      # which sources the kernel is built from
+    if rec.get("kernel_src_sha", {}).get(src) != kernel_source_sha(src):
         return None
     for r in rec.get("records", []):
         if r["config"] == config and r["kernel_family"] == kernel and r["decoys_per_launch"] == decoys_per_launch:
@@ -311,12 +312,12 @@ def cpu_e2e_baseline(synth, L, init_num, iterations, runs, n_folds=4):
                           "a chain's iterations are sequential, so more cores do not shorten them"}
 
 
-def e2e_batch_leg(pipe_mod, synth, L, n_targets=8, nmax=80, seed=3, in_flight=(8,)):
+def e2e_batch_leg(pipe_mod, synth, L, n_targets=16, nmax=40, seed=3, in_flight=(16,)):
     """Batch mode of run_inference.py (:339-348) on ONE GPU: n_targets targets (the same synthetic pair of maps under different names),
-    init_num=10, both models, Nmax shortened to `nmax`, `in_flight` targets at a time (pipeline.run_batch's default: eight = sixteen
+    init_num=10, both models, Nmax shortened to `nmax`, `in_flight` targets at a time (pipeline.run_batch's default: sixteen = thirty-two
     chains whose single-decoy folds share launch pairs, csrc/launch_engine.h; the files are byte-identical to one target after the
-    other with every fold launching for itself: tests/test_gpu_shared_launch.py).  Round 3 (four streams, two targets in flight):
-    64 decoys/s without the relax stage, 41.5 with it (profiles/README.md, round 4)."""
+    other with every fold launching for itself: tests/test_gpu_shared_launch.py).  Round 3's way (four streams, two targets in
+    flight, every fold its own launches): 64 decoys/s without the relax stage, 41.5 with it (profiles/README.md, round 4)."""
     work = tempfile.mkdtemp(prefix="trx2_e2eb_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         maps = [synth.make_map(L, seed=L + c) for c in range(2)]
@@ -439,6 +440,64 @@ def multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, wit
     for c in ctxs:
         c.close()
     return out
+
+
+def shared_launch_leg(T, synth, L, n_folds=32, evals=1500):
+    """The kernels of the product's throughput mode (batch mode's iteration phase): n_folds single-decoy folds of n_folds contexts --
+    each with its own tables of the synthetic all-channel map, as the chains of a batch job have -- at the same time, sharing launches
+    (csrc/launch_engine.h), one wave per row, a fixed evaluation budget from near the structure (the state a fold spends its time in).
+    Reported: fold-evaluations per second, and a roofline record of the shared pair kernel from launch pairs the engines bracket with
+    HIP events on their own streams (one per chunk of 16): algorithmic bytes of the folds a sampled launch held / its duration."""
+    import threading
+    LB = importlib.import_module("trrosettax2-dynamics_amd._lib")
+    m = synth.make_map(L, seed=L)
+    runs = T.protocol.build_runs(L, 2, fastrelax=True)
+    rng = np.random.default_rng(1)
+    ctxs = [T.Context(0) for _ in range(n_folds)]
+    try:
+        for c in ctxs:
+            c.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=m["seq"])
+            c.set_single_decoy_waves(1)
+        t0s = [(m["tors"] + rng.normal(size=m["tors"].shape) * 0.3).astype(np.float32)[None] for _ in range(n_folds)]
+        for c, t in zip(ctxs, t0s):
+            c.fold_batch(1, runs[5:], tors0=t, max_evals=20)
+        w = np.array(T.protocol.SF, np.float32)
+        ctxs[0].eval_batch(t0s[0], w)
+        _, term_evals = ctxs[0].time_pair_kernel(1, w, 1, L, n_rep=2)     # selected terms of one decoy of this map
+        LB.set_shared_launch_profiling(True)
+        s0 = LB.shared_launch_stats(0)
+        out = [None] * n_folds
+
+        def work(i):
+            out[i] = ctxs[i].fold_batch(1, runs[5:], tors0=t0s[i], max_evals=evals)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(n_folds)]
+        t0 = time.perf_counter()
+        [t.start() for t in th]
+        [t.join() for t in th]
+        el = time.perf_counter() - t0
+        LB.set_shared_launch_profiling(False)
+        s1 = LB.shared_launch_stats(0)
+        ev = sum(int(r["n_evals"][0]) for r in out)
+        ns = s1["samples"] - s0["samples"]
+        rec = {"workload": f"{n_folds} single-decoy folds (L={L}, all channels, own tables each) in flight at once, sharing launches; {evals} evaluations each from near the structure",
+               "fold_evaluations_per_sec": ev / el, "us_per_fold_evaluation": 1e6 * el / ev, "seconds": el}
+        if ns > 0:
+            folds = (s1["sampled_folds"] - s0["sampled_folds"]) / ns
+            pair_ms = (s1["pair_ms_sum"] - s0["pair_ms_sum"]) / ns
+            step_ms = (s1["step_ms_sum"] - s0["step_ms_sum"]) / ns
+            abytes = algorithmic_bytes(folds, term_evals, L)
+            tr = traffic_record("shared16", 16, "k_pair1_multi")
+            rec["roofline"] = {"bound": "hbm", "kernel": f"k_pair1_multi<all channels, segment cache> ({folds:.1f} folds per sampled launch, {int(ns)} samples)",
+                               "achieved": abytes / (pair_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "avg_launch_ms": pair_ms, "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": term_evals,
+                               "traffic": (tr["hbm_bytes_per_launch"] * folds / 16.0) if tr else None,
+                               "traffic_source": (tr or {}).get("method"),
+                               "step_avg_launch_ms": step_ms}
+        return rec
+    finally:
+        LB.set_shared_launch_profiling(False)
+        for c in ctxs:
+            c.close()
 
 
 def multi_gpu_plan(T, synth, local_rank, one_gpu_seconds):
@@ -686,6 +745,7 @@ def main():
                     out["e2e"]["init_num_64"] = e2e_leg(pipe_mod, synth, cfg["L"], 64)
                     out["e2e"]["init_num_10_candidates_8"] = e2e_leg(pipe_mod, synth, cfg["L"], 10, candidates=8)
                 out["e2e"]["batch_mode_one_gpu"] = e2e_batch_leg(pipe_mod, synth, cfg["L"])
+            out["shared_launches"] = shared_launch_leg(T, synth, cfg["L"])
             if with_cpu:
                 its = max(out["e2e"]["init_num_10"]["iterations"].values())
                 out["e2e"]["cpu_baseline"] = cpu_e2e_baseline(synth, cfg["L"], 10, its, T.protocol.build_runs(cfg["L"], 2, fastrelax=True))
@@ -725,7 +785,7 @@ def main():
             return round(float(d), 2)
         for key, path in (("e2e_init10", ("e2e", "init_num_10", "value")), ("e2e_example_L90_init10", ("e2e", "example_L90_init_num_10", "value")),
                           ("e2e_cpu_init10", ("e2e", "cpu_baseline", "value")), ("batch_mode_one_gpu", ("e2e", "batch_mode_one_gpu", "best", "value")),
-                          ("pooled_1280", ("pooled_queue", "value")), ("no_fastrelax", ("no_fastrelax", "value")),
+                          ("shared_fold_evals_per_s", ("shared_launches", "fold_evaluations_per_sec")), ("pooled_1280", ("pooled_queue", "value")), ("no_fastrelax", ("no_fastrelax", "value")),
                           ("c3", ("sub_records", "config3", "value")), ("c4", ("sub_records", "config4", "value")), ("c5_one_gpu", ("sub_records", "config5_one_gpu", "value")),
                           ("predicted_speedup_8gpu_unmeasured", ("multi_gpu_plan", "predicted", "8", "with_block_splits", "speedup_vs_three_in_flight"))):
             v = num(*path)

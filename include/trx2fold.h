@@ -100,9 +100,12 @@ int trx2_set_shared_launches(int mode);
  * residue's terms in different orders: results differ by rounding, as between batches of different widths; within one shape a
  * fold's result does not depend on what shares its launches.  pipeline.run_batch sets 1, everything else keeps 4. */
 int trx2_ctx_set_single_decoy_waves(trx2_ctx* ctx, int waves);
-/* measurement helper: out[5] = chunks of launch pairs the device's engines enqueued, folds x chunks (ratio: folds per launch), folds
- * completed, seconds their host threads spent enqueuing, seconds they waited for the GPU */
+/* measurement helpers: out[9] = chunks of launch pairs the device's engines enqueued, folds x chunks (ratio: folds per launch), folds
+ * completed, seconds their host threads spent enqueuing, seconds they waited for the GPU; and, while trx2_set_shared_launch_profiling(1)
+ * is on (one launch pair per chunk of 16 bracketed by HIP events on the engine's stream): summed milliseconds of the sampled pair and
+ * step launches, the number of samples, the folds they held */
 int trx2_shared_launch_stats(int device, double* out);
+int trx2_set_shared_launch_profiling(int on);
 int trx2_last_fold_slot_efficiency(trx2_ctx* ctx, double* eff);
 const char* trx2_last_error(const trx2_ctx* ctx);
 

@@ -18,7 +18,6 @@ for spec in "2 32" "2 640" "3 64" "4 16"; do
     bash tools/pmc_run.sh $1 $2 $k r04_profiles/pmc 20 || exit $?
   done
 done
-python3 tools/make_traffic_json.py $O/pmc $O/r04_traffic.json
 # the shared-launch shape (batch mode's iteration phase): kernel trace of sixteen targets in flight, and the PMC passes of the shared
 # kernels with sixteen folds in one engine's launches
 cd /tmp; rm -rf /tmp/ktb
@@ -32,3 +31,4 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_
   if [ -n "$f" ]; then python3 $R/tools/pmc_report.py $f 200 k_pair1_multi > $O/shared16_pair_$tag.json; python3 $R/tools/pmc_report.py $f 200 k_step_multi > $O/shared16_step_$tag.json; cat $O/shared16_pair_$tag.json; echo; fi
 done
 cd $R
+python3 tools/make_traffic_json.py $O/pmc $O/r04_traffic.json

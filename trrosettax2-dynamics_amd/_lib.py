@@ -97,6 +97,7 @@ def load():
     L.trx2_ctx_set_single_decoy_waves.argtypes = [vp, C.c_int]
     L.trx2_set_shared_launches.argtypes = [C.c_int]
     L.trx2_shared_launch_stats.argtypes = [C.c_int, dp]
+    L.trx2_set_shared_launch_profiling.argtypes = [C.c_int]
     L.trx2_last_fold_slot_efficiency.argtypes = [vp, dp]
     L.trx2_ctx_set_profiling.argtypes = [vp, C.c_int]
     L.trx2_last_fold_kernel_times.argtypes = [vp, dp, dp, ip]
@@ -111,9 +112,15 @@ def _p(a):
 
 def shared_launch_stats(device=0):
     """-> dict(chunks, folds_per_launch, folds, enqueue_s, wait_s) of the device's launch engines (trx2_shared_launch_stats)"""
-    v = (C.c_double * 5)()
+    v = (C.c_double * 9)()
     load().trx2_shared_launch_stats(int(device), v)
-    return dict(chunks=v[0], folds_per_launch=(v[1] / v[0] if v[0] else 0.0), folds=v[2], enqueue_s=v[3], wait_s=v[4])
+    return dict(chunks=v[0], folds_per_launch=(v[1] / v[0] if v[0] else 0.0), folds=v[2], enqueue_s=v[3], wait_s=v[4],
+                pair_ms_sum=v[5], step_ms_sum=v[6], samples=v[7], sampled_folds=v[8])
+
+
+def set_shared_launch_profiling(on):
+    """bracket one launch pair per chunk of the launch engines by HIP events (trx2_set_shared_launch_profiling); read with shared_launch_stats"""
+    load().trx2_set_shared_launch_profiling(int(bool(on)))
 
 
 def set_shared_launches(mode):

@@ -62,6 +62,9 @@ struct LaunchEngine {
   // statistics (trx2_shared_launch_stats): chunks enqueued, sum over chunks of the folds they held, folds completed, seconds the
   // host thread spent enqueuing / waiting for a chunk
   double st_chunks = 0, st_jobs = 0, st_done = 0, st_enqueue_s = 0, st_wait_s = 0;
+  // trx2_set_shared_launch_profiling: the first launch pair of every chunk bracketed by events (pair | step), summed here with the folds it held
+  hipEvent_t pev[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+  double st_pair_ms = 0, st_step_ms = 0, st_prof_n = 0, st_prof_folds = 0;
   size_t load() { return queued.size() + active.size(); }
 };
 
@@ -71,6 +74,7 @@ static const size_t ENG_OFF_CC = ENG_OFF_CA + sizeof(ChainArgs) * ENGINE_MAX_JOB
 static const size_t ENG_OFF_DP = ENG_OFF_CC + sizeof(CartArgs) * ENGINE_MAX_JOBS;
 static const size_t ENG_ARGS_BYTES = ENG_OFF_DP + sizeof(int*) * ENGINE_MAX_JOBS;
 
+static std::atomic<int> g_engine_prof{0};   // trx2_set_shared_launch_profiling
 static int g_engine_mode = -1;   // -1: TRX2_SHARED_LAUNCH decides (default on); 0 / 1: trx2_set_shared_launches
 static std::mutex g_engine_mutex;
 static std::map<int, std::vector<LaunchEngine*>> g_engines;   // per device; never destroyed (their threads outlive every context)
@@ -116,7 +120,7 @@ static void engine_fail(LaunchEngine* E, const std::string& why) {   // (mu held
 
 static void engine_main(LaunchEngine* E) {
   if (hipSetDevice(E->device) != hipSuccess) { std::lock_guard<std::mutex> lk(E->mu); engine_fail(E, "hipSetDevice failed in the engine thread"); return; }
-  struct Chunk { std::vector<EngineJob*> jobs; bool valid = false; } ch[2];
+  struct Chunk { std::vector<EngineJob*> jobs; bool valid = false; bool prof = false; int prof_folds = 0; } ch[2];
   std::vector<unsigned long long> uploaded;   // ids of the jobs the device arrays describe, in order
   long k = 0;
   int ring = 0;
@@ -177,10 +181,16 @@ static void engine_main(LaunchEngine* E) {
         }
         groups.push_back(g);
       }
+      C.prof = g_engine_prof.load() != 0 && groups.size() == 1 && E->pev[k & 1][0] != nullptr;   // (one class: the events bracket one kernel each)
+      C.prof_folds = n;
       for (int it = 0; it < ENGINE_CHUNK; it++)
         for (const Grp& g : groups) {
+          const bool samp = C.prof && it == ENGINE_CHUNK / 2;
+          if (samp) (void)hipEventRecord(E->pev[k & 1][0], E->stream);
           engine_launch_pair(g.fam != 0, g.wave1 != 0, g.segc != 0, g.n, g.items, E->stream, dpa + g.lo);
+          if (samp) (void)hipEventRecord(E->pev[k & 1][1], E->stream);
           engine_launch_step(g.cls, dim3((unsigned)(2 * g.maxB), (unsigned)g.n), g.dyn, E->stream, dca + g.lo, dcc + g.lo);
+          if (samp) (void)hipEventRecord(E->pev[k & 1][2], E->stream);
         }
       hipLaunchKernelGGL(k_gather_done, dim3(1), dim3(ENGINE_MAX_JOBS), 0, E->stream, n, (const int* const*)(E->d_args + ENG_OFF_DP), E->d_flags);
       if (!chk(hipGetLastError(), "shared launch")) return;
@@ -194,6 +204,14 @@ static void engine_main(LaunchEngine* E) {
       if (!chk(hipEventSynchronize(E->ev[(k + 1) & 1]), "hipEventSynchronize")) return;
       E->st_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
       std::lock_guard<std::mutex> lk(E->mu);
+      if (Pv.prof) {
+        float a = 0, b = 0;
+        hipEvent_t* pe = E->pev[(k + 1) & 1];
+        if (hipEventElapsedTime(&a, pe[0], pe[1]) == hipSuccess && hipEventElapsedTime(&b, pe[1], pe[2]) == hipSuccess) {
+          E->st_pair_ms += a; E->st_step_ms += b; E->st_prof_n += 1; E->st_prof_folds += Pv.prof_folds;
+        }
+        Pv.prof = false;
+      }
       bool woke = false;
       for (size_t i = 0; i < E->draining.size();) {   // named in no launch that is still in flight: the owner may have its buffers back
         EngineJob* j = E->draining[i];
@@ -229,6 +247,7 @@ static bool engine_start(LaunchEngine* E) {   // (g_engine_mutex held)
   bool ok = hipMalloc((void**)&E->d_args, ENG_ARGS_BYTES) == hipSuccess && hipMalloc((void**)&E->d_flags, sizeof(int) * ENGINE_MAX_JOBS) == hipSuccess;
   for (int i = 0; i < 3 && ok; i++) ok = hipHostMalloc((void**)&E->h_args[i], ENG_ARGS_BYTES) == hipSuccess;
   for (int i = 0; i < 2 && ok; i++) ok = hipHostMalloc((void**)&E->h_flags[i], sizeof(int) * ENGINE_MAX_JOBS) == hipSuccess && hipEventCreateWithFlags(&E->ev[i], hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < 2 && ok; i++) for (int q = 0; q < 3 && ok; q++) ok = hipEventCreate(&E->pev[i][q]) == hipSuccess;
   if (ok) {
     int lds_max = 0;
     if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, E->device) != hipSuccess || lds_max <= 0) lds_max = 65536;

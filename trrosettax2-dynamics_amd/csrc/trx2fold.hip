@@ -1298,17 +1298,21 @@ extern "C" int trx2_set_shared_launches(int mode) {
   return 0;
 }
 
-// out[5] summed over the device's engines: chunks of ENGINE_CHUNK launch pairs enqueued, folds x chunks (their ratio = folds per
-// launch), folds completed, seconds the engine threads spent enqueuing, seconds they waited for the GPU
+// out[9] summed over the device's engines: chunks of ENGINE_CHUNK launch pairs enqueued, folds x chunks (their ratio = folds per
+// launch), folds completed, seconds the engine threads spent enqueuing, seconds they waited for the GPU; with
+// trx2_set_shared_launch_profiling(1): summed milliseconds of the sampled pair / step launches (one launch pair per chunk, HIP events
+// on the engine's stream), their number, and the folds they held
+extern "C" int trx2_set_shared_launch_profiling(int on) { g_engine_prof = on ? 1 : 0; return 0; }
 extern "C" int trx2_shared_launch_stats(int device, double* out) {
   if (!out) return 1;
-  for (int i = 0; i < 5; i++) out[i] = 0;
+  for (int i = 0; i < 9; i++) out[i] = 0;
   std::lock_guard<std::mutex> lk(g_engine_mutex);
   auto it = g_engines.find(device);
   if (it == g_engines.end()) return 0;
   for (LaunchEngine* E : it->second) {
     std::lock_guard<std::mutex> l2(E->mu);
     out[0] += E->st_chunks; out[1] += E->st_jobs; out[2] += E->st_done; out[3] += E->st_enqueue_s; out[4] += E->st_wait_s;
+    out[5] += E->st_pair_ms; out[6] += E->st_step_ms; out[7] += E->st_prof_n; out[8] += E->st_prof_folds;
   }
   return 0;
 }
