@@ -128,7 +128,9 @@ enum {
 #define TRX2_RAND_CUM_INIT {0.135, 0.29, 0.363, 0.485, 0.982, 2.0}
 
 /* omega_bb: E = OMEGA_K * (wrap(omega - 180 deg) in degrees)^2 */
+#ifndef TRX2_OMEGA_K
 #define TRX2_OMEGA_K 0.05
+#endif
 
 /* cart_bonded surrogate (Cartesian run only): E = K (x - x0)^2 on bond lengths, bond angles and two impropers (CB
  * chirality, carbonyl planarity) around the ideal values above, weight 0.1 in sf_cart (folding/data/scorefxn_cart.wts).
@@ -136,9 +138,12 @@ enum {
  * (tools/derive_constants.py: bonds sd 0.009-0.011 A, N-CA-C sd 2.4 deg, C-N-CA sd 2.0 deg, omega sd 6.9 deg): with these
  * values tools/model_scan.py gives bonds 0.007-0.008 A, N-CA-C 2.6-2.8, C-N-CA 2.5-2.9, omega 4.7-7.0.  Softer angles
  * (K 80: spread 8.9 deg) let the chain cheat on the restraints; stiffer ones (K 8000) push the strain back into omega. */
-#define TRX2_CART_KLEN 15000.0 /* per A^2   */
-#define TRX2_CART_KANG 3000.0  /* per rad^2 */
-#define TRX2_CART_KIMP 300.0   /* per rad^2 */
+#ifndef TRX2_CART_KSCALE
+#define TRX2_CART_KSCALE 1.0 /* model scans only (tools/runs/r04_model_scan.sh) */
+#endif
+#define TRX2_CART_KLEN (15000.0 * TRX2_CART_KSCALE) /* per A^2   */
+#define TRX2_CART_KANG (3000.0 * TRX2_CART_KSCALE)  /* per rad^2 */
+#define TRX2_CART_KIMP (300.0 * TRX2_CART_KSCALE)   /* per rad^2 */
 
 /* ---- minimiser (own design; Rosetta's lbfgs_armijo_nonmonotone is not in the tree) --------------- */
 /* L-BFGS history (stored correction pairs).  No reference pin exists (Rosetta's value is not in the tree).  12 and 8 give

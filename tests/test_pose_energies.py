@@ -89,7 +89,8 @@ def test_surrogate_terms_against_the_reference_decoys_energy_tables(table, golde
             rho[n].append(r); ratio[n].append(a.sum() / bsum if abs(bsum) > 1e-9 else float("nan"))
             cells.append(("%10.2f" % r if np.isfinite(r) else "         -") + " | %6.2f / %7.2f" % (a.sum(), bsum))
         lines.append("%-9s" % dec + "".join("%26s" % c for c in cells))
-    lines.append("%-9s" % "median" + "".join("%10.2f | ratio %9.2f" % (np.nanmedian(rho[n]), np.nanmedian(ratio[n])) for n in names))
+    med = lambda v: float(np.median([x for x in v if np.isfinite(x)])) if any(np.isfinite(x) for x in v) else float("nan")
+    lines.append("%-9s" % "median" + "".join("%10.2f | ratio %9.2f" % (med(rho[n]), med(ratio[n])) for n in names))
     report = "\n".join(lines)
     print("\n" + report)
     if os.environ.get("TRX2_WRITE_REPORT") == "1":
