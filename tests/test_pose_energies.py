@@ -13,9 +13,11 @@ a sign error or a mis-assigned residue, no more -- every surrogate is a differen
 rama: a mixture of six basins, >= 0, vs sequence-dependent tables relative to the average; cart_bonded: backbone-only harmonic
 terms vs all atoms; fa_rep: five backbone atoms vs every atom with its hydrogens).  Rosetta prints the backbone hydrogen-bond
 energies per POSE only (its per-residue columns are zero: the term is context dependent), so that term is compared by totals.
-Findings: the bonded surrogate ranks residues like cart_bonded does (rho 0.6-0.75) at ~25 x the energy for the
-same deviations; the omega tether is ~10 x stiffer than ref2015's; the hydrogen-bond total is half of Rosetta's; the rama surrogate
-sits ~1.3 per residue above Rosetta's (the offset remove_clash's guard would need, trx2_model.h TRX2_RAMA_GUARD_OFFSET)."""
+Findings, with the constants of rounds 1-3: the bonded surrogate ranked residues like cart_bonded does (rho
+0.6-0.75) at 25 x the energy for the same deviations; the omega tether was 13 x ref2015's; the hydrogen-bond total is half of
+Rosetta's; the rama surrogate sits 1.3 per residue above Rosetta's.  Round 4 acts on it where ref2015 applies: the relax stage
+scales the two surrogates by 0.4 (protocol.SF_FA_SCALE: as far towards Rosetta's scale as the outcome improves) and remove_clash's
+guard gets the rama offset (trx2_model.h TRX2_RAMA_GUARD_OFFSET); the centroid stage keeps its calibration."""
 import importlib
 import json
 import os
@@ -95,7 +97,7 @@ def test_surrogate_terms_against_the_reference_decoys_energy_tables(table, golde
     print("\n" + report)
     if os.environ.get("TRX2_WRITE_REPORT") == "1":
         open(os.path.join(ROOT, "profiles", "r04_pose_energies.txt"), "w").write(report + "\n")
-    # measured medians over the eight decoys: rho omega 0.32, rama 0.15, cart_bonded 0.70, repulsion 0.37; totals: hydrogen bonds 0.52 x
+    # measured medians over the eight decoys: rho omega 0.32, rama 0.15, cart_bonded 0.70, repulsion 0.37; totals: hydrogen bonds 0.51 x
     # Rosetta's, cart_bonded 25 x, omega 13 x.  Floors at about half the measured correlation; bands around the measured ratios.
     assert np.nanmedian(rho["omega"]) > 0.15 and np.nanmedian(rho["cart_bonded"]) > 0.5 and np.nanmedian(rho["repulsion"]) > 0.2 and np.nanmedian(rho["rama"]) > 0.0, rho
-    assert 0.35 < np.nanmedian(ratio["hbond_bb"]) < 0.75 and 10 < np.nanmedian(ratio["cart_bonded"]) < 50, ratio
+    assert 0.35 < np.nanmedian(ratio["hbond_bb"]) < 0.75 and 12 < np.nanmedian(ratio["cart_bonded"]) < 50 and 6 < np.nanmedian(ratio["omega"]) < 26, ratio
