@@ -165,6 +165,10 @@ def test_device_af2_tables_eval_and_fold(ctx, data):
     for dd in range(5):
         fo, eo, go, _ = O.evaluate(Tb, tors[dd].astype(np.float64), w)
         assert abs(e[dd, 0] - eo[0]) <= 2e-4 * abs(eo[0]) + 0.1 and np.abs(gr[dd] - go).max() <= 1e-2 * np.abs(go).max(), dd
+    # a SINGLE decoy evaluates through the segment cache (60-knot C-alpha tables): cold, then warm, both equal to the batch's numbers
+    for rep in range(2):
+        f1, e1, g1, _ = ctx.eval_batch(tors[:1], w)
+        assert abs(e1[0, 0] - e[0, 0]) <= 1e-5 * abs(e[0, 0]) + 0.05 and np.abs(g1[0] - gr[0]).max() <= 2e-3 * np.abs(gr[0]).max() + 1e-3, rep   # (another summation order)
     r = ctx.fold_batch(8, T.protocol.build_runs(90, 2), seed=4)                 # C-alpha restraints fold the chain
     from oracle.kabsch import kabsch_rmsd
     ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_decoys.npz"))["conf_2_1"][:, 1]
@@ -183,6 +187,12 @@ def test_device_gpcr_tables(ctx, data):
     ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=data["seq"], idr=m["idr"])
     rows = R.gpcr_rows(m, data["known"], data["params"])
     Tb = O.Tables(m["dist"], m["omega"], m["theta"], m["phi"], seq=data["seq"])
+    # a single decoy BEFORE the edits: fills its segment cache from the unedited tables; the edits below must invalidate it
+    w0 = np.array(T.protocol.SF, np.float64)
+    t1 = O.random_torsions(90, 8, 0).astype(np.float32)[None]
+    for rep in range(2):
+        f_b, _, _, _ = ctx.eval_batch(t1, w0)
+        assert abs(f_b[0] - O.evaluate(Tb, t1[0].astype(np.float64), w0)[0]) <= 2e-4 * abs(f_b[0]) + 1.0
     for ch, (a, b, y) in rows.items():
         ctx.override_rows(ch, a, b, y)
         Tb.override_rows(ch, a, b, y)
@@ -195,5 +205,9 @@ def test_device_gpcr_tables(ctx, data):
     for d in range(3):
         fo, eo, go, _ = O.evaluate(Tb, tors[d].astype(np.float64), w)
         assert abs(f[d] - fo) <= 2e-4 * abs(fo) + 1.0 and np.abs(g[d] - go).max() <= 1e-2 * np.abs(go).max()
+    # ... and the single decoy AFTER them: the edited tables' energy, not the cached segments' (the edits move it by thousands)
+    f_a, _, g_a, _ = ctx.eval_batch(t1, w)
+    fo, _, go, _ = O.evaluate(Tb, t1[0].astype(np.float64), w)
+    assert abs(f_a[0] - fo) <= 2e-4 * abs(fo) + 1.0 and np.abs(g_a[0] - go).max() <= 1e-2 * np.abs(go).max() and abs(f_a[0] - f_b[0]) > 10.0, (f_a[0], f_b[0], fo)
     with pytest.raises(RuntimeError):
         ctx.override_rows("dist", [5], [2], np.zeros((1, 35)))                   # dist rows live at a < b

@@ -475,6 +475,9 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
     STAMP(10)  // contact scan
     // per-lane walk: every lane follows its own contact bits (max-over-lanes steps): repulsion over the 5 x 5 atom pairs and
     // the two hydrogen-bond candidates of the pair, gradient on residue a's atoms; symmetric energies counted from the lower row
+    // (Round 4, measured and not kept: the NEXT contact's residue requested before the current one is evaluated -- 20 more live
+    // registers: at three waves per SIMD every instantiation spilled 20-40 of them, at two the occupancy cost more than the overlap
+    // gave: config 2 326 -> 270 / 318 decoys/s, pooled queue 1664 -> 1480 / 1437, config 3 637 -> 588 / 575; profiles/README.md.)
     while (vmask) {  // per-lane trip count; lanes without further contacts idle
       const int v = __ffs((int)vmask) - 1;
       vmask &= vmask - 1;
