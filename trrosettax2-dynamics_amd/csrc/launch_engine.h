@@ -292,10 +292,12 @@ static LaunchEngine* engine_pick(int device) {
 }
 
 // Hands a prepared fold to an engine and sleeps until its decoys have reported (or its launch cap is reached).  0: done (job->done,
-// job->launches are set); 1: error (job->err).
+// job->launches are set); 1: error (job->err); 2: the engine is full (other threads filled it since engine_pick looked) -- nothing was
+// queued, the fold launches for itself.
 static int engine_run(LaunchEngine* E, EngineJob* job) {
   std::unique_lock<std::mutex> lk(E->mu);
   if (E->broken) { job->err = "shared launches: " + E->broken_why; return 1; }
+  if (E->load() >= ENGINE_MAX_JOBS) return 2;   // the argument arrays hold ENGINE_MAX_JOBS folds
   job->id = E->next_id++;
   job->state = 0;
   E->queued.push_back(job);

@@ -1183,10 +1183,13 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
       if (!ctx->ev_ready) HIPCHK(hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming));
       HIPCHK(hipEventRecord(ctx->ev_ready, ctx->stream));
       job.ready = ctx->ev_ready;
-      if (engine_run(E, &job)) { ctx->err = job.err; return 1; }
-      launches = (int)job.launches; slot_launches = (double)job.launches * B;
-      *ctx->h_done = job.done;
-      via_engine = true;
+      const int erc = engine_run(E, &job);
+      if (erc == 1) { ctx->err = job.err; return 1; }
+      if (erc == 0) {
+        launches = (int)job.launches; slot_launches = (double)job.launches * B;
+        *ctx->h_done = job.done;
+        via_engine = true;
+      }   // (2: the engine was full: this fold launches for itself below)
     }
   }
   // The chunk is a static graph (its only per-evaluation input, the sequence number, lives in device memory): capture it
