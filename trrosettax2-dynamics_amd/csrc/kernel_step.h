@@ -386,7 +386,10 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
       if (A.mode == MODE_STEP) { e_x = A.X[vr]; e_g = A.G[vr]; e_dv = A.D[vr]; }
     }
   }
-  constexpr bool HIST_LDS = (RPT == 1 && NT <= 256);  // chains of up to 256 residues: the history staged in LDS for the step
+  // chains of up to 512 residues (one residue per thread): the history staged in LDS for the step.  (256 < L <= 512 since round 4: 256 L
+  // bytes of dynamic LDS, 128 KB at 512 residues, beside 16 KB of static LDS now that the Cartesian role's arrays of that
+  // instantiation live in the dynamic buffer too; rounds 2-3 read it from global memory twice per step.)
+  constexpr bool HIST_LDS = (RPT == 1 && NT <= 512);
   // One residue per thread (chains of up to 512 residues on up to 512 threads): the recursion in its Gram form.  The 144
   // scalars do not depend on the chain length.  Beyond 256 residues the stored vectors are not staged in LDS (128 KB at 512
   // residues, beside the Cartesian role's static LDS) but read from global memory: the Gram form reads each of them twice
@@ -718,7 +721,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
             const int r = kr * NT + tid, rc = min(r, L - 1);
             // the reads of HB pairs issued together (a slot that holds no pair is read and discarded: one wait instead of HB).  Staged
             // history: all LBM pairs at once; from global memory (chains beyond 256 residues): four pairs at a time (registers)
-            constexpr int HB = HIST_LDS ? LBM : LBM / 2;
+            constexpr int HB = (HIST_LDS && NT <= 256) ? LBM : LBM / 2;   // (512 threads run at 256 registers: four pairs at a time)
 #pragma unroll
             for (int k0 = 0; k0 < LBM; k0 += HB) {
               float4 so[HB], yo[HB];
@@ -848,7 +851,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
         for (int kr = 0; kr < RPT; kr++) {
           const int r = kr * NT + tid, rc = min(r, L - 1);
           float4 q = make_float4(gam * g[kr].x, gam * g[kr].y, gam * g[kr].z, 0);
-          constexpr int HB = HIST_LDS ? LBM : LBM / 2;
+          constexpr int HB = (HIST_LDS && NT <= 256) ? LBM : LBM / 2;
 #pragma unroll
           for (int m0 = 0; m0 < LBM; m0 += HB) {
             float4 sm[HB], ym[HB];
@@ -1214,13 +1217,15 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
   // cost 2-5 % at the small launch shapes); in the low-register one they live in the launch's DYNAMIC LDS, in front of the staged
   // pairs and in rows L long (100 L bytes; the torsion role's workgroups use the same bytes for their history), so that the
   // kernel's static LDS is 9 KB instead of 35 and two workgroups share a CU up to 256 residues.
-  __shared__ float st_xyz[LOWREG ? 4 : NT * 16];
-  __shared__ float st_dt[LOWREG ? 4 : NT * 6];
-  __shared__ float st_gp[LOWREG ? 4 : NT * 3];
-  lds_f* const s_xyz = LOWREG ? (lds_f*)s_hist : (lds_f*)st_xyz;   // [.][16] trial coordinates (neighbours read each other's)
-  lds_f* const s_dt = LOWREG ? s_xyz + (size_t)L * 16 : (lds_f*)st_dt;  // [.][6] gradient a residue's psi, omega and link terms put on N and CA of the residue after it
-  lds_f* const s_gp = LOWREG ? s_dt + (size_t)L * 6 : (lds_f*)st_gp;    // [.][3] gradient a residue's phi and backbone H put on C of the residue before it
-  lds_f4* const c_hist = (lds_f4*)s_hist + (LOWREG ? CART_ARRAYS_BYTES(L) / 16 : 0);
+  // (... and in the 512-thread instantiation, whose torsion role stages its history in up to 128 KB of dynamic LDS: ARR_DYN)
+  constexpr bool ARR_DYN = LOWREG || NT > 256;
+  __shared__ float st_xyz[ARR_DYN ? 4 : NT * 16];
+  __shared__ float st_dt[ARR_DYN ? 4 : NT * 6];
+  __shared__ float st_gp[ARR_DYN ? 4 : NT * 3];
+  lds_f* const s_xyz = ARR_DYN ? (lds_f*)s_hist : (lds_f*)st_xyz;   // [.][16] trial coordinates (neighbours read each other's)
+  lds_f* const s_dt = ARR_DYN ? s_xyz + (size_t)L * 16 : (lds_f*)st_dt;  // [.][6] gradient a residue's psi, omega and link terms put on N and CA of the residue after it
+  lds_f* const s_gp = ARR_DYN ? s_dt + (size_t)L * 6 : (lds_f*)st_gp;    // [.][3] gradient a residue's phi and backbone H put on C of the residue before it
+  lds_f4* const c_hist = (lds_f4*)s_hist + (ARR_DYN ? CART_ARRAYS_BYTES(L) / 16 : 0);
   int* gi = A.st_i + (size_t)dec * SI_N;
   double* gd_ = A.st_d + (size_t)dec * SD_N;
   KSTAMP_DECL

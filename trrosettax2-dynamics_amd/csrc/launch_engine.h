@@ -252,8 +252,9 @@ static bool engine_start(LaunchEngine* E) {   // (g_engine_mutex held)
     int lds_max = 0;
     if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, E->device) != hipSuccess || lds_max <= 0) lds_max = 65536;
     if (lds_max > 160 * 1024) lds_max = 160 * 1024;
-    const void* f[2] = {(const void*)k_step_multi<1, 128, 128>, (const void*)k_step_multi<1, CHAIN_THREADS, CHAIN_THREADS>};
-    for (int q = 0; q < 2 && ok; q++) {
+    const void* f[3] = {(const void*)k_step_multi<1, 128, 128>, (const void*)k_step_multi<1, CHAIN_THREADS, CHAIN_THREADS>,
+                        (const void*)k_step_multi<1, 2 * CHAIN_THREADS, 2 * CHAIN_THREADS>};
+    for (int q = 0; q < 3 && ok; q++) {
       hipFuncAttributes fa;
       ok = hipFuncGetAttributes(&fa, f[q]) == hipSuccess &&
            hipFuncSetAttribute(f[q], hipFuncAttributeMaxDynamicSharedMemorySize, lds_max - (int)fa.sharedSizeBytes) == hipSuccess;

@@ -262,6 +262,14 @@ static int ctx_create_impl(int device, trx2_ctx** out, hipStream_t avoid_stream)
     const int hist[2] = {HIST_LDS_BYTES(128), HIST_LDS_BYTES(CHAIN_THREADS)};
     bool ok = hipFuncSetAttribute((const void*)k_chain<1, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, hist[0]) == hipSuccess &&
               hipFuncSetAttribute((const void*)k_chain<1, CHAIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, hist[1]) == hipSuccess;
+    {  // 256 < L <= 512: the torsion history (256 L bytes) in dynamic LDS too
+      const void* f512[2] = {(const void*)k_chain<1, 2 * CHAIN_THREADS>, (const void*)k_step<1, 2 * CHAIN_THREADS, 2 * CHAIN_THREADS>};
+      for (int k = 0; k < 2 && ok; k++) {
+        hipFuncAttributes fa;
+        ok = hipFuncGetAttributes(&fa, f512[k]) == hipSuccess && lds_max - (int)fa.sharedSizeBytes >= (int)HIST_LDS_BYTES(2 * CHAIN_THREADS) &&
+             hipFuncSetAttribute(f512[k], hipFuncAttributeMaxDynamicSharedMemorySize, lds_max - (int)fa.sharedSizeBytes) == hipSuccess;
+      }
+    }
     for (int k = 0; k < 2 && ok; k++) {
       hipFuncAttributes fa;
       ok = hipFuncGetAttributes(&fa, fstep[k]) == hipSuccess;
@@ -948,7 +956,7 @@ static void launch_chain_args(trx2_ctx* c, int B, const ChainArgs& A) {
   // scan combines two partials instead of four
   if (L <= 128) hipLaunchKernelGGL((k_chain<1, 128>), grid, dim3(128), HIST_LDS_BYTES(L), c->stream, A);
   else if (L <= CHAIN_THREADS) hipLaunchKernelGGL((k_chain<1, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), HIST_LDS_BYTES(L), c->stream, A);
-  else if (L <= 2 * CHAIN_THREADS) hipLaunchKernelGGL((k_chain<1, 2 * CHAIN_THREADS>), grid, dim3(2 * CHAIN_THREADS), 0, c->stream, A);  // one residue per thread, history from global memory
+  else if (L <= 2 * CHAIN_THREADS) hipLaunchKernelGGL((k_chain<1, 2 * CHAIN_THREADS>), grid, dim3(2 * CHAIN_THREADS), HIST_LDS_BYTES(L), c->stream, A);  // one residue per thread
   else hipLaunchKernelGGL((k_chain<4, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), 0, c->stream, A);
 }
 
@@ -1127,7 +1135,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   auto step_lds = [&](CartArgs& cc) -> size_t {
     const int k = L <= 128 ? 0 : 1;
     const size_t arrays = two_per_cu ? CART_ARRAYS_BYTES(L) : 0;
-    size_t dyn = L <= CHAIN_THREADS ? HIST_LDS_BYTES(L) : 0;
+    size_t dyn = L <= 2 * CHAIN_THREADS ? HIST_LDS_BYTES(L) : 0;   // (also covers the Cartesian role's arrays, 100 L bytes, where they are dynamic)
     if (L <= CHAIN_THREADS) {
       const int budget = (two_per_cu ? two_cap : step_dyn_budget(ctx, k, L)) - (int)arrays;
       cc.hist_lds = budget > 0 ? (int)std::min<size_t>(LBM, (size_t)budget / CART_HIST_BYTES(L)) : 0;
