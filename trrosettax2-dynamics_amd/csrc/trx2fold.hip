@@ -22,6 +22,9 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <vector>
 
 #include "../../include/trx2fold.h"
@@ -76,6 +79,38 @@ struct RowPlan {
   unsigned char* nslice = nullptr;  // device [L]
   size_t cap_items = 0, cap_L = 0;
 };
+// Host thread of a context's second lane (trx2_ctx_set_lanes): started with the lane, parked on a condition variable between
+// calls, joined when the lane goes -- a two-lane call hands it one job instead of creating a thread of its own every time.
+struct LaneWorker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<int()> job;
+  bool has_job = false, done = false, quit = false;
+  int rc = 0;
+  void main_loop() {
+    std::unique_lock<std::mutex> lk(mu);
+    while (true) {
+      cv.wait(lk, [&] { return has_job || quit; });
+      if (quit) return;
+      std::function<int()> f = std::move(job);
+      has_job = false;
+      lk.unlock();
+      const int r = f();
+      lk.lock();
+      rc = r; done = true;
+      cv.notify_all();
+    }
+  }
+  void start() { th = std::thread([this] { main_loop(); }); }
+  void submit(std::function<int()> f) { std::lock_guard<std::mutex> lk(mu); job = std::move(f); has_job = true; done = false; cv.notify_all(); }
+  int wait() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return done; }); done = false; return rc; }
+  void stop() {
+    { std::lock_guard<std::mutex> lk(mu); quit = true; cv.notify_all(); }
+    if (th.joinable()) th.join();
+  }
+};
+
 struct trx2_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -153,6 +188,7 @@ struct trx2_ctx {
   // second lane (trx2_ctx_set_lanes): a context of its own stream and batch buffers that BORROWS this one's tables, so that
   // one job can run as two half-batches whose pair and step kernels overlap
   trx2_ctx* child = nullptr;
+  LaneWorker* lane_worker = nullptr;   // the child's host thread (lives as long as the child)
   bool borrows_map = false;
   // feedback scratch (trx2_feedback_*): grows on demand
   void* fb_buf = nullptr; size_t fb_cap = 0;
@@ -437,10 +473,13 @@ extern "C" int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes) {
     k->pair1_waves = ctx->pair1_waves;
     k->compact = ctx->compact;
     ctx->child = k;
+    ctx->lane_worker = new LaneWorker();
+    ctx->lane_worker->start();
     if (ctx->L) { HIPCHK(hipStreamSynchronize(ctx->stream)); lend_map(ctx); }
   } else if (lanes == 1 && ctx->child) {
     trx2_ctx* k = ctx->child;
     ctx->child = nullptr;
+    if (ctx->lane_worker) { ctx->lane_worker->stop(); delete ctx->lane_worker; ctx->lane_worker = nullptr; }
     trx2_ctx_destroy(k);  // borrows_map: frees its batch buffers only
   }
   return 0;
@@ -450,6 +489,7 @@ extern "C" void trx2_ctx_destroy(trx2_ctx* ctx) {
   if (!ctx) return;
   g_live_contexts--;
   (void)hipSetDevice(ctx->device);
+  if (ctx->lane_worker) { ctx->lane_worker->stop(); delete ctx->lane_worker; ctx->lane_worker = nullptr; }
   if (ctx->child) { trx2_ctx* k = ctx->child; ctx->child = nullptr; trx2_ctx_destroy(k); }
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
@@ -1337,20 +1377,19 @@ extern "C" int trx2_fold_batch(trx2_ctx* ctx, int B, const trx2_run* runs, int n
                                double* f_final, int* status, int* n_evals, int* n_iters) {
   if (!ctx) return 1;
   trx2_ctx* k = ctx->child;
-  if (!k || B < TRX2_LANE_MIN_B || !ctx->L)
+  if (!k || !ctx->lane_worker || B < TRX2_LANE_MIN_B || !ctx->L)
     return fold_impl(ctx, B, runs, nruns, seed, decoy0, tors0, max_evals, tors_out, xyz_out, e_terms, f_final, status, n_evals, n_iters);
   const int B0 = (B + 1) / 2, B1 = B - B0;
   const size_t L = (size_t)ctx->L;
   auto t0 = std::chrono::steady_clock::now();
-  int rc1 = 0;
-  std::thread other([&]() {
-    rc1 = fold_impl(k, B1, runs, nruns, seed, decoy0 + (uint32_t)B0, tors0 ? tors0 + (size_t)B0 * L * 3 : nullptr, max_evals,
-                    tors_out ? tors_out + (size_t)B0 * L * 3 : nullptr, xyz_out ? xyz_out + (size_t)B0 * L * 15 : nullptr,
-                    e_terms ? e_terms + (size_t)B0 * TRX2_NTERMS : nullptr, f_final ? f_final + B0 : nullptr,
-                    status ? status + B0 : nullptr, n_evals ? n_evals + B0 : nullptr, n_iters ? n_iters + B0 : nullptr);
+  ctx->lane_worker->submit([&]() {
+    return fold_impl(k, B1, runs, nruns, seed, decoy0 + (uint32_t)B0, tors0 ? tors0 + (size_t)B0 * L * 3 : nullptr, max_evals,
+                     tors_out ? tors_out + (size_t)B0 * L * 3 : nullptr, xyz_out ? xyz_out + (size_t)B0 * L * 15 : nullptr,
+                     e_terms ? e_terms + (size_t)B0 * TRX2_NTERMS : nullptr, f_final ? f_final + B0 : nullptr,
+                     status ? status + B0 : nullptr, n_evals ? n_evals + B0 : nullptr, n_iters ? n_iters + B0 : nullptr);
   });
   const int rc0 = fold_impl(ctx, B0, runs, nruns, seed, decoy0, tors0, max_evals, tors_out, xyz_out, e_terms, f_final, status, n_evals, n_iters);
-  other.join();
+  const int rc1 = ctx->lane_worker->wait();   // (its references to this frame end here)
   if (rc1 != 0 && rc0 == 0) ctx->err = "second lane: " + k->err;
   ctx->last_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   ctx->last_launches = ctx->last_launches > k->last_launches ? ctx->last_launches : k->last_launches;

@@ -29,6 +29,8 @@ _CTX = {}           # (device, host thread) -> Context: successive calls reuse t
                     # thread-safe, distinct Contexts run concurrently (the NMR and X-ray chains are folded that way)
 _SEED = [0x5EED]    # advances per call: distinct decoys across calls unless the caller fixes `seed`
 _SEED_LOCK = threading.Lock()
+_CTX_LOCK = threading.Lock()
+_CTX_OWNER = {}   # (device, thread ident) -> the Thread object that made the cached context
 
 
 def parse_options(options):
@@ -70,12 +72,28 @@ SLOTS_PER_LANE = 960  # every decoy in flight up to this many per lane (tools/po
 
 
 def get_context(device=0, lanes=1):
+    """The calling thread's context on `device` (created on first use).  Contexts of threads that have ended without
+    close_contexts() are closed here, so a long-lived caller with thread churn does not pile up streams and buffers (and a new
+    thread that is handed a dead thread's ident never inherits its context)."""
     key = (device, threading.get_ident())
-    if key not in _CTX:
-        _CTX[key] = Context(device)
-    if _CTX[key].lanes != lanes:
-        _CTX[key].set_lanes(lanes)
-    return _CTX[key]
+    with _CTX_LOCK:
+        alive = {t.ident for t in threading.enumerate()}
+        dead = [_CTX.pop(k) for k in list(_CTX) if k[1] not in alive]
+        ctx = _CTX.get(key)
+        if ctx is None:
+            ctx = _CTX[key] = Context(device)
+            _CTX_OWNER[key] = threading.current_thread()
+        elif _CTX_OWNER.get(key) is not threading.current_thread():   # ident reused by a new thread before the sweep saw the old one gone
+            dead.append(ctx)
+            ctx = _CTX[key] = Context(device)
+            _CTX_OWNER[key] = threading.current_thread()
+        for k in [k for k in _CTX_OWNER if k not in _CTX]:
+            del _CTX_OWNER[k]
+    for c in dead:
+        c.close()
+    if ctx.lanes != lanes:
+        ctx.set_lanes(lanes)
+    return ctx
 
 
 def close_contexts(all_threads=False):
@@ -83,8 +101,12 @@ def close_contexts(all_threads=False):
     A context holds a stream, its maps and its batch buffers on the GPU; a worker thread that ends without this leaves them
     allocated until the process ends."""
     me = threading.get_ident()
-    for key in [k for k in list(_CTX) if all_threads or k[1] == me]:
-        _CTX.pop(key).close()
+    with _CTX_LOCK:
+        mine = [_CTX.pop(k) for k in list(_CTX) if all_threads or k[1] == me]
+        for k in [k for k in _CTX_OWNER if k not in _CTX]:
+            del _CTX_OWNER[k]
+    for c in mine:
+        c.close()
 
 
 def set_restraints(ctx, npz, seq, args, ang):

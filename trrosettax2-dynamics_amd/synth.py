@@ -6,6 +6,11 @@ Two kinds of target structure:
       pivot Monte-Carlo on the loop torsions only (simulated annealing on radius of gyration + C-alpha clashes).  Rigid rods
       joined by short loops cannot thread through each other, so the target is free of the knots and entanglements that made
       the round-1 random-coil targets unfoldable from random starts (measured: DESIGN.md section 2).
+  "meander", "mixed": the same construction with extended strands (phi, psi = -120, 130) of 5-9 residues and turns of 2-4 in place
+      of the helices, or with helices and strands in turn: extended chains whose residues sit in the beta basin of the torsion
+      potential and whose restraints are mostly long-range (a helical bundle's are half local).  The strands are NOT paired into
+      hydrogen-bonded sheets (the pivot Monte-Carlo does not find a registry; tried with a pairing reward, 0.5 units of the
+      model's hydrogen-bond energy against 33 in a bundle of the same length).
   "coil": the round-1 recipe below, kept for the evaluation-parity tests (any structure will do there).
 
 Recipe ("coil"): a backbone is built by NeRF from torsions drawn from the reference's start table
@@ -111,21 +116,29 @@ def _rot(points, origin, axis, ang):
     return origin + v * c + np.cross(k, v) * s_ + np.outer(v @ k, k) * (1 - c)
 
 
-def bundle_torsions(L, seed, n_moves=None):
-    """Helical-bundle target: secondary-structure layout from the seed, then pivot Monte-Carlo over the loop torsions."""
-    rng = np.random.default_rng(seed + 7919)
-    ss = np.zeros(L, bool)                      # True = helix
+def bundle_torsions(L, seed, n_moves=None, kind="bundle"):
+    """Secondary-structure layout from the seed, then pivot Monte-Carlo over the loop torsions.  kind: "bundle" rigid helices of
+    12-24 residues joined by loops of 3-6; "meander" extended strands of 5-9 residues joined by turns of 2-4; "mixed" helices and
+    strands in turn."""
+    rng = np.random.default_rng(seed + 7919 + {"bundle": 0, "meander": 101, "mixed": 211}[kind])
+    ss = np.zeros(L, bool)                      # True = rigid element
+    strand = np.zeros(L, bool)                  # ... which is an extended strand
     i = int(rng.integers(1, 4))
+    k = 0
     while i < L - 8:
-        n = int(rng.integers(12, 25))
+        is_strand = kind == "meander" or (kind == "mixed" and k % 2 == 1)
+        n = int(rng.integers(5, 10)) if is_strand else int(rng.integers(12, 25))
         ss[i:min(L - 2, i + n)] = True
-        i += n + int(rng.integers(3, 7))
+        strand[i:min(L - 2, i + n)] = is_strand
+        i += n + (int(rng.integers(2, 5)) if is_strand else int(rng.integers(3, 7)))
+        k += 1
     loops = np.nonzero(~ss)[0]
     loops = loops[(loops > 0) & (loops < L - 1)]
     loop_basins = BASINS[[0, 1, 2, 3]]          # beta / PPII / bridge regions of the reference's start table
     tors = np.empty((L, 3))
     tors[:, 2] = np.pi
     tors[:, :2] = BASINS[4]                     # (-61, -41): alpha helix
+    tors[strand, :2] = np.radians((-120.0, 130.0))   # antiparallel-sheet region
     for r in np.nonzero(~ss)[0]:
         tors[r, :2] = loop_basins[rng.integers(0, 4)] + rng.normal(size=2) * np.radians(10)
     N, CA, C, _ = nerf_backbone(tors)
@@ -185,8 +198,8 @@ def _blur_mix(onehot, sigma=1.5, mix=None):
 
 
 def make_map(L, seed=None, n_moves=None, kind=None):
-    """-> dict(dist[L,L,37], omega[L,L,25], theta[L,L,25], phi[L,L,13], tors[L,3], seq).  kind: "bundle" (default) or "coil"
-    (default when n_moves is given: the short-Monte-Carlo coils of the evaluation-parity tests)."""
+    """-> dict(dist[L,L,37], omega[L,L,25], theta[L,L,25], phi[L,L,13], tors[L,3], seq).  kind: "bundle" (default), "meander",
+    "mixed" (bundle_torsions) or "coil" (default when n_moves is given: the short-Monte-Carlo coils of the evaluation-parity tests)."""
     seed = L if seed is None else seed
     kind = kind or ("coil" if n_moves is not None else "bundle")
     cache = os.path.join(os.environ.get("TRX2_SYNTH_CACHE", os.path.join(tempfile.gettempdir(), "trx2_synth")),
@@ -206,7 +219,7 @@ def make_map(L, seed=None, n_moves=None, kind=None):
 
 
 def _make_map(L, seed, n_moves, kind="bundle"):
-    tors, _ = (bundle_torsions if kind == "bundle" else compact_torsions)(L, seed, n_moves)
+    tors, _ = bundle_torsions(L, seed, n_moves, kind) if kind in ("bundle", "meander", "mixed") else compact_torsions(L, seed, n_moves)
     N, CA, C, CB = nerf_backbone(tors)
     i, j = np.meshgrid(np.arange(L), np.arange(L), indexing="ij")
     with np.errstate(invalid="ignore", divide="ignore"):
