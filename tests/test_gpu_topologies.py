@@ -42,12 +42,14 @@ def test_non_bundle_targets_evaluate_like_the_oracle_and_fold(kind, L):
         med, lo, rm, mir = check_fold_properties(r, r2, m, Tb, True)
         print(f"{kind} L={L}: worst eval deviations {w}; tracking {trk}; evals median {int(np.median(r['n_evals']))}; "
               f"RMSD to target sorted {np.round(np.sort(rm), 2)}")
-        assert med > 0.90, med
+        # (the default protocol ends with the unrestrained closing minimisation: the restraint-energy depth of the last run is 0 by
+        # construction, so the fold is judged on the structure)
         assert np.median(rm) < RMSD_MEDIAN_MAX[kind] and (rm < 2.0).sum() >= WITHIN_2A_MIN[kind] * B, np.sort(rm)
     finally:
         ctx.close()
 
 
-# measured on MI355X (tools/runs/r04_run19.sh) + margin
-RMSD_MEDIAN_MAX = {"meander": 2.0, "mixed": 2.0}
-WITHIN_2A_MIN = {"meander": 0.5, "mixed": 0.5}
+# measured on MI355X (tools/runs/r04_run19.sh): meander median 0.40 A, 32 of 32 within 2 A (worst 1.61); mixed 0.32 A, 32 of 32
+# (worst 1.01); no mirror images (all four channels).  Limits = measured + margin.
+RMSD_MEDIAN_MAX = {"meander": 0.7, "mixed": 0.6}
+WITHIN_2A_MIN = {"meander": 0.9, "mixed": 0.9}
