@@ -48,7 +48,8 @@ int trx2_abi_version(void);
 int trx2_ctx_create(int device, trx2_ctx** out);
 void trx2_ctx_destroy(trx2_ctx* ctx);
 /* lanes = 2: trx2_fold_batch folds batches of 32 or more decoys as two halves on two streams (second half from an internal
- * host thread), so that one half's step kernel overlaps the other half's pair kernel: +24 % (distances only) / +32 % (all
+ * host thread that lives as long as the second lane: started by this call, parked between folds, joined by lanes = 1 or
+ * trx2_ctx_destroy), so that one half's step kernel overlaps the other half's pair kernel: +24 % (distances only) / +32 % (all
  * channels) decoys/s at L=150, B=64 on MI355X.  The reference has no counterpart: its decoys are separate OS processes
  * (utils_trX2dy/utils.py:501-503).  Every decoy keeps its identity (seed, decoy0 + index); results equal those of folding the
  * two halves as separate batches.  lanes = 1 (default) restores one stream.  Measured on MI355X, round 3 (one call of 64 decoys,
