@@ -20,7 +20,7 @@ CHECK_LIB = os.path.join(ROOT, "trrosettax2-dynamics_amd", "libtrx2fold_check.so
     # every other instantiation the library launches: the shared-launch kernels of single-decoy folds (k_step_multi of the three
     # thread counts, default protocol: B = 1 goes through the launch engine) and the 256-register step kernels that batches of
     # >= 128 / 160 slots per lane use (k_step<1, 128, 128, true>, k_step<1, 256, 256, true>)
-    (150, 1, 100000, 1, 1), (90, 1, 100000, 1, 1), (400, 1, 600, 1, 1), (150, 192, 400, 0, 0), (100, 160, 400, 1, 0)])
+    (150, 1, 100000, 1, 1), (90, 1, 100000, 1, 1), (400, 1, 100000, 1, 1), (150, 192, 100000, 0, 0), (100, 160, 100000, 1, 0)])
 def test_step_kernels_check_themselves(L, B, evals, orient, relax):
     """one residue per thread (L = 150, 90: 256- and 128-thread workgroups) through whole folds, chains of 257-512 residues (L = 400,
     the 512-thread kernel) through the declash runs and into the restraint stage"""
