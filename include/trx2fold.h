@@ -81,8 +81,10 @@ int trx2_ctx_set_pool(trx2_ctx* ctx, int slots);
  * Environment (A/B timing and tests only): TRX2_NSPLIT=n cuts every row into n slices whatever the shape; TRX2_ROW_TARGET=t sets
  * the plan's target of list entries per slice and partner residue of a wave step (default 18). */
 int trx2_ctx_set_tail_compaction(trx2_ctx* ctx, int mode);
-/* Shared launches (process-wide; default on, TRX2_SHARED_LAUNCH=0 turns them off, TRX2_ENGINE_STREAMS=1..3 sets the engines per device,
- * default 2).  A fold of ONE decoy -- every feedback iteration of run_inference.py:97-139 is one -- leaves the chip idle: a launch pair
+/* Shared launches (process-wide; TRX2_ENGINE_STREAMS=1..3 sets the engines per device, default 2).  Default: on as soon as five
+ * contexts are alive in the process (second lanes not counted) -- up to four chains fold 3-28 % faster launching for themselves, one
+ * hardware queue each; from the fifth on the queues are shared and the engines win (6 / 8 / 12 folds in flight: 6.3 / 5.3 / 4.5 us per
+ * fold-evaluation against 9.7 / 7.3 / 7.1; MI355X, L=150, tools/runs/r04_run23.sh).  TRX2_SHARED_LAUNCH=0 / 1 or mode 0 / 1 below force either.  A fold of ONE decoy -- every feedback iteration of run_inference.py:97-139 is one -- leaves the chip idle: a launch pair
  * of ~24 us on a few workgroups, thousands of them in sequence.  With shared launches such a fold does not launch for itself: it hands
  * its argument blocks (its own map's tables, row lists and row plan; its own state and buffers) to an engine thread of the library,
  * whose launch pairs step the single-decoy folds of ALL contexts that are folding at that moment (k_pair1_multi: blockIdx.z = fold,
@@ -90,7 +92,7 @@ int trx2_ctx_set_tail_compaction(trx2_ctx* ctx, int mode);
  * per chain calling trx2_fold_batch, as pipeline.run_batch does for the chains of run_inference.py:339-348's targets -- and neither do
  * the results: a fold's arithmetic does not depend on what shares its launches (bit-identical to mode 0: tests).  The reference's
  * counterpart is its process pool over `python folding.py` children (utils_trX2dy/utils.py:501-503).
- * mode 1 on, 0 off, -1 back to the environment's choice. */
+ * mode 1 on, 0 off, -1 back to the default rule. */
 int trx2_set_shared_launches(int mode);
 /* Shape of the pair kernel for the context's SINGLE-decoy folds.  waves = 4 (default): one workgroup of four waves per row of the
  * restraint lists -- the shortest evaluation while few folds are in flight (run_inference.py on one target: two chains).  waves = 1:

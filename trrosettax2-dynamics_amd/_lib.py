@@ -124,8 +124,8 @@ def set_shared_launch_profiling(on):
 
 
 def set_shared_launches(mode):
-    """trx2_set_shared_launches: 1 = single-decoy folds of all contexts share launch pairs (default), 0 = every fold launches for
-    itself, -1 = back to the environment's choice (TRX2_SHARED_LAUNCH)"""
+    """trx2_set_shared_launches: 1 = single-decoy folds of all contexts share launch pairs, 0 = every fold launches for itself,
+    -1 = the library's rule (TRX2_SHARED_LAUNCH if set; otherwise shared from the fifth live context on: include/trx2fold.h)"""
     if load().trx2_set_shared_launches(int(mode)) != 0:
         raise ValueError("mode must be -1, 0 or 1")
 

@@ -79,10 +79,19 @@ static int g_engine_mode = -1;   // -1: TRX2_SHARED_LAUNCH decides (default on);
 static std::mutex g_engine_mutex;
 static std::map<int, std::vector<LaunchEngine*>> g_engines;   // per device; never destroyed (their threads outlive every context)
 
-static bool engine_enabled() {
+// Who launches a single-decoy fold.  Forced by trx2_set_shared_launches(0 / 1) or TRX2_SHARED_LAUNCH=0 / 1; otherwise by the number
+// of contexts alive in the process (second lanes not counted): up to four chains fold fastest launching for themselves, each on one
+// of the library's four streams (hardware queues); from the fifth on the streams are shared and the engines win.  Measured on
+// MI355X, L=150, all channels, microseconds per fold-evaluation with 1 / 2 / 3 / 4 / 6 / 8 / 12 folds in flight
+// (tools/runs/r04_run23.sh): own launches 25.3 / 13.2 / 9.3 / 6.9 / 9.7 / 7.3 / 7.1, engines 26.0 / 13.5 / 10.2 / 8.8 / 6.3 / 5.3 / 4.5.
+#ifndef TRX2_ENGINE_MIN_CONTEXTS
+#define TRX2_ENGINE_MIN_CONTEXTS 5
+#endif
+static bool engine_enabled(int chains_alive) {
   if (g_engine_mode >= 0) return g_engine_mode != 0;
-  static const bool env_on = !(getenv("TRX2_SHARED_LAUNCH") && atoi(getenv("TRX2_SHARED_LAUNCH")) == 0);
-  return env_on;
+  static const int env = [] { const char* e = getenv("TRX2_SHARED_LAUNCH"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  if (env >= 0) return env != 0;
+  return chains_alive >= TRX2_ENGINE_MIN_CONTEXTS;
 }
 
 template <int FAM, bool SEGC>

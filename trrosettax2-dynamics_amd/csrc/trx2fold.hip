@@ -216,6 +216,7 @@ static double round_txt(double v, int dp) {
   return strtod(buf, nullptr);
 }
 
+static std::atomic<int> g_lane_contexts{0};  // ... of which second lanes (trx2_ctx_set_lanes)
 static std::atomic<int> g_live_contexts{0};  // contexts alive in this process (lanes are contexts too): step_dyn_budget
 
 // Stream pool.  HIP maps a process's streams onto GPU_MAX_HW_QUEUES = 4 hardware queues, and a stream that has launched work keeps
@@ -469,6 +470,7 @@ extern "C" int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes) {
     trx2_ctx* k = nullptr;
     if (ctx_create_impl(ctx->device, &k, ctx->stream) != 0) { ctx->err = "trx2_ctx_set_lanes: cannot create the second lane"; return 1; }
     k->borrows_map = true;
+    g_lane_contexts++;
     k->pool = ctx->pool;
     k->pair1_waves = ctx->pair1_waves;
     k->compact = ctx->compact;
@@ -488,6 +490,7 @@ extern "C" int trx2_ctx_set_lanes(trx2_ctx* ctx, int lanes) {
 extern "C" void trx2_ctx_destroy(trx2_ctx* ctx) {
   if (!ctx) return;
   g_live_contexts--;
+  if (ctx->borrows_map) g_lane_contexts--;
   (void)hipSetDevice(ctx->device);
   if (ctx->lane_worker) { ctx->lane_worker->stop(); delete ctx->lane_worker; ctx->lane_worker = nullptr; }
   if (ctx->child) { trx2_ctx* k = ctx->child; ctx->child = nullptr; trx2_ctx_destroy(k); }
@@ -1211,7 +1214,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   // Shared launches (launch_engine.h): a single-decoy fold -- every feedback iteration of run_inference.py is one -- does not launch
   // for itself; it hands its argument blocks to an engine whose launch pairs step the folds of many contexts at once, and sleeps.
   bool via_engine = false;
-  if (B == 1 && N == 1 && has_cart && L <= 2 * CHAIN_THREADS && pe == 0 && getenv("TRX2_GRAPH") == nullptr && engine_enabled()) {
+  if (B == 1 && N == 1 && has_cart && L <= 2 * CHAIN_THREADS && pe == 0 && getenv("TRX2_GRAPH") == nullptr && engine_enabled(g_live_contexts.load() - g_lane_contexts.load())) {
     if (LaunchEngine* E = engine_pick(ctx->device)) {
       EngineJob job;
       job.pa = pair_args(ctx, B);

@@ -285,7 +285,7 @@ def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, 
     targets_in_flight: a rank's targets are folded that many at a time on host threads (default: as many as keep THIRTY-TWO chains in
     flight -- sixteen targets with both models; measured on one MI355X at L=150: 8 / 16 / 32 of 32 targets in flight -> 102 / 134 / 154
     decoys/s).  A chain's iteration phase folds one decoy at a time and leaves the chip idle;
-    with shared launches (csrc/launch_engine.h, the library's default) the single-decoy folds of all chains in flight advance in
+    with shared launches (csrc/launch_engine.h, the library's rule from five live contexts on) the single-decoy folds of all chains in flight advance in
     one launch pair per evaluation, which costs about what one chain's launch pair costs (round 3, without them: four chains on
     four streams were the ceiling, 3.6 x one chain).  A target's files do not depend on what folds beside it: its decoys are
     identified by (seed, index), its contexts are its threads' own, and a fold's arithmetic does not depend on what shares its
