@@ -120,7 +120,11 @@ def _batch_worker(rank, world, port, q, tmp):
         res = P.run_batch(names, tmp, tmp, rank=rank, world=world, dist=dist, device=rank, run=fake_run_single, init_num=4,
                           mult_two_models=True, targets_in_flight=1)
         dist.barrier()
-        q.put((rank, res))
+        # a second job in the same process group: its queue starts from its own zero (the key names the job), on the same store
+        res2 = P.run_batch(["t90", "t120", "t45"], tmp, tmp + "/second", rank=rank, world=world, dist=dist, device=rank, run=fake_run_single,
+                           init_num=4, mult_two_models=True, targets_in_flight=1)
+        dist.barrier()
+        q.put((rank, (res, res2)))
     finally:
         dist.destroy_process_group()
 
@@ -133,6 +137,7 @@ def test_world_size_2_gloo_batch_mode_pulls_targets_from_a_shared_queue(tmp_path
     Ls = (40, 90, 60, 120, 75, 50, 45)
     for L in Ls:
         (tmp_path / f"t{L}.fasta").write_text(f">t{L}\n" + "A" * L + "\n")
+    (tmp_path / "second").mkdir()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -145,10 +150,12 @@ def test_world_size_2_gloo_batch_mode_pulls_targets_from_a_shared_queue(tmp_path
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert got[0] == got[1]                                   # every rank holds the same summary
-    res = got[0]
+    assert got[0] == got[1]                                   # every rank holds the same summaries
+    res, res2 = got[0]
+    assert res2["failed"] == 0 and res2["decoys"] == 3 * 11 and sorted(t for p in res2["per_rank"] for t in p["targets"]) == ["t120", "t45", "t90"]
     assert res["failed"] == 1 and res["errors"] == ["t60: RuntimeError: fold failed for decoys [1]"]
     assert res["decoys"] == 6 * 11 and len(res["per_rank"]) == 2
+    assert len([f for f in os.listdir(tmp_path / "second") if ".rank" in f]) == 3
     done = sorted(f for f in os.listdir(tmp_path) if ".rank" in f)
     assert sorted(d.split(".")[0] for d in done) == sorted(f"t{L}" for L in Ls if L != 60)      # each surviving target exactly once
     by_rank = {r: sorted(p["targets"]) for r, p in enumerate(res["per_rank"])}

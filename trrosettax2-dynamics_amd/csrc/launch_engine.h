@@ -75,7 +75,7 @@ static const size_t ENG_OFF_DP = ENG_OFF_CC + sizeof(CartArgs) * ENGINE_MAX_JOBS
 static const size_t ENG_ARGS_BYTES = ENG_OFF_DP + sizeof(int*) * ENGINE_MAX_JOBS;
 
 static std::atomic<int> g_engine_prof{0};   // trx2_set_shared_launch_profiling
-static int g_engine_mode = -1;   // -1: TRX2_SHARED_LAUNCH decides (default on); 0 / 1: trx2_set_shared_launches
+static std::atomic<int> g_engine_mode{-1};   // -1: engine_enabled()'s rule; 0 / 1: trx2_set_shared_launches
 static std::mutex g_engine_mutex;
 static std::map<int, std::vector<LaunchEngine*>> g_engines;   // per device; never destroyed (their threads outlive every context)
 
@@ -88,7 +88,8 @@ static std::map<int, std::vector<LaunchEngine*>> g_engines;   // per device; nev
 #define TRX2_ENGINE_MIN_CONTEXTS 5
 #endif
 static bool engine_enabled(int chains_alive) {
-  if (g_engine_mode >= 0) return g_engine_mode != 0;
+  const int forced = g_engine_mode.load();
+  if (forced >= 0) return forced != 0;
   static const int env = [] { const char* e = getenv("TRX2_SHARED_LAUNCH"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
   if (env >= 0) return env != 0;
   return chains_alive >= TRX2_ENGINE_MIN_CONTEXTS;
@@ -205,14 +206,17 @@ static void engine_main(LaunchEngine* E) {
       if (!chk(hipGetLastError(), "shared launch")) return;
       if (!chk(hipMemcpyAsync(E->h_flags[k & 1], E->d_flags, sizeof(int) * n, hipMemcpyDeviceToHost, E->stream), "hipMemcpyAsync(flags)")) return;
       if (!chk(hipEventRecord(E->ev[k & 1], E->stream), "hipEventRecord")) return;
-      E->st_chunks += 1; E->st_jobs += n;
     }
     const auto t_wait = std::chrono::steady_clock::now();
-    E->st_enqueue_s += std::chrono::duration<double>(t_wait - t_enq).count();
+    {   // (the statistics are read by trx2_shared_launch_stats under the same lock)
+      std::lock_guard<std::mutex> lk(E->mu);
+      if (C.valid) { E->st_chunks += 1; E->st_jobs += (double)C.jobs.size(); }
+      E->st_enqueue_s += std::chrono::duration<double>(t_wait - t_enq).count();
+    }
     if (Pv.valid) {
       if (!chk(hipEventSynchronize(E->ev[(k + 1) & 1]), "hipEventSynchronize")) return;
-      E->st_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
       std::lock_guard<std::mutex> lk(E->mu);
+      E->st_wait_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
       if (Pv.prof) {
         float a = 0, b = 0;
         hipEvent_t* pe = E->pev[(k + 1) & 1];

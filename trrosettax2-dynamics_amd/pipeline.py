@@ -23,6 +23,8 @@ import numpy as np
 from . import sched
 from .feedback import calculate_reliability_score, feedback_labels
 from .fold import FoldError, close_contexts, fold_arrays_to_pdb, fold_resident_to_pdb, get_context
+
+_BATCH_CALLS = 0   # run_batch calls of this process (part of the shared queue's key)
 from .pdbio import as_read_from_pdb, read_backbone, read_fasta
 
 
@@ -300,12 +302,18 @@ def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, 
     init_num = kw.get("init_num", 10)
     fasta = {n: os.path.join(fasta_dir, n + ".fasta") for n in names}
     # Order of the queue: modelled seconds of a target, longest first.  ITER_EST stands in for the unknowable iteration count
-    # (the convergence test fired after 53-64 iterations on the reference's example; never more than Nmax).
+    # (the convergence test fired after 47-80 iterations on the reference's example; never more than Nmax).
     ITER_EST = 60
     items = [sched.Item(n, "all", len(read_fasta(fasta[n])), 0, init_num * n_chain, iterations=min(int(kw.get("Nmax", 300)), ITER_EST)) for n in names]
     items.sort(key=lambda it: (-it.cost, it.target))
     group = sched.summary_group(dist)                                # created up front: new_group is itself a collective
-    queue = sched.DynamicQueue(len(items), store if store is not None else (sched.queue_store(dist) if world > 1 else None))
+    # the counter's key names THIS job: every rank calls run_batch the same number of times with the same name list, so the call
+    # count and a checksum of the names agree across ranks; a second job on the same store starts from its own zero
+    global _BATCH_CALLS
+    _BATCH_CALLS += 1
+    import zlib
+    key = f"trx2_next_item/{_BATCH_CALLS}/{zlib.crc32(' '.join(it.target for it in items).encode()):08x}"
+    queue = sched.DynamicQueue(len(items), store if store is not None else (sched.queue_store(dist) if world > 1 else None), key=key)
     local = dict(decoys=0, seconds=0.0, failed=0, targets=[], errors=[])
     if targets_in_flight is None:
         targets_in_flight = 32 // n_chain

@@ -137,7 +137,7 @@ def shard_range(n, rank, world):
 class DynamicQueue:
     """A shared counter that hands out item indices in order: every rank calls next() when it is free and gets the next index
     nobody has taken (torch.distributed TCPStore.add is atomic; no collective, no data on the wire but the integer).  With
-    iteration counts that nobody can know beforehand (a chain stops when its maps converge: 53-64 iterations on the reference's
+    iteration counts that nobody can know beforehand (a chain stops when its maps converge: 47-80 iterations on the reference's
     example, 300 = Nmax on others) a static longest-first plan straggles; a queue ordered longest-first by the model does not.
     store = None: a process-local counter (single rank)."""
 
@@ -165,10 +165,14 @@ def queue_store(dist, port_offset=1):
     from torch.distributed import TCPStore
     host = os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = int(os.environ.get("MASTER_PORT", "29500")) + int(port_offset)
-    return TCPStore(host, port, dist.get_world_size(), is_master=dist.get_rank() == 0, timeout=datetime.timedelta(hours=GATHER_TIMEOUT_H),
+    if (host, port) in _STORES:      # one store per process and address: a second job reuses it (its queue has a key of its own)
+        return _STORES[(host, port)]
+    _STORES[(host, port)] = TCPStore(host, port, dist.get_world_size(), is_master=dist.get_rank() == 0, timeout=datetime.timedelta(hours=GATHER_TIMEOUT_H),
                     wait_for_workers=False)
+    return _STORES[(host, port)]
 
 
+_STORES = {}
 GATHER_TIMEOUT_H = 24  # ranks finish hours apart on long name lists; the summary gather must outwait the slowest one
 
 
