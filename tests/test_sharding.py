@@ -165,3 +165,41 @@ def test_world_size_2_gloo_batch_mode_pulls_targets_from_a_shared_queue(tmp_path
     slow = {t: r for r in (0, 1) for t in by_rank[r] if t in ("t50", "t40")}
     assert len(slow) == 2 and slow["t50"] != slow["t40"], by_rank
     assert res["seconds"] < 1.6, res["seconds"]
+
+
+def test_short_name_list_is_shared_fairly_between_ranks(tmp_path):
+    """Four targets, two ranks, sixteen targets in flight allowed per rank: a rank starts at most its fair share (two) at once, so
+    the rank that arrives first cannot take the whole list.  Two 'ranks' = two threads of this process on one counter."""
+    import threading
+    import time
+    P = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
+    names = [f"s{k}" for k in range(4)]
+    for n in names:
+        (tmp_path / f"{n}.fasta").write_text(f">{n}\n" + "A" * 50 + "\n")
+
+    class Counter:                       # what sched.DynamicQueue needs of a TCPStore
+        def __init__(self):
+            self.v, self.lock = {}, threading.Lock()
+
+        def add(self, key, n):
+            with self.lock:
+                self.v[key] = self.v.get(key, 0) + n
+                return self.v[key]
+
+    store, took = Counter(), {0: [], 1: []}
+
+    def fake(name, fasta_file, save_dir, device=0, **kw):
+        took[device].append(name)
+        time.sleep(0.4)
+        return 1
+
+    def rank(r, delay):
+        time.sleep(delay)                # rank 1 arrives late
+        P._BATCH_CALLS = 0               # both 'ranks' live in one process: same call count, hence the same queue key
+        P.run_batch(names, str(tmp_path), str(tmp_path), rank=r, world=2, dist=None, device=r, run=fake, store=store, targets_in_flight=16,
+                    init_num=1, mult_two_models=True)
+
+    th = [threading.Thread(target=rank, args=(r, 0.15 * r)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert sorted(took[0] + took[1]) == names and len(took[0]) == 2 and len(took[1]) == 2, took

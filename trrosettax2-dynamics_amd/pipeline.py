@@ -340,7 +340,9 @@ def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, 
                 return
             one(items[i])
 
-    n_workers = max(1, min(int(targets_in_flight), len(items)))
+    # never more workers than a rank's fair share of the list: with a list shorter than world x targets_in_flight the first ranks
+    # to arrive would otherwise take every target and leave the others idle
+    n_workers = max(1, min(int(targets_in_flight), -(-len(items) // max(1, int(world)))))
     if n_workers == 1:
         worker()
     else:
