@@ -23,17 +23,27 @@ ctx = T.Context(0)
 for tag, refs in (("NMR", ("conf_2_1", "conf_2_2")), ("Xray", ("conf_1_1", "conf_1_2"))):
     m = np.load(os.path.join(g, f"seq_{tag}.npz")); ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
     runs = T.protocol.build_runs(90, 2, fastrelax=True) if relax else T.protocol.build_runs(90, 2)
-    rm, mir, tw, ev, sec = [], [], [], [], 0.0
+    rm, mir, tw, ev, sec, cas = [], [], [], [], 0.0, []
     for b in range(nb):
         r = ctx.fold_batch(64, runs, seed=seed0 + b)
         assert np.all(r["status"] == 0)
         sec += r["seconds"]; ev += list(r["n_evals"])
         for i in range(64):
             ca = r["xyz"][i, :, 1].astype(np.float64)
+            cas.append(ca)
             rm.append(min(rmsd(ca, dec[k][:, 1]) for k in refs)); mir.append(min(rmsd(ca * [1, 1, -1], dec[k][:, 1]) for k in refs))
             dw = np.degrees(np.abs((r["tors"][i, :-1, 2] % (2 * np.pi)) - np.pi)); tw.append(dw.max() > 60)
     rm, mir = np.array(rm), np.array(mir); n = len(rm); gross = rm > 3
     print(f"{os.path.basename(os.environ.get('TRX2FOLD_LIB', 'default')):28s} {tag:4s} n={n}: RMSD median {np.median(rm):.3f}  quartiles {np.percentile(rm,25):.2f}-{np.percentile(rm,75):.2f}  "
           f"<=0.5A {100*(rm<=0.5).mean():.0f}%  <=1A {100*(rm<=1).mean():.0f}%  >3A {100*gross.mean():.1f}% (mirror {100*(gross&(mir<rm)).mean():.1f}%)  "
           f"twisted>60 {100*np.mean(tw):.0f}%  evals median {np.median(ev):.0f} mean {np.mean(ev):.0f}  {n/sec:.0f} decoys/s")
+    # Two-sample reading: the reference's two decoys of this map are two draws of ITS distribution; how far apart are two draws of
+    # OURS?  (non-mirror decoys only -- the reference's pair holds none; 300 decoys -> 44 850 pairs)
+    ok = [c for c, g_ in zip(cas, gross) if not g_][:300]
+    pw = np.array([rmsd(ok[i], ok[j]) for i in range(len(ok)) for j in range(i + 1, len(ok))])
+    ref_pair = rmsd(dec[refs[0]][:, 1], dec[refs[1]][:, 1])
+    to_ref = np.array([[rmsd(c, dec[k][:, 1]) for k in refs] for c in ok])
+    print(f"{'':28s} {tag:4s} two draws of this build: median {np.median(pw):.3f} A (5-95 %: {np.percentile(pw, 5):.2f}-{np.percentile(pw, 95):.2f}); "
+          f"the reference's two draws: {ref_pair:.3f} A = percentile {100 * (pw < ref_pair).mean():.0f} of ours; "
+          f"a draw of ours to ONE reference draw: median {np.median(to_ref):.3f} A ({refs[0]} {np.median(to_ref[:, 0]):.3f}, {refs[1]} {np.median(to_ref[:, 1]):.3f})")
 ctx.close()
