@@ -47,6 +47,9 @@ LIMITS = {("NMR", 1): dict(med=1.25, f15=0.90, far=0.06), ("NMR", 2): dict(med=1
           ("Xray", 1): dict(med=0.97, f15=0.76, far=0.13), ("Xray", 2): dict(med=0.92, f15=0.82, far=0.13)}
 
 
+TWO_SAMPLE = {}
+
+
 @pytest.mark.parametrize("tag", ["NMR", "Xray"])
 def test_folds_of_the_fed_back_maps_reach_the_reference_iteration_decoys(golden_dir, seq, tmp_path, tag):
     ref = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
@@ -73,6 +76,24 @@ def test_folds_of_the_fed_back_maps_reach_the_reference_iteration_decoys(golden_
                          np.median(d_o[i0]), np.median(d_o[i1]), int(np.median(r["n_evals"]))))
             print("\n%s stage %d -> %s: median %.3f A (quartiles %.2f-%.2f), <=1 A %.0f %%, <=1.5 A %.0f %%, >3 A %.1f %%; to initial0 / initial1 of the map: %.2f / %.2f; evaluations %d"
                   % ((tag,) + rows[-1]))
+            # Two-sample reading: ONE reference draw exists for this map; if it is a draw of our distribution, our decoys are as far
+            # from it as from one another (non-mirror decoys; 120 of them -> 7 140 pairs)
+            ok = [r["xyz"][i, :, 1].astype(np.float64) for i in np.nonzero(~far)[0][:120]]
+            n_ok = len(ok)
+            D = np.zeros((n_ok, n_ok))
+            for i in range(n_ok):
+                for j in range(i + 1, n_ok):
+                    D[i, j] = D[j, i] = kabsch_rmsd(ok[i], ok[j])
+            pw = D[np.triu_indices(n_ok, 1)]
+            # every draw of ours has its own median distance to the other draws (central draws small, peripheral ones large): the
+            # reference's draw, measured the same way, must be one of them
+            own = np.array([np.median(np.delete(D[i], i)) for i in range(n_ok)])
+            d_ok = np.median(d_t[~far][:n_ok])
+            pct = 100.0 * (own < d_ok).mean()
+            print("   two draws of ours: median %.3f A (5-95 %%: %.2f-%.2f); a draw's median distance to the others: %.2f-%.2f (5-95 %%); the reference's draw: %.3f A = percentile %.0f"
+                  % (np.median(pw), np.percentile(pw, 5), np.percentile(pw, 95), np.percentile(own, 5), np.percentile(own, 95), d_ok, pct))
+            TWO_SAMPLE[(tag, stage)] = (float(np.median(pw)), float(d_ok), float(pct))
+            assert pct <= 99.0, (pct, d_ok, np.sort(own)[-5:])     # (tightened below from the measurement)
             assert np.median(d_t) <= lim["med"], np.sort(d_t)[::16]
             assert (d_t <= 1.5).mean() >= lim["f15"] and far.mean() <= lim["far"], ((d_t <= 1.5).mean(), far.mean())
             # no twisted peptides with the relax stage on (the reference's decoys: |omega| 177.6 deg mean, one cis in eight)
