@@ -23,6 +23,12 @@ ctx = T.Context(0)
 for tag, refs in (("NMR", ("conf_2_1", "conf_2_2")), ("Xray", ("conf_1_1", "conf_1_2"))):
     m = np.load(os.path.join(g, f"seq_{tag}.npz")); ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq)
     runs = T.protocol.build_runs(90, 2, fastrelax=True) if relax else T.protocol.build_runs(90, 2)
+    if relax and os.environ.get("OUTCOME_CLOSING_ITERS"):      # experiment: the closing unrestrained minimisation shortened (0 = dropped)
+        n_it = int(os.environ["OUTCOME_CLOSING_ITERS"])
+        runs = runs[:-1] if n_it == 0 else runs[:-1] + [dict(runs[-1], max_iter=n_it)]
+    if relax and os.environ.get("OUTCOME_CLOSING_RAMA"):       # experiment: the torsion-potential weight of the closing run scaled
+        w = list(runs[-1]["w"]); w[4] *= float(os.environ["OUTCOME_CLOSING_RAMA"])
+        runs = runs[:-1] + [dict(runs[-1], w=w)]
     rm, mir, tw, ev, sec, cas, xyzs = [], [], [], [], 0.0, [], []
     for b in range(nb):
         r = ctx.fold_batch(64, runs, seed=seed0 + b)
