@@ -43,7 +43,8 @@ def fold_stats(ctx, ref, target, others, seed):
 # (0.97-1.35; 89 %, 1.6 %), X-ray stage 1 0.82 A (0.44-1.23; 84 %, 8.2 %), X-ray stage 2 0.76 A (0.54-1.26; 91 %, 8.2 %).  The reference's own decoys of one map differ by 0.81-1.51 A (NMR) and 0.34-0.72 A (X-ray) among themselves
 # (SURVEY.md section 4): these folds sit inside the NMR spread and at the upper end of the X-ray one.  Limits = measured + margin
 # (sampling error of a median at n = 256: ~0.03 A on the unimodal NMR map, ~0.1 A on the bimodal X-ray map).
-LIMITS = {("NMR", 1): dict(med=1.25, f15=0.90, far=0.06), ("NMR", 2): dict(med=1.22, f15=0.80, far=0.06),
+# Closing build of round 4 (relax-stage scale, guard offset): 1.146 / 1.076 / 0.807 / 0.774 A; beyond 3 A 2.3 / 5.1 / 3.9 / 8.2 % (sd of a fraction of 5 % at n = 256: 1.4 %).
+LIMITS = {("NMR", 1): dict(med=1.25, f15=0.90, far=0.06), ("NMR", 2): dict(med=1.22, f15=0.80, far=0.08),
           ("Xray", 1): dict(med=0.97, f15=0.76, far=0.13), ("Xray", 2): dict(med=0.92, f15=0.82, far=0.13)}
 
 
