@@ -138,3 +138,38 @@ np.savez(sys.argv[2], **out)
     for k in res["1"]:
         assert np.array_equal(res["1"][k], res["0"][k]), k
     assert np.all(np.isfinite(res["1"]["b40_xyz"])) and res["1"]["b40_ev"].min() > 500
+
+
+def test_who_launches_follows_the_number_of_live_contexts(golden_dir, seq):
+    """The library's rule (include/trx2fold.h, trx2_set_shared_launches(-1)): with fewer than five contexts alive a single-decoy fold
+    launches for itself (the engines' chunk counter does not move); from the fifth on it goes to the engines.  Same bits either way."""
+    if os.environ.get("TRX2_SHARED_LAUNCH") is not None:
+        pytest.skip("TRX2_SHARED_LAUNCH forces one route")
+    L_.set_shared_launches(-1)
+    real = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
+    runs = T.protocol.build_runs(90, 2, fastrelax=True)
+    ctxs = []
+    try:
+        def add(n):
+            for _ in range(n):
+                c = T.Context(0)
+                c.set_map(real["dist"], real["omega"], real["theta"], real["phi"], seq=seq)
+                ctxs.append(c)
+        add(2)
+        s0 = L_.shared_launch_stats(0)["chunks"]
+        few = [c.fold_batch(1, runs, seed=77, max_evals=400) for c in ctxs]
+        s1 = L_.shared_launch_stats(0)["chunks"]
+        assert s1 == s0, (s0, s1)                       # two contexts: nobody went to an engine
+        add(4)                                           # six alive
+        many = [None] * 6
+        th = [threading.Thread(target=lambda i=i: many.__setitem__(i, ctxs[i].fold_batch(1, runs, seed=77, max_evals=400))) for i in range(6)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        s2 = L_.shared_launch_stats(0)["chunks"]
+        assert s2 > s1, (s1, s2)                         # six contexts: the engines stepped them
+        for r in many:
+            for k in KEYS:
+                assert np.array_equal(r[k], few[0][k]), k     # same map, same seed: the same fold whoever launched it
+    finally:
+        for c in ctxs:
+            c.close()
