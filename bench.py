@@ -205,6 +205,10 @@ def pair_roofline(ctx, T, tors, L, config, fold_times=None):
            "binding_limit": "vector-ALU issue + dependent-load latency, not HBM bandwidth (DESIGN.md section 5)"}
     if fold_times and fold_times[2]:
         out["avg_launch_ms_over_fold"] = fold_times[0]
+        # the conservative reading: the same bytes over the fold's own average launch, which includes the narrower launches of the tail
+        # (fewer decoys, fewer bytes, shorter) -- `frac` uses replays of the full-width launch on the fold's final coordinates; the
+        # rocprofv3 average of the full-width instantiation (profiles/r04_c*_kernel_stats.csv) lies between the two
+        out["frac_over_fold"] = abytes / (fold_times[0] * 1e-3) / 1e9 / HBM_PEAK_GBS
     return out
 
 
@@ -676,7 +680,7 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
 
 
 def compact_roofline(r):
-    return {q: r[q] for q in ("kernel", "achieved", "frac", "unit", "avg_launch_ms", "avg_launch_ms_over_fold", "algorithmic_bytes_per_launch", "traffic") if q in r} if r else None
+    return {q: r[q] for q in ("kernel", "achieved", "frac", "frac_over_fold", "unit", "avg_launch_ms", "avg_launch_ms_over_fold", "algorithmic_bytes_per_launch", "traffic") if q in r} if r else None
 
 
 def compact(rec):
