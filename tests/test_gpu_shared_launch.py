@@ -173,3 +173,14 @@ def test_who_launches_follows_the_number_of_live_contexts(golden_dir, seq):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_mixed_chain_lengths_in_flight_files_do_not_depend_on_the_schedule():
+    """tools/soak_batch.py, small: twelve targets of six chain lengths (all three step-kernel classes in the same shared launches),
+    folded with eight and with three targets in flight: every PDB byte for byte the same."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_batch.py"), root, "12", "3", "8", "3"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert "files identical between the two passes: True (120 files)" in out.stdout, out.stdout[-800:]
