@@ -25,8 +25,8 @@ def main(argv=None):
     p.add_argument("--npz_nmr", type=str, default=None, help="precomputed NMR-model distogram (extension)")
     p.add_argument("--npz_xray", type=str, default=None, help="precomputed X-ray-model distogram (extension)")
     p.add_argument("--seed", type=int, default=None, help="seed of the random start torsions (extension)")
-    p.add_argument("--targets_in_flight", type=int, default=None, help="batch mode: targets a rank folds at a time (extension; default keeps thirty-two "
-                   "chains in flight, whose single-decoy folds share launches: 16 targets with both models, 32 with one; 1 = one after the other "
+    p.add_argument("--targets_in_flight", type=int, default=None, help="batch mode: targets a rank folds at a time (extension; default keeps sixty-four "
+                   "chains in flight, whose single-decoy folds share launches: 32 targets with both models, 64 with one; 1 = one after the other "
                    "as the reference does; the files do not depend on it)")
     p.add_argument("--candidates", type=int, default=1, help="decoys folded and written per feedback iteration, candidate 0 fed back "
                    "(extension; 1 = the reference's chain)")

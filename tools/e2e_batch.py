@@ -1,5 +1,5 @@
 """Batch mode of run_inference on ONE GPU: n targets (the same synthetic pair of maps under n names), folded 1 / 2 / .. at a time.
-usage: e2e_batch.py <repo> <L> <n targets> <Nmax> <targets in flight ...>"""
+usage: e2e_batch.py <repo> <L> <n targets> <Nmax> <targets in flight ...>   (0 = run_batch's default)"""
 import contextlib, importlib, io, json, os, shutil, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, sys.argv[1])
@@ -20,7 +20,7 @@ try:
         save = os.path.join(work, f"out{k}")
         t0 = time.perf_counter()
         with contextlib.redirect_stdout(io.StringIO()):
-            res = PL.run_batch(names, fdir, save, targets_in_flight=k, init_num=10, Nmax=nmax, angle=True, mult_two_models=True, seed=3,
+            res = PL.run_batch(names, fdir, save, targets_in_flight=(k or None), init_num=10, Nmax=nmax, angle=True, mult_two_models=True, seed=3,
                                npz_nmr=paths[0], npz_xray=paths[1])
         el = time.perf_counter() - t0
         print(json.dumps(dict(L=L, targets=n, Nmax=nmax, targets_in_flight=k, decoys=res["decoys"], failed=res["failed"], seconds=round(el, 2),

@@ -284,9 +284,9 @@ def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, 
     first exception); the summary -- gathered with all_gather_object -- carries the failures and the caller turns them into a
     non-zero exit code.  `run` stands in for run_single in the CPU tests; `store` for the TCPStore (default: sched.queue_store).
 
-    targets_in_flight: a rank's targets are folded that many at a time on host threads (default: as many as keep THIRTY-TWO chains in
-    flight -- sixteen targets with both models; measured on one MI355X at L=150: 8 / 16 / 32 of 32 targets in flight -> 102 / 134 / 154
-    decoys/s).  A chain's iteration phase folds one decoy at a time and leaves the chip idle;
+    targets_in_flight: a rank's targets are folded that many at a time on host threads (default: as many as keep SIXTY-FOUR chains in
+    flight -- thirty-two targets with both models, fewer for very long chains; measured on one MI355X at L=150: 8 / 16 / 32 / 64 targets
+    in flight -> 102 / 134-136 / 153-154 / 154 decoys/s).  A chain's iteration phase folds one decoy at a time and leaves the chip idle;
     with shared launches (csrc/launch_engine.h, the library's rule from five live contexts on) the single-decoy folds of all chains in flight advance in
     one launch pair per evaluation, which costs about what one chain's launch pair costs (round 3, without them: four chains on
     four streams were the ceiling, 3.6 x one chain).  A target's files do not depend on what folds beside it: its decoys are
@@ -316,7 +316,11 @@ def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, 
     queue = sched.DynamicQueue(len(items), store if store is not None else (sched.queue_store(dist) if world > 1 else None), key=key)
     local = dict(decoys=0, seconds=0.0, failed=0, targets=[], errors=[])
     if targets_in_flight is None:
-        targets_in_flight = 32 // n_chain
+        # sixty-four chains in flight (measured on one MI355X, 64 targets of L=150: 16 / 32 / 64 targets in flight -> 136 / 153 / 154
+        # decoys/s), fewer where the chains' tables would not leave room: a chain's context holds ~L^2 x 100 knots x 16 B of spline
+        # tables (0.04 GB at L=150, 0.3 GB at L=400, 1.7 GB at L=1000) -- at most ~100 GB of the 288 for them
+        per_chain = 1.3 * max(it.L for it in items) ** 2 * 100 * 16 if items else 1.0
+        targets_in_flight = max(1, min(64, int(100e9 // per_chain)) // n_chain)
     lock = threading.Lock()
     t_all = time.perf_counter()
 
