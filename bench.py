@@ -318,8 +318,8 @@ def cpu_e2e_baseline(synth, L, init_num, iterations, runs, n_folds=4):
 
 def e2e_batch_leg(pipe_mod, synth, L, n_targets=16, nmax=40, seed=3, in_flight=(16,)):
     """Batch mode of run_inference.py (:339-348) on ONE GPU: n_targets targets (the same synthetic pair of maps under different names),
-    init_num=10, both models, Nmax shortened to `nmax`, `in_flight` targets at a time (pipeline.run_batch's default: sixteen = thirty-two
-    chains whose single-decoy folds share launch pairs, csrc/launch_engine.h; the files are byte-identical to one target after the
+    init_num=10, both models, Nmax shortened to `nmax`, `in_flight` targets at a time (pipeline.run_batch's default: up to thirty-two =
+    sixty-four chains whose single-decoy folds share launch pairs, csrc/launch_engine.h; the files are byte-identical to one target after the
     other with every fold launching for itself: tests/test_gpu_shared_launch.py).  Round 3's way (four streams, two targets in
     flight, every fold its own launches): 64 decoys/s without the relax stage, 41.5 with it (profiles/README.md, round 4)."""
     work = tempfile.mkdtemp(prefix="trx2_e2eb_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -749,6 +749,8 @@ def main():
                     out["e2e"]["init_num_64"] = e2e_leg(pipe_mod, synth, cfg["L"], 64)
                     out["e2e"]["init_num_10_candidates_8"] = e2e_leg(pipe_mod, synth, cfg["L"], 10, candidates=8)
                 out["e2e"]["batch_mode_one_gpu"] = e2e_batch_leg(pipe_mod, synth, cfg["L"])
+                # ... and the shape VERDICT r3 set its target on: 8 targets x 2 models, Nmax = 80, all eight in flight
+                out["e2e"]["batch_mode_8_targets_nmax80"] = e2e_batch_leg(pipe_mod, synth, cfg["L"], n_targets=8, nmax=80, in_flight=(8,))
             out["shared_launches"] = shared_launch_leg(T, synth, cfg["L"])
             if with_cpu:
                 its = max(out["e2e"]["init_num_10"]["iterations"].values())
@@ -789,6 +791,7 @@ def main():
             return round(float(d), 2)
         for key, path in (("e2e_init10", ("e2e", "init_num_10", "value")), ("e2e_example_L90_init10", ("e2e", "example_L90_init_num_10", "value")),
                           ("e2e_cpu_init10", ("e2e", "cpu_baseline", "value")), ("batch_mode_one_gpu", ("e2e", "batch_mode_one_gpu", "best", "value")),
+                          ("batch_8x2_nmax80", ("e2e", "batch_mode_8_targets_nmax80", "best", "value")),
                           ("shared_fold_evals_per_s", ("shared_launches", "fold_evaluations_per_sec")), ("pooled_1280", ("pooled_queue", "value")), ("no_fastrelax", ("no_fastrelax", "value")),
                           ("c3", ("sub_records", "config3", "value")), ("c4", ("sub_records", "config4", "value")), ("c5_one_gpu", ("sub_records", "config5_one_gpu", "value")),
                           ("predicted_speedup_8gpu_unmeasured", ("multi_gpu_plan", "predicted", "8", "with_block_splits", "speedup_vs_three_in_flight"))):
