@@ -167,6 +167,15 @@ enum {
 #ifndef TRX2_MIN_TOL
 #define TRX2_MIN_TOL 1.0e-6  /* folding.py:91 fractional tolerance: 2|f0-f1| <= tol (|f0|+|f1|+eps) */
 #endif
+/* The first step of a minimiser run.  A cold start (no correction pair yet) is a steepest-descent step of unit length, alpha =
+ * min(1, 1/|g|); 26 of the default protocol's 35 runs start from the converged point of a run on nearly the same function (RepeatMover,
+ * remove_clash, the FastRelax ramps) and needed 7-10 halvings to get from there to an acceptable step -- 10-20 evaluations for 1-2 accepted
+ * iterations in every ramp run (profiles/r05_run_profile_*.txt).  A run flagged TRX2_RUN_WARM that starts in the space (torsion /
+ * Cartesian) of the decoy's last stored pair scales its first step by that pair's s.y / y.y (what L-BFGS would have used had the run
+ * gone on), still capped at unit length: alpha = min(gamma, 1/|g|).  Own design, as the whole minimiser (Rosetta's is not in the tree);
+ * which runs carry the flag is the protocol table's business (protocol.py). */
+#define TRX2_RUN_PRECHECK 1 /* trx2_run.precheck bit 0: remove_clash's guard            */
+#define TRX2_RUN_WARM 2     /* trx2_run.precheck bit 1: warm first step (see above)     */
 #define TRX2_CLASH_BREAK 10.0 /* utils_ros.py:701 */
 /* Offset per rama residue used ONLY in remove_clash's guard `rama + vdw < 10` (not in the minimised energy).  Rosetta's rama is
  * negative in favoured regions, so a clash-free pose passes the guard and remove_clash stops; this surrogate is >= 0 (about +1
@@ -202,7 +211,7 @@ typedef struct trx2_run {
   int max_iter;     /* MinMover.max_iter                                                       */
   int sep_lo;       /* restraints with sep_lo <= |a-b| < sep_hi are active (add_rst)           */
   int sep_hi;
-  int precheck;     /* 1: before running, if rama+vdw (raw) < CLASH_BREAK jump to skip_to      */
+  int precheck;     /* bit 0 (TRX2_RUN_PRECHECK): before running, if rama+vdw (raw) < CLASH_BREAK jump to skip_to; bit 1: TRX2_RUN_WARM */
   int skip_to;      /* run index to continue with when the precheck fires                      */
   int cartesian;    /* 1: minimise Cartesian coordinates (MinMover.cartesian(True))            */
   int pair_filter;  /* TRX2_FILTER_*: 1: only restraints of pairs NOT flagged in the map's idr mask (add_idr_rst with the complement,

@@ -1,13 +1,14 @@
 """Per-phase cycle shares of the torsion-space step (diagnostic -DTRX2_STAMP build, loaded through TRX2FOLD_LIB).
-Thread 0 of decoy 0's workgroup stamps every STEP launch of one fold.  usage: stamp_chain.py <repo> <config 2|3|4>"""
+Thread 0 of decoy 0's workgroup stamps every STEP launch of one fold.  usage: stamp_chain.py <repo> <config 2|3|4> [decoys per launch]"""
 import ctypes as C, importlib, sys
 import numpy as np
 sys.path.insert(0, sys.argv[1])
 T = importlib.import_module("trrosettax2-dynamics_amd"); S = importlib.import_module("trrosettax2-dynamics_amd.synth")
 L, B, orient = {2: (150, 64, False), 3: (150, 64, True), 4: (400, 16, True)}[int(sys.argv[2])]
+if len(sys.argv) > 3: B = int(sys.argv[3])   # decoys per launch
 m = S.make_map(L); ctx = T.Context(0)
 ctx.set_map(m["dist"], *([m["omega"], m["theta"], m["phi"]] if orient else []), seq=m["seq"])
-runs = T.protocol.build_runs(L, 2)
+runs = T.protocol.build_runs(L, 2, fastrelax=True)
 lib = T.load(); out = (C.c_ulonglong * 32)()
 ctx.fold_batch(B, runs, seed=1)
 assert lib.trx2_debug_chain_stamps(out, 1) == 0

@@ -7,7 +7,7 @@ if L == 90:
     g = os.path.join(sys.argv[1], "tests", "golden"); m = np.load(os.path.join(g, "seq_NMR.npz")); seq = None
 else:
     m = importlib.import_module("trrosettax2-dynamics_amd.synth").make_map(L); seq = m["seq"]
-ctx = T.Context(0); ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq); runs = T.protocol.build_runs(L, 2)
+ctx = T.Context(0); ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=seq); runs = T.protocol.build_runs(L, 2, fastrelax=True)
 lib = T.load(); out = (C.c_ulonglong * 32)()
 ctx.fold_batch(1, runs, seed=1); lib.trx2_debug_chain_stamps(out, 1)
 for i in range(5): ctx.fold_batch(1, runs, seed=2 + i)

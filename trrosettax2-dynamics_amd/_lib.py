@@ -49,7 +49,7 @@ def make_runs(runs):
         for k in range(NW):
             arr[i].w[k] = float(r["w"][k])
         arr[i].max_iter, arr[i].sep_lo, arr[i].sep_hi = int(r["max_iter"]), int(r["sep_lo"]), int(r["sep_hi"])
-        arr[i].precheck, arr[i].skip_to, arr[i].cartesian = int(r.get("precheck", 0)), int(r.get("skip_to", 0)), int(r.get("cartesian", 0))
+        arr[i].precheck, arr[i].skip_to, arr[i].cartesian = int(r.get("precheck", 0)) | (2 if r.get("warm") else 0), int(r.get("skip_to", 0)), int(r.get("cartesian", 0))
         arr[i].pair_filter = int(r.get("pair_filter", 0))
         arr[i].tol = float(r.get("tol", 0.0))
     return arr

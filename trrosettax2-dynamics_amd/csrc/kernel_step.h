@@ -13,7 +13,9 @@ enum { MODE_INIT = 0, MODE_STEP = 1, MODE_FINISH = 2 };
 // SI_RUN and SI_SEQ share one aligned 8-byte word: in the fused step launch the two workgroups of a decoy read its state
 // while one of them may be writing a run transition; a single 8-byte store / load cannot be seen half-updated, so a
 // reader gets (old run, old seq) or (new run, seq of THIS launch -> "already stepped"), never a mixture.
-enum { SI_RUN = 0, SI_SEQ, SI_PHASE, SI_ITER, SI_NLS, SI_HL, SI_HH, SI_NH, SI_STATUS, SI_NEVALS, SI_NITERS, SI_N = 16 };
+// SI_WSPACE: the space the decoy's last stored correction pair lived in (0 none, 1 torsion, 2 Cartesian): a run that starts in the same
+// space takes its first step with that pair's Hessian scale SD_GAMMA instead of 1 / |g| (runs flagged TRX2_RUN_WARM, trx2_model.h)
+enum { SI_RUN = 0, SI_SEQ, SI_PHASE, SI_ITER, SI_NLS, SI_HL, SI_HH, SI_NH, SI_STATUS, SI_NEVALS, SI_NITERS, SI_WSPACE, SI_N = 16 };
 // double state slots
 // SD_GAMMA: s.y / y.y of the newest stored pair = the initial Hessian scaling of the two-loop recursion (torsion role)
 enum { SD_F = 0, SD_ALPHA, SD_GD, SD_FH0, SD_FH1, SD_FH2, SD_GAMMA, SD_N = 8 };
@@ -568,7 +570,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
     // (see `started`).  The totals are wave-uniform by construction and are marked so (uniform_d): every decision of the state
     // machine is a scalar branch.  tests/test_gpu_configs.py (configuration 4) and the checking build (TRX2_SELFCHECK,
     // tests/test_gpu_selfcheck.py: run starts whose window was not seeded) guard it.
-    const bool all_terms = A.mode != MODE_STEP || phase == PH_REPORT || (phase == PH_START && R.precheck);
+    const bool all_terms = A.mode != MODE_STEP || phase == PH_REPORT || (phase == PH_START && (R.precheck & TRX2_RUN_PRECHECK));
     double f_t;
     if (all_terms) {
       block_sum_n<9, NW>(esum, s_buf, flip);
@@ -651,7 +653,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
       if (tid == 0) {
         A.slot_id[dec] = nid;
         gi[SI_PHASE] = PH_START; gi[SI_ITER] = 0; gi[SI_NLS] = 0; gi[SI_HL] = 0; gi[SI_HH] = 0; gi[SI_NH] = 0; gi[SI_STATUS] = 0;
-        gi[SI_NEVALS] = 0; gi[SI_NITERS] = 0;
+        gi[SI_NEVALS] = 0; gi[SI_NITERS] = 0; gi[SI_WSPACE] = 0;
         *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32);  // run 0, stepped in this launch
         for (int q = 0; q < SD_N; q++) gd_[q] = 0.0;
       }
@@ -677,6 +679,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
     double f = s_d[SD_F], alpha = s_d[SD_ALPHA], gdir = s_d[SD_GD];
     double fh[3] = {s_d[SD_FH0], s_d[SD_FH1], s_d[SD_FH2]};
     double gamma_h = s_d[SD_GAMMA];
+    int wspace = s_i[SI_WSPACE];
     bool next_run = false, new_dir = false, steepest = false, new_trial = false, started = false;
     float4 s_new[RPT], y_new[RPT];  // two residues per thread, Gram form: the pair stored in this step, kept for the direction pass
     bool have_new = false;
@@ -687,7 +690,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
     if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
     else if (phase == PH_START) {
       // (a pre-checked start reduced all nine terms: esum[] holds workgroup totals here)
-      if (R.precheck && uniform_d(esum[5]) + (double)TRX2_RAMA_GUARD_OFFSET * (double)max(L - 2, 0) + uniform_d(esum[4]) < (double)TRX2_CLASH_BREAK) {
+      if ((R.precheck & TRX2_RUN_PRECHECK) && uniform_d(esum[5]) + (double)TRX2_RAMA_GUARD_OFFSET * (double)max(L - 2, 0) + uniform_d(esum[4]) < (double)TRX2_CLASH_BREAK) {
         run = R.skip_to;
         if (run >= A.nruns) phase = PH_DONE;
         need_nerf = false;
@@ -769,6 +772,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
             if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
           }
           gamma_h = v3[0] / v3[2];
+          wspace = 1;
           if (!GRAM) bsync<NW>();
           if (GRAM && !HIST_LDS) {  // the new pair, for the direction pass below (its global copy was stored a moment ago)
 #pragma unroll
@@ -950,7 +954,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
       if (!(v1[0] > 0)) next_run = true;
       else {
         gdir = -v1[0];
-        alpha = fmin(1.0, 1.0 / sqrt(v1[0]));
+        // a run's first step: the Hessian scale of the last pair stored in this space (the previous run's), not longer than a unit step
+        alpha = ((R.precheck & TRX2_RUN_WARM) && started && wspace == 1 && gamma_h > 0.0) ? fmin(gamma_h, 1.0 / sqrt(v1[0])) : fmin(1.0, 1.0 / sqrt(v1[0]));
         nls = 0;
         new_trial = true;
       }
@@ -993,7 +998,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
     }
     if (tid == 0) {
       gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
-      gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
+      gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters; gi[SI_WSPACE] = wspace;
       *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
       gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
       gd_[SD_GAMMA] = gamma_h;
@@ -1416,6 +1421,8 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
   double f = s_d[SD_F], alpha = s_d[SD_ALPHA], gdir = s_d[SD_GD];
   double fh[3] = {s_d[SD_FH0], s_d[SD_FH1], s_d[SD_FH2]};
   double gamma_h = s_d[SD_GAMMA];
+  int wspace = s_i[SI_WSPACE];
+  bool started = false;
   float4 x[4], g[4], dv[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
@@ -1435,7 +1442,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
 #pragma unroll
     for (int q = 0; q < 4; q++) { x[q] = xt[q]; g[q] = gt[q]; }
     hl = 0; hh = 0; nh = 1; fh[0] = f; iter = 0;
-    steepest = true;
+    steepest = true; started = true;
   } else {
     double fref = fh[0];
     for (int k = 1; k < nh; k++) fref = fmax(fref, fh[k]);
@@ -1507,6 +1514,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
             }
           stored = true;
           gamma_h = v3[0] / v3[2];
+          wspace = 2;
           hh = (hh + 1) % LBM;
           if (hl < LBM) hl++;
         }
@@ -1527,6 +1535,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
         __syncthreads();
         if (tid == 0) s_rho[hh] = (float)(1.0 / v3[0]);
         gamma_h = v3[0] / v3[2];
+        wspace = 2;
         __syncthreads();
         hh = (hh + 1) % LBM;
         if (hl < LBM) hl++;
@@ -1709,7 +1718,10 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
     for (int q = 0; q < 4; q++) { dv[q] = make_float4(-g[q].x, -g[q].y, -g[q].z, -g[q].w); v1[0] += (double)dot4(g[q], g[q]); }
     block_sum_n<1, NW>(v1, s_buf, flip);
     if (!(v1[0] > 0)) next_run = true;
-    else { gdir = -v1[0]; alpha = fmin(1.0, 1.0 / sqrt(v1[0])); nls = 0; new_trial = true; }
+    else {
+      gdir = -v1[0]; nls = 0; new_trial = true;
+      alpha = ((R.precheck & TRX2_RUN_WARM) && started && wspace == 2 && gamma_h > 0.0) ? fmin(gamma_h, 1.0 / sqrt(v1[0])) : fmin(1.0, 1.0 / sqrt(v1[0]));
+    }
   }
   if (next_run) {
     run++;
@@ -1808,7 +1820,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
   }
   if (tid == 0) {
     gi[SI_PHASE] = phase; gi[SI_ITER] = iter; gi[SI_NLS] = nls; gi[SI_HL] = hl; gi[SI_HH] = hh;
-    gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters;
+    gi[SI_NH] = nh; gi[SI_STATUS] = status; gi[SI_NEVALS] = n_evals; gi[SI_NITERS] = n_iters; gi[SI_WSPACE] = wspace;
     *reinterpret_cast<volatile unsigned long long*>(gi) = ((unsigned long long)(unsigned)seq << 32) | (unsigned long long)(unsigned)run;  // last, in one piece
     gd_[SD_F] = f; gd_[SD_ALPHA] = alpha; gd_[SD_GD] = gdir; gd_[SD_FH0] = fh[0]; gd_[SD_FH1] = fh[1]; gd_[SD_FH2] = fh[2];
     gd_[SD_GAMMA] = gamma_h;
