@@ -94,7 +94,7 @@ def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med
     runs = P.build_runs(90, 2, fastrelax=relax)
     assert any(q["cartesian"] for q in runs)
     if relax and tag == "Xray":
-        f05_min = 0.46            # measured 58 % of 1024 (sampling sd of a fraction at n = 256: 3 %)
+        f05_min = 0.55            # measured 64.8 % of 4096 with round 5's fitted rama term (58 % before; sampling sd of a fraction at n = 256: 3 %)
     r = ctx.fold_batch(B, runs, seed=4242)
     assert np.all(r["status"] == 0) and np.all(np.isfinite(r["xyz"]))
     best = np.array([min(kabsch_rmsd(r["xyz"][i, :, 1], dec[k][:, 1]) for k in refs) for i in range(B)])
@@ -147,7 +147,9 @@ def test_full_protocol_with_cartesian_stage(ctx, golden_dir, seq, tag, refs, med
     assert bond_sd < 0.02 and ang_sd < 4.5 and (relax or ang_sd > 1.5), (bond_sd, ang_sd)
     # twisted peptides: none with the relax stage (measured 0 of 1024 per map; the reference's eight decoys hold one cis peptide and
     # none twisted); without it 4-11 % (deviation 2): measured + margin each
-    assert twisted <= (0.02 if relax else 0.15) * B, twisted
+    # round 5 (fitted omega tether, 3 x ref2015's stiffness about its own centre): 0.1 / 0.2 % of 4096 with the relax stage, 7.5 % (NMR) /
+    # 28.9 % (X-ray) without (profiles/r05_model_final_n4096.txt; rounds 1-4's tether at 180 degrees: 4 % / 12 %); sd of a fraction of 29 % at n = 256: 2.8 %
+    assert twisted <= (0.02 if relax else (0.36 if tag == "Xray" else 0.13)) * B, twisted
 
 
 def test_cartesian_run_on_a_chain_longer_than_256(ctx):

@@ -30,4 +30,44 @@ run5() {  # relax tolerance scale, fine steps, warm starts on; 4096 decoys per c
   O=$R/gpurun_out/r05_run5; mkdir -p $O
   timeout -k 10 900 python3 tools/tol_sweep_relax.py $R 4096 1000 fine > $O/tol_sweep_fine.txt 2>&1; echo "rc=$?"
 }
+run6() {  # fitted rama / omega terms: device against oracle, then outcome A/B against the rounds-1-4 terms (2 x 2048 decoys per cell)
+  O=$R/gpurun_out/r05_run6; mkdir -p $O
+  timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_cartesian.py tests/test_gpu_relax.py -q -m gpu -k "eval or tracks or short or relax" > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt
+  for sc in 1.0,0.4 0.4,0.4 1.0,1.0; do echo "== fitted terms, TRX2_SF_FA_SCALE=$sc"; TRX2_SF_FA_SCALE=$sc timeout -k 10 300 python3 tools/tol_sweep_relax.py $R 2048 1000 model; done > $O/model_ab.txt 2>&1
+  echo "== rounds 1-4 terms (TRX2_BACKBONE_FIT=0), TRX2_SF_FA_SCALE=0.4,0.4" >> $O/model_ab.txt
+  TRX2FOLD_LIB=$R/trrosettax2-dynamics_amd/libtrx2fold_nofit.so TRX2_SF_FA_SCALE=0.4,0.4 timeout -k 10 300 python3 tools/tol_sweep_relax.py $R 2048 1000 model >> $O/model_ab.txt 2>&1
+  echo "model rc=$?"
+}
+run7() {  # model scan: rama fit alone, fitted omega at stiffness 2 / 3 / 4 / 6, relax-stage scale 0.4 / 1.0 (2 x 2048 decoys per cell)
+  O=$R/gpurun_out/r05_run7; mkdir -p $O; : > $O/model_scan.txt
+  for v in nofit rama o2 o3 o4 o6 omegaonly4; do for sc in 0.4,0.4 1.0,0.4; do
+    lib=$R/trrosettax2-dynamics_amd/libv_$v.so; [ $v = nofit ] && lib=$R/trrosettax2-dynamics_amd/libtrx2fold_nofit.so
+    echo "== $v TRX2_SF_FA_SCALE=$sc" >> $O/model_scan.txt
+    TRX2FOLD_LIB=$lib TRX2_SF_FA_SCALE=$sc timeout -k 10 300 python3 tools/tol_sweep_relax.py $R 2048 1000 model 2>&1 | grep -v "^#" >> $O/model_scan.txt
+  done; done
+  echo "rc=$?"
+}
+run8() {  # model scan 2: shrinkage of the fitted rama surface / helix term (TRX2_RAMA_SCAN), omega stiffness 1 / 2 / 4; twisted peptides counted without the terminus
+  O=$R/gpurun_out/r05_run8; mkdir -p $O; : > $O/model_scan2.txt
+  for v in o1 o2 o4; do echo "== $v (rama fit as fitted), TRX2_SF_FA_SCALE=1.0,0.4" >> $O/model_scan2.txt
+    TRX2FOLD_LIB=$R/trrosettax2-dynamics_amd/libv_$v.so TRX2_SF_FA_SCALE=1.0,0.4 timeout -k 10 300 python3 tools/tol_sweep_relax.py $R 2048 1000 model 2>&1 | grep -v "^#" >> $O/model_scan2.txt; done
+  for sc in 0,0 0,1 0.25,1 0.5,1 0.5,0.5 1,0 0.25,0.25; do echo "== rama-only lib (rounds 1-4 omega), TRX2_RAMA_SCAN=$sc" >> $O/model_scan2.txt
+    TRX2FOLD_LIB=$R/trrosettax2-dynamics_amd/libv_rama.so TRX2_RAMA_SCAN=$sc TRX2_SF_FA_SCALE=0.4,0.4 timeout -k 10 300 python3 tools/tol_sweep_relax.py $R 2048 1000 model 2>&1 | grep -v "^#" >> $O/model_scan2.txt; done
+  echo "rc=$?"
+}
+run9() {  # model scan 3: fitted omega (every peptide tethered) at stiffness 1 / 2 / 3 / 4 with the rama surface shrunk to one half
+  O=$R/gpurun_out/r05_run9; mkdir -p $O; : > $O/model_scan3.txt
+  for v in rama o1 o2 o3 o4; do for sc in 1.0,0.4 0.4,0.4; do echo "== $v, TRX2_RAMA_SCAN=0.5,1 TRX2_SF_FA_SCALE=$sc" >> $O/model_scan3.txt
+    TRX2FOLD_LIB=$R/trrosettax2-dynamics_amd/libv_$v.so TRX2_RAMA_SCAN=0.5,1 TRX2_SF_FA_SCALE=$sc timeout -k 10 300 python3 tools/tol_sweep_relax.py $R 2048 1000 model 2>&1 | grep -v "^#" >> $O/model_scan3.txt; done; done
+  echo "rc=$?"
+}
+run10() {  # the shipped model (two-pass rama fit, surface at one half, omega stiffness 3): parity tests + outcome on 2 x 4096 decoys, against the rounds-1-4 terms
+  O=$R/gpurun_out/r05_run10; mkdir -p $O
+  timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_cartesian.py tests/test_gpu_relax.py -q -m gpu -k "eval or tracks or short or relax" > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt
+  echo "== shipped: fitted rama (surface x 0.5, two-pass constants / propensities), fitted omega x 3, TRX2_SF_FA_SCALE=1.0,0.4" > $O/model_final.txt
+  timeout -k 10 300 python3 tools/tol_sweep_relax.py $R 4096 1000 model 2>&1 | grep -v "^#" >> $O/model_final.txt
+  echo "== rounds 1-4 terms, TRX2_SF_FA_SCALE=0.4,0.4" >> $O/model_final.txt
+  TRX2FOLD_LIB=$R/trrosettax2-dynamics_amd/libtrx2fold_nofit.so TRX2_SF_FA_SCALE=0.4,0.4 timeout -k 10 300 python3 tools/tol_sweep_relax.py $R 4096 1000 model 2>&1 | grep -v "^#" >> $O/model_final.txt
+  echo "rc=$?"
+}
 "$@"

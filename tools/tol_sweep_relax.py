@@ -61,7 +61,9 @@ def sample(tag, refs, runs):
     x = np.concatenate(xs); t = np.concatenate(ts); ev = np.concatenate(ev).astype(float)
     ca = x[:, :, 1].astype(np.float64)
     rr = np.stack([rmsd_many(ca, dec[k][:, 1]) for k in refs], 1); rm = rr.min(1)
-    tw = np.degrees(np.abs((t[:, :-1, 2] % (2 * np.pi)) - np.pi)).max(1) > 60
+    dw_ = np.degrees(np.abs((t[:, :-1, 2] % (2 * np.pi)) - np.pi))
+    tw = dw_[:, 1:].max(1) > 60            # the first peptide apart: Rosetta does not tether a terminus (conf_1_1's is cis)
+    tw0 = dw_[:, 0] > 60
     ok = rm < 3.0
     pp = phipsi(x[ok]); ppr = [phipsi(dec[k]) for k in refs]
     to = np.stack([cdiff(pp, pr) for pr in ppr], 1)                 # [n, 2 refs, 2 angles]
@@ -73,7 +75,7 @@ def sample(tag, refs, runs):
     u, v = xd[:, :, 0] - xd[:, :, 1], xd[:, :, 2] - xd[:, :, 1]
     ang = np.degrees(np.arccos((u * v).sum(-1) / np.linalg.norm(u, axis=-1) / np.linalg.norm(v, axis=-1))).std(1).mean()
     return (f"{tag} med {np.median(rm):.3f} q {np.percentile(rm,25):.2f}-{np.percentile(rm,75):.2f} <=.5 {100*(rm<=0.5).mean():4.1f}% <=1 {100*(rm<=1).mean():4.1f}% "
-            f">3 {100*(rm>3).mean():3.1f}% tw {100*tw.mean():3.1f}% dphi/dpsi ref {np.median(to[:,0]):4.1f}/{np.median(to[:,1]):4.1f} own {np.median(own[:,0]):4.1f}/{np.median(own[:,1]):4.1f} "
+            f">3 {100*(rm>3).mean():3.1f}% tw {100*tw.mean():3.1f}% (first peptide {100*tw0.mean():3.1f}%) dphi/dpsi ref {np.median(to[:,0]):4.1f}/{np.median(to[:,1]):4.1f} own {np.median(own[:,0]):4.1f}/{np.median(own[:,1]):4.1f} "
             f"CA-C sd {cac:.4f} NCAC sd {ang:.2f} ev med {np.median(ev):.0f} mean {ev.mean():.0f} max {ev.max():.0f} [{sec:.1f}s]")
 
 
@@ -107,6 +109,9 @@ if part in ("grid", "all"):
     for c in (1e-6, 3e-6, 1e-5, 3e-5, 1e-4):
         for s in (0.01, 0.1, 1.0):
             cell(f"centroid {c:g} relax x{s:g}", protocol(c, s))
+if part == "model":
+    cell("default protocol", P.build_runs(90, 2, fastrelax=True))
+    cell("--no-fastrelax", P.build_runs(90, 2))
 if part == "fine":
     for sc in (0.01, 0.02, 0.03, 0.05, 0.1):
         cell(f"centroid 1e-6 relax x{sc:g}", protocol(1e-6, sc))

@@ -94,6 +94,62 @@ __device__ __forceinline__ f3 place_h(f3 Cp, f3 N, f3 CA) {
   return N + u * ((float)TRX2_HB_B_NH * rsqrtf(dot(u, u)));
 }
 
+// ---- rama / omega terms (trx2_model.h: six-basin prior + the surfaces fitted to the reference decoys' energy tables; oracle: rama_term,
+// omega_term).  The per-residue parameter block of the rama term (TRX2_RAMA_NPAR floats = 3 float4) lives behind the map's hasH bytes.
+__device__ __forceinline__ const float4* rama_par_ptr(const unsigned char* hasH, int L) {
+  return reinterpret_cast<const float4*>(hasH + (((size_t)L + 255) & ~(size_t)255));
+}
+// energy of one residue from sin / cos of phi, psi; gph, gps = dE/dphi, dE/dpsi (unweighted)
+__device__ __forceinline__ float rama_eval(float sph, float cph, float sps, float cps, const float4 (&rp)[3], float& gph, float& gps) {
+  float s = 0, dph = 0, dps = 0, h = 0, dhph = 0, dhps = 0;
+#pragma unroll
+  for (int j = 0; j < TRX2_RAMA_NB; j++) {
+    // sin / cos of (phi - phi_k), (psi - psi_k) by the angle-addition identities: 2 sincosf per residue, not 12
+    const float sk = c_rama_sc[j * 4], ck = c_rama_sc[j * 4 + 1], tk = c_rama_sc[j * 4 + 2], uk = c_rama_sc[j * 4 + 3];
+    const float sa = sph * ck - cph * sk, ca = cph * ck + sph * sk;
+    const float sb = sps * uk - cps * tk, cb = cps * uk + sps * tk;
+    const float t = c_rama[j * 3 + 2] * expf((float)TRX2_RAMA_KAPPA * (ca + cb - 2.0f));
+    const float ta = t * (float)TRX2_RAMA_KAPPA * sa, tb = t * (float)TRX2_RAMA_KAPPA * sb;
+    s += t; dph -= ta; dps -= tb;
+    if (TRX2_RAMA_FIT_ON && (j == 3 || j == 4)) { h += t; dhph -= ta; dhps -= tb; }   // the two right-handed helical basins
+  }
+  const float inv = 1.0f / (s + (float)TRX2_RAMA_FLOOR);
+  float E = -logf((s + (float)TRX2_RAMA_FLOOR) * (1.0f / (float)TRX2_RAMA_PREF));
+  gph = -dph * inv; gps = -dps * inv;
+  if (TRX2_RAMA_FIT_ON) {
+    const float cm = cph * cps + sph * sps, sm = sph * cps - cph * sps, cp = cph * cps - sph * sps, sp = sph * cps + cph * sps;
+    const float r = h * inv;
+    const float p0 = rp[0].x, p1 = rp[0].y, p2 = rp[0].z, p3 = rp[0].w, p4 = rp[1].x, p5 = rp[1].y, p6 = rp[1].z, p7 = rp[1].w, p8 = rp[2].x, p9 = rp[2].y;
+    E += p0 + p1 * cps + p2 * sps + p3 * cm + p4 * sm + p5 * cph + p6 * sph + p7 * cp + p8 * sp + p9 * r;
+    gph += -p3 * sm + p4 * cm - p5 * sph + p6 * cph - p7 * sp + p8 * cp + p9 * (dhph - r * dph) * inv;
+    gps += -p1 * sps + p2 * cps + p3 * sm - p4 * cm - p7 * sp + p8 * cp + p9 * (dhps - r * dps) * inv;
+  }
+  return E;
+}
+// energy of one peptide's omega tether from sin / cos of psi_i and omega_i (radians); gps, gom = dE/dpsi, dE/domega (unweighted)
+__device__ __forceinline__ float omega_eval(float sps, float cps, float om, float& gps, float& gom) {
+  if (!TRX2_OMEGA_FIT_ON) {
+    float dw = om - TRX2_PI_F;
+    dw -= 2.0f * TRX2_PI_F * rintf(dw * (0.5f / TRX2_PI_F));
+    dw *= (1.0f / TRX2_DEG_F);
+    gps = 0.0f; gom = 2.0f * (float)TRX2_OMEGA_K * dw * (1.0f / TRX2_DEG_F);
+    return (float)TRX2_OMEGA_K * dw * dw;
+  }
+  constexpr float q[9] = TRX2_OMEGA_FIT;
+  float x = om - TRX2_PI_F;
+  x -= 2.0f * TRX2_PI_F * rintf(x * (0.5f / TRX2_PI_F));
+  x *= (0.1f / TRX2_DEG_F);
+  const float A = q[0] + q[1] * cps + q[2] * sps, B = q[3] + q[4] * cps + q[5] * sps, C = q[6] + q[7] * cps + q[8] * sps;
+  constexpr float st = (float)TRX2_OMEGA_STIFF;
+  gom = st * (B + 2.0f * C * x) * (0.1f / TRX2_DEG_F);
+  gps = (-q[1] * sps + q[2] * cps) + st * ((-q[4] * sps + q[5] * cps) + (-q[7] * sps + q[8] * cps) * x) * x;
+  return A + st * (B + C * x) * x;
+}
+// peptides that carry the tether: all of them, as in rounds 1-4.  (Rosetta scores none on a terminus -- the reference decoys' tables show ~0
+// for the first peptide whatever its angle, conf_1_1's is cis -- and the fit leaves that sample out; but with the first peptide free half of
+// this model's decoys twist it beyond 60 degrees, where seven of the reference's eight keep it trans: profiles/r05_model_scan2.txt.)
+__device__ __forceinline__ bool omega_on(int r, int L) { return r < L - 1; }
+
 #ifdef TRX2_DBG
 __device__ double g_dbg[256][12];  // diagnostic build only: decoy 0's line-search record per evaluation (tools/dbg_linesearch.py)
 #endif
@@ -367,7 +423,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
   // coordinates, the first slice of the pair records, the accepted point with its gradient and direction.  Requested before the
   // role test instead of after it, their round trip runs beside the state's instead of behind it (~2000 cycles of a step).  A
   // workgroup whose role is not the decoy's current one has asked in vain: 13 % of the torsion role's launches.
-  float4 e_xt, e_c[6], e_fa[6], e_x, e_g, e_dv;
+  float4 e_xt, e_c[6], e_fa[6], e_x, e_g, e_dv, e_rp[3];
+  e_rp[0] = e_rp[1] = e_rp[2] = make_float4(0, 0, 0, 0);
   e_xt = e_x = e_g = e_dv = make_float4(0, 0, 0, 0);
 #pragma unroll
   for (int q = 0; q < 6; q++) e_c[q] = e_fa[q] = make_float4(0, 0, 0, 0);
@@ -378,6 +435,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
       nsl_pre = A.nslice[rc];
       const size_t vr = (size_t)dec * L + rc;
       e_xt = A.XT[vr];
+      if (TRX2_RAMA_FIT_ON) { const float4* rpp = rama_par_ptr(A.hasH, L) + (size_t)rc * 3; e_rp[0] = rpp[0]; e_rp[1] = rpp[1]; e_rp[2] = rpp[2]; }
       const float4* xp = A.P + vr * 5;
 #pragma unroll
       for (int q = 0; q < 5; q++) e_c[q] = xp[q];
@@ -483,32 +541,25 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
         // so it belongs to the suffix sums (every torsion before r moves it) and to none of the residue's own moved sets
         g2[k] = gN + gCA + gC_[k] + gO_[k] + gCB_[k] + gH;
         g1[k] = cross(pN[k], gN) + cross(pCA[k], gCA) + cross(pC[k], gC_[k]) + cross(pO[k], gO_[k]) + cross(pCB[k], gCB_[k]) + cross(pH, gH);
-        // torsion-space terms: rama (residues 2..L-1) and omega_bb (1..L-1)
-        if (r >= 1 && r < L - 1) {
-          float s = 0, dph = 0, dps = 0;
-          // sin/cos of (phi - phi_k), (psi - psi_k) by the angle-addition identities: 2 sincosf per residue, not 12
+        // torsion-space terms: rama (residues 2..L-1) and omega_bb (peptides 1..L-1; 2..L-1 with the fitted terms)
+        if (r < L - 1) {
           float sph, cph, sps, cps;
           fast_sincosf(xt[k].x, &sph, &cph);
           fast_sincosf(xt[k].y, &sps, &cps);
-#pragma unroll
-          for (int j = 0; j < TRX2_RAMA_NB; j++) {
-            const float sk = c_rama_sc[j * 4], ck = c_rama_sc[j * 4 + 1], tk = c_rama_sc[j * 4 + 2], uk = c_rama_sc[j * 4 + 3];
-            const float sa = sph * ck - cph * sk, ca = cph * ck + sph * sk;
-            const float sb = sps * uk - cps * tk, cb = cps * uk + sps * tk;
-            float t = c_rama[j * 3 + 2] * expf((float)TRX2_RAMA_KAPPA * (ca + cb - 2.0f));
-            s += t; dph -= t * (float)TRX2_RAMA_KAPPA * sa; dps -= t * (float)TRX2_RAMA_KAPPA * sb;
+          if (r >= 1) {
+            float4 rp[3] = {e_rp[0], e_rp[1], e_rp[2]};
+            if (RPT > 1 && TRX2_RAMA_FIT_ON) { const float4* rpp = rama_par_ptr(A.hasH, L) + (size_t)r * 3; rp[0] = rpp[0]; rp[1] = rpp[1]; rp[2] = rpp[2]; }
+            float gph, gps;
+            esum[5] += (double)rama_eval(sph, cph, sps, cps, rp, gph, gps);
+            gt[k].x += R.w[4] * gph;
+            gt[k].y += R.w[4] * gps;
           }
-          float inv = 1.0f / (s + (float)TRX2_RAMA_FLOOR);
-          esum[5] += -(double)logf((s + (float)TRX2_RAMA_FLOOR) * (1.0f / (float)TRX2_RAMA_PREF));
-          gt[k].x += -R.w[4] * dph * inv;
-          gt[k].y += -R.w[4] * dps * inv;
-        }
-        if (r < L - 1) {
-          float dw = xt[k].z - TRX2_PI_F;
-          dw -= 2.0f * TRX2_PI_F * rintf(dw * (0.5f / TRX2_PI_F));
-          dw *= (1.0f / TRX2_DEG_F);
-          esum[6] += (double)((float)TRX2_OMEGA_K * dw * dw);
-          gt[k].z += R.w[5] * 2.0f * (float)TRX2_OMEGA_K * dw * (1.0f / TRX2_DEG_F);
+          if (omega_on(r, L)) {
+            float gps, gom;
+            esum[6] += (double)omega_eval(sps, cps, xt[k].z, gps, gom);
+            gt[k].y += R.w[5] * gps;
+            gt[k].z += R.w[5] * gom;
+          }
         }
       }
     }
@@ -1245,6 +1296,8 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
   if (tid < LBM) s_rho[tid] = A.rho[(size_t)dec * LBM + tid];
   const int nsl_pre = A.nslice[min(tid, L - 1)];       // slices of this residue's row; backbone H of this residue: requested with the state
   const bool hH_me = A.hasH[min(tid, L - 1)] != 0;
+  float4 e_rp[3];
+  { const float4* rpp = rama_par_ptr(A.hasH, L) + (size_t)min(tid, L - 1) * 3; e_rp[0] = rpp[0]; e_rp[1] = rpp[1]; e_rp[2] = rpp[2]; }
   // The decoy's Gram scalars (kernel_step.h, "Gram form"): one set per decoy serves both roles -- a decoy is in one role at a
   // time and every run starts from an empty history, whose scalars are zeros.
   double gr_old0 = 0, gr_old1 = 0;
@@ -1325,30 +1378,29 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
       const f3 g1 = (gp - e1 * dot(e1, gp)) * il1, g2 = (gp - e2 * dot(e2, gp)) * il2;
       aN = gH + g1 + g2; aCA = g2 * -1.0f; toC = g1 * -1.0f;
     }
-    // rama (residues 2..L-1) and omega_bb (1..L-1)
+    // rama (residues 2..L-1) and omega_bb (peptides 1..L-1; the fitted tether's centre and width follow psi)
     f3 t1, t2, t3, t4;
-    if (r >= 1 && r < L - 1) {
-      f3 p1, p2, p3, p4;
-      const float ph = dihedral_grad(Pv.C, Me.N, Me.CA, Me.C, p1, p2, p3, p4), ps = dihedral_grad(Me.N, Me.CA, Me.C, Nx.N, t1, t2, t3, t4);
-      float sph, cph, sps, cps, sm = 0, a1 = 0, a2 = 0;
-      fast_sincosf(ph, &sph, &cph); fast_sincosf(ps, &sps, &cps);
-#pragma unroll
-      for (int j = 0; j < TRX2_RAMA_NB; j++) {
-        const float sk = c_rama_sc[j * 4], ck = c_rama_sc[j * 4 + 1], tk = c_rama_sc[j * 4 + 2], uk = c_rama_sc[j * 4 + 3];
-        const float sa = sph * ck - cph * sk, ca = cph * ck + sph * sk, sb = sps * uk - cps * tk, cb = cps * uk + sps * tk;
-        const float t = c_rama[j * 3 + 2] * expf((float)TRX2_RAMA_KAPPA * (ca + cb - 2.0f));
-        sm += t; a1 -= t * (float)TRX2_RAMA_KAPPA * sa; a2 -= t * (float)TRX2_RAMA_KAPPA * sb;
-      }
-      const float inv = 1.0f / (sm + (float)TRX2_RAMA_FLOOR);
-      esum[5] += -(double)logf((sm + (float)TRX2_RAMA_FLOOR) * (1.0f / (float)TRX2_RAMA_PREF));
-      const float dphi = -R.w[4] * a1 * inv, dpsi = -R.w[4] * a2 * inv;
-      toC = fma3(p1, dphi, toC); aN = fma3(p2, dphi, aN); aCA = fma3(p3, dphi, aCA); aC = fma3(p4, dphi, aC);
-      aN = fma3(t1, dpsi, aN); aCA = fma3(t2, dpsi, aCA); aC = fma3(t3, dpsi, aC); toN = fma3(t4, dpsi, toN);
-    }
     if (r < L - 1) {
-      const float dw = wrap_pi_f(dihedral_grad(Me.CA, Me.C, Nx.N, Nx.CA, t1, t2, t3, t4) - TRX2_PI_F) * (1.0f / TRX2_DEG_F);
-      esum[6] += (double)((float)TRX2_OMEGA_K * dw * dw);
-      const float dom = R.w[5] * 2.0f * (float)TRX2_OMEGA_K * dw * (1.0f / TRX2_DEG_F);
+      const float ps = dihedral_grad(Me.N, Me.CA, Me.C, Nx.N, t1, t2, t3, t4);
+      float sps, cps, dpsi = 0.0f;
+      fast_sincosf(ps, &sps, &cps);
+      if (r >= 1) {
+        f3 p1, p2, p3, p4;
+        const float ph = dihedral_grad(Pv.C, Me.N, Me.CA, Me.C, p1, p2, p3, p4);
+        float sph, cph, gph, gps;
+        fast_sincosf(ph, &sph, &cph);
+        esum[5] += (double)rama_eval(sph, cph, sps, cps, e_rp, gph, gps);
+        const float dphi = R.w[4] * gph;
+        dpsi = R.w[4] * gps;
+        toC = fma3(p1, dphi, toC); aN = fma3(p2, dphi, aN); aCA = fma3(p3, dphi, aCA); aC = fma3(p4, dphi, aC);
+      }
+      // the omega term's part on psi joins the rama term's before psi's gradient vectors go (value first: one set of vectors live at a time)
+      float gps_o, gom;
+      esum[6] += (double)omega_eval(sps, cps, dihedral_val(Me.CA, Me.C, Nx.N, Nx.CA), gps_o, gom);
+      dpsi += R.w[5] * gps_o;
+      const float dom = R.w[5] * gom;
+      aN = fma3(t1, dpsi, aN); aCA = fma3(t2, dpsi, aCA); aC = fma3(t3, dpsi, aC); toN = fma3(t4, dpsi, toN);
+      dihedral_grad(Me.CA, Me.C, Nx.N, Nx.CA, t1, t2, t3, t4);
       aCA = fma3(t1, dom, aCA); aC = fma3(t2, dom, aC); toN = fma3(t3, dom, toN); toCA = fma3(t4, dom, toCA);
     }
     CSTAMP(18)  // backbone H, rama / omega

@@ -167,6 +167,14 @@ __device__ __forceinline__ float dihedral_grad(f3 p1, f3 p2, f3 p3, f3 p4, f3& d
   return ang;
 }
 
+// the value alone (same operations as dihedral_grad's)
+__device__ __forceinline__ float dihedral_val(f3 p1, f3 p2, f3 p3, f3 p4) {
+  f3 F = p1 - p2, G = p2 - p3, H = p4 - p3;
+  f3 A = cross(F, G), B = cross(H, G);
+  float iGn = frsq(dot(G, G));
+  return fast_atan2f(dot(cross(B, A), G) * iGn, dot(A, B));
+}
+
 // planar angle p1-p2-p3 in [0,pi] and gradient
 __device__ __forceinline__ float angle_grad(f3 p1, f3 p2, f3 p3, f3& d1, f3& d2, f3& d3) {
   f3 v = p1 - p2, w = p3 - p2;

@@ -723,8 +723,24 @@ static int set_map_impl(trx2_ctx* ctx, int L, const char* seq, const float* dist
   {  // residues that donate a backbone hydrogen bond: every residue with a predecessor except proline (trx2_model.h)
     std::vector<unsigned char> hh((size_t)L);
     for (int i = 0; i < L; i++) hh[i] = (i >= 1 && !(i < (int)ctx->seq.size() && ctx->seq[i] == 'P')) ? 1 : 0;
-    HIPCHK(hipMalloc((void**)&ctx->hasH, (size_t)L));
-    HIPCHK(hipMemcpy(ctx->hasH, hh.data(), (size_t)L, hipMemcpyHostToDevice));
+    // ... and behind the flags, 256-byte aligned, the per-residue parameter block of the rama term (trx2_model.h trx2_rama_params;
+    // kernel_step.h rama_par_ptr): one allocation, so that every owner / borrower of hasH owns / borrows both
+    const size_t off = ((size_t)L + 255) & ~(size_t)255;
+    std::vector<unsigned char> blk(off + (size_t)L * TRX2_RAMA_NPAR * sizeof(float), 0);
+    memcpy(blk.data(), hh.data(), (size_t)L);
+    const std::string sq = ctx->seq.size() >= (size_t)L ? ctx->seq : std::string((size_t)L, 'A');
+    for (int i = 0; i < L; i++) trx2_rama_params(sq.c_str(), i, L, reinterpret_cast<float*>(blk.data() + off) + (size_t)i * TRX2_RAMA_NPAR);
+    if (const char* e = getenv("TRX2_RAMA_SCAN")) {   // model scans only (tools/tol_sweep_relax.py): "surface scale,helix scale" on the fitted parts
+      float sf = 1.0f, sh = 1.0f;
+      if (sscanf(e, "%f,%f", &sf, &sh) == 2)
+        for (int i = 0; i < L; i++) {
+          float* p = reinterpret_cast<float*>(blk.data() + off) + (size_t)i * TRX2_RAMA_NPAR;
+          for (int k = 1; k <= 8; k++) p[k] *= sf;
+          p[9] *= sh;
+        }
+    }
+    HIPCHK(hipMalloc((void**)&ctx->hasH, blk.size()));
+    HIPCHK(hipMemcpy(ctx->hasH, blk.data(), blk.size(), hipMemcpyHostToDevice));
   }
   if (orient) {
     HIPCHK(hipMalloc((void**)&ctx->To, LL * KO * sizeof(float2)));

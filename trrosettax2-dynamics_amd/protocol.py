@@ -50,13 +50,25 @@ CART_MAX_L = 512  # the Cartesian step kernel handles one residue per thread, up
 # weighted here with ref2015_cart's published weights for the terms they stand in for [Rosetta, from memory -- unverified]:
 # fa_rep 0.55 -> vdw (times the script's ramp), rama_prepro 0.45 -> rama, omega 0.4, cart_bonded 0.5, hbond_sr_bb = hbond_lr_bb 1.0.
 SF_FA = [5.0, 1.0, 1.0, 0.55, 0.45, 0.4, 0.5, 1.0]
-# Scale of the omega / bonded SURROGATES in the relax stage.  SF_FA's weights were written for Rosetta's terms; on the reference's
-# decoys the surrogates are 13 x (omega) and 25 x (cart_bonded) Rosetta's columns (tests/test_pose_energies.py).  0.4 on both is as
-# far towards Rosetta's scale as the outcome improves (2 x 1024 decoys per map, profiles/README.md round 4: X-ray decoys within 1 A
-# 82.5 -> 86.5 %, medians and the NMR map unchanged, 3 % fewer evaluations; 0.25 on omega starts to twist peptides).  The centroid
-# stage keeps the constants it was calibrated with.  TRX2_SF_FA_SCALE="omega,bonded" overrides (model scans).
+# Scale of the omega / bonded terms in the relax stage.  SF_FA's weights were written for Rosetta's terms.  omega: since round 5 the term IS
+# fitted to ref2015's column of the reference decoys' energy tables (include/trx2_model.h TRX2_OMEGA_FIT), so its scale is 1 (rounds 1-4:
+# 0.4 on a tether 13 x Rosetta's).  cart_bonded: the surrogate is 25 x Rosetta's column (tests/test_pose_energies.py); 0.4 is as far
+# towards Rosetta's scale as the outcome improved (round 4, 2 x 1024 decoys per map).  TRX2_SF_FA_SCALE="omega,bonded" overrides (model scans).
 import os as _os
-SF_FA_SCALE = tuple(float(x) for x in _os.environ.get("TRX2_SF_FA_SCALE", "0.4,0.4").split(","))
+
+
+def _sf_fa_scale():
+    txt = _os.environ.get("TRX2_SF_FA_SCALE", "1.0,0.4")
+    try:
+        v = tuple(float(x) for x in txt.split(","))
+        if len(v) != 2 or not all(0.0 <= x <= 100.0 for x in v):
+            raise ValueError
+    except ValueError:
+        raise ValueError(f"TRX2_SF_FA_SCALE must be two non-negative numbers 'omega,bonded', got {txt!r}") from None
+    return v
+
+
+SF_FA_SCALE = _sf_fa_scale()
 # folding/data/1relax_round1.txt, 2relax_round2.txt: `ramp_repack_min <fa_rep scale> <min tolerance> <coord-cst weight> <max iter>`
 RELAX_RAMP_TORSION = [(0.02, 0.01, 100), (0.25, 0.01, 100), (0.55, 0.01, 100), (1.0, 0.00001, 100)]
 RELAX_RAMP_CART = [(0.02, 0.01, 50), (0.25, 0.01, 50), (0.55, 0.01, 100), (1.0, 0.00001, 200)]
