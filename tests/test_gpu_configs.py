@@ -91,7 +91,7 @@ def check_tracking(ctx, Tb, t0, runs, n_evals=20, med_tol=5e-3, tail_tol=1e-1, r
     _, _, st, _ = O.fold_batch(Tb, t0.astype(np.float64), runs, max_evals=n_evals)
     oi = np.array([s["n_iters"] for s in st])
     of = np.array([s["f_final"] for s in st])
-    rel = np.abs(r["f"] - of) / np.abs(of)
+    rel = np.abs(r["f"] - of) / np.maximum(np.abs(of), np.median(np.abs(of)))   # (an energy that passes through zero is no scale: the batch's median magnitude is the floor)
     ratio, same = r["n_iters"].sum() / max(oi.sum(), 1), int((oi == r["n_iters"]).sum())
     print(f"\n   tracking L={t0.shape[1]} B={B} runs={len(runs)}: iter ratio {ratio:.3f}, identical counts {same}/{B}, rel f sorted tail {np.round(np.sort(rel)[-4:], 5)}, median {np.median(rel):.2e}")
     assert np.all(r["n_evals"] == n_evals) and np.all(np.isfinite(r["xyz"]))
@@ -102,14 +102,27 @@ def check_tracking(ctx, Tb, t0, runs, n_evals=20, med_tol=5e-3, tail_tol=1e-1, r
     return float(ratio), same, float(np.median(rel))
 
 
-def check_fold_properties(r, r_again, m, Tb, orient):
+def check_relax_segment(ctx, Tb, m, B, seed, n_evals=30, **kw):
+    """The 21 runs the default protocol adds to --no-fastrelax (protocol.relax_runs: restraints re-selected at PCUT 0.15 / 0.30 without
+    glycine pairs, ref2015_cart's weights, torsion and Cartesian ramps, the closing unrestrained run), from near-target starts, which is
+    where a fold enters them, for 30 evaluations: the first ramp's four runs and the start of the second (the runs
+    bench.py times at L = 150 and 400 had met the oracle only at L = 90)."""
+    runs = T.protocol.build_runs(len(m["tors"]), 2, fastrelax=True)
+    assert len(runs) == 35 and runs[14]["pair_filter"] == 2 and runs[14]["warm"] == 1
+    return check_tracking(ctx, Tb, near_starts(m, B, seed, noise=0.03), runs[14:], n_evals=n_evals, **kw)
+
+
+def check_fold_properties(r, r_again, m, Tb, orient, ctx_eval=None):
     B = r["xyz"].shape[0]
     assert np.all(r["status"] == 0), r["status"]
     assert np.all(np.isfinite(r["xyz"])) and np.all(np.isfinite(r["f"]))
     assert np.array_equal(r["xyz"], r_again["xyz"]) and np.array_equal(r["n_evals"], r_again["n_evals"])   # bitwise reproducible
     # restraint-energy depth: the distance energy of a folded decoy relative to the map's own target structure
     _, e_t, _, _ = O.evaluate(Tb, np.asarray(m["tors"], np.float64), SF, grad=False)
-    depth = r["e_terms"][:, 0] / e_t[0]
+    e_dist = r["e_terms"][:, 0]
+    if not np.any(e_dist):      # the default protocol's last run carries no restraints: its report's restraint channels are 0 -> evaluate the folded torsions
+        e_dist = ctx_eval(r)[:, 0]
+    depth = e_dist / e_t[0]
     # and does it FOLD: C-alpha RMSD to the map's own target structure, and to its mirror image (distances alone cannot tell)
     from oracle.kabsch import kabsch_rmsd
     ca = S.nerf_backbone(m["tors"])[1]
@@ -118,6 +131,14 @@ def check_fold_properties(r, r_again, m, Tb, orient):
     print(f"   fold quality: RMSD to target median {np.median(rm):.2f} A, < 2 A: {(rm < 2).sum()}/{B}; to the mirror image < 3.5 A: {(mir < 3.5).sum()}/{B}; "
           f"dist-energy depth median {np.median(depth):.3f} min {depth.min():.3f}")
     return float(np.median(depth)), float(depth.min()), rm, mir
+
+
+# relax-segment tracking bounds per config: (median relative energy difference, all but the worst eighth, accepted-iteration ratio, identical
+# counts).  Measured on MI355X (round 5, 30 evaluations from near-target starts): config 2 (64 decoys, distances only) ratio 0.990, 55 / 64
+# identical, median 3.1e-3, worst eighth from 0.09; config 3 (all channels) 1.004, 51 / 64, 5.2e-3, from 0.24; config 4 (L = 400, 16 decoys,
+# Cartesian ramps on 512 threads) 0.964, 6 / 16, 4.2e-2, from 0.3 (a 400-residue chain's float32 / float64 trajectories separate within the
+# first ramp).  Bounds = measured + margin.
+RELAX_TRACK = {"c2": (2e-2, 0.3, 0.95, 0.5), "c3": (3e-2, 0.5, 0.95, 0.5), "c4": (0.15, 1.5, 0.90, 0.1)}
 
 
 @pytest.fixture(scope="module")
@@ -137,14 +158,18 @@ def test_config2_L150_B64_dist_only(ctx):
     t0 = np.stack([O.random_torsions(L, 150, d) for d in range(B)]).astype(np.float32)
     trk = check_tracking(ctx, Tb, t0, runs)           # first 20 evaluations: the declash prelude (repulsion + rama only)
     check_tracking(ctx, Tb, near_starts(m, B, 7), runs[5:], med_tol=5e-2, tail_tol=0.5)   # and the restraint stage (sf, all selected restraints) near the target
+    rlx = check_relax_segment(ctx, Tb, m, B, 17, med_tol=RELAX_TRACK["c2"][0], tail_tol=RELAX_TRACK["c2"][1], ratio_min=RELAX_TRACK["c2"][2], same_frac=RELAX_TRACK["c2"][3])
+    runs = T.protocol.build_runs(L, 2, fastrelax=True)     # the whole fold: the protocol that ships and is benched (35 runs)
     r, r2 = ctx.fold_batch(B, runs, seed=150), ctx.fold_batch(B, runs, seed=150)
-    med, lo, rm, mir = check_fold_properties(r, r2, m, Tb, False)
-    print(f"\nconfig 2: worst eval deviations {w}; 20-eval tracking (iter ratio, identical counts, median rel f) {trk}; "
+    med, lo, rm, mir = check_fold_properties(r, r2, m, Tb, False, lambda q: ctx.eval_batch(q["tors"], SF)[1])
+    print(f"\nconfig 2: worst eval deviations {w}; 20-eval tracking (iter ratio, identical counts, median rel f) {trk}; relax segment {rlx}; "
           f"evals median {int(np.median(r['n_evals']))}")
     # Distances alone do not fix handedness (the reference's --no-orient folds of its own map: half are mirror images, DESIGN.md
     # section 2): measured on this map 15 of 64 within 2 A of the target, depth median 0.90.  A target that does NOT fold (the
     # round-1 random coil: 0 of 64, depth 0.61) must fail here.
-    assert med > 0.80 and (rm < 2.5).sum() + (mir < 3.5).sum() >= B // 8, (med, np.sort(rm)[:8], np.sort(mir)[:8])
+    # (round 5: the fold is the DEFAULT protocol -- its relax stage re-selects the restraints at PCUT 0.15 / 0.30 and ends unrestrained, so the
+    # depth under the full PCUT-0.05 selection is lower than after --no-fastrelax's last restrained run: measured 0.685, 23 + 7 of 64)
+    assert med > 0.60 and (rm < 2.5).sum() + (mir < 3.5).sum() >= B // 8, (med, np.sort(rm)[:8], np.sort(mir)[:8])
 
 
 def test_config3_L150_B64_all_channels_two_models():
@@ -163,13 +188,15 @@ def test_config3_L150_B64_all_channels_two_models():
             print(f"\nconfig 3, model {k}: worst eval deviations {w}")
         t0 = np.stack([O.random_torsions(L, 151, d) for d in range(B)]).astype(np.float32)
         print("config 3: 20-eval tracking", check_tracking(ctxs[0], Tbs[0], t0, runs), check_tracking(ctxs[1], Tbs[1], near_starts(ms[1], B, 8), runs[5:], med_tol=1e-2, tail_tol=0.5))
+        print("config 3: relax segment", check_relax_segment(ctxs[0], Tbs[0], ms[0], B, 18, med_tol=RELAX_TRACK["c3"][0], tail_tol=RELAX_TRACK["c3"][1], ratio_min=RELAX_TRACK["c3"][2], same_frac=RELAX_TRACK["c3"][3]))
+        runs = T.protocol.build_runs(L, 2, fastrelax=True)     # the whole fold: the protocol that ships and is benched
         solo = [ctxs[k].fold_batch(B, runs, seed=150 + k) for k in range(2)]
         with ThreadPoolExecutor(max_workers=2) as ex:
             both = list(ex.map(lambda k: ctxs[k].fold_batch(B, runs, seed=150 + k), range(2)))
         for k in range(2):
-            med, lo, rm, mir = check_fold_properties(both[k], solo[k], ms[k], Tbs[k], True)
+            med, lo, rm, mir = check_fold_properties(both[k], solo[k], ms[k], Tbs[k], True, lambda q, k=k: ctxs[k].eval_batch(q["tors"], SF)[1])
             print(f"config 3, model {k}: evals median {int(np.median(both[k]['n_evals']))}")
-            assert med > 0.95 and np.median(rm) < 1.0 and (rm < 2).sum() >= 0.9 * B   # measured: median 0.33 A, 64 of 64
+            assert med > 0.85 and np.median(rm) < 1.0 and (rm < 2).sum() >= 0.9 * B   # measured (default protocol): depth 0.913, median 0.23 A, 64 of 64
     finally:
         for c in ctxs:
             c.close()
@@ -189,11 +216,13 @@ def test_config4_L400_B32_all_channels(ctx):
     # 16-decoy ratios ranged 0.948 .. 1.040)
     trk = check_tracking(ctx, Tb, t0, runs, med_tol=1e-2, ratio_min=0.94)
     check_tracking(ctx, Tb, near_starts(m, 16, 9), runs[5:], med_tol=0.15, tail_tol=0.5, same_frac=0.1)   # measured: 0.973, 3/16, 6.3e-2
+    rlx = check_relax_segment(ctx, Tb, m, 16, 19, med_tol=RELAX_TRACK["c4"][0], tail_tol=RELAX_TRACK["c4"][1], ratio_min=RELAX_TRACK["c4"][2], same_frac=RELAX_TRACK["c4"][3])
+    runs = T.protocol.build_runs(L, 2, fastrelax=True)     # the whole fold: the protocol that ships and is benched (Cartesian ramps on 512 threads)
     r, r2 = ctx.fold_batch(B, runs, seed=400), ctx.fold_batch(B, runs, seed=400)
-    med, lo, rm, mir = check_fold_properties(r, r2, m, Tb, True)
-    print(f"\nconfig 4: worst eval deviations {w}; tracking {trk}; evals median {int(np.median(r['n_evals']))}")
+    med, lo, rm, mir = check_fold_properties(r, r2, m, Tb, True, lambda q: ctx.eval_batch(q["tors"], SF)[1])
+    print(f"\nconfig 4: worst eval deviations {w}; tracking {trk}; relax segment {rlx}; evals median {int(np.median(r['n_evals']))}")
     # the helical-bundle target folds from random starts (oracle: 7 of 8 within 3.4 A); the round-1 coil ended 6-25 A away
-    assert med > 0.93 and np.median(rm) < 4.0, (med, np.sort(rm))
+    assert med > 0.70 and np.median(rm) < 3.0, (med, np.sort(rm))     # measured (default protocol): depth 0.789, median 1.23 A, 18 of 32 within 2 A
 
 
 def test_config5_eight_targets_B32_on_one_gpu():
@@ -207,7 +236,7 @@ def test_config5_eight_targets_B32_on_one_gpu():
             Tb = oracle_tables(ms[L], True)
             w = check_eval_every_decoy(ctxs[L], Tb, mixed_starts(ms[L], B, L), SF, 3e-3)
             t0 = np.stack([O.random_torsions(L, L, d) for d in range(8)]).astype(np.float32)
-            trk = check_tracking(ctxs[L], Tb, t0, T.protocol.build_runs(L, 2))
+            trk = check_tracking(ctxs[L], Tb, t0, T.protocol.build_runs(L, 2), med_tol=1e-2 if L >= 300 else 5e-3)   # (as config 4: measured 7.8e-3 at L = 400 on 8 decoys)
             print(f"\nconfig 5, L={L}: worst eval deviations {w}; tracking {trk}")
 
         def fold(L):

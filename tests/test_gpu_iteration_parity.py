@@ -94,7 +94,7 @@ def test_folds_of_the_fed_back_maps_reach_the_reference_iteration_decoys(golden_
             print("   two draws of ours: median %.3f A (5-95 %%: %.2f-%.2f); a draw's median distance to the others: %.2f-%.2f (5-95 %%); the reference's draw: %.3f A = percentile %.0f"
                   % (np.median(pw), np.percentile(pw, 5), np.percentile(pw, 95), np.percentile(own, 5), np.percentile(own, 95), d_ok, pct))
             TWO_SAMPLE[(tag, stage)] = (float(np.median(pw)), float(d_ok), float(pct))
-            assert pct <= 99.0, (pct, d_ok, np.sort(own)[-5:])     # (tightened below from the measurement)
+            assert 1.0 <= pct <= 99.0, (pct, d_ok, np.sort(own)[-5:])     # two-sided: neither outside the cloud nor implausibly central; the joint statement is below
             assert np.median(d_t) <= lim["med"], np.sort(d_t)[::16]
             assert (d_t <= 1.5).mean() >= lim["f15"] and far.mean() <= lim["far"], ((d_t <= 1.5).mean(), far.mean())
             # no twisted peptides with the relax stage on (the reference's decoys: |omega| 177.6 deg mean, one cis in eight)
@@ -102,3 +102,4 @@ def test_folds_of_the_fed_back_maps_reach_the_reference_iteration_decoys(golden_
             assert (dw.max(1) > 60).mean() <= 0.03, (dw.max(1) > 60).mean()
     finally:
         ctx.close()
+

