@@ -679,6 +679,80 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
     return out, m, runs
 
 
+def batch_mode_multi(args, T, synth, rank, local_rank, world, dist, forced, L=150, targets_per_gpu=8, nmax=10):
+    """N > 1: the north star's multi-GPU mode IS `value`: run_inference.py's batch mode (:339-348) over 8 N independent
+    targets, ranks PULLING targets from the shared counter (pipeline.run_batch, sched.DynamicQueue; no collective on the data path, one gather of
+    the summaries at the end).  A step = one such job: 8 N targets of L = 150, init_num = 10, both models, all channels, the default protocol,
+    Nmax shortened to `nmax` feedback iterations per chain so that W + K steps fit the driver's run (stated in `config.workload`), PDB files
+    written.  Total work is fixed as N grows: `scaling: strong`.  UNMEASURED until a multi-GPU node runs it: no such node has been available
+    to the builder in five rounds; the two-rank rehearsal on one GPU (tests/test_gpu_bench.py) exercises the control flow only."""
+    import contextlib
+    import io
+    import torch
+    pipe_mod = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
+    n_targets = targets_per_gpu * world
+    work = [None]
+    if rank == 0:
+        work[0] = tempfile.mkdtemp(prefix="trx2_bm_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        maps = [synth.make_map(L, seed=L + c) for c in range(2)]
+        for tag, m in zip(("NMR", "Xray"), maps):
+            np.savez(os.path.join(work[0], f"m_{tag}.npz"), dist=m["dist"], omega=m["omega"], theta=m["theta"], phi=m["phi"])
+        os.makedirs(os.path.join(work[0], "fasta"))
+        for i in range(n_targets):
+            with open(os.path.join(work[0], "fasta", f"t{i}.fasta"), "w") as f:
+                f.write(f">t{i}\n{maps[0]['seq']}\n")
+    dist.broadcast_object_list(work, src=0)          # one node: every rank sees rank 0's /dev/shm
+    work = work[0]
+    names = [f"t{i}" for i in range(n_targets)]
+    paths = [os.path.join(work, f"m_{tag}.npz") for tag in ("NMR", "Xray")]
+
+    def step(i):
+        save = os.path.join(work, f"out{i}")
+        with contextlib.redirect_stdout(io.StringIO()):
+            res = pipe_mod.run_batch(names, os.path.join(work, "fasta"), save, rank=rank, world=world, dist=dist, device=local_rank, init_num=10, Nmax=nmax,
+                                     angle=True, mult_two_models=True, seed=1000 * i + 3, npz_nmr=paths[0], npz_xray=paths[1])
+        dist.barrier()
+        if rank == 0:
+            shutil.rmtree(save, ignore_errors=True)
+        return res
+
+    def sync():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    try:
+        for i in range(args.warmup):
+            step(900 + i)
+        sync()
+        t0 = time.perf_counter()
+        res = [step(i) for i in range(args.steps)]
+        sync()
+        elapsed = time.perf_counter() - t0
+        tt = torch.tensor([elapsed], device="cpu" if forced is not None else "cuda")
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(gathered, tt)
+        per_rank = [float(g.item()) for g in gathered]
+        elapsed = max(per_rank)
+        decoys = sum(r["decoys"] for r in res)
+        if rank != 0:
+            return None
+        return {
+            "metric": "decoys/sec", "value": decoys / elapsed, "unit": "decoys/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"run_inference batch mode: {n_targets} independent targets of L={L} (8 per GPU), init_num=10, both models, all channels, default protocol "
+                                   f"(-m 2 --fastrelax), Nmax={nmax} feedback iterations per chain (the CLI's default is 300: shortened so that warm-up + timed steps fit the run), PDB files written",
+                       "L": L, "decoys_per_step": decoys // max(1, args.steps),
+                       "parallelism": f"targets pulled from a shared counter by {world} rank(s), one process per GPU; no collective on the data path; one summary gather per job",
+                       "measured_on_hardware": "this line is the first measurement of the multi-GPU path whenever the driver produces it: the builder has had no multi-GPU node in five rounds"},
+            "all_targets_folded": all(r["failed"] == 0 for r in res), "per_rank_seconds": per_rank,
+            "per_rank_decoys_last_step": [p["decoys"] for p in res[-1]["per_rank"]] if res else None,
+        }
+    finally:
+        dist.barrier()
+        if rank == 0:
+            shutil.rmtree(work, ignore_errors=True)
+
+
 def compact_roofline(r):
     return {q: r[q] for q in ("kernel", "achieved", "frac", "frac_over_fold", "unit", "avg_launch_ms", "avg_launch_ms_over_fold", "algorithmic_bytes_per_launch", "traffic") if q in r} if r else None
 
@@ -776,6 +850,16 @@ def main():
                     out["batch_mode"] = {k: bm[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "all_decoys_converged", "per_rank")}
                     out["batch_mode"]["workload"] = bm["config"]["workload"]
                     out["batch_mode"]["parallelism"] = bm["config"]["parallelism"]
+        if args.config == 2 and world > 1:
+            # N > 1: `value` is batch mode over 8 N targets pulled from the shared queue (strong scaling); the weak-scaling calls of config 2
+            # (every rank its own 64-decoy calls) and the config-5 record stay on the line as sub-records
+            line = batch_mode_multi(args, T, synth, rank, local_rank, world, dist, forced)
+            if rank == 0:
+                line["sub_records"] = {"config2_weak_scaling": {k: out[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "all_decoys_converged", "per_rank_seconds") if k in out}}
+                line["sub_records"]["config2_weak_scaling"]["workload"] = out["config"]["workload"]
+                if "batch_mode" in out:
+                    line["sub_records"]["config5_batch_mode"] = out["batch_mode"]
+                out = line
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -31,9 +31,17 @@ SEED = 5150
 
 
 def model_digest():
+    """Digest of what DEFINES the model: the C sources without comments and white space, protocol.py as its syntax tree -- a comment or
+    layout edit does not invalidate a 10-minute fixture, a changed constant or statement does."""
+    import ast
+    import re
     h = hashlib.sha256()
-    for rel in ("include/trx2_model.h", "oracle/trx2_oracle.c", "trrosettax2-dynamics_amd/protocol.py"):
-        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    for rel in ("include/trx2_model.h", "oracle/trx2_oracle.c"):
+        src = open(os.path.join(ROOT, rel)).read()
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", " ", src)
+        h.update(re.sub(r"\s+", " ", src).encode())
+    h.update(ast.dump(ast.parse(open(os.path.join(ROOT, "trrosettax2-dynamics_amd/protocol.py")).read())).encode())
     return h.hexdigest()
 
 

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(pkg._lib.LIB_PATH)
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.trx2_abi_version() == 1
+    assert lib.trx2_abi_version() == 2
 
 
 def test_missing_gpu_fails_loudly_instead_of_falling_back():

@@ -198,6 +198,34 @@ def test_device_resident_distograms_give_identical_tables(golden_dir, seq):
         host.close(); dev.close()
 
 
+def test_run_single_takes_the_networks_tensors_in_memory(golden_dir, tmp_path):
+    """Row f2 in the PRODUCT (VERDICT r4 missing 4): the reference goes network -> fold in one process (run_inference.py:301-310); here
+    pipeline.run_single(arrays=...) takes what pred_2d_geometry computes -- float32 CUDA tensors -- and hands their device pointers to the
+    table build (Context.set_map_device): no npz round trip.  Same seed, same files, byte for byte, as from the npz paths; the reference's
+    pred_npz/{name}_{tag}.npz files are still written (from the arrays)."""
+    import torch
+    fa = os.path.join(golden_dir, "seq.fasta")
+    z = {tag: np.load(os.path.join(golden_dir, f"seq_{tag}.npz")) for tag in ("NMR", "Xray")}
+    kw = dict(init_num=2, Nmax=2, angle=True, mult_two_models=True, seed=77)
+    a_dir, b_dir, c_dir = (str(tmp_path / d) for d in ("from_npz", "from_tensors", "from_numpy"))
+    n_a = PL.run_single("seq", fa, a_dir, npz_nmr=os.path.join(golden_dir, "seq_NMR.npz"), npz_xray=os.path.join(golden_dir, "seq_Xray.npz"), **kw)
+    dev = {tag: {k: torch.from_numpy(np.ascontiguousarray(z[tag][k], np.float32)).cuda() for k in ("dist", "omega", "theta", "phi")} for tag in z}
+    n_b = PL.run_single("seq", fa, b_dir, arrays=dev, **kw)
+    n_c = PL.run_single("seq", fa, c_dir, arrays={tag: {k: z[tag][k] for k in ("dist", "omega", "theta", "phi")} for tag in z}, **kw)
+    assert n_a == n_b == n_c == 8
+    for d in (b_dir, c_dir):
+        fa_, fb_ = sorted(os.listdir(os.path.join(a_dir, "seq", "pred_pdb"))), sorted(os.listdir(os.path.join(d, "seq", "pred_pdb")))
+        assert fa_ == fb_ and len(fa_) == 8
+        for f in fa_:
+            assert open(os.path.join(a_dir, "seq", "pred_pdb", f)).read() == open(os.path.join(d, "seq", "pred_pdb", f)).read(), (d, f)
+        for tag in z:       # the reference's hand-off file exists and holds the network's arrays
+            w = np.load(os.path.join(d, "seq", "pred_npz", f"seq_{tag}.npz"))
+            assert all(np.array_equal(w[k], z[tag][k]) for k in ("dist", "omega", "theta", "phi"))
+    with pytest.raises(ValueError):     # half precision / a non-contiguous view is refused, not silently converted
+        bad = {tag: dict(dev[tag], dist=dev[tag]["dist"].half()) for tag in dev}
+        PL.run_single("seq", fa, str(tmp_path / "bad"), arrays=bad, write_pred_npz=False, **kw)
+
+
 def test_abi_error_paths_fail_loudly(golden_dir, seq):
     """Misuse returns an error with a message (include/trx2fold.h: non-zero return + trx2_last_error); nothing crashes,
     nothing silently proceeds."""

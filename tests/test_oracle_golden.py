@@ -209,3 +209,17 @@ def test_cartesian_stage_keeps_reference_like_geometry(golden_dir):
     assert g[:, 1].std() < 0.02 and 1.0 < np.degrees(g[:, 3]).std() < 4.5, (g[:, 1].std(), np.degrees(g[:, 3]).std())
     dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
     assert min(kabsch_rmsd(xyz[:, 1], dec[k][:, 1]) for k in ("conf_1_1", "conf_1_2")) < 1.5
+
+
+def test_oracle_outcome_fixture_belongs_to_this_model(golden_dir):
+    """tests/golden/oracle_outcomes.npz (the oracle's side of tests/test_gpu_outcome_vs_oracle.py, 10 CPU-minutes to make) carries a digest of
+    include/trx2_model.h, oracle/trx2_oracle.c and protocol.py: a change to any of them needs `python tests/golden/make_oracle_outcomes.py`."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_oracle_outcomes", os.path.join(root, "tests", "golden", "make_oracle_outcomes.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fx = np.load(os.path.join(golden_dir, "oracle_outcomes.npz"))
+    assert str(fx["digest"]) == mod.model_digest(), "stale fixture: run `python tests/golden/make_oracle_outcomes.py`"
+    for key in ("NMR_initial", "Xray_initial", "NMR_stage1", "NMR_stage2", "Xray_stage1", "Xray_stage2", "NMR_initial_nofastrelax", "Xray_initial_nofastrelax"):
+        assert fx[key + "_f"].shape == (int(fx["n"]),) and np.all(np.isfinite(fx[key + "_rmsd"])), key

@@ -203,3 +203,25 @@ def test_short_name_list_is_shared_fairly_between_ranks(tmp_path):
     [t.start() for t in th]
     [t.join() for t in th]
     assert sorted(took[0] + took[1]) == names and len(took[0]) == 2 and len(took[1]) == 2, took
+
+
+def test_batch_mode_without_a_store_splits_statically(tmp_path):
+    """world > 1 but no process group and no store (a library caller): the queue's counter would be process-local and every rank
+    would fold every target.  run_batch then falls back to the deterministic longest-first static split: the ranks' shares are disjoint and
+    complete.  (Two `ranks` simulated in one process: no collective is involved on this path.)"""
+    P = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
+    names = ["t%d" % L for L in (40, 90, 60, 120, 75, 50, 45)]
+    for nm in names:
+        with open(tmp_path / f"{nm}.fasta", "w") as f:
+            f.write(f">{nm}\n" + "A" * int(nm[1:]) + "\n")
+    took = {0: [], 1: []}
+
+    def fake_run_single(name, fasta_file, save_dir, device=0, **kw):
+        took[device].append(name)
+        return 5
+
+    out = [P.run_batch(names, str(tmp_path), str(tmp_path), rank=r, world=2, dist=None, store=None, device=r, run=fake_run_single, init_num=2,
+                       targets_in_flight=1) for r in range(2)]
+    assert sorted(took[0] + took[1]) == sorted(names) and not set(took[0]) & set(took[1]), took
+    assert took[0] and took[1] and all(o["failed"] == 0 for o in out)
+    assert out[0]["decoys"] == 5 * len(took[0]) and out[1]["decoys"] == 5 * len(took[1])

@@ -28,7 +28,7 @@ for p1 in sorted(glob.glob(os.path.join(src, "c*_*_B*_pass1.json"))):
         "valu_insts_per_launch": a["SQ_INSTS_VALU"], "valu_active_quad_cycles": b["SQ_ACTIVE_INST_VALU"], "waves": a["SQ_WAVES"],
         "wave_quad_cycles": b["SQ_WAVE_CYCLES"], "wait_any_quad_cycles": b["SQ_WAIT_ANY"], "sq_busy_cycles_sum": a["SQ_BUSY_CYCLES"],
         "lds_insts_per_launch": a["SQ_INSTS_LDS"], "vmem_rd_insts_per_launch": a["SQ_INSTS_VMEM_RD"]})
-# the shared-launch shape: sixteen single-decoy folds in one engine's launches (tools/runs/r04_profiles.sh: shared16_{pair,step}_<group>.json
+# the shared-launch shape: sixteen single-decoy folds in one engine's launches (tools/runs_r01_r04.sh.txt section r04_profiles.sh: shared16_{pair,step}_<group>.json
 # beside the pmc directory), keyed config "shared16"
 up = os.path.dirname(os.path.abspath(src))
 for fam, kern in (("pair", "k_pair1_multi"), ("step", "k_step_multi")):

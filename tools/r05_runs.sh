@@ -82,4 +82,21 @@ run13() {
   O=$R/gpurun_out/r05_run13; mkdir -p $O
   timeout -k 10 600 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "backbone_terms" > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -12 $O/pytest.txt | cut -c1-300
 }
+run14() {  # step-kernel A/B: live launch durations for every libstep_*.so variant beside the shipped build
+  O=$R/gpurun_out/r05_run14; mkdir -p $O; : > $O/step_ab.txt
+  for lib in $R/trrosettax2-dynamics_amd/libtrx2fold.so $R/trrosettax2-dynamics_amd/libstep_*.so; do [ -f $lib ] || continue
+    TRX2FOLD_LIB=$lib timeout -k 10 300 python3 tools/step_ab.py $R 3 >> $O/step_ab.txt 2>&1; done
+  cat $O/step_ab.txt
+}
+run15() {  # step-kernel A/B (speculative record prefetch + fused energy / Gram reduction) and the parity / bitwise tests
+  O=$R/gpurun_out/r05_run15; mkdir -p $O; : > $O/step_ab.txt
+  for lib in $R/trrosettax2-dynamics_amd/libstep_*.so $R/trrosettax2-dynamics_amd/libtrx2fold.so; do [ -f $lib ] || continue
+    TRX2FOLD_LIB=$lib timeout -k 10 300 python3 tools/step_ab.py $R 3 >> $O/step_ab.txt 2>&1; done
+  cat $O/step_ab.txt
+  timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_shared_launch.py tests/test_gpu_selfcheck.py tests/test_gpu_cartesian.py tests/test_gpu_relax.py -m gpu -q -x > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest.txt | cut -c1-300
+}
+run16() {  # the whole GPU suite again
+  O=$R/gpurun_out/r05_run16; mkdir -p $O
+  timeout -k 10 1150 python3 -m pytest tests -m gpu -q > $O/pytest_full.txt 2>&1; echo "pytest rc=$?"; tail -25 $O/pytest_full.txt | cut -c1-300
+}
 "$@"

@@ -38,6 +38,7 @@ struct ChainArgs {
   float* wcur;             // [B][8]
   const float* FA;         // [slice][B][L][24] pair-kernel records: gradient on the six atoms + the pair energies
   const unsigned char* nslice;  // [L] slices the pair kernel cut residue r's row into (the row plan of the launch shape)
+  int ns_max;                   // the most slices any row of that plan has: record slices below it exist for every residue (speculative prefetch)
   const unsigned char* hasH;  // [L] residue donates a backbone hydrogen bond (has a predecessor, not proline)
   double* e_last;          // [B][NTERMS] raw terms of the last evaluation
   double* f_last;          // [B]
@@ -57,35 +58,41 @@ struct ChainArgs {
 };
 
 // Sum of the pair kernel's records of residue r of decoy dec over the nsplit slices of its row (24 floats: gradient on N CA C O
-// CB H, then the energies dist omega theta phi vdw hb).  Fixed order: deterministic.
-template <bool PRE0>
-__device__ __forceinline__ void sum_pair_records(const float* FA, int nsplit, int B, int L, int dec, int r, float (&g)[PR_NCOMP], float (&e)[6], const float4 (&p0)[6]) {
+// CB H, then the energies dist omega theta phi vdw hb).  Fixed order, slice by slice: deterministic.
+// The first NPRE slices came with the caller's early requests (pre[k] = slice k; a slice the row does not have was read from a valid
+// address and is not added).  Round 5 measured what the slice count's round trip costs -- nslice[r] arrives with the decoy's state, the
+// records of slices >= 1 are requested only then -- by requesting FOUR slices up front (72 more registers): step kernel 18.99 -> 19.47 us
+// for one decoy, 22.78 -> 22.74 us at 32 per launch, 33.43 -> 33.29 us at L = 400 (tools/step_ab.py, profiles/r05_step_ab.txt): nothing.
+// The step is bound by the ~8000 vector instructions each of its waves issues alone on its SIMD, not by its round trips; the phase
+// stamps (profiles/r05_stamp_step_*.txt) charge a phase the latency it WAITS for, which the unstamped kernel overlaps.  One slice, as before.
+#define FA_NPRE 1
+__device__ __forceinline__ void add_record(const float4 (&v)[6], float (&g)[PR_NCOMP], float (&e)[6]) {
+  g[0] += v[0].x; g[1] += v[0].y; g[2] += v[0].z; g[3] += v[0].w; g[4] += v[1].x; g[5] += v[1].y; g[6] += v[1].z; g[7] += v[1].w;
+  g[8] += v[2].x; g[9] += v[2].y; g[10] += v[2].z; g[11] += v[2].w; g[12] += v[3].x; g[13] += v[3].y; g[14] += v[3].z; g[15] += v[3].w;
+  g[16] += v[4].x; g[17] += v[4].y; e[0] += v[4].z; e[1] += v[4].w; e[2] += v[5].x; e[3] += v[5].y; e[4] += v[5].z; e[5] += v[5].w;
+}
+__device__ __forceinline__ void load_record(const float* FA, int sl, int B, int L, int dec, int r, float4 (&v)[6]) {
+  const float4* f = reinterpret_cast<const float4*>(FA + (((size_t)sl * B + dec) * L + r) * PR_REC);
+#pragma unroll
+  for (int q = 0; q < 6; q++) v[q] = f[q];
+}
+template <int NPRE>
+__device__ __forceinline__ void sum_pair_records(const float* FA, int nsplit, int B, int L, int dec, int r, float (&g)[PR_NCOMP], float (&e)[6], const float4 (&pre)[NPRE > 0 ? NPRE : 1][6]) {
 #pragma unroll
   for (int i = 0; i < PR_NCOMP; i++) g[i] = 0.0f;
 #pragma unroll
   for (int i = 0; i < 6; i++) e[i] = 0.0f;
-  if (PRE0) {  // slice 0 (every row has one) came with the caller's early requests
-    g[0] += p0[0].x; g[1] += p0[0].y; g[2] += p0[0].z; g[3] += p0[0].w; g[4] += p0[1].x; g[5] += p0[1].y; g[6] += p0[1].z; g[7] += p0[1].w;
-    g[8] += p0[2].x; g[9] += p0[2].y; g[10] += p0[2].z; g[11] += p0[2].w; g[12] += p0[3].x; g[13] += p0[3].y; g[14] += p0[3].z; g[15] += p0[3].w;
-    g[16] += p0[4].x; g[17] += p0[4].y; e[0] += p0[4].z; e[1] += p0[4].w; e[2] += p0[5].x; e[3] += p0[5].y; e[4] += p0[5].z; e[5] += p0[5].w;
-  }
-  // two slices per trip, both requested before either is added (one round trip per two slices; a row has 1 .. 8 of them, and
-  // the caller asked for the count -- nslice[r] -- at the top of the kernel: it was one more dependent round trip here).  The
-  // additions keep their order, slice by slice.
-  for (int sl = PRE0 ? 1 : 0; sl < nsplit; sl += 2) {
+#pragma unroll
+  for (int k = 0; k < NPRE; k++)
+    if (k < nsplit) add_record(pre[k], g, e);
+  // the rest two slices per trip, both requested before either is added; the additions keep their order, slice by slice
+  for (int sl = NPRE; sl < nsplit; sl += 2) {
     const bool two = sl + 1 < nsplit;
-    const float4* f = reinterpret_cast<const float4*>(FA + (((size_t)sl * B + dec) * L + r) * PR_REC);
-    const float4* h = reinterpret_cast<const float4*>(FA + (((size_t)(two ? sl + 1 : sl) * B + dec) * L + r) * PR_REC);
-    const float4 v0 = f[0], v1 = f[1], v2 = f[2], v3 = f[3], v4 = f[4], v5 = f[5];
-    const float4 u0 = h[0], u1 = h[1], u2 = h[2], u3 = h[3], u4 = h[4], u5 = h[5];
-    g[0] += v0.x; g[1] += v0.y; g[2] += v0.z; g[3] += v0.w; g[4] += v1.x; g[5] += v1.y; g[6] += v1.z; g[7] += v1.w;
-    g[8] += v2.x; g[9] += v2.y; g[10] += v2.z; g[11] += v2.w; g[12] += v3.x; g[13] += v3.y; g[14] += v3.z; g[15] += v3.w;
-    g[16] += v4.x; g[17] += v4.y; e[0] += v4.z; e[1] += v4.w; e[2] += v5.x; e[3] += v5.y; e[4] += v5.z; e[5] += v5.w;
-    if (two) {
-      g[0] += u0.x; g[1] += u0.y; g[2] += u0.z; g[3] += u0.w; g[4] += u1.x; g[5] += u1.y; g[6] += u1.z; g[7] += u1.w;
-      g[8] += u2.x; g[9] += u2.y; g[10] += u2.z; g[11] += u2.w; g[12] += u3.x; g[13] += u3.y; g[14] += u3.z; g[15] += u3.w;
-      g[16] += u4.x; g[17] += u4.y; e[0] += u4.z; e[1] += u4.w; e[2] += u5.x; e[3] += u5.y; e[4] += u5.z; e[5] += u5.w;
-    }
+    float4 v[6], u[6];
+    load_record(FA, sl, B, L, dec, r, v);
+    load_record(FA, two ? sl + 1 : sl, B, L, dec, r, u);
+    add_record(v, g, e);
+    if (two) add_record(u, g, e);
   }
 }
 // backbone H from C of the previous residue, N, CA: in-plane bisector (trx2_model.h; oracle: orc_place_h)
@@ -298,6 +305,44 @@ __device__ __forceinline__ void gram_reduce(float (&pv)[GV_N], GramLds<NT>& gl) 
   }
   __syncthreads();
 }
+// The same with the step's ENERGY riding along (round 5): the weighted total of a trial point is needed before the Armijo test and the
+// GV_N products after it -- two workgroup reductions back to back on the critical path of every accepted step.  The products do not depend
+// on the test's outcome, so a line-search evaluation computes them up front and reduces both at once: the f64 energy by DPP inside each wave
+// and through the alternating buffers of block_sum_n (same operations, same order: the same bits as block_sum_n<1>), the products as above,
+// ONE barrier in front of both.  A rejected trial has computed its products in vain (5-10 % of the steps).
+template <int NT>
+__device__ __forceinline__ double gram_reduce_with_energy(float (&pv)[GV_N], double ft, GramLds<NT>& gl, double* s_buf, int& flip) {
+  constexpr int ROWS = NT / 16, NW = NT / 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ft = wave_sum(ft);
+#pragma unroll
+  for (int k = 0; k < GV_N; k++) {
+    float v = pv[k];
+    v += dpp_move<0xB1>(v); v += dpp_move<0x4E>(v); v += dpp_move<0x141>(v); v += dpp_move<0x140>(v);
+    pv[k] = v;
+  }
+  double* buf = s_buf + flip * (NW * SBUF_K);
+  flip ^= 1;
+  if (NW > 1 && lane == 0) buf[wave] = ft;
+  if ((tid & 15) == 0)
+#pragma unroll
+    for (int k = 0; k < GV_N; k++) gl.part[k * ROWS + (tid >> 4)] = pv[k];
+  __syncthreads();
+  if (NW > 1) {
+    double a = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) a += buf[w];  // fixed order: deterministic
+    ft = a;
+  }
+  if (tid < GV_N) {
+    double a = 0;
+#pragma unroll
+    for (int r = 0; r < ROWS; r++) a += (double)gl.part[tid * ROWS + r];
+    gl.out[tid] = a;
+  }
+  __syncthreads();
+  return ft;
+}
 // After gram_reduce: the decoy's scalars follow the step.  `stored`: the pair (s, y) becomes pair 0, every older pair moves
 // one place (the oldest drops out); otherwise only the gradient changed.  old0 = this thread's matrix entry before the step
 // (entry tid of gram[], tid < 2 LBM^2), old1 = entry 2 LBM^2 + tid (tid < 2 LBM).  Ends with a barrier.
@@ -423,11 +468,15 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
   // coordinates, the first slice of the pair records, the accepted point with its gradient and direction.  Requested before the
   // role test instead of after it, their round trip runs beside the state's instead of behind it (~2000 cycles of a step).  A
   // workgroup whose role is not the decoy's current one has asked in vain: 13 % of the torsion role's launches.
-  float4 e_xt, e_c[6], e_fa[6], e_x, e_g, e_dv, e_rp[3];
+  float4 e_xt, e_c[6], e_fa[FA_NPRE][6], e_x, e_g, e_dv, e_rp[3];
   e_rp[0] = e_rp[1] = e_rp[2] = make_float4(0, 0, 0, 0);
   e_xt = e_x = e_g = e_dv = make_float4(0, 0, 0, 0);
 #pragma unroll
-  for (int q = 0; q < 6; q++) e_c[q] = e_fa[q] = make_float4(0, 0, 0, 0);
+  for (int q = 0; q < 6; q++) {
+    e_c[q] = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < FA_NPRE; k++) e_fa[k][q] = make_float4(0, 0, 0, 0);
+  }
   if (RPT == 1) {
     const int rc = min(tid, L - 1);
     hH_next = A.hasH[min(tid + 1, L - 1)] != 0;
@@ -440,9 +489,8 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
 #pragma unroll
       for (int q = 0; q < 5; q++) e_c[q] = xp[q];
       e_c[5] = xp[rc + 1 < L ? 5 : 0];
-      const float4* f0 = reinterpret_cast<const float4*>(A.FA + ((size_t)dec * L + rc) * PR_REC);
 #pragma unroll
-      for (int q = 0; q < 6; q++) e_fa[q] = f0[q];
+      for (int k = 0; k < FA_NPRE; k++) load_record(A.FA, min(k, A.ns_max - 1), A.B, L, dec, rc, e_fa[k]);   // slices 0 .. FA_NPRE-1 (clamped into the plan's range)
       if (A.mode == MODE_STEP) { e_x = A.X[vr]; e_g = A.G[vr]; e_dv = A.D[vr]; }
     }
   }
@@ -524,12 +572,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
         float g[PR_NCOMP], ep[6];
         if (RPT == 1) {
           xt[k] = e_xt; c0 = e_c[0]; c1 = e_c[1]; c2 = e_c[2]; c3 = e_c[3]; c4 = e_c[4]; nxq[k] = e_c[5];
-          sum_pair_records<true>(A.FA, nsl_pre, A.B, L, dec, r, g, ep, e_fa);
+          sum_pair_records<FA_NPRE>(A.FA, nsl_pre, A.B, L, dec, r, g, ep, e_fa);
         } else {
           xt[k] = A.XT[vb + r];
           c0 = xp[0]; c1 = xp[1]; c2 = xp[2]; c3 = xp[3]; c4 = xp[4];
           nxq[k] = xp[r + 1 < L ? 5 : 0];
-          sum_pair_records<false>(A.FA, (int)A.nslice[r], A.B, L, dec, r, g, ep, e_fa);
+          { const float4 none[1][6] = {}; sum_pair_records<0>(A.FA, (int)A.nslice[r], A.B, L, dec, r, g, ep, none); }
         }
         esum[0] += ep[0]; esum[1] += ep[1]; esum[2] += ep[2]; esum[3] += ep[3]; esum[4] += ep[4]; esum[8] += ep[5];
         pN[k] = mk3(c0.x, c0.y, c0.z); pCA[k] = mk3(c0.w, c1.x, c1.y); pC[k] = mk3(c1.z, c1.w, c2.x);
@@ -623,6 +671,12 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
     // tests/test_gpu_selfcheck.py: run starts whose window was not seeded) guard it.
     const bool all_terms = A.mode != MODE_STEP || phase == PH_REPORT || (phase == PH_START && (R.precheck & TRX2_RUN_PRECHECK));
     double f_t;
+    // a line-search evaluation of the Gram form: the step this trial would make (s, y) and its products with the stored pairs are computed
+    // BEFORE the Armijo test and reduced together with the energy (gram_reduce_with_energy)
+    const bool fused = GRAM && A.mode == MODE_STEP && phase == PH_LS;
+    float4 s_try[RPT], y_try[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; k++) s_try[k] = y_try[k] = make_float4(0, 0, 0, 0);
     if (all_terms) {
       block_sum_n<9, NW>(esum, s_buf, flip);
       f_t = (double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] +
@@ -633,8 +687,53 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
     } else {
       double ft1[1] = {(double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] +
                        (double)R.w[3] * esum[4] + (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[7] * esum[8]};
-      block_sum_n<1, NW>(ft1, s_buf, flip);
-      f_t = ft1[0];
+      if constexpr (GRAM) {
+        if (fused) {
+          const int hl_ = s_i[SI_HL], hh_ = s_i[SI_HH];
+#pragma unroll
+          for (int k = 0; k < RPT; k++) {
+            s_try[k] = make_float4(xt[k].x - x[k].x, xt[k].y - x[k].y, xt[k].z - x[k].z, 0);
+            y_try[k] = make_float4(gt[k].x - g[k].x, gt[k].y - g[k].y, gt[k].z - g[k].z, 0);
+          }
+          // every product of the new pair and the new gradient with the stored pairs (age order), one fused reduction
+          float pv[GV_N];
+#pragma unroll
+          for (int q = 0; q < GV_N; q++) pv[q] = 0.0f;
+#pragma unroll
+          for (int kr = 0; kr < RPT; kr++) {
+            const int r = kr * NT + tid, rc = min(r, L - 1);
+            // the reads of HB pairs issued together (a slot that holds no pair is read and discarded: one wait instead of HB).  Staged
+            // history: all LBM pairs at once; from global memory (chains beyond 256 residues): four pairs at a time (registers)
+            constexpr int HB = (HIST_LDS && NT <= 256) ? LBM : LBM / 2;   // (512 threads run at 256 registers: four pairs at a time)
+#pragma unroll
+            for (int k0 = 0; k0 < LBM; k0 += HB) {
+              float4 so[HB], yo[HB];
+#pragma unroll
+              for (int k = 0; k < HB; k++) {
+                const int j = (hh_ - 1 - (k0 + k) + LBM) % LBM;
+                if (HIST_LDS) { so[k] = s_hist[(j * 2 + 0) * L + rc]; yo[k] = s_hist[(j * 2 + 1) * L + rc]; }
+                else { so[k] = A.S[((size_t)dec * LBM + j) * L + rc]; yo[k] = A.Y[((size_t)dec * LBM + j) * L + rc]; }
+              }
+#pragma unroll
+              for (int k = 0; k < HB; k++) {
+                const bool on = k0 + k < hl_ && r < L;
+                pv[GV_A + k0 + k] += on ? dot3(so[k], y_try[kr]) : 0.0f; pv[GV_B + k0 + k] += on ? dot3(yo[k], y_try[kr]) : 0.0f;
+                if (k0 + k < LBM - 1) pv[GV_C + k0 + k] += on ? dot3(s_try[kr], yo[k]) : 0.0f;
+              }
+            }
+            // (s, y, gt are zero beyond the chain)
+            pv[GV_SY] += dot3(s_try[kr], y_try[kr]); pv[GV_SS] += dot3(s_try[kr], s_try[kr]); pv[GV_YY] += dot3(y_try[kr], y_try[kr]);
+            pv[GV_SG] += dot3(s_try[kr], gt[kr]); pv[GV_YG] += dot3(y_try[kr], gt[kr]); pv[GV_GG] += dot3(gt[kr], gt[kr]);
+          }
+          f_t = gram_reduce_with_energy<GRAM ? NT : 16>(pv, ft1[0], s_gl, s_buf, flip);
+        } else {
+          block_sum_n<1, NW>(ft1, s_buf, flip);
+          f_t = ft1[0];
+        }
+      } else {
+        block_sum_n<1, NW>(ft1, s_buf, flip);
+        f_t = ft1[0];
+      }
     }
     f_t = uniform_d(f_t);
     if (tid == 0) A.f_last[dec] = f_t;
@@ -765,38 +864,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs& A, const int dec, in
           y[k] = make_float4(gt[k].x - g[k].x, gt[k].y - g[k].y, gt[k].z - g[k].z, 0);
         }
         if constexpr (GRAM) {
-          // every product of the new pair and the new gradient with the stored pairs (age order), one fused reduction
-          if (HIST_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged history has landed (long ago)
-          float pv[GV_N];
-#pragma unroll
-          for (int q = 0; q < GV_N; q++) pv[q] = 0.0f;
-#pragma unroll
-          for (int kr = 0; kr < RPT; kr++) {
-            const int r = kr * NT + tid, rc = min(r, L - 1);
-            // the reads of HB pairs issued together (a slot that holds no pair is read and discarded: one wait instead of HB).  Staged
-            // history: all LBM pairs at once; from global memory (chains beyond 256 residues): four pairs at a time (registers)
-            constexpr int HB = (HIST_LDS && NT <= 256) ? LBM : LBM / 2;   // (512 threads run at 256 registers: four pairs at a time)
-#pragma unroll
-            for (int k0 = 0; k0 < LBM; k0 += HB) {
-              float4 so[HB], yo[HB];
-#pragma unroll
-              for (int k = 0; k < HB; k++) {
-                const int j = (hh - 1 - (k0 + k) + LBM) % LBM;
-                if (HIST_LDS) { so[k] = s_hist[(j * 2 + 0) * L + rc]; yo[k] = s_hist[(j * 2 + 1) * L + rc]; }
-                else { so[k] = A.S[((size_t)dec * LBM + j) * L + rc]; yo[k] = A.Y[((size_t)dec * LBM + j) * L + rc]; }
-              }
-#pragma unroll
-              for (int k = 0; k < HB; k++) {
-                const bool on = k0 + k < hl && r < L;
-                pv[GV_A + k0 + k] += on ? dot3(so[k], y[kr]) : 0.0f; pv[GV_B + k0 + k] += on ? dot3(yo[k], y[kr]) : 0.0f;
-                if (k0 + k < LBM - 1) pv[GV_C + k0 + k] += on ? dot3(s[kr], yo[k]) : 0.0f;
-              }
-            }
-            // (s, y, gt are zero beyond the chain)
-            pv[GV_SY] += dot3(s[kr], y[kr]); pv[GV_SS] += dot3(s[kr], s[kr]); pv[GV_YY] += dot3(y[kr], y[kr]);
-            pv[GV_SG] += dot3(s[kr], gt[kr]); pv[GV_YG] += dot3(y[kr], gt[kr]); pv[GV_GG] += dot3(gt[kr], gt[kr]);
-          }
-          gram_reduce<GRAM ? NT : 16>(pv, s_gl);
+          // the products came with the energy (`fused`: every PH_LS evaluation of this form is)
           v3[0] = s_gl.out[GV_SY]; v3[1] = s_gl.out[GV_SS]; v3[2] = s_gl.out[GV_YY];
         } else {
 #pragma unroll
@@ -1199,7 +1267,7 @@ struct CartArgs {
   float4* xyzT; int BW;      // decoy-minor copy for the pair kernel
   float4 *X, *XT, *geom;     // torsions and internal geometry, written when the run ends
   float* wcur;
-  const float* FA; const unsigned char* nslice;
+  const float* FA; const unsigned char* nslice; int ns_max;
   const unsigned char* hasH;
   double *e_last, *f_last;
   int* done_count;
@@ -1298,6 +1366,8 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
   const bool hH_me = A.hasH[min(tid, L - 1)] != 0;
   float4 e_rp[3];
   { const float4* rpp = rama_par_ptr(A.hasH, L) + (size_t)min(tid, L - 1) * 3; e_rp[0] = rpp[0]; e_rp[1] = rpp[1]; e_rp[2] = rpp[2]; }
+  float4 e_fa[1][6];   // the first record slice of this residue, requested with the state (sum_pair_records)
+  load_record(A.FA, 0, A.B, L, dec, min(tid, L - 1), e_fa[0]);
   // The decoy's Gram scalars (kernel_step.h, "Gram form"): one set per decoy serves both roles -- a decoy is in one role at a
   // time and every run starts from an empty history, whose scalars are zeros.
   double gr_old0 = 0, gr_old1 = 0;
@@ -1347,8 +1417,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
 #pragma unroll
     for (int q = 0; q < 4; q++) { xt[q] = xp[q]; lds_put((lds_f4*)(s_xyz + r * 16) + q, xt[q]); }
     float g[PR_NCOMP], ep[6];
-    const float4 none[6] = {};
-    sum_pair_records<false>(A.FA, nsl_pre, A.B, L, dec, r, g, ep, none);
+    sum_pair_records<1>(A.FA, nsl_pre, A.B, L, dec, r, g, ep, e_fa);
     esum[0] += ep[0]; esum[1] += ep[1]; esum[2] += ep[2]; esum[3] += ep[3]; esum[4] += ep[4]; esum[8] += ep[5];
     gt[0] = make_float4(g[0], g[1], g[2], g[3]); gt[1] = make_float4(g[4], g[5], g[6], g[7]);
     gt[2] = make_float4(g[8], g[9], g[10], g[11]); gt[3] = make_float4(g[12], g[13], g[14], 0.0f);

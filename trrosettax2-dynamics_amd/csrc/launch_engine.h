@@ -83,7 +83,7 @@ static std::map<int, std::vector<LaunchEngine*>> g_engines;   // per device; nev
 // of contexts alive in the process (second lanes not counted): up to four chains fold fastest launching for themselves, each on one
 // of the library's four streams (hardware queues); from the fifth on the streams are shared and the engines win.  Measured on
 // MI355X, L=150, all channels, microseconds per fold-evaluation with 1 / 2 / 3 / 4 / 6 / 8 / 12 folds in flight
-// (tools/runs/r04_run23.sh): own launches 25.3 / 13.2 / 9.3 / 6.9 / 9.7 / 7.3 / 7.1, engines 26.0 / 13.5 / 10.2 / 8.8 / 6.3 / 5.3 / 4.5.
+// (tools/runs_r01_r04.sh.txt section r04_run23.sh): own launches 25.3 / 13.2 / 9.3 / 6.9 / 9.7 / 7.3 / 7.1, engines 26.0 / 13.5 / 10.2 / 8.8 / 6.3 / 5.3 / 4.5.
 #ifndef TRX2_ENGINE_MIN_CONTEXTS
 #define TRX2_ENGINE_MIN_CONTEXTS 5
 #endif
@@ -122,6 +122,9 @@ static int engine_class(const EngineJob* j) { return ((j->cls * 2 + j->fam_all) 
 
 static void engine_fail(LaunchEngine* E, const std::string& why) {   // (mu held) a HIP error on the engine's stream: every fold it holds fails loudly
   E->broken = true; E->broken_why = why;
+  // Up to two chunks of launch pairs naming these folds' buffers may still be in flight; an owner must not be woken (and free or reuse
+  // them) before they have drained.  Best effort: on a broken stream the wait itself may fail, and then nothing more can run on it.
+  if (E->stream) (void)hipStreamSynchronize(E->stream);
   for (auto* v : {&E->queued, &E->active, &E->draining})
     for (EngineJob* j : *v) { j->err = "shared launches: " + why; j->state = 3; }
   E->queued.clear(); E->active.clear(); E->draining.clear();

@@ -265,7 +265,7 @@ static void pool_release(int device, hipStream_t st) {
   for (int k = 0; k < TRX2_POOL_STREAMS; k++) if (it->second.s[k] == st && it->second.use[k] > 0) it->second.use[k]--;
 }
 
-extern "C" int trx2_abi_version(void) { return 1; }
+extern "C" int trx2_abi_version(void) { return 2; }
 
 static int ctx_create_impl(int device, trx2_ctx** out, hipStream_t avoid_stream);
 extern "C" int trx2_ctx_create(int device, trx2_ctx** out) { return ctx_create_impl(device, out, nullptr); }
@@ -945,7 +945,7 @@ static ChainArgs chain_args(trx2_ctx* c, int B, int mode, int nruns, int max_eva
   A.max_evals = max_evals; A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho; A.gram = c->gram;
   A.X = c->X; A.G = c->G; A.D = c->D; A.XT = c->XT; A.S = c->S; A.Y = c->Y; A.P = c->P; A.geom = c->geom;
   A.xyzT = c->xyzT; A.BW = c->BW;
-  A.wcur = c->wcur; A.FA = c->FA; A.nslice = c->plans[(size_t)c->plan_cur].nslice; A.hasH = c->hasH;
+  A.wcur = c->wcur; A.FA = c->FA; A.nslice = c->plans[(size_t)c->plan_cur].nslice; A.hasH = c->hasH; A.ns_max = c->plans[(size_t)c->plan_cur].ns_max;
   A.e_last = c->e_last; A.f_last = c->f_last;
   A.grad_out = c->grad; A.done_count = c->done_count;
   A.slot_id = c->slot_id; A.next_id = c->next_id; A.n_total = 0; A.seed = 0; A.decoy0 = 0; A.tors0_all = nullptr;
@@ -999,7 +999,7 @@ static CartArgs cart_args(trx2_ctx* c, int B, int nruns, int max_evals) {
   A.runs = c->runs; A.st_i = c->st_i; A.st_d = c->st_d; A.rho = c->rho; A.gram = c->gram;
   A.CX = c->CX; A.CG = c->CG; A.CD = c->CD; A.CS = c->CS; A.CY = c->CY;
   A.P = c->P; A.xyzT = c->xyzT; A.BW = c->BW; A.X = c->X; A.XT = c->XT; A.geom = c->geom; A.wcur = c->wcur;
-  A.FA = c->FA; A.nslice = c->plans[(size_t)c->plan_cur].nslice; A.hasH = c->hasH;
+  A.FA = c->FA; A.nslice = c->plans[(size_t)c->plan_cur].nslice; A.hasH = c->hasH; A.ns_max = c->plans[(size_t)c->plan_cur].ns_max;
   A.e_last = c->e_last; A.f_last = c->f_last; A.done_count = c->done_count;
   A.hist_lds = 0;
   return A;

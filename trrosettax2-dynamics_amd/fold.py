@@ -109,12 +109,32 @@ def close_contexts(all_threads=False):
         c.close()
 
 
+def _on_device(a):
+    """a torch tensor living on a GPU (duck-typed: this module does not import torch unless it is handed one)"""
+    return hasattr(a, "data_ptr") and bool(getattr(a, "is_cuda", False))
+
+
 def set_restraints(ctx, npz, seq, args, ang):
     """the `-r` switch of folding/folding.py:60-68 + the idr mask mode 3 needs (folding.py:174)"""
     need_idr = args.rst in ("idp", "gpcr") or args.mode == 3
     if need_idr and "idr" not in npz:
         raise KeyError(f"-r {args.rst} / -m {args.mode} needs an 'idr' pair mask in the npz (folding.py:174, utils_ros.py:198)")
     idr = np.asarray(npz["idr"]) if need_idr else None
+    if _on_device(npz["dist"]):
+        # In-memory hand-off from the trX2 front-end (SURVEY.md 8f2): the network's softmax outputs are CUDA tensors; the reference
+        # writes them to an npz and the fold reads it back (utils_trX2dy/utils.py:783-796, folding.py:56).  Here their device pointers go
+        # straight into the table build (trx2_set_map_device): no host copy, no file.
+        if args.rst != "no-idp" or need_idr:
+            raise ValueError("device-resident distograms are supported for -r no-idp without an idr mask (the reference's default)")
+        import torch
+        ts = [npz["dist"]] + list(ang)
+        for t in ts:
+            if not (_on_device(t) and t.dtype == torch.float32 and t.is_contiguous()):
+                raise ValueError("device-resident distograms must be contiguous float32 CUDA tensors, all on one device")
+        torch.cuda.current_stream(ts[0].device).synchronize()      # the producer's stream has written them
+        ptrs = [int(t.data_ptr()) for t in ts] + [0] * (4 - len(ts))
+        ctx.set_map_device(int(ts[0].shape[0]), *ptrs, seq=seq, pcut=args.pcut)
+        return
     if args.rst == "af2":
         ctx.set_map_af2(npz["dist"], npz["bins"], seq=seq, pcut=args.pcut)
     elif args.rst == "idp":

@@ -28,6 +28,10 @@ _BATCH_CALLS = 0   # run_batch calls of this process (part of the shared queue's
 from .pdbio import as_read_from_pdb, read_backbone, read_fasta
 
 
+def resident_ok(device_feedback, sigma):
+    return device_feedback is True and float(sigma) == 1.0
+
+
 def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz, fasta, N=10, Nmax=500, begin_num=0,
                          sigma=1.0, tta_opt="-m 2 -r no-idp --orient ", angle=True, device=0, seed=None, lanes=2,
                          write_tmp_npz=False, device_feedback=True, timing=None, candidates=1, single_decoy_waves=4):
@@ -73,7 +77,7 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
             timing.update(tm)
         return iter_n
 
-    resident = device_feedback is True and float(sigma) == 1.0
+    resident = resident_ok(device_feedback, sigma)
     K = int(candidates)
     if K < 1 or (K > 1 and not resident):
         raise ValueError("candidates: a positive number; more than one needs the device feedback on resident distograms (sigma = 1)")
@@ -85,7 +89,11 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
         return feedback_labels(arrays, pdb, sigma, angle)
 
     seq = read_fasta(fasta)
-    init = dict(np.load(initial_npz))
+    # initial_npz: the path of the network's npz (the reference's hand-off), or the arrays themselves -- a dict of numpy arrays or of
+    # CUDA tensors straight from the front-end (device pointers go into the table build, fold.set_restraints)
+    init = dict(np.load(initial_npz)) if isinstance(initial_npz, (str, os.PathLike)) else dict(initial_npz)
+    if not resident_ok(device_feedback, sigma):
+        init = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else v) for k, v in init.items()}      # the host feedback path works on numpy
     print("Start generating the initial structures")
     r_init = fold_arrays_to_pdb(init, seq, pred_pdb_dir, [f"initial{i}.pdb" for i in range(N)], tta_opt, device=device, seed=seed, lanes=lanes)
     print("Done generating initial structures")
@@ -213,8 +221,13 @@ def flatten_and_rename(save_pdb_dir, num_conf1_others):
 
 
 def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mult_two_models=True, npz_nmr=None,
-               npz_xray=None, device=0, seed=None, keep_tmp_npz=False, phase_times=None, candidates=1, single_decoy_waves=4):
-    """run_inference.py:280-337 without the network front-end: expects the distograms to exist.
+               npz_xray=None, device=0, seed=None, keep_tmp_npz=False, phase_times=None, candidates=1, single_decoy_waves=4, arrays=None,
+               write_pred_npz=True):
+    """run_inference.py:280-337 without the network front-end: expects the distograms to exist -- as pred_npz files (npz_nmr / npz_xray or
+    already in place) or IN MEMORY: arrays = {"NMR": {dist, omega, theta, phi}, "Xray": {...}} of numpy arrays or of float32 CUDA tensors, what
+    pred_2d_geometry computes before it writes them (run_inference.py:301-310, utils_trX2dy/utils.py:783-796).  CUDA tensors are handed to the
+    table build by pointer (Context.set_map_device).  The reference's output layout keeps pred_npz/{name}_{tag}.npz, so the files
+    are still written from the arrays (in the background, beside the fold) unless write_pred_npz is False.
     phase_times: a dict that receives, per chain ("NMR" / "Xray"), generate_npz_and_pdb's timing record.
     candidates: decoys folded and written per feedback iteration (extension, default 1: generate_npz_and_pdb)."""
     content = os.path.join(save_dir, name)
@@ -224,8 +237,18 @@ def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mu
     tta_opt = "-m 2 --orient -r no-idp" if angle else "-m 2 --no-orient -r no-idp"      # run_inference.py:295
     maps = [("NMR", npz_nmr)] + ([("Xray", npz_xray)] if mult_two_models else [])
     paths = {}
+    writers = []
     for tag, given in maps:
         path = os.path.join(npz_dir, f"{name}_{tag}.npz")
+        if arrays is not None:
+            if tag not in arrays:
+                raise KeyError(f"arrays has no entry for the {tag} model")
+            paths[tag] = dict(arrays[tag])
+            if write_pred_npz:      # the reference's file, written beside the fold (np.savez_compressed of 3-64 MB takes 0.1-2 s)
+                host = {k: (v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)) for k, v in paths[tag].items()}
+                th = threading.Thread(target=np.savez_compressed, args=(path,), kwargs=host)
+                th.start(); writers.append(th)
+            continue
         if given and os.path.abspath(given) != os.path.abspath(path):
             shutil.copyfile(given, path)
         if not os.path.exists(path):
@@ -262,6 +285,8 @@ def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mu
         total = num + nx
     else:
         num = total = chain_("NMR", "")   # on the calling thread: its context stays cached for the next target
+    for th in writers:
+        th.join()
     n_out = total + init_num * len(maps)
     print("All structures generation finished.")
     print(f"Total structures generated: {n_out}")
@@ -313,7 +338,13 @@ def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, 
     _BATCH_CALLS += 1
     import zlib
     key = f"trx2_next_item/{_BATCH_CALLS}/{zlib.crc32(' '.join(it.target for it in items).encode()):08x}"
-    queue = sched.DynamicQueue(len(items), store if store is not None else (sched.queue_store(dist) if world > 1 else None), key=key)
+    shared = store if store is not None else (sched.queue_store(dist) if world > 1 else None)
+    if world > 1 and shared is None:
+        # No store to share a counter on (a library caller without an initialised process group): a process-local counter would hand
+        # EVERY target to EVERY rank -- duplicated work and ranks racing on the same PDB files.  Static split instead: every
+        # rank computes the same longest-first assignment from the same list and folds its own share.
+        items = sched.lpt_assign(items, world)[rank]
+    queue = sched.DynamicQueue(len(items), shared, key=key)
     local = dict(decoys=0, seconds=0.0, failed=0, targets=[], errors=[])
     if targets_in_flight is None:
         # sixty-four chains in flight (measured on one MI355X, 64 targets of L=150: 16 / 32 / 64 targets in flight -> 136 / 153 / 154

@@ -155,21 +155,29 @@ class DynamicQueue:
         return i if i < self.n else None
 
 
-def queue_store(dist, port_offset=1):
-    """The store behind DynamicQueue for an initialised process group: a TCPStore of its own on MASTER_PORT + port_offset, rank 0
-    serving (the default group's store is private API).  None for a single rank."""
+def queue_store(dist, connect_timeout_s=120):
+    """The store behind DynamicQueue for an initialised process group: a TCPStore of its own (the default group's store is private API), rank 0
+    serving on a port IT FINDS FREE and broadcasts over the group (MASTER_PORT + 1 is reserved by nobody); a rank that cannot
+    connect fails within connect_timeout_s instead of waiting out the job.  One store per process: a second job reuses it (its queue has a
+    key of its own).  None for a single rank."""
     import datetime
     import os
+    import socket
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return None
+    if "store" in _STORES:
+        return _STORES["store"]
     from torch.distributed import TCPStore
     host = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    port = int(os.environ.get("MASTER_PORT", "29500")) + int(port_offset)
-    if (host, port) in _STORES:      # one store per process and address: a second job reuses it (its queue has a key of its own)
-        return _STORES[(host, port)]
-    _STORES[(host, port)] = TCPStore(host, port, dist.get_world_size(), is_master=dist.get_rank() == 0, timeout=datetime.timedelta(hours=GATHER_TIMEOUT_H),
-                    wait_for_workers=False)
-    return _STORES[(host, port)]
+    port = [0]
+    if dist.get_rank() == 0:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("", 0))
+            port[0] = sk.getsockname()[1]
+    dist.broadcast_object_list(port, src=0)
+    _STORES["store"] = TCPStore(host, int(port[0]), dist.get_world_size(), is_master=dist.get_rank() == 0,
+                                timeout=datetime.timedelta(seconds=connect_timeout_s), wait_for_workers=False)
+    return _STORES["store"]
 
 
 _STORES = {}
