@@ -61,7 +61,7 @@ MAX_SLOTS = 640  # decoy slots per lane of the pooled leg = every decoy of its q
                  # tools/pool_sweep.py, round 3: 1280 decoys on 2 x 192 / 320 / 640 slots -> 1121 / 1425 / 1675 decoys/s)
 POOLED_QUEUE = 1280  # decoys of the pooled_queue leg (fixed: the leg does not depend on --steps)
 LEG_QUEUE = 320      # decoys of the in_flight_B / single_stream legs
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
 KERNEL_SOURCES = {"k_pair": ("kernel_pair.h", "trx2_device.h"), "k_step": ("kernel_step.h", "trx2_device.h")}
 
 
@@ -207,7 +207,7 @@ def pair_roofline(ctx, T, tors, L, config, fold_times=None):
         out["avg_launch_ms_over_fold"] = fold_times[0]
         # the conservative reading: the same bytes over the fold's own average launch, which includes the narrower launches of the tail
         # (fewer decoys, fewer bytes, shorter) -- `frac` uses replays of the full-width launch on the fold's final coordinates; the
-        # rocprofv3 average of the full-width instantiation (profiles/r04_c*_kernel_stats.csv) lies between the two
+        # rocprofv3 average of the full-width instantiation (profiles/r05_c*_kernel_stats.csv) lies between the two
         out["frac_over_fold"] = abytes / (fold_times[0] * 1e-3) / 1e9 / HBM_PEAK_GBS
     return out
 

@@ -19,6 +19,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <cstdint>
 
 typedef int hipError_t;
 enum { hipSuccess = 0 };
@@ -80,6 +81,10 @@ inline hipError_t hipStreamSynchronize(hipStream_t s) {
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.01f; return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t st) { st->push([=] { memcpy(d, s, n); }); return hipSuccess; }
 inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 65536; return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* least, int* greatest) { *least = 0; *greatest = -1; return hipSuccess; }
+enum { hipStreamNonBlocking = 1, hipDeviceAttributeMultiprocessorCount = 9 };
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, unsigned, const unsigned*) { *s = new MockStream(); return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, int, int) { *s = new MockStream(); return hipSuccess; }
 inline hipError_t hipFuncGetAttributes(hipFuncAttributes* a, const void*) { *a = hipFuncAttributes(); return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 #define hipLaunchKernelGGL(kernel, grid, block, dyn, stream, ...) \

@@ -99,4 +99,78 @@ run16() {  # the whole GPU suite again
   O=$R/gpurun_out/r05_run16; mkdir -p $O
   timeout -k 10 1150 python3 -m pytest tests -m gpu -q > $O/pytest_full.txt 2>&1; echo "pytest rc=$?"; tail -25 $O/pytest_full.txt | cut -c1-300
 }
+run17() {  # interim bench line (default flags) with the round's model and minimiser changes in
+  O=$R/gpurun_out/r05_run17; mkdir -p $O
+  timeout -k 10 1100 python3 bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 600 $O/bench.json
+}
+run18() {  # engine stream priorities (TRX2_ENGINE_PRIORITY): batch mode with 16 and 8 targets in flight, with and without
+  O=$R/gpurun_out/r05_run18; mkdir -p $O; : > $O/engine_prio.txt
+  for p in 0 1 0 1; do
+    echo "== TRX2_ENGINE_PRIORITY=$p" >> $O/engine_prio.txt
+    TRX2_ENGINE_PRIORITY=$p timeout -k 10 300 python3 tools/e2e_batch.py $R 150 16 40 16 2>&1 | cut -c1-400 >> $O/engine_prio.txt
+    TRX2_ENGINE_PRIORITY=$p timeout -k 10 300 python3 tools/e2e_batch.py $R 150 8 80 8 2>&1 | cut -c1-400 >> $O/engine_prio.txt
+  done
+  cat $O/engine_prio.txt | cut -c1-330
+}
+run() { local t=$1; shift; timeout -k 10 $t "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT/KILL rc=$rc: $*"; exit $rc; fi; return $rc; }
+profiles() {  # Round-5 profile records: kernel traces of the three single-GPU configs at the shape bench.py's `value` times, of run_inference on
+  # one target (the metric's own job) and of batch mode with sixteen targets in flight; then the PMC passes (separate rocprofv3 --pmc runs)
+  # of the pair and step kernels at those shapes; results under gpurun_out/r05_profiles/, copied to profiles/ afterwards.
+  O=$R/gpurun_out/r05_profiles; rm -rf $O; mkdir -p $O
+  export TMPDIR=/tmp
+  for cfg in 2 3 4; do
+    cd /tmp; rm -rf /tmp/kt$cfg
+    run 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt$cfg -- python3 $R/bench.py --config $cfg --steps 5 --warmup 1 --no-cpu-baseline --no-sub-records --no-legs --no-e2e > $O/bench_c${cfg}_under_profiler.json 2> $O/bench_c${cfg}.err
+    f=$(find /tmp/kt$cfg -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/r05_c${cfg}_kernel_stats.csv && cut -c1-150 $O/r05_c${cfg}_kernel_stats.csv | head -6
+    cd $R
+  done
+  cd /tmp; rm -rf /tmp/kt_e2e
+  run 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_e2e -- python3 $R/tools/e2e_single.py $R 150 60 > $O/e2e_single.log 2>&1
+  f=$(find /tmp/kt_e2e -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/r05_e2e_single_kernel_stats.csv && cut -d, -f1-5 $O/r05_e2e_single_kernel_stats.csv | head -6
+  rm -rf /tmp/ktb
+  run 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktb -- python3 $R/tools/e2e_batch.py $R 150 16 40 16 > $O/batch16_under_profiler.txt 2>&1
+  f=$(find /tmp/ktb -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/r05_batch16_kernel_stats.csv && cut -c1-150 $O/r05_batch16_kernel_stats.csv | head -6
+  cd $R
+  for spec in "2 32" "2 640" "3 64" "4 16"; do
+    set -- $spec
+    for k in pair step; do
+      bash tools/pmc_run.sh $1 $2 $k r05_profiles/pmc 20 || exit $?
+    done
+  done
+  cd /tmp
+  for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES"; do
+    tag=$(echo $grp | cut -d' ' -f1)
+    rm -rf /tmp/pmcs
+    SCALING_WAVES=1 TRX2_ENGINE_STREAMS=1 run 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmcs -- python3 $R/tools/shared_scaling.py $R 150 400 16 > $O/shared16_pmc_$tag.log 2>&1
+    f=$(find /tmp/pmcs -name '*counter_collection.csv' | head -1)
+    if [ -n "$f" ]; then python3 $R/tools/pmc_report.py $f 200 k_pair1_multi > $O/shared16_pair_$tag.json; python3 $R/tools/pmc_report.py $f 200 k_step_multi > $O/shared16_step_$tag.json; fi
+  done
+  cd $R
+  python3 tools/make_traffic_json.py $O/pmc $O/r05_traffic.json
+}
+final() {  # Round-5 closing sequence on the GPU box: the GPU suite, smoke, the profile records, the bench lines (with the fresh traffic records)
+  O=$R/gpurun_out/r05_final; mkdir -p $O
+  run 1150 python3 -m pytest tests -m gpu -q > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest.txt | cut -c1-200
+  run 300 python3 -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.txt | cut -c1-200
+}
+benches() {
+  O=$R/gpurun_out/r05_final; mkdir -p $O
+  [ -f $R/gpurun_out/r05_profiles/r05_traffic.json ] && cp $R/gpurun_out/r05_profiles/r05_traffic.json $R/profiles/r05_traffic.json
+  run 1000 python3 bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 300 $O/bench.json
+  run 1000 python3 bench.py --steps 20 --warmup 5 > $O/bench_s20.json 2> $O/bench_s20.err; echo "bench rc=$?"; tail -c 300 $O/bench_s20.json
+}
+run19() {  # four lanes of 16 against two of 32 for the call of 64 (probe with independent contexts)
+  O=$R/gpurun_out/r05_run19; mkdir -p $O
+  TRX2_SHARED_LAUNCH=0 timeout -k 10 400 python3 tools/lanes4_probe.py $R 5 2 > $O/lanes4_c2.txt 2>&1; cat $O/lanes4_c2.txt
+  TRX2_SHARED_LAUNCH=0 timeout -k 10 400 python3 tools/lanes4_probe.py $R 5 3 > $O/lanes4_c3.txt 2>&1; cat $O/lanes4_c3.txt
+}
+run20() {  # engine streams confined to disjoint CU sets (TRX2_ENGINE_CUMASK): batch mode with 16 and 8 targets in flight
+  O=$R/gpurun_out/r05_run20; mkdir -p $O; : > $O/engine_cumask.txt
+  for m in 0 1 2 0 1 2; do
+    echo "== TRX2_ENGINE_CUMASK=$m" >> $O/engine_cumask.txt
+    TRX2_ENGINE_CUMASK=$m timeout -k 10 300 python3 tools/e2e_batch.py $R 150 16 40 16 2>&1 | cut -c1-330 >> $O/engine_cumask.txt
+    TRX2_ENGINE_CUMASK=$m timeout -k 10 300 python3 tools/e2e_batch.py $R 150 8 80 8 2>&1 | cut -c1-330 >> $O/engine_cumask.txt
+  done
+  cut -c1-170 $O/engine_cumask.txt
+}
 "$@"

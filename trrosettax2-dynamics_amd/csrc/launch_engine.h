@@ -62,7 +62,7 @@ struct LaunchEngine {
   // statistics (trx2_shared_launch_stats): chunks enqueued, sum over chunks of the folds they held, folds completed, seconds the
   // host thread spent enqueuing / waiting for a chunk
   double st_chunks = 0, st_jobs = 0, st_done = 0, st_enqueue_s = 0, st_wait_s = 0;
-  // trx2_set_shared_launch_profiling: the first launch pair of every chunk bracketed by events (pair | step), summed here with the folds it held
+  // trx2_set_shared_launch_profiling: ONE launch pair of every chunk (the one in its middle: it == ENGINE_CHUNK / 2) bracketed by events (pair | step), summed here with the folds it held
   hipEvent_t pev[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
   double st_pair_ms = 0, st_step_ms = 0, st_prof_n = 0, st_prof_folds = 0;
   size_t load() { return queued.size() + active.size(); }
@@ -255,10 +255,35 @@ static void engine_main(LaunchEngine* E) {
   }
 }
 
-static bool engine_start(LaunchEngine* E) {   // (g_engine_mutex held)
+static bool engine_start(LaunchEngine* E, int index) {   // (g_engine_mutex held)
   if (hipSetDevice(E->device) != hipSuccess) return false;
-  // a stream of its own out of the library's four (pool_acquire), marked so that contexts avoid it while others are free
-  E->stream = pool_acquire(E->device, nullptr, 1000);
+  // TRX2_ENGINE_PRIORITY=1 (experiment, round 5): the engines get streams of their own with DIFFERENT priorities -- engine 0 the greatest,
+  // the others the least -- so that when both engines' pair kernels are ready the dispatcher serves engine 0's first and engine 1's fills
+  // the CUs engine 0's (narrow) step kernel leaves idle: the two engines otherwise lock in phase (pair beside pair, step beside step).
+  static const int prio_mode = getenv("TRX2_ENGINE_PRIORITY") ? atoi(getenv("TRX2_ENGINE_PRIORITY")) : 0;
+  // TRX2_ENGINE_CUMASK=1 / 2 (experiment, round 5): every engine's stream is confined to its own share of the CUs (1: contiguous blocks of the
+  // mask's bits, 2: interleaved bits), so that one engine's pair kernel -- thousands of one-wave workgroups that fill every SIMD they are
+  // allowed on -- cannot keep the other engine's step workgroups (256 + 108 registers: they need a nearly empty CU) waiting for a CU to drain.
+  static const int cumask_mode = getenv("TRX2_ENGINE_CUMASK") ? atoi(getenv("TRX2_ENGINE_CUMASK")) : 0;
+  if (cumask_mode) {
+    int n_eng = 2;
+    if (const char* e = getenv("TRX2_ENGINE_STREAMS")) n_eng = std::max(1, std::min(3, atoi(e)));
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, E->device) != hipSuccess || n_cu <= 0) return false;
+    std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+    for (int c = 0; c < n_cu; c++) {
+      const int owner = cumask_mode == 2 ? c % n_eng : (int)((long)c * n_eng / n_cu);
+      if (owner == index) mask[(size_t)c / 32] |= 1u << (c % 32);
+    }
+    if (hipExtStreamCreateWithCUMask(&E->stream, (uint32_t)mask.size(), mask.data()) != hipSuccess) return false;
+  } else if (prio_mode) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
+    if (hipStreamCreateWithPriority(&E->stream, hipStreamNonBlocking, index == 0 ? greatest : least) != hipSuccess) return false;
+  } else {
+    // a stream of its own out of the library's four (pool_acquire), marked so that contexts avoid it while others are free
+    E->stream = pool_acquire(E->device, nullptr, 1000);
+  }
   if (!E->stream) return false;
   bool ok = hipMalloc((void**)&E->d_args, ENG_ARGS_BYTES) == hipSuccess && hipMalloc((void**)&E->d_flags, sizeof(int) * ENGINE_MAX_JOBS) == hipSuccess;
   for (int i = 0; i < 3 && ok; i++) ok = hipHostMalloc((void**)&E->h_args[i], ENG_ARGS_BYTES) == hipSuccess;
@@ -292,7 +317,7 @@ static LaunchEngine* engine_pick(int device) {
     for (int i = 0; i < n; i++) {
       LaunchEngine* E = new LaunchEngine();
       E->device = device;
-      if (!engine_start(E)) { E->broken = true; E->broken_why = "could not start"; }
+      if (!engine_start(E, i)) { E->broken = true; E->broken_why = "could not start"; }
       v.push_back(E);
     }
   }
