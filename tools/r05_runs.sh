@@ -173,4 +173,15 @@ run20() {  # engine streams confined to disjoint CU sets (TRX2_ENGINE_CUMASK): b
   done
   cut -c1-170 $O/engine_cumask.txt
 }
+run21() {  # Cartesian role: energy + Gram products in one reduction, state loads before it -- A/B and the bitwise / parity tests
+  O=$R/gpurun_out/r05_run21; mkdir -p $O; : > $O/step_ab.txt
+  for lib in $R/trrosettax2-dynamics_amd/libstep_*.so $R/trrosettax2-dynamics_amd/libtrx2fold.so; do [ -f $lib ] || continue
+    TRX2FOLD_LIB=$lib timeout -k 10 300 python3 tools/step_ab.py $R 3 >> $O/step_ab.txt 2>&1; done
+  cat $O/step_ab.txt
+  timeout -k 10 900 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_shared_launch.py tests/test_gpu_selfcheck.py tests/test_gpu_cartesian.py tests/test_gpu_relax.py -m gpu -q -x > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest.txt | cut -c1-300
+}
+run22() {
+  O=$R/gpurun_out/r05_run22; mkdir -p $O
+  timeout -k 10 300 python3 tools/straggler_profile.py $R > $O/stragglers_c2.txt 2>&1; cat $O/stragglers_c2.txt
+}
 "$@"

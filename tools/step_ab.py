@@ -25,5 +25,13 @@ for name, m, orient, B in (("1 decoy L=150 all channels", m150, True, 1), ("32 d
     r = ctx.fold_batch(B, runs, seed=2)
     out.append(f"{name:30s} pair {np.mean(ps):6.2f} us  step {np.mean(ss):6.2f} us  (spread {np.ptp(ss):.2f}) | unprofiled fold: {r['seconds']*1e3:.1f} ms for {r['n_evals'].max()} evaluations = {r['seconds']*1e6/r['n_evals'].max():.2f} us per evaluation")
     ctx.close()
+# the pooled shape (bench.py's pooled_queue leg): 1280 decoys on 2 lanes x 640 slots, the low-register step instantiation
+ctx = T.Context(0, lanes=2); ctx.set_map(m150["dist"], seq=m150["seq"]); ctx.set_pool(640)
+runs = T.protocol.build_runs(150, 2, fastrelax=True)
+ctx.fold_batch(1280, runs, seed=149, decoy0=10 ** 6, max_evals=1)
+import time
+t0 = time.perf_counter(); r = ctx.fold_batch(1280, runs, seed=150); el = time.perf_counter() - t0
+out.append(f"{'pooled 1280 on 2 x 640 slots':30s} {1280 / el:7.1f} decoys/s ({el:.3f} s)")
+ctx.close()
 print(f"== {tag}")
 print("\n".join(out), flush=True)
