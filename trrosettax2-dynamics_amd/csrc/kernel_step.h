@@ -1514,30 +1514,73 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
     gt[3].x += aCB.x; gt[3].y += aCB.y; gt[3].z += aCB.z;
   }
   CSTAMP(20)  // neighbours' parts, gradient assembled
-  // accepted point, its gradient and the direction (the state machine's inputs; the line-search evaluation's products need x and g)
+  // the minimiser needs the weighted total only (the terms are reported by the torsion role's report evaluation): ONE f64
+  // workgroup sum instead of nine
+  double ft1[1] = {(double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] + (double)R.w[3] * esum[4] +
+                   (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[6] * esum[7] + (double)R.w[7] * esum[8]};
+  block_sum_n<1, NW>(ft1, s_buf, flip);
+  const double f_t = uniform_d(ft1[0]);
+  if (tid == 0) A.f_last[dec] = f_t;
+#ifdef TRX2_SELFCHECK
+  {  // checking build only: the Cartesian role's one sum against the nine terms reduced one by one (g_selfcheck[2], [3])
+    double chk[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) chk[k] = esum[k];
+    block_sum_n<9, NW>(chk, s_buf, flip);
+    const double f9 = (double)R.w[0] * chk[0] + (double)R.w[1] * (chk[1] + chk[2]) + (double)R.w[2] * chk[3] + (double)R.w[3] * chk[4] +
+                      (double)R.w[4] * chk[5] + (double)R.w[5] * chk[6] + (double)R.w[6] * chk[7] + (double)R.w[7] * chk[8];
+    if (tid == 0) {
+      atomicAdd(&g_selfcheck[2], 1ull);
+      if (!(fabs(f9 - f_t) <= 1e-9 * fabs(f9) + 1e-9)) atomicAdd(&g_selfcheck[3], 1ull);
+    }
+  }
+#endif
+
+  // ------------------------------------------------------------------ minimiser state machine (as k_chain, 4 float4 per residue)
+  int iter = s_i[SI_ITER], nls = s_i[SI_NLS], hl = s_i[SI_HL], hh = s_i[SI_HH], nh = s_i[SI_NH];
+  int n_evals = s_i[SI_NEVALS] + 1, n_iters = s_i[SI_NITERS], status = s_i[SI_STATUS];
+  double f = s_d[SD_F], alpha = s_d[SD_ALPHA], gdir = s_d[SD_GD];
+  double fh[3] = {s_d[SD_FH0], s_d[SD_FH1], s_d[SD_FH2]};
+  double gamma_h = s_d[SD_GAMMA];
+  int wspace = s_i[SI_WSPACE];
+  bool started = false;
   float4 x[4], g[4], dv[4];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     x[q] = g[q] = dv[q] = make_float4(0, 0, 0, 0);
     if (act) { x[q] = A.CX[(vb + r) * 4 + q]; g[q] = A.CG[(vb + r) * 4 + q]; dv[q] = A.CD[(vb + r) * 4 + q]; }
   }
-  float4 sv[4], yv[4];  // the pair of the step this trial would make: the newest pair of the recursion, taken from registers
+  bool next_run = false, new_dir = false, steepest = false, new_trial = false;
+  float4 sv[4], yv[4];  // the pair of the step just accepted: the newest pair of the recursion, taken from registers
+  bool stored = false;
 #pragma unroll
   for (int q = 0; q < 4; q++) sv[q] = yv[q] = make_float4(0, 0, 0, 0);
-  int hl = s_i[SI_HL], hh = s_i[SI_HH];
-  // the minimiser needs the weighted total only (the terms are reported by the torsion role's report evaluation): ONE f64
-  // workgroup sum instead of nine
-  double ft1[1] = {(double)R.w[0] * esum[0] + (double)R.w[1] * (esum[1] + esum[2]) + (double)R.w[2] * esum[3] + (double)R.w[3] * esum[4] +
-                   (double)R.w[4] * esum[5] + (double)R.w[5] * esum[6] + (double)R.w[6] * esum[7] + (double)R.w[7] * esum[8]};
-  // a line-search evaluation of the Gram form reduces the step's products WITH its energy (gram_reduce_with_energy, as the torsion role)
-  const bool fused = CG && phase == PH_LS;
-  if constexpr (CG) {
-    if (fused) {
+  const bool finite_t = isfinite(f_t);
+  CSTAMP(21)  // energy reduction, loads of X, G, D
+  if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
+  else if (phase == PH_START) {
+    f = f_t;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { x[q] = xt[q]; g[q] = gt[q]; }
+    hl = 0; hh = 0; nh = 1; fh[0] = f; iter = 0;
+    steepest = true; started = true;
+  } else {
+    double fref = fh[0];
+    for (int k = 1; k < nh; k++) fref = fmax(fref, fh[k]);
+    const bool accept = finite_t && f_t <= fref + (double)TRX2_LS_C1 * alpha * gdir;
+    if (accept) {
+      double v3[3] = {0, 0, 0};
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         sv[q] = make_float4(xt[q].x - x[q].x, xt[q].y - x[q].y, xt[q].z - x[q].z, xt[q].w - x[q].w);
         yv[q] = make_float4(gt[q].x - g[q].x, gt[q].y - g[q].y, gt[q].z - g[q].z, gt[q].w - g[q].w);
       }
+      if constexpr (CG) {
+        // Every product of the new pair and the new gradient with the stored pairs, ONE fused reduction (as the torsion role;
+        // the two-loop form made 2 x 8 dependent rounds of { dot, workgroup sum, axpy } here: 42 % of this role's step at
+        // L = 150, profiles/README.md round 3).  The stored pairs by their age BEFORE this step: age k < nl was staged in
+        // LDS slot k at the top of the step, the others come from global memory, two pairs at a time.  Everything is indexed
+        // by compile-time constants (a runtime index would move pv[] to scratch); the tests on hl / nl are wave-uniform.
         if (NT <= 256) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the staged pairs have landed (long ago)
         float pv[GV_N];
 #pragma unroll
@@ -1581,63 +1624,7 @@ __device__ __forceinline__ void cart_body(const CartArgs& A, const int dec, int*
           pv[GV_SY] += dot4(sv[q], yv[q]); pv[GV_SS] += dot4(sv[q], sv[q]); pv[GV_YY] += dot4(yv[q], yv[q]);
           pv[GV_SG] += dot4(sv[q], gt[q]); pv[GV_YG] += dot4(yv[q], gt[q]); pv[GV_GG] += dot4(gt[q], gt[q]);
         }
-      ft1[0] = gram_reduce_with_energy<NT>(pv, ft1[0], s_gl, s_buf, flip);
-    } else block_sum_n<1, NW>(ft1, s_buf, flip);
-  } else block_sum_n<1, NW>(ft1, s_buf, flip);
-  const double f_t = uniform_d(ft1[0]);
-  if (tid == 0) A.f_last[dec] = f_t;
-#ifdef TRX2_SELFCHECK
-  {  // checking build only: the Cartesian role's one sum against the nine terms reduced one by one (g_selfcheck[2], [3])
-    double chk[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) chk[k] = esum[k];
-    block_sum_n<9, NW>(chk, s_buf, flip);
-    const double f9 = (double)R.w[0] * chk[0] + (double)R.w[1] * (chk[1] + chk[2]) + (double)R.w[2] * chk[3] + (double)R.w[3] * chk[4] +
-                      (double)R.w[4] * chk[5] + (double)R.w[5] * chk[6] + (double)R.w[6] * chk[7] + (double)R.w[7] * chk[8];
-    if (tid == 0) {
-      atomicAdd(&g_selfcheck[2], 1ull);
-      if (!(fabs(f9 - f_t) <= 1e-9 * fabs(f9) + 1e-9)) atomicAdd(&g_selfcheck[3], 1ull);
-    }
-  }
-#endif
-
-  // ------------------------------------------------------------------ minimiser state machine (as k_chain, 4 float4 per residue)
-  int iter = s_i[SI_ITER], nls = s_i[SI_NLS], nh = s_i[SI_NH];
-  int n_evals = s_i[SI_NEVALS] + 1, n_iters = s_i[SI_NITERS], status = s_i[SI_STATUS];
-  double f = s_d[SD_F], alpha = s_d[SD_ALPHA], gdir = s_d[SD_GD];
-  double fh[3] = {s_d[SD_FH0], s_d[SD_FH1], s_d[SD_FH2]};
-  double gamma_h = s_d[SD_GAMMA];
-  int wspace = s_i[SI_WSPACE];
-  bool started = false;
-  bool next_run = false, new_dir = false, steepest = false, new_trial = false;
-  bool stored = false;
-  const bool finite_t = isfinite(f_t);
-  CSTAMP(21)  // energy reduction, loads of X, G, D
-  if (!finite_t && phase == PH_START) { status = TRX2_DIVERGED; phase = PH_DONE; }
-  else if (phase == PH_START) {
-    f = f_t;
-#pragma unroll
-    for (int q = 0; q < 4; q++) { x[q] = xt[q]; g[q] = gt[q]; }
-    hl = 0; hh = 0; nh = 1; fh[0] = f; iter = 0;
-    steepest = true; started = true;
-  } else {
-    double fref = fh[0];
-    for (int k = 1; k < nh; k++) fref = fmax(fref, fh[k]);
-    const bool accept = finite_t && f_t <= fref + (double)TRX2_LS_C1 * alpha * gdir;
-    if (accept) {
-      double v3[3] = {0, 0, 0};
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        sv[q] = make_float4(xt[q].x - x[q].x, xt[q].y - x[q].y, xt[q].z - x[q].z, xt[q].w - x[q].w);
-        yv[q] = make_float4(gt[q].x - g[q].x, gt[q].y - g[q].y, gt[q].z - g[q].z, gt[q].w - g[q].w);
-      }
-      if constexpr (CG) {
-        // Every product of the new pair and the new gradient with the stored pairs, ONE fused reduction (as the torsion role;
-        // the two-loop form made 2 x 8 dependent rounds of { dot, workgroup sum, axpy } here: 42 % of this role's step at
-        // L = 150, profiles/README.md round 3).  The stored pairs by their age BEFORE this step: age k < nl was staged in
-        // LDS slot k at the top of the step, the others come from global memory, two pairs at a time.  Everything is indexed
-        // by compile-time constants (a runtime index would move pv[] to scratch); the tests on hl / nl are wave-uniform.
-        // (the products came with the energy: every PH_LS evaluation of this form is `fused`, above)
+        gram_reduce<NT>(pv, s_gl);
         v3[0] = s_gl.out[GV_SY]; v3[1] = s_gl.out[GV_SS]; v3[2] = s_gl.out[GV_YY];
         if (v3[0] > 1e-12 * sqrt(v3[1] * v3[2])) {
           if (act)
