@@ -338,7 +338,7 @@ def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, 
     _BATCH_CALLS += 1
     import zlib
     key = f"trx2_next_item/{_BATCH_CALLS}/{zlib.crc32(' '.join(it.target for it in items).encode()):08x}"
-    shared = store if store is not None else (sched.queue_store(dist) if world > 1 else None)
+    shared = store if store is not None else (sched.queue_store(dist, group=group) if world > 1 else None)
     if world > 1 and shared is None:
         # No store to share a counter on (a library caller without an initialised process group): a process-local counter would hand
         # EVERY target to EVERY rank -- duplicated work and ranks racing on the same PDB files.  Static split instead: every

@@ -155,11 +155,12 @@ class DynamicQueue:
         return i if i < self.n else None
 
 
-def queue_store(dist, connect_timeout_s=120):
+def queue_store(dist, connect_timeout_s=120, group=None):
     """The store behind DynamicQueue for an initialised process group: a TCPStore of its own (the default group's store is private API), rank 0
     serving on a port IT FINDS FREE and broadcasts over the group (MASTER_PORT + 1 is reserved by nobody); a rank that cannot
     connect fails within connect_timeout_s instead of waiting out the job.  One store per process: a second job reuses it (its queue has a
-    key of its own).  None for a single rank."""
+    key of its own).  None for a single rank.  group: the group the port is broadcast on -- run_batch passes its gloo summary group, so that the
+    job's first collective is not an RCCL one (object broadcasts on an NCCL group stage through the GPU)."""
     import datetime
     import os
     import socket
@@ -174,7 +175,7 @@ def queue_store(dist, connect_timeout_s=120):
         with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
             sk.bind(("", 0))
             port[0] = sk.getsockname()[1]
-    dist.broadcast_object_list(port, src=0)
+    dist.broadcast_object_list(port, src=0, group=group)
     _STORES["store"] = TCPStore(host, int(port[0]), dist.get_world_size(), is_master=dist.get_rank() == 0,
                                 timeout=datetime.timedelta(seconds=connect_timeout_s), wait_for_workers=False)
     return _STORES["store"]
