@@ -96,6 +96,14 @@ int trx2_ctx_set_tail_compaction(trx2_ctx* ctx, int mode);
  * counterpart is its process pool over `python folding.py` children (utils_trX2dy/utils.py:501-503).
  * mode 1 on, 0 off, -1 back to the default rule. */
 int trx2_set_shared_launches(int mode);
+/* Shape of the shared launches.  A step launch of n folds is n workgroups walking a chain of dependent phases; a pair launch fills the
+ * chip; one after the other the chip does pair work half of the time.  In half-evaluation form (k_half_multi) the folds of an engine
+ * run in two halves half an evaluation apart, and ONE kernel carries the step role of one half beside the pair role of the other --
+ * same arithmetic, bit-identical results (tests/test_gpu_shared_launch.py).  Pays when a pair launch fills the chip: measured on MI355X
+ * in batch mode at L=150 (profiles/README.md, round 5) 3 / 8 / 16 / 32 targets in flight -4 % / +1.5 % / +15 % / +6 %.
+ * mode 1 on, 0 off, -1 (default) the library's rule: TRX2_ENGINE_HALF if set, otherwise from twelve live contexts on.
+ * Serves folds with one wave per row (trx2_ctx_set_single_decoy_waves(ctx, 1)), the segment cache, and chains of up to 256 residues. */
+int trx2_set_shared_launch_halves(int mode);
 /* Shape of the pair kernel for the context's SINGLE-decoy folds.  waves = 4 (default): one workgroup of four waves per row of the
  * restraint lists -- the shortest evaluation while few folds are in flight (run_inference.py on one target: two chains).  waves = 1:
  * one wave per row (k_pair1): a row's ~70 entries and the chain's partner residues in 2-3 steps of one wave, no workgroup barrier,

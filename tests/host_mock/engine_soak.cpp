@@ -17,10 +17,13 @@ static void fold_thread(int tid, int n_jobs) {
     int* evals = new int(0);
     int* done = new int(0);
     const bool capped = rnd() % 11 == 0;                     // a fold that never reports: given up at its cap
-    job.pa.evals = evals;
+    int* pairs = new int(0);
+    job.pa.evals = evals; job.pa.pairs = pairs; job.ca.pairs = pairs;
     job.ca.evals = evals; job.ca.done_count = done; job.ca.B = 1; job.ca.need = capped ? 1 << 30 : ENGINE_CHUNK * (1 + (int)(rnd() % 6)) - (int)(rnd() % ENGINE_CHUNK);
     job.done_count = done; job.B = 1; job.n_items = 1 + (int)(rnd() % 40); job.dyn = 1024 * (rnd() % 8);
     job.cls = (int)(rnd() % 3); job.fam_all = (int)(rnd() % 2); job.wave1 = (int)(rnd() % 2); job.segc = (int)(rnd() % 2);
+    job.lowreg = (job.cls < 2 && rnd() % 2) ? 1 : 0;
+    job.half = (job.lowreg && job.wave1 && job.segc && rnd() % 4 != 0) ? 1 : 0;   // half-evaluation launches (most of the folds that qualify)
     job.cap = capped ? 3 * ENGINE_CHUNK : 100000;
     hipEventCreate(&job.ready);
     hipEventRecord(job.ready, own);                          // the fold's start-up work on its own stream
@@ -36,7 +39,7 @@ static void fold_thread(int tid, int n_jobs) {
     if (capped) { if (job.launches < job.cap) { fprintf(stderr, "capped fold released after %ld launches\n", job.launches); _exit(3); } g_capped++; }
     else if (*done != 1 || *evals < job.ca.need || job.done < 1) { fprintf(stderr, "fold woken before its decoy reported: done %d evals %d need %d\n", *done, *evals, job.ca.need); _exit(4); }
     // woken: by the engine's promise no launch in flight names these buffers any more -- give them back at once
-    delete evals; delete done;
+    delete evals; delete done; delete pairs;
     hipEventDestroy(job.ready);
     g_done++;
     if (rnd() % 4 == 0) std::this_thread::sleep_for(std::chrono::microseconds(rnd() % 300));

@@ -20,6 +20,7 @@
 #include <thread>
 #include <vector>
 #include <cstdint>
+#include <unistd.h>
 
 typedef int hipError_t;
 enum { hipSuccess = 0 };
@@ -96,16 +97,24 @@ inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess
 #define FAM_DIST 1
 #define FAM_VDW 4
 #define FAM_ALL 7
-struct PairArgs { const int* evals; };                               // (the real blocks hold ~40 pointers each; the engine only copies them)
-struct ChainArgs { int* evals; int* done_count; int B; int need; };
+struct PairArgs { const int* evals; int* pairs; };                   // (the real blocks hold ~40 pointers each; the engine only copies them)  pairs: pair launches that named the fold
+struct ChainArgs { int* evals; int* done_count; int B; int need; const int* pairs; };
 struct CartArgs { int unused; };
-template <int FAM, bool SEGC> void k_pair_multi(dim3 g, const PairArgs* a) { for (unsigned z = 0; z < g.z; z++) (void)*(volatile const int*)a[z].evals; }
-template <int FAM, bool SEGC> void k_pair1_multi(dim3, const PairArgs* a, int n_folds, int, int) { for (int i = 0; i < n_folds; i++) (void)*(volatile const int*)a[i].evals; }
-template <int RPT, int TN, int NT> void k_step_multi(dim3 g, const ChainArgs* a, const CartArgs*) {
-  for (unsigned y = 0; y < g.y; y++) {       // one evaluation of every fold of the launch: a fold reports after `need` of them
-    if (*a[y].done_count >= a[y].B) continue;        // (retired slots leave at once, as PH_DONE workgroups do)
-    if (++*a[y].evals >= a[y].need) *a[y].done_count = a[y].B;
-  }
+inline void mock_pair(const PairArgs& a) { (void)*(volatile const int*)a.evals; ++*a.pairs; }
+// one evaluation of a fold: it reports after `need` of them.  ORDER: the step of evaluation e comes after exactly e + 1 pair launches of the
+// fold -- a step before its pair launch (or two pair launches without a step between) is what a wrong half-evaluation schedule would do
+inline void mock_step(const ChainArgs& a) {
+  if (*a.done_count >= a.B) return;               // (retired slots leave at once, as PH_DONE workgroups do)
+  if (*a.pairs != *a.evals + 1) { fprintf(stderr, "mock: step of evaluation %d after %d pair launches\n", *a.evals, *a.pairs); _exit(6); }
+  if (++*a.evals >= a.need) *a.done_count = a.B;
+}
+template <int FAM, bool SEGC> void k_pair_multi(dim3 g, const PairArgs* a) { for (unsigned z = 0; z < g.z; z++) mock_pair(a[z]); }
+template <int FAM, bool SEGC> void k_pair1_multi(dim3, const PairArgs* a, int n_folds, int, int) { for (int i = 0; i < n_folds; i++) mock_pair(a[i]); }
+template <int RPT, int TN, int NT, bool LOWREG> void k_step_multi(dim3 g, const ChainArgs* a, const CartArgs*) { for (unsigned y = 0; y < g.y; y++) mock_step(a[y]); }
+// the half-evaluation launch: the two roles touch disjoint folds, in no particular order (here: the pair role first)
+template <int FAM, bool SEGC, int TN> void k_half_multi(dim3, const ChainArgs* ca, const CartArgs*, int n_step, const PairArgs* pa, int n_pair, int, int) {
+  for (int i = 0; i < n_pair; i++) mock_pair(pa[i]);
+  for (int i = 0; i < n_step; i++) mock_step(ca[i]);
 }
 inline void k_gather_done(dim3, int n, const int* const* dp, int* flags) { for (int i = 0; i < n; i++) flags[i] = *dp[i]; }
 inline hipStream_t pool_acquire(int, hipStream_t = nullptr, int = 1) { return new MockStream(); }

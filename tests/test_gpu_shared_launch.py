@@ -24,11 +24,14 @@ KEYS = ("xyz", "tors", "e_terms", "f", "status", "n_evals", "n_iters")
 def restore_mode():
     yield
     L_.set_shared_launches(-1)
+    L_.set_shared_launch_halves(-1)
 
 
 @pytest.mark.parametrize("waves", [4, 1], ids=["four-waves-per-row", "one-wave-per-row"])
 def test_shared_launches_are_bitwise_the_folds_own(golden_dir, seq, waves):
-    """both pair-kernel shapes of a single-decoy fold (Context.set_single_decoy_waves): the default, and the one batch mode sets"""
+    """both pair-kernel shapes of a single-decoy fold (Context.set_single_decoy_waves): the default, and the one batch mode sets -- the latter
+    also in half-evaluation form (trx2_set_shared_launch_halves: one kernel steps one half of an engine's folds beside the pair terms of the
+    other half; the L=300 folds do not qualify, so the same chunks also hold a launch class in pair | step form)"""
     real = np.load(os.path.join(golden_dir, "seq_NMR.npz"))
     cases = [("real90", dict(dist=real["dist"], omega=real["omega"], theta=real["theta"], phi=real["phi"], seq=seq), True, 0),
              ("L150", S.make_map(150, seed=150), True, 900), ("L150d", S.make_map(150, seed=151), False, 900),
@@ -42,8 +45,9 @@ def test_shared_launches_are_bitwise_the_folds_own(golden_dir, seq, waves):
                 c.set_single_decoy_waves(waves)
                 ctxs.append((name, len(m["seq"]), cap, rep, c))
         out = {}
-        for mode in (0, 1):
-            L_.set_shared_launches(mode)
+        for mode in (0, 1) + ((2,) if waves == 1 else ()):
+            L_.set_shared_launches(min(mode, 1))
+            L_.set_shared_launch_halves(1 if mode == 2 else 0)
             res = [None] * len(ctxs)
 
             def work(i):
@@ -68,6 +72,8 @@ def test_shared_launches_are_bitwise_the_folds_own(golden_dir, seq, waves):
                 assert np.all(np.isfinite(a["xyz"])) and (cap > 0 or a["status"][0] == 0)
                 for k in KEYS:
                     assert np.array_equal(a[k], b[k]), (name, rep, it, k)
+                    if 2 in out:
+                        assert np.array_equal(a[k], out[2][i][it][k]), ("half-evaluation launches", name, rep, it, k)
         ev = [int(out[1][i][1]["n_evals"][0]) for i in range(len(ctxs))]
         print("\nshared launches: %d folds on %d contexts bit for bit equal to their own launches; evaluations of the second folds %s" % (2 * len(ctxs), len(ctxs), ev))
     finally:
@@ -87,14 +93,15 @@ def test_batch_mode_files_do_not_depend_on_shared_launches(golden_dir, tmp_path)
     kw = dict(init_num=2, Nmax=4, angle=True, mult_two_models=True, seed=5,
               npz_nmr=os.path.join(golden_dir, "seq_NMR.npz"), npz_xray=os.path.join(golden_dir, "seq_Xray.npz"))
     out = {}
-    for mode, inflight in ((0, 1), (1, 3)):
-        L_.set_shared_launches(mode)
+    for mode, inflight in ((0, 1), (1, 3), (2, 3)):      # 2: shared launches in half-evaluation form
+        L_.set_shared_launches(min(mode, 1))
+        L_.set_shared_launch_halves(1 if mode == 2 else 0)
         save = str(tmp_path / f"out{mode}")
         res = PL.run_batch(names, str(fdir), save, targets_in_flight=inflight, **kw)
         assert res["failed"] == 0 and res["decoys"] == 3 * (2 * 2 + 2 * 4), res
         out[mode] = {(n, f): open(os.path.join(save, n, "pred_pdb", f), "rb").read() for n in names for f in sorted(os.listdir(os.path.join(save, n, "pred_pdb")))}
-    assert out[0].keys() == out[1].keys() and len(out[0]) == 36
-    assert all(out[0][k] == out[1][k] for k in out[0])
+    assert out[0].keys() == out[1].keys() == out[2].keys() and len(out[0]) == 36
+    assert all(out[0][k] == out[1][k] == out[2][k] for k in out[0])
 
 
 def test_segment_cache_changes_no_bit(golden_dir, tmp_path):

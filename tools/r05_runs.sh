@@ -184,4 +184,63 @@ run22() {
   O=$R/gpurun_out/r05_run22; mkdir -p $O
   timeout -k 10 300 python3 tools/straggler_profile.py $R > $O/stragglers_c2.txt 2>&1; cat $O/stragglers_c2.txt
 }
+run23() {  # do two engines overlap? 28 single-decoy folds in flight on two engines / on one: wall time without the profiler, then the kernel-trace timeline
+  O=$R/gpurun_out/r05_run23; mkdir -p $O; rm -f $O/overlap.txt
+  cd /tmp && export TMPDIR=/tmp
+  for ne in 2 1; do
+    echo "== $ne engine(s), 28 folds in flight, 3000 evaluations each; without the profiler:" >> $O/overlap.txt
+    SCALING_WAVES=1 TRX2_ENGINE_STREAMS=$ne timeout -k 10 300 python3 $R/tools/shared_scaling.py $R 150 3000 28 2>&1 | grep '^{' >> $O/overlap.txt || return $?
+    rm -rf /tmp/kt_ov$ne
+    SCALING_WAVES=1 TRX2_ENGINE_STREAMS=$ne timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/kt_ov$ne -- python3 $R/tools/shared_scaling.py $R 150 3000 28 > $O/scaling_engines$ne.txt 2>&1 || return $?
+    f=$(find /tmp/kt_ov$ne -name '*kernel_trace.csv' | head -1)
+    echo "under rocprofv3 --kernel-trace:" >> $O/overlap.txt; grep '^{' $O/scaling_engines$ne.txt >> $O/overlap.txt
+    python3 $R/tools/overlap_timeline.py $f 0.6 >> $O/overlap.txt 2>&1
+  done
+  cat $O/overlap.txt
+}
+run24() {  # half-evaluation launches (k_half_multi): bitwise tests, then A/B against pair | step launches -- folds in flight, batch mode
+  O=$R/gpurun_out/r05_run24; mkdir -p $O
+  timeout -k 10 600 python3 -m pytest tests/test_gpu_shared_launch.py -x -q -m gpu > $O/pytest.txt 2>&1; rc=$?; tail -3 $O/pytest.txt; [ $rc -eq 0 ] || return $rc
+  for half in 0 1; do for ne in 2 1; do
+    echo "== TRX2_ENGINE_HALF=$half TRX2_ENGINE_STREAMS=$ne" >> $O/scaling.txt
+    SCALING_WAVES=1 TRX2_ENGINE_HALF=$half TRX2_ENGINE_STREAMS=$ne timeout -k 10 300 python3 tools/shared_scaling.py $R 150 1500 8 16 28 32 64 2>&1 | grep '^{' | cut -c1-400 >> $O/scaling.txt || return $?
+  done; done
+  cat $O/scaling.txt
+  for half in 0 1; do for ne in 2 1; do
+    echo "== TRX2_ENGINE_HALF=$half TRX2_ENGINE_STREAMS=$ne" >> $O/batch.txt
+    TRX2_ENGINE_HALF=$half TRX2_ENGINE_STREAMS=$ne timeout -k 10 400 python3 tools/e2e_batch.py $R 150 16 40 16 8 2>&1 | grep '^{' | cut -c1-330 >> $O/batch.txt || return $?
+  done; done
+  cat $O/batch.txt
+}
+run25() {  # half-evaluation launches in batch mode: from how many folds per launch class on?  two shapes, every cell twice
+  O=$R/gpurun_out/r05_run25; mkdir -p $O; rm -f $O/batch.txt
+  for rep in 1 2; do for cell in "0 0" "1 0" "1 8" "1 12" "1 1000"; do
+    set -- $cell
+    echo "== TRX2_ENGINE_HALF=$1 TRX2_ENGINE_HALF_MIN=$2 (two engines)" >> $O/batch.txt
+    TRX2_ENGINE_HALF=$1 TRX2_ENGINE_HALF_MIN=$2 timeout -k 10 400 python3 tools/e2e_batch.py $R 150 16 40 16 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
+    TRX2_ENGINE_HALF=$1 TRX2_ENGINE_HALF_MIN=$2 timeout -k 10 400 python3 tools/e2e_batch.py $R 150 8 80 8 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
+  done; done
+  cat $O/batch.txt
+}
+run26() {  # half-evaluation launches at the ends of the range: 3 and 32 targets in flight; three engines
+  O=$R/gpurun_out/r05_run26; mkdir -p $O; rm -f $O/batch.txt
+  for rep in 1 2; do for half in 0 1; do
+    echo "== TRX2_ENGINE_HALF=$half (two engines)" >> $O/batch.txt
+    TRX2_ENGINE_HALF=$half timeout -k 10 400 python3 tools/e2e_batch.py $R 150 6 40 3 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
+    TRX2_ENGINE_HALF=$half timeout -k 10 400 python3 tools/e2e_batch.py $R 150 32 20 32 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
+  done; done
+  for ne in 3 1; do
+    echo "== TRX2_ENGINE_HALF=1 TRX2_ENGINE_STREAMS=$ne" >> $O/batch.txt
+    TRX2_ENGINE_STREAMS=$ne timeout -k 10 400 python3 tools/e2e_batch.py $R 150 32 20 32 16 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
+  done
+  cat $O/batch.txt
+}
+run27() {  # half-evaluation launches under the library's rule (from twelve live contexts on): tests, then batch mode at 3 / 8 / 16 targets in flight
+  O=$R/gpurun_out/r05_run27; mkdir -p $O; rm -f $O/batch.txt
+  timeout -k 10 900 python3 -m pytest tests/test_gpu_shared_launch.py tests/test_abi.py -x -q -m gpu > $O/pytest.txt 2>&1; rc=$?; tail -3 $O/pytest.txt; [ $rc -eq 0 ] || return $rc
+  timeout -k 10 400 python3 tools/e2e_batch.py $R 150 16 40 16 8 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
+  timeout -k 10 400 python3 tools/e2e_batch.py $R 150 6 40 3 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
+  timeout -k 10 400 python3 tools/e2e_batch.py $R 150 8 80 8 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
+  cat $O/batch.txt
+}
 "$@"

@@ -96,6 +96,7 @@ def load():
     L.trx2_ctx_set_tail_compaction.argtypes = [vp, C.c_int]
     L.trx2_ctx_set_single_decoy_waves.argtypes = [vp, C.c_int]
     L.trx2_set_shared_launches.argtypes = [C.c_int]
+    L.trx2_set_shared_launch_halves.argtypes = [C.c_int]
     L.trx2_shared_launch_stats.argtypes = [C.c_int, dp]
     L.trx2_set_shared_launch_profiling.argtypes = [C.c_int]
     L.trx2_last_fold_slot_efficiency.argtypes = [vp, dp]
@@ -127,6 +128,14 @@ def set_shared_launches(mode):
     """trx2_set_shared_launches: 1 = single-decoy folds of all contexts share launch pairs, 0 = every fold launches for itself,
     -1 = the library's rule (TRX2_SHARED_LAUNCH if set; otherwise shared from the fifth live context on: include/trx2fold.h)"""
     if load().trx2_set_shared_launches(int(mode)) != 0:
+        raise ValueError("mode must be -1, 0 or 1")
+
+
+def set_shared_launch_halves(mode):
+    """trx2_set_shared_launch_halves: 1 = shared launches in half-evaluation form (one kernel steps one half of an engine's folds beside the
+    pair terms of the other half), 0 = a pair launch and a step launch per evaluation, -1 = the library's rule (TRX2_ENGINE_HALF if set;
+    otherwise from twelve live contexts on: include/trx2fold.h).  Results are bit-identical either way."""
+    if load().trx2_set_shared_launch_halves(int(mode)) != 0:
         raise ValueError("mode must be -1, 0 or 1")
 
 

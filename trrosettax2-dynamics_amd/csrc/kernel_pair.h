@@ -192,9 +192,13 @@ __device__ __forceinline__ void seg_fetch(bool use_c, unsigned tag, int idx, flo
 // SEGC: the instantiation that keeps a segment cache (PairArgs) -- single-decoy folds only (BW == 1).  With several decoys per wave
 // the lanes of a sub-lane look up the SAME pair's table row, a few cache lines for the whole wave, and a block per (entry, decoy)
 // would fetch sixteen times as much (measured: config 3 -26 % with it); with one decoy per wave every lane is another pair.
-template <int BW, int FAM, int NW = PAIR_WAVES, bool SEGC = false>
+// SUBW > 1 (k_half_multi, kernel_step.h): the workgroup holds SUBW INDEPENDENT one-wave work items (NW == 1), one per wave, each with
+// its own LDS arrays and no barrier between them; rows of at most PAIR_SUB_ENT entries (chains of up to 256 residues).
+#define PAIR_SUB_ENT 256
+template <int BW, int FAM, int NW = PAIR_WAVES, bool SEGC = false, int SUBW = 1>
 __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, const int grp) {
   static_assert(NW == PAIR_WAVES || (NW == 1 && BW == 1), "the one-wave workgroup serves single-decoy folds");
+  static_assert(SUBW == 1 || NW == 1, "independent work items per wave: the one-wave form only");
   static_assert(!SEGC || BW == 1, "the segment cache serves single-decoy folds");
   constexpr int NT = NW * 64;   // threads of the workgroup
   constexpr int PW = 64 / BW;
@@ -204,21 +208,27 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
   const uint2 item2 = A.items[bx];
   const unsigned item = item2.x;
   const int a = (int)(item & PAIR_ROW_B_BITS), split = (int)((item >> 10) & 15u), nsl = (int)(item >> 14);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = SUBW > 1 ? 0 : (int)(threadIdx.x >> 6);
+  const int sub = SUBW > 1 ? (int)(threadIdx.x >> 6) : 0;        // which of the workgroup's independent work items this wave is
+  const int tix = SUBW > 1 ? lane : (int)threadIdx.x;           // thread index within the work item
   const int d = lane % BW, h = lane / BW;
   const int dec = grp * BW + d;
   const bool live = dec < A.B;
   const int decc = min(dec, A.B - 1);
 
   STAMP_DECL
-  __shared__ float s_kn[TRX2_KTOT_MAX];
+  constexpr int ENT_CAP = SUBW > 1 ? PAIR_SUB_ENT : 1024;
+  __shared__ float s_kn_[SUBW][TRX2_KTOT_MAX];
   __shared__ float s_red[NW == 1 ? 1 : NW * 64 * RED_STRIDE];  // [wave][decoy][24 (+1 pad: bank-conflict-free)]; unused by a one-wave workgroup
-  __shared__ unsigned s_ent[1024];                       // this workgroup's slice of row a's list (a row has < L <= 1024 entries)
-  __shared__ unsigned short s_rx[1024];                  // ... and the entries' relax-stage masks
+  __shared__ unsigned s_ent_[SUBW][ENT_CAP];             // this workgroup's slice of row a's list (a row has < L <= 1024 entries)
+  __shared__ unsigned short s_rx_[SUBW][ENT_CAP];        // ... and the entries' relax-stage masks
+  float* const s_kn = s_kn_[sub];
+  unsigned* const s_ent = s_ent_[sub];
+  unsigned short* const s_rx = s_rx_[sub];
   // One evaluation = one sequence number.  Kept in device memory (not a kernel argument) so that a chunk of
   // (pair, step) launches is a STATIC graph that can be replayed.  The step kernel of this evaluation starts after this
   // kernel has finished (same stream), so every one of its workgroups reads the same, final value.
-  if (bx == 0 && grp == 0 && threadIdx.x == 0 && A.seq_ctr) *A.seq_ctr += 1;
+  if (bx == 0 && grp == 0 && tix == 0 && A.seq_ctr) *A.seq_ctr += 1;
   // this lane's weights and residue a: requested first, so that their latency (they were written by the step kernel on
   // other CUs a moment ago) runs under the LDS fill and its barrier instead of after it
   const float4* wp = reinterpret_cast<const float4*>(A.wcur + (size_t)decc * 8);
@@ -231,12 +241,12 @@ __device__ __forceinline__ void pair_body(const PairArgs& A, const unsigned bx, 
   // (launch_engine.h), leave here instead of filling LDS and storing zeros.  The waves of a workgroup hold the same decoys: they
   // all leave or all stay (no barrier is left waiting).
   if (!__any((int)(live && w1.z != 0.0f))) return;
-  for (int i = threadIdx.x; i < ktot; i += NT) s_kn[i] = A.knots[i];
+  for (int i = tix; i < ktot; i += NT) s_kn[i] = A.knots[i];
   // equal slices of the row's list: every workgroup of a row gets the same number of restraint visits.  The bounds come with the
   // work item (the host made the plan from the rows' lengths): reading the length here was one more dependent round trip in
   // front of the list itself.
   const int e_lo = (int)(item2.y & 0xffffu), e_hi = (int)(item2.y >> 16);
-  for (int i = e_lo + (int)threadIdx.x; i < e_hi; i += NT) {
+  for (int i = e_lo + tix; i < e_hi; i += NT) {
     s_ent[i - e_lo] = A.rows[(size_t)a * L + i];
     s_rx[i - e_lo] = A.rows_rx[(size_t)a * L + i];
   }

@@ -1996,6 +1996,49 @@ __global__ __launch_bounds__(NT, (LOWREG ? 2 : 1)) void k_step_multi(const Chain
     cart_body<NT, LOWREG>(C, (int)blockIdx.x, s_runs, s_gl);
   }
 }
+// Half-evaluation launch (launch_engine.h, round 5): ONE launch steps the single-decoy folds of group X (the second half of their
+// evaluation: records -> trial point) and evaluates the pair terms of group Y (the first half of theirs) -- disjoint folds, so the
+// two kinds of work have no dependency inside the launch, and the few step workgroups (one wave per SIMD of one CU per fold, a
+// chain of dependent phases: latency) run beside the thousands of pair waves (throughput) instead of before or after them.  Two
+// kernels on one stream cannot overlap on this device (hipExtAnyOrderLaunch is ignored on gfx9: tools/probes/anyorder_probe.hip) and a
+// dependency across streams costs 11-12 us (profiles/README.md, round 4), hence one kernel with two roles:
+//   workgroups [0, 2 n_step): fold = id / 2, Cartesian role (even) | torsion role (odd) -- the step kernel's low-register form
+//   (256 registers: two workgroups per CU, which is what the pair role's 199 registers allow too);
+//   the rest: TN / 64 independent one-wave pair work items per workgroup (pair_body<.., SUBW>), no barrier among them.
+// The arithmetic of either role is that of k_step_multi<.., true> / k_pair1_multi: results are bit-identical (tests).
+template <int FAM, bool SEGC, int TN>
+__global__ __launch_bounds__(TN, 2) void k_half_multi(const ChainArgs* AA, const CartArgs* CC, int n_step, const PairArgs* PA, int n_pair, int max_items, int xcd_groups) {
+  __shared__ int s_runs[STEP_RUNS_INTS];
+  __shared__ GramLds<TN> s_gl;
+  constexpr int SUBW = TN / 64;
+  const unsigned nsb = 2u * (unsigned)n_step;
+  if (blockIdx.x < nsb) {
+    const unsigned fold = blockIdx.x >> 1;
+    if (blockIdx.x & 1u) {
+      const ChainArgs A = load_args(AA + fold);
+      chain_body<1, TN>(A, 0, s_runs, s_gl);
+    } else {
+      const CartArgs C = load_args(CC + fold);
+      cart_body<TN, true>(C, 0, s_runs, s_gl);
+    }
+    return;
+  }
+  const unsigned pb = blockIdx.x - nsb, sub = threadIdx.x >> 6;
+  unsigned fold, item;
+  if (xcd_groups) {   // all rows of a fold on workgroups with the same id modulo 8 (one XCD, one L2: k_pair1_multi)
+    const unsigned x = (blockIdx.x & 7u), sidx = (pb >> 3) * SUBW + sub;
+    fold = x + 8u * (sidx / (unsigned)max_items);
+    item = sidx % (unsigned)max_items;
+  } else {
+    const unsigned id = pb * SUBW + sub;
+    fold = id / (unsigned)max_items;
+    item = id % (unsigned)max_items;
+  }
+  if ((int)fold >= n_pair) return;
+  const PairArgs A = load_args(PA + fold);
+  if ((int)item >= A.n_items) return;
+  pair_body<1, FAM, 1, SEGC, SUBW>(A, item, 0);
+}
 // one pass over the folds of a shared launch: each fold's count of retired slots, gathered for ONE copy to the host
 __global__ void k_gather_done(int n, const int* const* done, int* out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

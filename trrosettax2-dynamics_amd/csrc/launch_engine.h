@@ -17,6 +17,13 @@
 // fold found finished after chunk k-1 is still named in chunk k (already enqueued; its workgroups leave at once: PH_DONE), so it
 // is released when chunk k has completed -- no launch in flight ever refers to buffers whose owner has been woken.  Folds join
 // at chunk boundaries; their start-up work (on their own stream) is ordered before the chunk by an event.
+//
+// Half-evaluation launches (round 5; EngineJob::half, k_half_multi in kernel_step.h).  A step launch of n folds is n workgroups -- a chain
+// of dependent phases on n of 256 CUs -- and a pair launch fills the chip; one after the other, the chip does pair work half of the time
+// (kernel-trace timeline, profiles/r05_engine_overlap.txt).  The folds of a launch class are therefore cut into halves X and Y that run
+// half an evaluation apart inside a chunk: launch 2i carries pair(X) beside step(Y), launch 2i+1 step(X) beside pair(Y) -- one kernel,
+// two roles, disjoint folds, each fold still pair -> step -> pair in stream order.  Both halves are in step at the chunk boundaries
+// (the first launch of a chunk has no step role, a last one steps Y alone), so joining, leaving and draining work as before.
 #pragma once
 #include <condition_variable>
 
@@ -30,6 +37,8 @@ struct EngineJob {
   int fam_all = 1;        // pair kernel: all channels | distances only
   int segc = 0;           // pair kernel: the instantiation with the segment cache
   int wave1 = 0;          // pair kernel: one wave per row (k_pair1_multi) | the four-wave workgroups (k_pair_multi<1>)
+  int lowreg = 0;         // step kernel: the fold's Cartesian arguments are laid out for the low-register instantiation (k_step_multi<.., true>)
+  int half = 0;           // half-evaluation launches (k_half_multi): wave1, segc, lowreg, one slot, chains of <= 256 residues
   int bw = 1;             // decoys per wave of the pair kernel (one decoy group per fold)
   int B = 1;              // slots
   int n_items = 0;        // workgroups of the fold's row plan
@@ -95,6 +104,30 @@ static bool engine_enabled(int chains_alive) {
   return chains_alive >= TRX2_ENGINE_MIN_CONTEXTS;
 }
 
+// Half-evaluation launches: forced by trx2_set_shared_launch_halves(0 / 1) or TRX2_ENGINE_HALF=0 / 1 (results are bit-identical either way);
+// otherwise by the number of chains alive in the process, as engine_enabled: they pay when a pair launch fills the chip.  Batch mode at L=150,
+// 3 / 8 / 16 / 32 targets (6 / 16 / 32 / 64 chains) in flight: 55.8 -> 53.6, 94.5 -> 95.7, 141 -> 162, 170 -> 179 decoys/s (tools/r05_runs.sh run25, run26).
+#ifndef TRX2_ENGINE_HALF_MIN_CONTEXTS
+#define TRX2_ENGINE_HALF_MIN_CONTEXTS 12
+#endif
+static std::atomic<int> g_engine_half_mode{-1};
+static bool engine_half_enabled(int chains_alive) {
+  const int forced = g_engine_half_mode.load();
+  if (forced >= 0) return forced != 0;
+  static const int env = [] { const char* e = getenv("TRX2_ENGINE_HALF"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  if (env >= 0) return env != 0;
+  return chains_alive >= TRX2_ENGINE_HALF_MIN_CONTEXTS;
+}
+// ... used by a chunk for a launch class that holds at least this many folds (TRX2_ENGINE_HALF_MIN, A/B timing: 0 / 8 / 12 measured the same
+// in batch mode; the classes below fall back to a pair launch and a low-register step launch)
+#ifndef TRX2_ENGINE_HALF_MIN_FOLDS
+#define TRX2_ENGINE_HALF_MIN_FOLDS 0
+#endif
+static int engine_half_min_folds() {
+  static const int v = [] { const char* e = getenv("TRX2_ENGINE_HALF_MIN"); return e ? atoi(e) : TRX2_ENGINE_HALF_MIN_FOLDS; }();
+  return v;
+}
+
 template <int FAM, bool SEGC>
 static void engine_launch_pair_t(bool wave1, int n_folds, int max_items, hipStream_t st, const PairArgs* a) {
   if (!wave1) {
@@ -111,14 +144,31 @@ static void engine_launch_pair(bool fam_all, bool wave1, bool segc, int n_folds,
   if (fam_all) { if (segc) engine_launch_pair_t<FAM_ALL, true>(wave1, n_folds, max_items, st, a); else engine_launch_pair_t<FAM_ALL, false>(wave1, n_folds, max_items, st, a); }
   else { if (segc) engine_launch_pair_t<FAM_DIST | FAM_VDW, true>(wave1, n_folds, max_items, st, a); else engine_launch_pair_t<FAM_DIST | FAM_VDW, false>(wave1, n_folds, max_items, st, a); }
 }
-static void engine_launch_step(int cls, dim3 grid, size_t dyn, hipStream_t st, const ChainArgs* a, const CartArgs* c) {
-  if (cls == 0) hipLaunchKernelGGL((k_step_multi<1, 128, 128>), grid, dim3(128), dyn, st, a, c);
-  else if (cls == 1) hipLaunchKernelGGL((k_step_multi<1, CHAIN_THREADS, CHAIN_THREADS>), grid, dim3(CHAIN_THREADS), dyn, st, a, c);
-  else hipLaunchKernelGGL((k_step_multi<1, 2 * CHAIN_THREADS, 2 * CHAIN_THREADS>), grid, dim3(2 * CHAIN_THREADS), dyn, st, a, c);
+static void engine_launch_step(int cls, bool lowreg, dim3 grid, size_t dyn, hipStream_t st, const ChainArgs* a, const CartArgs* c) {
+  if (cls == 0 && lowreg) hipLaunchKernelGGL((k_step_multi<1, 128, 128, true>), grid, dim3(128), dyn, st, a, c);
+  else if (cls == 0) hipLaunchKernelGGL((k_step_multi<1, 128, 128, false>), grid, dim3(128), dyn, st, a, c);
+  else if (cls == 1 && lowreg) hipLaunchKernelGGL((k_step_multi<1, CHAIN_THREADS, CHAIN_THREADS, true>), grid, dim3(CHAIN_THREADS), dyn, st, a, c);
+  else if (cls == 1) hipLaunchKernelGGL((k_step_multi<1, CHAIN_THREADS, CHAIN_THREADS, false>), grid, dim3(CHAIN_THREADS), dyn, st, a, c);
+  else hipLaunchKernelGGL((k_step_multi<1, 2 * CHAIN_THREADS, 2 * CHAIN_THREADS, false>), grid, dim3(2 * CHAIN_THREADS), dyn, st, a, c);
+}
+// one half-evaluation launch: the step role for n_step folds (single-slot folds: two workgroups each) beside the pair role for n_pair folds
+template <int FAM, int TN>
+static void engine_launch_half_t(int n_step, const ChainArgs* ca, const CartArgs* cc, int n_pair, const PairArgs* pa, int max_items, size_t dyn, hipStream_t st) {
+  constexpr unsigned SUBW = TN / 64;
+  const int xg = n_pair >= 8;   // every fold's rows on one XCD, as in engine_launch_pair_t
+  const unsigned units = n_pair <= 0 ? 0u : (xg ? (unsigned)((n_pair + 7) / 8) : (unsigned)n_pair) * (unsigned)max_items;   // one-wave work items (per XCD column with xg)
+  const unsigned pair_blocks = (xg ? 8u : 1u) * ((units + SUBW - 1) / SUBW);
+  const unsigned blocks = 2u * (unsigned)std::max(n_step, 0) + pair_blocks;
+  if (blocks == 0) return;
+  hipLaunchKernelGGL((k_half_multi<FAM, true, TN>), dim3(blocks), dim3(TN), n_step > 0 ? dyn : 0, st, ca, cc, std::max(n_step, 0), pa, std::max(n_pair, 0), max_items, xg);
+}
+static void engine_launch_half(int cls, bool fam_all, int n_step, const ChainArgs* ca, const CartArgs* cc, int n_pair, const PairArgs* pa, int max_items, size_t dyn, hipStream_t st) {
+  if (cls == 0) { if (fam_all) engine_launch_half_t<FAM_ALL, 128>(n_step, ca, cc, n_pair, pa, max_items, dyn, st); else engine_launch_half_t<FAM_DIST | FAM_VDW, 128>(n_step, ca, cc, n_pair, pa, max_items, dyn, st); }
+  else { if (fam_all) engine_launch_half_t<FAM_ALL, CHAIN_THREADS>(n_step, ca, cc, n_pair, pa, max_items, dyn, st); else engine_launch_half_t<FAM_DIST | FAM_VDW, CHAIN_THREADS>(n_step, ca, cc, n_pair, pa, max_items, dyn, st); }
 }
 
 // launch class of a job: folds of one class share a launch pair (same instantiations); a chunk launches every class it holds
-static int engine_class(const EngineJob* j) { return ((j->cls * 2 + j->fam_all) * 2 + j->wave1) * 2 + j->segc; }
+static int engine_class(const EngineJob* j) { return ((((j->cls * 2 + j->fam_all) * 2 + j->wave1) * 2 + j->segc) * 2 + j->lowreg) * 2 + j->half; }
 
 static void engine_fail(LaunchEngine* E, const std::string& why) {   // (mu held) a HIP error on the engine's stream: every fold it holds fails loudly
   E->broken = true; E->broken_why = why;
@@ -183,10 +233,10 @@ static void engine_main(LaunchEngine* E) {
       const PairArgs* dpa = (const PairArgs*)(E->d_args + ENG_OFF_PA);
       const ChainArgs* dca = (const ChainArgs*)(E->d_args + ENG_OFF_CA);
       const CartArgs* dcc = (const CartArgs*)(E->d_args + ENG_OFF_CC);
-      struct Grp { int lo, n, items, maxB, cls, fam, wave1, segc; size_t dyn; };
+      struct Grp { int lo, n, items, maxB, cls, fam, wave1, segc, lowreg, half; size_t dyn; };
       std::vector<Grp> groups;
       for (int i = 0; i < n;) {
-        Grp g{i, 0, 0, 0, C.jobs[(size_t)i]->cls, C.jobs[(size_t)i]->fam_all, C.jobs[(size_t)i]->wave1, C.jobs[(size_t)i]->segc, 0};
+        Grp g{i, 0, 0, 0, C.jobs[(size_t)i]->cls, C.jobs[(size_t)i]->fam_all, C.jobs[(size_t)i]->wave1, C.jobs[(size_t)i]->segc, C.jobs[(size_t)i]->lowreg, C.jobs[(size_t)i]->half, 0};
         while (i < n && engine_class(C.jobs[(size_t)i]) == engine_class(C.jobs[(size_t)g.lo])) {
           const EngineJob* j = C.jobs[(size_t)i];
           g.items = std::max(g.items, j->n_items); g.maxB = std::max(g.maxB, j->B); g.dyn = std::max(g.dyn, j->dyn);
@@ -200,11 +250,22 @@ static void engine_main(LaunchEngine* E) {
         for (const Grp& g : groups) {
           const bool samp = C.prof && it == ENGINE_CHUNK / 2;
           if (samp) (void)hipEventRecord(E->pev[k & 1][0], E->stream);
-          engine_launch_pair(g.fam != 0, g.wave1 != 0, g.segc != 0, g.n, g.items, E->stream, dpa + g.lo);
-          if (samp) (void)hipEventRecord(E->pev[k & 1][1], E->stream);
-          engine_launch_step(g.cls, dim3((unsigned)(2 * g.maxB), (unsigned)g.n), g.dyn, E->stream, dca + g.lo, dcc + g.lo);
+          if (g.half && g.n >= engine_half_min_folds()) {
+            // halves X = [lo, lo + nx) and Y = the rest, Y half an evaluation behind: pair(X) beside step(Y) of the previous evaluation, then
+            // step(X) beside pair(Y).  (The sampled events bracket the two half-evaluation launches instead of a pair | step kernel.)
+            const int nx = (g.n + 1) / 2, ny = g.n - nx, y = g.lo + nx;
+            engine_launch_half(g.cls, g.fam != 0, it > 0 ? ny : 0, dca + y, dcc + y, nx, dpa + g.lo, g.items, g.dyn, E->stream);
+            if (samp) (void)hipEventRecord(E->pev[k & 1][1], E->stream);
+            engine_launch_half(g.cls, g.fam != 0, nx, dca + g.lo, dcc + g.lo, ny, dpa + y, g.items, g.dyn, E->stream);
+          } else {
+            engine_launch_pair(g.fam != 0, g.wave1 != 0, g.segc != 0, g.n, g.items, E->stream, dpa + g.lo);
+            if (samp) (void)hipEventRecord(E->pev[k & 1][1], E->stream);
+            engine_launch_step(g.cls, g.lowreg != 0, dim3((unsigned)(2 * g.maxB), (unsigned)g.n), g.dyn, E->stream, dca + g.lo, dcc + g.lo);
+          }
           if (samp) (void)hipEventRecord(E->pev[k & 1][2], E->stream);
         }
+      for (const Grp& g : groups)   // the second halves' last step of the chunk: every fold has now had ENGINE_CHUNK evaluations
+        if (g.half && g.n >= engine_half_min_folds() && g.n > 1) { const int nx = (g.n + 1) / 2; engine_launch_half(g.cls, g.fam != 0, g.n - nx, dca + g.lo + nx, dcc + g.lo + nx, 0, dpa, g.items, g.dyn, E->stream); }
       hipLaunchKernelGGL(k_gather_done, dim3(1), dim3(ENGINE_MAX_JOBS), 0, E->stream, n, (const int* const*)(E->d_args + ENG_OFF_DP), E->d_flags);
       if (!chk(hipGetLastError(), "shared launch")) return;
       if (!chk(hipMemcpyAsync(E->h_flags[k & 1], E->d_flags, sizeof(int) * n, hipMemcpyDeviceToHost, E->stream), "hipMemcpyAsync(flags)")) return;
@@ -293,9 +354,10 @@ static bool engine_start(LaunchEngine* E, int index) {   // (g_engine_mutex held
     int lds_max = 0;
     if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, E->device) != hipSuccess || lds_max <= 0) lds_max = 65536;
     if (lds_max > 160 * 1024) lds_max = 160 * 1024;
-    const void* f[3] = {(const void*)k_step_multi<1, 128, 128>, (const void*)k_step_multi<1, CHAIN_THREADS, CHAIN_THREADS>,
-                        (const void*)k_step_multi<1, 2 * CHAIN_THREADS, 2 * CHAIN_THREADS>};
-    for (int q = 0; q < 3 && ok; q++) {
+    const void* f[5] = {(const void*)k_step_multi<1, 128, 128, false>, (const void*)k_step_multi<1, CHAIN_THREADS, CHAIN_THREADS, false>,
+                        (const void*)k_step_multi<1, 2 * CHAIN_THREADS, 2 * CHAIN_THREADS, false>,
+                        (const void*)k_step_multi<1, 128, 128, true>, (const void*)k_step_multi<1, CHAIN_THREADS, CHAIN_THREADS, true>};
+    for (int q = 0; q < 5 && ok; q++) {
       hipFuncAttributes fa;
       ok = hipFuncGetAttributes(&fa, f[q]) == hipSuccess &&
            hipFuncSetAttribute(f[q], hipFuncAttributeMaxDynamicSharedMemorySize, lds_max - (int)fa.sharedSizeBytes) == hipSuccess;

@@ -181,6 +181,7 @@ struct trx2_ctx {
   int step_dyn_floor[2] = {0, 0};  // ... and the most the torsion role needs of it (its staged history at 128 / 256 residues)
   int step_static[2] = {0, 0};     // static LDS of the two fused step kernels
   int step2_static[2] = {0, 0};    // ... and of their low-register instantiations (k_step<1, NT, NT, true>)
+  int half_static[2] = {0, 0};     // ... and of the half-evaluation kernels of the shared launches (k_half_multi<.., 128 | 256>)
   int pair_static = 32 * 1024;     // static LDS of a pair-kernel workgroup
   int lds_total = 160 * 1024;      // LDS of a CU
   std::vector<hipEvent_t> prof_ev;
@@ -334,6 +335,18 @@ static int ctx_create_impl(int device, trx2_ctx** out, hipStream_t avoid_stream)
         ctx->step2_static[k] = (int)fa.sharedSizeBytes;
         ok = hipFuncSetAttribute(f2[k], hipFuncAttributeMaxDynamicSharedMemorySize, lds_max - (int)fa.sharedSizeBytes) == hipSuccess;
       }
+    }
+    {  // the half-evaluation kernels of the shared launches (kernel_step.h, k_half_multi): same occupancy as the low-register step kernels
+      const void* fh[2][2] = {{(const void*)k_half_multi<FAM_ALL, true, 128>, (const void*)k_half_multi<FAM_DIST | FAM_VDW, true, 128>},
+                              {(const void*)k_half_multi<FAM_ALL, true, CHAIN_THREADS>, (const void*)k_half_multi<FAM_DIST | FAM_VDW, true, CHAIN_THREADS>}};
+      for (int k = 0; k < 2 && ok; k++)
+        for (int q = 0; q < 2 && ok; q++) {
+          hipFuncAttributes fa;
+          ok = hipFuncGetAttributes(&fa, fh[k][q]) == hipSuccess;
+          if (!ok) break;
+          ctx->half_static[k] = std::max(ctx->half_static[k], (int)fa.sharedSizeBytes);
+          ok = hipFuncSetAttribute(fh[k][q], hipFuncAttributeMaxDynamicSharedMemorySize, lds_max - (int)fa.sharedSizeBytes) == hipSuccess;
+        }
     }
     if (!ok) {
       pool_release(device, ctx->stream);
@@ -1188,7 +1201,18 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
     ca.n_total = N; ca.seed = seed; ca.decoy0 = decoy0; ca.tors0_all = tors0 ? ctx->tors0_all : nullptr;
   };
   int two_cap = 0;
-  const bool two_per_cu = has_cart && step_two_per_cu(ctx, L, B0, &two_cap);
+  bool two_per_cu = has_cart && step_two_per_cu(ctx, L, B0, &two_cap);
+  // Shared launches in half-evaluation form (launch_engine.h, k_half_multi): the fold's step runs in the low-register instantiation
+  // inside a kernel that also carries other folds' pair work items -- its step arguments are laid out for that form from the start
+  // (also when the engines turn out to be full and the fold launches for itself: k_step<.., true>, the same arithmetic).
+  const bool want_engine = B == 1 && N == 1 && has_cart && L <= 2 * CHAIN_THREADS && ctx->prof_every == 0 && getenv("TRX2_GRAPH") == nullptr &&
+                           engine_enabled(g_live_contexts.load() - g_lane_contexts.load());
+  bool engine_half = false;
+  if (want_engine && !two_per_cu && engine_half_enabled(g_live_contexts.load() - g_lane_contexts.load()) && ctx->pair1_waves == 1 && L <= CHAIN_THREADS && L <= PAIR_SUB_ENT && seg_on(ctx)) {
+    const int k = L <= 128 ? 0 : 1, n = L <= 128 ? 4 : 2;
+    const int cap = (ctx->lds_total - n * ctx->half_static[k]) / n / 16 * 16;
+    if (ctx->half_static[k] > 0 && (int)HIST_LDS_BYTES(L) <= cap && (int)CART_ARRAYS_BYTES(L) <= cap) { two_per_cu = true; two_cap = cap; engine_half = true; }
+  }
   // dynamic LDS of a step launch: the larger of the torsion role's staged history and the Cartesian role's staged pairs (behind its
   // own arrays in the low-register instantiation); sets how many stored pairs the Cartesian role stages
   auto step_lds = [&](CartArgs& cc) -> size_t {
@@ -1230,7 +1254,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   // Shared launches (launch_engine.h): a single-decoy fold -- every feedback iteration of run_inference.py is one -- does not launch
   // for itself; it hands its argument blocks to an engine whose launch pairs step the folds of many contexts at once, and sleeps.
   bool via_engine = false;
-  if (B == 1 && N == 1 && has_cart && L <= 2 * CHAIN_THREADS && pe == 0 && getenv("TRX2_GRAPH") == nullptr && engine_enabled(g_live_contexts.load() - g_lane_contexts.load())) {
+  if (want_engine) {
     if (LaunchEngine* E = engine_pick(ctx->device)) {
       EngineJob job;
       job.pa = pair_args(ctx, B);
@@ -1242,6 +1266,8 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
       job.fam_all = ctx->use_orient ? 1 : 0;
       job.wave1 = ctx->pair1_waves == 1 ? 1 : 0;
       job.segc = job.pa.segc ? 1 : 0;
+      job.lowreg = two_per_cu ? 1 : 0;
+      job.half = (engine_half && job.segc && job.wave1) ? 1 : 0;
       job.bw = ctx->BW; job.B = B; job.n_items = job.pa.n_items; job.done_count = ctx->done_count; job.cap = cap;
       const RowPlan& rp = ctx->plans[(size_t)ctx->plan_cur];
       if (ctx->BW != 1 || rp.epoch != ctx->rows_epoch || rp.pw != 64 || (size_t)rp.ns_max * B * L > ctx->fa_cap) {
@@ -1365,6 +1391,11 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
 extern "C" int trx2_set_shared_launches(int mode) {
   if (mode < -1 || mode > 1) return 1;
   g_engine_mode = mode;
+  return 0;
+}
+extern "C" int trx2_set_shared_launch_halves(int mode) {
+  if (mode < -1 || mode > 1) return 1;
+  g_engine_half_mode = mode;
   return 0;
 }
 
