@@ -679,10 +679,11 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
     return out, m, runs
 
 
-def batch_mode_multi(args, T, synth, rank, local_rank, world, dist, forced, L=150, targets_per_gpu=8, nmax=10):
-    """N > 1: the north star's multi-GPU mode IS `value`: run_inference.py's batch mode (:339-348) over 8 N independent
+def batch_mode_multi(args, T, synth, rank, local_rank, world, dist, forced, L=150, targets_per_gpu=16, nmax=10):
+    """N > 1: the north star's multi-GPU mode IS `value`: run_inference.py's batch mode (:339-348) over 16 N independent
     targets, ranks PULLING targets from the shared counter (pipeline.run_batch, sched.DynamicQueue; no collective on the data path, one gather of
-    the summaries at the end).  A step = one such job: 8 N targets of L = 150, init_num = 10, both models, all channels, the default protocol,
+    the summaries at the end).  Sixteen targets per GPU -- 32 chains in flight -- is where a GPU's shared launches fill the chip (one GPU: 8 / 16 / 32
+    targets in flight 95 / 162 / 179 decoys/s).  A step = one such job: 16 N targets of L = 150, init_num = 10, both models, all channels, the default protocol,
     Nmax shortened to `nmax` feedback iterations per chain so that W + K steps fit the driver's run (stated in `config.workload`), PDB files
     written.  Total work is fixed as N grows: `scaling: strong`.  UNMEASURED until a multi-GPU node runs it: no such node has been available
     to the builder in five rounds; the two-rank rehearsal on one GPU (tests/test_gpu_bench.py) exercises the control flow only."""
@@ -739,7 +740,7 @@ def batch_mode_multi(args, T, synth, rank, local_rank, world, dist, forced, L=15
         return {
             "metric": "decoys/sec", "value": decoys / elapsed, "unit": "decoys/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"run_inference batch mode: {n_targets} independent targets of L={L} (8 per GPU), init_num=10, both models, all channels, default protocol "
+            "config": {"workload": f"run_inference batch mode: {n_targets} independent targets of L={L} ({targets_per_gpu} per GPU), init_num=10, both models, all channels, default protocol "
                                    f"(-m 2 --fastrelax), Nmax={nmax} feedback iterations per chain (the CLI's default is 300: shortened so that warm-up + timed steps fit the run), PDB files written",
                        "L": L, "decoys_per_step": decoys // max(1, args.steps),
                        "parallelism": f"targets pulled from a shared counter by {world} rank(s), one process per GPU; no collective on the data path; one summary gather per job",
@@ -851,7 +852,7 @@ def main():
                     out["batch_mode"]["workload"] = bm["config"]["workload"]
                     out["batch_mode"]["parallelism"] = bm["config"]["parallelism"]
         if args.config == 2 and world > 1:
-            # N > 1: `value` is batch mode over 8 N targets pulled from the shared queue (strong scaling); the weak-scaling calls of config 2
+            # N > 1: `value` is batch mode over 16 N targets pulled from the shared queue (strong scaling); the weak-scaling calls of config 2
             # (every rank its own 64-decoy calls) and the config-5 record stay on the line as sub-records
             line = batch_mode_multi(args, T, synth, rank, local_rank, world, dist, forced)
             if rank == 0:

@@ -33,10 +33,10 @@ def test_bench_two_ranks_on_one_gpu():
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = last_json(r.stdout)
-    # N > 1: the line IS batch mode -- 8 targets per GPU pulled from the shared queue, strong scaling
+    # N > 1: the line IS batch mode -- 16 targets per GPU pulled from the shared queue, strong scaling
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["all_targets_folded"]
-    assert d["metric"] == "decoys/sec" and "16 independent targets" in d["config"]["workload"] and len(d["per_rank_seconds"]) == 2
-    assert d["config"]["decoys_per_step"] == 16 * (2 * 10 + 2 * 10) and sum(d["per_rank_decoys_last_step"]) == 640 and min(d["per_rank_decoys_last_step"]) > 0
+    assert d["metric"] == "decoys/sec" and "32 independent targets" in d["config"]["workload"] and len(d["per_rank_seconds"]) == 2
+    assert d["config"]["decoys_per_step"] == 32 * (2 * 10 + 2 * 10) and sum(d["per_rank_decoys_last_step"]) == 1280 and min(d["per_rank_decoys_last_step"]) > 0
     w = d["sub_records"]["config2_weak_scaling"]       # the weak-scaling calls of config 2 stay on the line as a sub-record
     assert w["scaling"] == "weak" and w["n_gpus"] == 2 and w["value"] > 0 and w["all_decoys_converged"] and len(w["per_rank_seconds"]) == 2
     bm = d["sub_records"]["config5_batch_mode"]
