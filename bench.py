@@ -450,8 +450,10 @@ def shared_launch_leg(T, synth, L, n_folds=32, evals=1500):
     """The kernels of the product's throughput mode (batch mode's iteration phase): n_folds single-decoy folds of n_folds contexts --
     each with its own tables of the synthetic all-channel map, as the chains of a batch job have -- at the same time, sharing launches
     (csrc/launch_engine.h), one wave per row, a fixed evaluation budget from near the structure (the state a fold spends its time in).
-    Reported: fold-evaluations per second, and a roofline record of the shared pair kernel from launch pairs the engines bracket with
-    HIP events on their own streams (one per chunk of 16): algorithmic bytes of the folds a sampled launch held / its duration."""
+    Two passes: under the library's rule (32 contexts: half-evaluation launches, k_half_multi) -> fold-evaluations per second and the durations of
+    the two launches of an evaluation; then with a pair launch and a step launch per evaluation (trx2_set_shared_launch_halves(0)) -> the same figure
+    and a roofline record of the shared pair kernel from launch pairs the engines bracket with HIP events on their own streams (one per chunk of
+    16): algorithmic bytes of the folds a sampled launch held / its duration."""
     import threading
     LB = importlib.import_module("trrosettax2-dynamics_amd._lib")
     m = synth.make_map(L, seed=L)
@@ -468,30 +470,47 @@ def shared_launch_leg(T, synth, L, n_folds=32, evals=1500):
         w = np.array(T.protocol.SF, np.float32)
         ctxs[0].eval_batch(t0s[0], w)
         _, term_evals = ctxs[0].time_pair_kernel(1, w, 1, L, n_rep=2)     # selected terms of one decoy of this map
-        LB.set_shared_launch_profiling(True)
-        s0 = LB.shared_launch_stats(0)
-        out = [None] * n_folds
+        def measure(halves):
+            """one pass: halves = -1 the library's rule (half-evaluation launches from twelve live contexts on), 0 = a pair launch and a step launch per evaluation"""
+            LB.set_shared_launch_halves(halves)
+            LB.set_shared_launch_profiling(True)
+            s0 = LB.shared_launch_stats(0)
+            out = [None] * n_folds
 
-        def work(i):
-            out[i] = ctxs[i].fold_batch(1, runs[5:], tors0=t0s[i], max_evals=evals)
-        th = [threading.Thread(target=work, args=(i,)) for i in range(n_folds)]
-        t0 = time.perf_counter()
-        [t.start() for t in th]
-        [t.join() for t in th]
-        el = time.perf_counter() - t0
-        LB.set_shared_launch_profiling(False)
-        s1 = LB.shared_launch_stats(0)
-        ev = sum(int(r["n_evals"][0]) for r in out)
-        ns = s1["samples"] - s0["samples"]
-        rec = {"workload": f"{n_folds} single-decoy folds (L={L}, all channels, own tables each) in flight at once, sharing launches; {evals} evaluations each from near the structure",
-               "fold_evaluations_per_sec": ev / el, "us_per_fold_evaluation": 1e6 * el / ev, "seconds": el}
-        if ns > 0:
-            folds = (s1["sampled_folds"] - s0["sampled_folds"]) / ns
-            pair_ms = (s1["pair_ms_sum"] - s0["pair_ms_sum"]) / ns
-            step_ms = (s1["step_ms_sum"] - s0["step_ms_sum"]) / ns
+            def work(i):
+                out[i] = ctxs[i].fold_batch(1, runs[5:], tors0=t0s[i], max_evals=evals)
+            th = [threading.Thread(target=work, args=(i,)) for i in range(n_folds)]
+            t0 = time.perf_counter()
+            [t.start() for t in th]
+            [t.join() for t in th]
+            el = time.perf_counter() - t0
+            LB.set_shared_launch_profiling(False)
+            s1 = LB.shared_launch_stats(0)
+            ev = sum(int(r["n_evals"][0]) for r in out)
+            ns = s1["samples"] - s0["samples"]
+            r = {"fold_evaluations_per_sec": ev / el, "us_per_fold_evaluation": 1e6 * el / ev, "seconds": el}
+            if ns > 0:
+                r["_folds"] = (s1["sampled_folds"] - s0["sampled_folds"]) / ns
+                r["_a_ms"] = (s1["pair_ms_sum"] - s0["pair_ms_sum"]) / ns
+                r["_b_ms"] = (s1["step_ms_sum"] - s0["step_ms_sum"]) / ns
+                r["_ns"] = int(ns)
+            return r
+
+        rec = {"workload": f"{n_folds} single-decoy folds (L={L}, all channels, own tables each) in flight at once, sharing launches; {evals} evaluations each from near the structure"}
+        h = measure(-1)
+        rec.update({k: v for k, v in h.items() if not k.startswith("_")})
+        rec["form"] = ("half-evaluation launches (k_half_multi: one kernel steps one half of an engine's folds beside the pair terms of the other half; the library's rule "
+                       "from twelve live contexts on)")
+        if "_ns" in h:
+            rec["half_launch_ms"] = [h["_a_ms"], h["_b_ms"]]
+            rec["folds_per_sampled_launch_class"] = h["_folds"]
+        p = measure(0)
+        rec["pair_step_form"] = {k: v for k, v in p.items() if not k.startswith("_")}
+        if "_ns" in p:
+            folds, pair_ms, step_ms, ns = p["_folds"], p["_a_ms"], p["_b_ms"], p["_ns"]
             abytes = algorithmic_bytes(folds, term_evals, L)
             tr = traffic_record("shared16", 16, "k_pair1_multi")
-            rec["roofline"] = {"bound": "hbm", "kernel": f"k_pair1_multi<all channels, segment cache> ({folds:.1f} folds per sampled launch, {int(ns)} samples)",
+            rec["roofline"] = {"bound": "hbm", "kernel": f"k_pair1_multi<all channels, segment cache> ({folds:.1f} folds per sampled launch, {int(ns)} samples; pair | step form)",
                                "achieved": abytes / (pair_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "avg_launch_ms": pair_ms, "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": term_evals,
                                "traffic": (tr["hbm_bytes_per_launch"] * folds / 16.0) if tr else None,
@@ -500,6 +519,7 @@ def shared_launch_leg(T, synth, L, n_folds=32, evals=1500):
         return rec
     finally:
         LB.set_shared_launch_profiling(False)
+        LB.set_shared_launch_halves(-1)
         for c in ctxs:
             c.close()
 

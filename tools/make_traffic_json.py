@@ -31,7 +31,7 @@ for p1 in sorted(glob.glob(os.path.join(src, "c*_*_B*_pass1.json"))):
 # the shared-launch shape: sixteen single-decoy folds in one engine's launches (tools/runs_r01_r04.sh.txt section r04_profiles.sh: shared16_{pair,step}_<group>.json
 # beside the pmc directory), keyed config "shared16"
 up = os.path.dirname(os.path.abspath(src))
-for fam, kern in (("pair", "k_pair1_multi"), ("step", "k_step_multi")):
+for fam, kern in (("pair", "k_pair1_multi"), ("step", "k_step_multi"), ("half", "k_half_multi")):   # half: the same folds in half-evaluation form (eight per role and launch)
     ps = [os.path.join(up, f"shared16_{fam}_{g}.json") for g in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "SQ_WAVES")]
     if all(os.path.exists(q) and os.path.getsize(q) for q in ps):
         f, w, t, q = (json.load(open(x)) for x in ps)
@@ -40,8 +40,8 @@ for fam, kern in (("pair", "k_pair1_multi"), ("step", "k_step_multi")):
             "fetch_bytes_raw": f["FETCH_SIZE"] * 1024.0, "write_bytes": w["WRITE_SIZE"] * 1024.0,
             "hbm_bytes_per_launch": 2.0 * f["FETCH_SIZE"] * 1024.0 + w["WRITE_SIZE"] * 1024.0,
             "l2_requests": t.get("TCC_REQ_sum"), "l2_hits": t.get("TCC_HIT_sum"), "l2_misses": t.get("TCC_MISS_sum"),
-            "method": "rocprofv3 --pmc in separate runs of tools/shared_scaling.py (16 folds, one engine, one wave per row; mean of the last "
-                      f"{f['launches']} dispatches); KiB -> bytes; FETCH_SIZE doubled as for the other records (the guide's correction is calibrated for wide "
+            "method": "rocprofv3 --pmc in separate runs of tools/shared_scaling.py (16 folds, one engine, one wave per row; mean of "
+                      f"{f['launches']} dispatches before the engine's last three chunks, which name folds that have already reported); KiB -> bytes; FETCH_SIZE doubled as for the other records (the guide's correction is calibrated for wide "
                       "coalesced reads; these are 64-byte gathers: L2 misses x 64 B equal the RAW FETCH_SIZE, so the doubled figure is an upper bound)",
             "valu_insts_per_launch": q.get("SQ_INSTS_VALU"), "waves": q.get("SQ_WAVES"), "wave_quad_cycles": q.get("SQ_WAVE_CYCLES"), "wait_any_quad_cycles": q.get("SQ_WAIT_ANY")})
 json.dump(rec, open(out, "w"), indent=1)

@@ -141,9 +141,13 @@ profiles() {  # Round-5 profile records: kernel traces of the three single-GPU c
   for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES"; do
     tag=$(echo $grp | cut -d' ' -f1)
     rm -rf /tmp/pmcs
-    SCALING_WAVES=1 TRX2_ENGINE_STREAMS=1 run 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmcs -- python3 $R/tools/shared_scaling.py $R 150 400 16 > $O/shared16_pmc_$tag.log 2>&1
+    SCALING_WAVES=1 TRX2_ENGINE_STREAMS=1 TRX2_ENGINE_HALF=0 run 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmcs -- python3 $R/tools/shared_scaling.py $R 150 800 16 > $O/shared16_pmc_$tag.log 2>&1
     f=$(find /tmp/pmcs -name '*counter_collection.csv' | head -1)
-    if [ -n "$f" ]; then python3 $R/tools/pmc_report.py $f 200 k_pair1_multi > $O/shared16_pair_$tag.json; python3 $R/tools/pmc_report.py $f 200 k_step_multi > $O/shared16_step_$tag.json; fi
+    if [ -n "$f" ]; then python3 $R/tools/pmc_report.py $f 200 k_pair1_multi 48 > $O/shared16_pair_$tag.json; python3 $R/tools/pmc_report.py $f 200 k_step_multi 48 > $O/shared16_step_$tag.json; fi
+    rm -rf /tmp/pmcs   # the same sixteen folds in half-evaluation form: one kernel, eight folds in either role per launch
+    SCALING_WAVES=1 TRX2_ENGINE_STREAMS=1 TRX2_ENGINE_HALF=1 run 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d /tmp/pmcs -- python3 $R/tools/shared_scaling.py $R 150 800 16 > $O/shared16_half_pmc_$tag.log 2>&1
+    f=$(find /tmp/pmcs -name '*counter_collection.csv' | head -1)
+    if [ -n "$f" ]; then python3 $R/tools/pmc_report.py $f 200 k_half_multi 99 > $O/shared16_half_$tag.json; fi
   done
   cd $R
   python3 tools/make_traffic_json.py $O/pmc $O/r05_traffic.json
@@ -241,6 +245,17 @@ run27() {  # half-evaluation launches under the library's rule (from twelve live
   timeout -k 10 400 python3 tools/e2e_batch.py $R 150 16 40 16 8 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
   timeout -k 10 400 python3 tools/e2e_batch.py $R 150 6 40 3 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
   timeout -k 10 400 python3 tools/e2e_batch.py $R 150 8 80 8 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
+  cat $O/batch.txt
+}
+run28() {  # half-evaluation kernel on 512-thread workgroups (a step workgroup keeps its CU to itself): bitwise tests, batch mode at 16 / 8 / 32 / 3 targets in flight
+  O=$R/gpurun_out/r05_run28; mkdir -p $O; rm -f $O/batch.txt
+  timeout -k 10 900 python3 -m pytest tests/test_gpu_shared_launch.py -x -q -m gpu > $O/pytest.txt 2>&1; rc=$?; tail -3 $O/pytest.txt; [ $rc -eq 0 ] || return $rc
+  for rep in 1 2; do
+    timeout -k 10 400 python3 tools/e2e_batch.py $R 150 16 40 16 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
+    timeout -k 10 400 python3 tools/e2e_batch.py $R 150 8 80 8 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
+    timeout -k 10 400 python3 tools/e2e_batch.py $R 150 32 20 32 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
+  done
+  TRX2_ENGINE_HALF=1 timeout -k 10 400 python3 tools/e2e_batch.py $R 150 6 40 3 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
   cat $O/batch.txt
 }
 "$@"
