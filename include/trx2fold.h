@@ -43,7 +43,8 @@ typedef struct trx2_params {
 #define TRX2_MAXEVAL 2  /* evaluation budget exhausted before the protocol finished */
 
 /* 2 since round 5: trx2_run.precheck became a bit field (bit 0 the remove_clash guard, bit 1 TRX2_RUN_WARM: include/trx2_model.h) and
- * TRX2_MAX_RUNS is 64 (48 under version 1's first builds); exports added in round 4 (shared launches, single-decoy waves) kept their names. */
+ * TRX2_MAX_RUNS is 64 (48 under version 1's first builds); exports added in round 4 (shared launches, single-decoy waves) kept their names;
+ * round 5 also added trx2_set_shared_launch_halves (an addition: no existing entry point changed with it). */
 int trx2_abi_version(void);
 
 /* replaces pyrosetta.init + process start-up (folding/folding.py:48): binds a GPU and creates a stream */
@@ -116,7 +117,8 @@ int trx2_ctx_set_single_decoy_waves(trx2_ctx* ctx, int waves);
 /* measurement helpers: out[9] = chunks of launch pairs the device's engines enqueued, folds x chunks (ratio: folds per launch), folds
  * completed, seconds their host threads spent enqueuing, seconds they waited for the GPU; and, while trx2_set_shared_launch_profiling(1)
  * is on (one launch pair per chunk of 16 bracketed by HIP events on the engine's stream): summed milliseconds of the sampled pair and
- * step launches, the number of samples, the folds they held */
+ * step launches, the number of samples, the folds they held (in half-evaluation form: of the sampled evaluation's first and second
+ * half launch -- pair role of one half of the folds beside the step role of the other, then the reverse) */
 int trx2_shared_launch_stats(int device, double* out);
 int trx2_set_shared_launch_profiling(int on);
 int trx2_last_fold_slot_efficiency(trx2_ctx* ctx, double* eff);
