@@ -633,7 +633,7 @@ def single_target(args, cfg, config, T, synth, rank, local_rank, world, dist, fo
     evals = np.concatenate([r["n_evals"] for r in flat])
     launches = sum(r["launches"] for r in flat)   # per lane: both lanes of a context make about the same number
     legs = {}
-    if full and rank == 0 and world == 1 and not args.no_legs:
+    if full and rank == 0 and dist is None and not args.no_legs:
         def leg(lanes_, pool_, n_queue, note):
             for c_ in ctxs:
                 c_.set_lanes(lanes_); c_.set_pool(pool_)
@@ -813,7 +813,11 @@ def main():
     forced = os.environ.get("TRX2_BENCH_FORCE_DEVICE")
     if forced is not None:
         local_rank = int(forced)
-    if world > 1:
+    # Rehearsal of the N > 1 path on RCCL with the one GPU a box has: TRX2_BENCH_REHEARSE_NCCL=1 under torchrun with ONE rank takes every branch a
+    # multi-GPU run takes (process group on nccl, barriers, object broadcast, CUDA all-gather, the queue's store and gloo group) -- world size 1, so
+    # what it shows is that RCCL initialises and the collectives run with this code, nothing about scaling (tests/test_gpu_bench.py).
+    multi = world > 1 or os.environ.get("TRX2_BENCH_REHEARSE_NCCL") == "1"
+    if multi:
         import datetime
         import torch
         import torch.distributed as dist
@@ -825,14 +829,14 @@ def main():
 
     T = importlib.import_module("trrosettax2-dynamics_amd")
     synth = importlib.import_module("trrosettax2-dynamics_amd.synth")
-    with_cpu = world == 1 and not args.no_cpu_baseline
+    with_cpu = not multi and not args.no_cpu_baseline
     if "targets" in cfg:
         out = multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, with_cpu)
     else:
         out, m, runs = single_target(args, cfg, args.config, T, synth, rank, local_rank, world, dist, forced, args.steps, args.warmup, True)
         if rank == 0 and with_cpu:
             out["cpu_baseline"] = cpu_baseline(m, cfg, runs)
-        if args.config == 2 and world == 1 and rank == 0 and not args.no_e2e and not args.no_legs:
+        if args.config == 2 and not multi and rank == 0 and not args.no_e2e and not args.no_legs:
             pipe_mod = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
             import contextlib
             import io
@@ -851,7 +855,7 @@ def main():
                 its = max(out["e2e"]["init_num_10"]["iterations"].values())
                 out["e2e"]["cpu_baseline"] = cpu_e2e_baseline(synth, cfg["L"], 10, its, T.protocol.build_runs(cfg["L"], 2, fastrelax=True))
         if args.config == 2 and not args.no_sub_records:
-            if world == 1:
+            if not multi:
                 # the other single-GPU configs of BASELINE.json, shorter legs of the same measurement
                 sub = {}
                 for c in (3, 4):
@@ -871,7 +875,7 @@ def main():
                     out["batch_mode"] = {k: bm[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "all_decoys_converged", "per_rank")}
                     out["batch_mode"]["workload"] = bm["config"]["workload"]
                     out["batch_mode"]["parallelism"] = bm["config"]["parallelism"]
-        if args.config == 2 and world > 1:
+        if args.config == 2 and multi:
             # N > 1: `value` is batch mode over 16 N targets pulled from the shared queue (strong scaling); the weak-scaling calls of config 2
             # (every rank its own 64-decoy calls) and the config-5 record stay on the line as sub-records
             line = batch_mode_multi(args, T, synth, rank, local_rank, world, dist, forced)

@@ -41,3 +41,23 @@ def test_bench_two_ranks_on_one_gpu():
     assert w["scaling"] == "weak" and w["n_gpus"] == 2 and w["value"] > 0 and w["all_decoys_converged"] and len(w["per_rank_seconds"]) == 2
     bm = d["sub_records"]["config5_batch_mode"]
     assert bm["scaling"] == "strong" and len(bm["per_rank"]) == 2 and bm["all_decoys_converged"] and bm["value"] > 0
+
+
+def test_bench_on_rccl_with_one_rank():
+    """The N > 1 path on RCCL itself, as far as one GPU allows: torchrun with ONE rank and TRX2_BENCH_REHEARSE_NCCL=1 takes every branch a
+    multi-GPU run takes in bench.py -- process group on nccl (= RCCL) bound to the device, barriers around the timed steps, the object broadcast
+    of the work directory, the CUDA all-gather / all-reduce of the per-rank seconds, teardown -- in the same process as libtrx2fold's streams and
+    engine threads.  World size 1: it shows that RCCL initialises and the collectives run with this code ('nobody has seen
+    RCCL initialise with this code'), nothing about scaling; the queue's store and the gloo summary group short-circuit at one rank and are
+    covered by the two-rank tests (tests/test_sharding.py, test_bench_two_ranks_on_one_gpu)."""
+    env = dict(os.environ, TRX2_BENCH_REHEARSE_NCCL="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("TRX2_BENCH_FORCE_DEVICE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["value"] > 0 and d["all_targets_folded"] and "16 independent targets" in d["config"]["workload"]
+    assert d["config"]["decoys_per_step"] == 16 * (2 * 10 + 2 * 10) and len(d["per_rank_seconds"]) == 1
+    w = d["sub_records"]["config2_weak_scaling"]
+    assert w["scaling"] == "weak" and w["value"] > 0 and w["all_decoys_converged"]
