@@ -174,6 +174,45 @@ def test_no_angle_iteration_converges_or_stops_at_nmax(golden_dir, tmp_path):
     assert open(os.path.join(pdbd, f"t{last}.pdb")).read() == first                   # and the decoys are the same
 
 
+def test_baseline_config_0_as_written(golden_dir, tmp_path):
+    """BASELINE.json configs[0] as written -- the reference's example, init_num=2, Nmax=5, --no-angle -- through run_single (both models): two initial
+    decoys per model + one decoy per feedback iteration until the reference's convergence test or Nmax; the reference's file names; every decoy a
+    fold of the map OR of its mirror image (distances alone cannot tell the two apart: the orientation channels do); the run is reproducible byte
+    for byte."""
+    kw = dict(init_num=2, Nmax=5, angle=False, mult_two_models=True, seed=21,
+              npz_nmr=os.path.join(golden_dir, "seq_NMR.npz"), npz_xray=os.path.join(golden_dir, "seq_Xray.npz"))
+    save = str(tmp_path / "out")
+    n = PL.run_single("seq", os.path.join(golden_dir, "seq.fasta"), save, **kw)
+    pdb_dir = os.path.join(save, "seq", "pred_pdb")
+    files = sorted(os.listdir(pdb_dir))
+    per_model = {m: [f for f in files if f.startswith(f"conf_{m}_")] for m in (1, 2)}
+    assert n == len(files) and all(3 <= len(v) <= 2 + 5 for v in per_model.values()), files           # 2 initial + 1 .. 5 iteration decoys per model
+    assert all(v == [f"conf_{m}_{k}.pdb" for k in range(1, len(v) + 1)] for m, v in per_model.items()), files
+    dec = np.load(os.path.join(golden_dir, "ref_decoys.npz"))
+    refs = {1: ("conf_1_1", "conf_1_2"), 2: ("conf_2_1", "conf_2_2")}
+    rows = []
+    for m, v in per_model.items():
+        for f in v:
+            xyz, _ = P.read_backbone(os.path.join(pdb_dir, f))
+            ca = xyz[:, 1]
+            direct = min(kabsch_rmsd(ca, dec[r][:, 1]) for r in refs[m])
+            mirror = min(kabsch_rmsd(ca * np.array([1.0, 1.0, -1.0]), dec[r][:, 1]) for r in refs[m])
+            rows.append((f, direct, mirror))
+    print("\nconfigs[0]: file, C-alpha RMSD to the closer initial reference decoy of its model, and of its mirror image (A)")
+    for r in rows:
+        print("  %-14s %5.2f %5.2f" % r)
+    # distances alone fix the fold up to its mirror image and more loosely than the four channels do (measured: 1.2 - 3.2 A to the reference decoy or to
+    # its mirror image, the other one at ~12.5 A); the reference's example decoys were folded WITH angles, so these are bounds on "a fold of this map"
+    best = np.array([min(r[1], r[2]) for r in rows])
+    # (a few decoys of such a run sit ~8 A from both: part of the chain in one hand, part in the other -- distances allow that too; this config
+    # is the reference's plumbing baseline, and what is asserted on it is plumbing plus "most decoys are folds of the map")
+    assert np.median(best) < 3.2 and np.mean(best < 3.5) >= 0.6, rows
+    again = str(tmp_path / "again")
+    assert PL.run_single("seq", os.path.join(golden_dir, "seq.fasta"), again, **kw) == n
+    for f in files:
+        assert open(os.path.join(pdb_dir, f), "rb").read() == open(os.path.join(again, "seq", "pred_pdb", f), "rb").read(), f
+
+
 def test_device_resident_distograms_give_identical_tables(golden_dir, seq):
     """trx2_set_map_device (hand-off from the network front-end without the npz round trip): tables, masks
     and a fold from CUDA tensors equal those from the host arrays."""
