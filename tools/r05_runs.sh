@@ -258,4 +258,18 @@ run28() {  # half-evaluation kernel on 512-thread workgroups (a step workgroup k
   TRX2_ENGINE_HALF=1 timeout -k 10 400 python3 tools/e2e_batch.py $R 150 6 40 3 2>&1 | grep '^{' | cut -c1-250 >> $O/batch.txt || return $?
   cat $O/batch.txt
 }
+run29() {  # more streams than the default four hardware queues: TRX2_POOL_STREAMS x GPU_MAX_HW_QUEUES, batch mode (16 x Nmax 40, 8 x Nmax 80), one target, config 2
+  O=$R/gpurun_out/r05_run29; mkdir -p $O; rm -f $O/pool.txt
+  for cell in "4 -" "8 -" "8 8" "6 8" "4 8"; do
+    set -- $cell
+    echo "== TRX2_POOL_STREAMS=$1 GPU_MAX_HW_QUEUES=$2" >> $O/pool.txt
+    ( [ "$2" != "-" ] && export GPU_MAX_HW_QUEUES=$2; export TRX2_POOL_STREAMS=$1
+      timeout -k 10 400 python3 tools/e2e_batch.py $R 150 16 40 16 2>&1 | grep '^{' | cut -c1-170
+      timeout -k 10 400 python3 tools/e2e_batch.py $R 150 8 80 8 2>&1 | grep '^{' | cut -c1-170
+      timeout -k 10 400 python3 tools/e2e_single.py $R 150 60 2>&1 | grep -i "decoys\|^{" | tail -2 | cut -c1-200
+      timeout -k 10 400 python3 bench.py --config 2 --steps 5 --warmup 1 --no-cpu-baseline --no-sub-records --no-legs --no-e2e 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config 2 value', round(d['value'],1))"
+    ) >> $O/pool.txt 2>&1 || return $?
+  done
+  cat $O/pool.txt
+}
 "$@"
