@@ -1,6 +1,6 @@
 """Where along the chain do this build's decoys differ from the reference's?  Folds n decoys of each example map (default protocol), superposes every decoy
 on the closer of the map's two initial reference decoys (C-alpha, Kabsch) and prints the per-residue RMS deviation, next to the same profile between
-the reference's own two decoys of the map.  usage: per_residue_deviation.py <repo> [n = 1024]"""
+the reference's own two decoys of the map.  usage: tests/diag/per_residue_deviation.py <repo> [n = 1024]"""
 import importlib, os, sys
 import numpy as np
 sys.path.insert(0, sys.argv[1])

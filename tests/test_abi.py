@@ -70,3 +70,15 @@ def test_every_mode_with_the_relax_stage_fits_the_protocol_table():
     assert FO.relax_lite(FO.parse_options("-m 2 --orient -r no-idp")) and not FO.relax_lite(FO.parse_options("--no-fastrelax"))
     relax = P.build_runs(90, 2, fastrelax=True)[14:]
     assert [r["pair_filter"] for r in relax] == [2] * 12 + [3] * 9 and sum(r["cartesian"] for r in relax) == 13
+
+
+def test_tools_never_import_the_oracle():
+    """diagnostics that need the oracle as their checker live under tests/diag/; tools/ holds measurement scripts of the product alone"""
+    tdir = os.path.join(ROOT, "tools")
+    for dp, _, fs in os.walk(tdir):
+        if "scratch_r01_r04" in dp:
+            continue        # rounds 1-4's one-off scripts, kept for the record (tools/README or the file headers say so)
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f

@@ -1,7 +1,7 @@
 """GPU: the north star's parity criterion -- "C-alpha RMSD to the reference PyRosetta decoys within 0.5 A" -- read where the reference itself is defined.
 
 The global RMSD of a 90-residue decoy is dominated by a handful of residues on which the reference's OWN two decoys of a map disagree by 1 - 5 A
-(both termini, the GGG loop 33-35, two more loops: tools/per_residue_deviation.py prints the profile): the reference pair is 0.86 A (NMR map) and
+(both termini, the GGG loop 33-35, two more loops: tests/diag/per_residue_deviation.py prints the profile): the reference pair is 0.86 A (NMR map) and
 0.62 A (X-ray map) apart globally, but 0.30 / 0.22 A on the 80 residues on which it agrees best.  The core is therefore defined BY THE REFERENCE --
 the k residues with the smallest deviation between its two initial decoys of the map after their superposition -- never by this build's decoys,
 and every decoy is superposed on the core alone.  Measured on 1024 decoys per map, default protocol (profiles/r05_core_parity.txt):

@@ -4,7 +4,6 @@ import importlib, os, sys
 import numpy as np
 sys.path.insert(0, sys.argv[1])
 T = importlib.import_module("trrosettax2-dynamics_amd")
-from oracle import oracle as O
 tag, lo, hi = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 n = int(sys.argv[5]) if len(sys.argv) > 5 else 512
 g = os.path.join(sys.argv[1], "tests", "golden")
@@ -13,12 +12,19 @@ seq = "".join(l.strip() for l in open(os.path.join(g, "seq.fasta")) if not l.sta
 names = {"NMR": ("conf_2_1", "conf_2_2", "conf_1_3", "conf_1_4"), "Xray": ("conf_1_1", "conf_1_2", "conf_2_3", "conf_2_4")}[tag]
 
 
+def dihedral(a, b, c, d):
+    b0, b1, b2 = a - b, c - b, d - c
+    b1 = b1 / np.linalg.norm(b1)
+    v, w = b0 - (b0 @ b1) * b1, b2 - (b2 @ b1) * b1
+    return np.arctan2(np.cross(b1, v) @ w, v @ w)
+
+
 def phipsi(x):
     N, CA, C = x[:, 0], x[:, 1], x[:, 2]
     L = len(x); ph = np.full(L, np.nan); ps = np.full(L, np.nan)
     for i in range(L):
-        if i > 0: ph[i] = O.dihedral(C[i - 1], N[i], CA[i], C[i])
-        if i + 1 < L: ps[i] = O.dihedral(N[i], CA[i], C[i], N[i + 1])
+        if i > 0: ph[i] = dihedral(C[i - 1], N[i], CA[i], C[i])
+        if i + 1 < L: ps[i] = dihedral(N[i], CA[i], C[i], N[i + 1])
     return np.degrees(ph), np.degrees(ps)
 
 
