@@ -200,7 +200,7 @@ static inline void trx2_rama_params(const char* seq, int i, int L, float* p) {
  * chirality, carbonyl planarity) around the ideal values above, weight 0.1 in sf_cart (folding/data/scorefxn_cart.wts).
  * Stiffness is CALIBRATED so that --no-fastrelax decoys reproduce the geometry spread measured on the reference's decoys
  * (tools/derive_constants.py: bonds sd 0.009-0.011 A, N-CA-C sd 2.4 deg, C-N-CA sd 2.0 deg, omega sd 6.9 deg): with these
- * values tools/model_scan.py gives bonds 0.007-0.008 A, N-CA-C 2.6-2.8, C-N-CA 2.5-2.9, omega 4.7-7.0.  Softer angles
+ * values tests/diag/scratch_r01_r04/model_scan.py gives bonds 0.007-0.008 A, N-CA-C 2.6-2.8, C-N-CA 2.5-2.9, omega 4.7-7.0.  Softer angles
  * (K 80: spread 8.9 deg) let the chain cheat on the restraints; stiffer ones (K 8000) push the strain back into omega.
  * TRX2_CART_KSCALE: model scans only. */
 #ifndef TRX2_CART_KSCALE

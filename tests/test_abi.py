@@ -76,8 +76,6 @@ def test_tools_never_import_the_oracle():
     """diagnostics that need the oracle as their checker live under tests/diag/; tools/ holds measurement scripts of the product alone"""
     tdir = os.path.join(ROOT, "tools")
     for dp, _, fs in os.walk(tdir):
-        if "scratch_r01_r04" in dp:
-            continue        # rounds 1-4's one-off scripts, kept for the record (tools/README or the file headers say so)
         for f in fs:
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()

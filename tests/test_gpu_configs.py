@@ -212,7 +212,7 @@ def test_config4_L400_B32_all_channels(ctx):
     assert any(q["cartesian"] for q in runs)
     t0 = np.stack([O.random_torsions(L, 400, d) for d in range(B)]).astype(np.float32)
     # all 32 decoys: a 16-decoy ratio scatters by +-0.02 between builds and batch shapes (one flipped line-search decision moves a
-    # decoy's count by 1-3 of ~16; tools/scratch_r01_r04/track_L400.py on 128 decoys: 0.989 / 0.990 / 0.989 for three round-3 builds whose
+    # decoy's count by 1-3 of ~16; tests/diag/scratch_r01_r04/track_L400.py on 128 decoys: 0.989 / 0.990 / 0.989 for three round-3 builds whose
     # 16-decoy ratios ranged 0.948 .. 1.040)
     trk = check_tracking(ctx, Tb, t0, runs, med_tol=1e-2, ratio_min=0.94)
     check_tracking(ctx, Tb, near_starts(m, 16, 9), runs[5:], med_tol=0.15, tail_tol=0.5, same_frac=0.1)   # measured: 0.973, 3/16, 6.3e-2

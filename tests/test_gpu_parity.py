@@ -284,7 +284,7 @@ def test_minimiser_on_a_chain_longer_than_512(ctx):
     """L = 520: four residues per thread in the step kernel, history read from global memory (the LDS-staged history is for
     L <= 256), more than 64 visits per wave in the pair kernel (three blocks of its contact-bit walk).  Torsion-space
     protocol (the Cartesian kernel stops at 512 residues); same start and evaluation budget as the oracle.
-    tools/horizon_check.py on this start: agreement to 1e-7 .. 1e-6 for the first evaluations, identical iteration counts up
+    tests/diag/scratch_r01_r04/horizon_check.py on this start: agreement to 1e-7 .. 1e-6 for the first evaluations, identical iteration counts up
     to 8, then the float32 and float64 trajectories separate (1e-5 at 3 evaluations for one decoy, 3e-4 at 4, percent level
     from 8 on) -- so the comparison is pinned at 4 evaluations and the longer run is a sanity check."""
     S = importlib.import_module("trrosettax2-dynamics_amd.synth")
@@ -313,7 +313,7 @@ def test_minimiser_on_a_chain_longer_than_512(ctx):
 def test_minimiser_tracks_oracle_over_short_horizons(ctx, maps, seq):
     """Same start, same protocol, same evaluation budget as the oracle.  Outcome tests cannot see a minimiser that
     converges wastefully; this can.  Statistic: accepted iterations summed over 12 decoys, device / oracle.
-    Calibration (profiles/README.md, tools/traj_stats.py): a healthy minimiser gives 0.99-1.00 at 20 evaluations (11-12 of
+    Calibration (profiles/README.md, tests/diag/scratch_r01_r04/traj_stats.py): a healthy minimiser gives 0.99-1.00 at 20 evaluations (11-12 of
     12 per-decoy counts identical), 0.89-0.92 at 80 and 0.87-0.98 at 160 over three seeds -- the float32 device is 5-10 %
     less efficient per evaluation than the float64 oracle once the trajectories have separated.  An experimental
     Gram-matrix L-BFGS with float-accumulated dot products lost its directions to cancellation and scored 0.69 at 80."""
@@ -329,7 +329,7 @@ def test_minimiser_tracks_oracle_over_short_horizons(ctx, maps, seq):
         orc = [O.fold(Tb, t0[d].astype(np.float64), runs, max_evals=n)[2] for d in range(B)]
         oi = np.array([o["n_iters"] for o in orc])
         ratio[n], same[n] = r["n_iters"].sum() / oi.sum(), int((oi == r["n_iters"]).sum())
-        if n == 20:  # before most line-search decisions have flipped.  Calibration (tools/traj20.py, 3 seeds x 12 decoys):
+        if n == 20:  # before most line-search decisions have flipped.  Calibration (tests/diag/scratch_r01_r04/traj20.py, 3 seeds x 12 decoys):
             # relative energy difference median 4e-5 .. 3e-4, 11-12 of 12 below 5e-3; identical iteration counts 10-12 of 12.
             # A single flipped line-search decision in this steep phase moves one decoy by up to 10 % (seen once in 36), so the
             # bound is on the median and on all decoys but one.
