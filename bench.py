@@ -316,6 +316,50 @@ def cpu_e2e_baseline(synth, L, init_num, iterations, runs, n_folds=4):
                           "a chain's iterations are sequential, so more cores do not shorten them"}
 
 
+def cpu_e2e_measured(synth, L, runs, init_num=2, nmax=2):
+    """The e2e job RUN on the CPU port, end to end, on a bounded sample (the figure above is derived): both models side by side (two threads),
+    per model init_num initial decoys (OpenMP over them), the reference's ranking (calculate_reliability_score on the PDB files), then nmax feedback
+    iterations of { host feedback step on the best / latest PDB, tables from the fed-back maps, ONE oracle fold from a fresh random start, PDB file } --
+    run_inference.py:50-139 with the oracle in the fold's place and the package's host mirror of the feedback (itself pinned bit for bit to the reference)."""
+    import threading
+    from oracle import oracle as O
+    FB = importlib.import_module("trrosettax2-dynamics_amd.feedback")
+    PD = importlib.import_module("trrosettax2-dynamics_amd.pdbio")
+    work = tempfile.mkdtemp(prefix="trx2_cpue2e_")
+    maps = [synth.make_map(L, seed=L + c) for c in range(2)]
+    t_iter = [[], []]
+
+    def chain(c):
+        m = maps[c]
+        host = {k: m[k] for k in ("dist", "theta", "omega", "phi")}
+        Tb = O.Tables(host["dist"], host["omega"], host["theta"], host["phi"], seq=m["seq"])
+        _, xyz, _, _ = O.fold_batch(Tb, np.stack([O.random_torsions(L, 900 + c, d) for d in range(init_num)]), runs, nthreads=init_num)
+        paths = []
+        for d in range(init_num):
+            q = os.path.join(work, f"c{c}_initial{d}.pdb"); PD.write_pdb(q, m["seq"], xyz[d]); paths.append(q)
+        last = paths[int(np.argmax([FB.calculate_reliability_score(q) for q in paths]))]
+        for it in range(nmax):
+            t0 = time.time()
+            host = FB.feedback_labels(host, last, 1.0, True)
+            Tb = O.Tables(host["dist"], host["omega"], host["theta"], host["phi"], seq=m["seq"])
+            _, xyz, _, _ = O.fold_batch(Tb, O.random_torsions(L, 950 + c, it)[None], runs, nthreads=1)
+            last = os.path.join(work, f"c{c}_it{it}.pdb"); PD.write_pdb(last, m["seq"], xyz[0])
+            t_iter[c].append(time.time() - t0)
+
+    try:
+        t0 = time.time()
+        th = [threading.Thread(target=chain, args=(c,)) for c in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        wall = time.time() - t0
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    n = 2 * (init_num + nmax)
+    return {"value": n / wall, "unit": "decoys/sec", "kind": "port", "cores": 2 * init_num, "seconds": wall, "decoys": n,
+            "seconds_per_iteration": float(np.mean(t_iter[0] + t_iter[1])),
+            "sample": f"run end to end: both models of the synthetic L={L} pair, init_num={init_num}, Nmax={nmax} (the job itself has 10 and up to 300), default protocol, PDB files written"}
+
+
 def e2e_batch_leg(pipe_mod, synth, L, n_targets=16, nmax=40, seed=3, in_flight=(16,)):
     """Batch mode of run_inference.py (:339-348) on ONE GPU: n_targets targets (the same synthetic pair of maps under different names),
     init_num=10, both models, Nmax shortened to `nmax`, `in_flight` targets at a time (pipeline.run_batch's default: up to thirty-two =
@@ -854,6 +898,7 @@ def main():
             if with_cpu:
                 its = max(out["e2e"]["init_num_10"]["iterations"].values())
                 out["e2e"]["cpu_baseline"] = cpu_e2e_baseline(synth, cfg["L"], 10, its, T.protocol.build_runs(cfg["L"], 2, fastrelax=True))
+                out["e2e"]["cpu_baseline"]["measured_sample"] = cpu_e2e_measured(synth, cfg["L"], T.protocol.build_runs(cfg["L"], 2, fastrelax=True))
         if args.config == 2 and not args.no_sub_records:
             if not multi:
                 # the other single-GPU configs of BASELINE.json, shorter legs of the same measurement
