@@ -272,4 +272,15 @@ run29() {  # more streams than the default four hardware queues: TRX2_POOL_STREA
   done
   cat $O/pool.txt
 }
+run30() {  # the step kernel's LDS reserve for the other lane's pair workgroups at the headline shape (2 x 32 slots): TRX2_STEP_LDS_RESERVE=0 / 29696 / default
+  O=$R/gpurun_out/r05_run30; mkdir -p $O; rm -f $O/reserve.txt
+  for rep in 1 2; do for rs in default 0 29696; do
+    echo "== TRX2_STEP_LDS_RESERVE=$rs" >> $O/reserve.txt
+    for cfg in 2 3; do
+      ( [ "$rs" != "default" ] && export TRX2_STEP_LDS_RESERVE=$rs
+        timeout -k 10 400 python3 bench.py --config $cfg --steps 8 --warmup 2 --no-cpu-baseline --no-sub-records --no-legs --no-e2e 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('config $cfg value', round(d['value'],1), 'step ms', round(d.get('roofline_step',{}).get('avg_launch_ms',0)*1e3,2), 'us')" ) >> $O/reserve.txt 2>&1 || return $?
+    done
+  done; done
+  cat $O/reserve.txt
+}
 "$@"
