@@ -45,4 +45,6 @@ def test_the_harness_sees_a_fold_woken_too_early(tmp_path):
     (hdr / "launch_engine.h").write_text(h.replace(good, "{ j->state = 3; woke = true; (void)in_next; }"))
     exe = build(str(tmp_path), "-fsanitize=address", str(src))
     r = subprocess.run([exe, "32", "16"], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0 exitcode=66"), capture_output=True, text=True, timeout=600)
-    assert r.returncode != 0 and ("heap-use-after-free" in r.stderr or "woken before" in r.stderr), (r.returncode, r.stderr[-1500:])
+    # (whichever sees it first: AddressSanitizer in a mock kernel, the soak's own check of a woken fold, or the mock kernels' order check reading
+    # the counters of a fold whose buffers have been freed and handed to the next one)
+    assert r.returncode != 0 and any(t in r.stderr for t in ("heap-use-after-free", "woken before", "mock: step of evaluation")), (r.returncode, r.stderr[-1500:])
