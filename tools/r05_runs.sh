@@ -283,4 +283,15 @@ run30() {  # the step kernel's LDS reserve for the other lane's pair workgroups 
   done; done
   cat $O/reserve.txt
 }
+run31() {  # the one-wave pair kernel with the segment cache at THREE waves per SIMD (libtrx2fold_w3.so, -DTRX2_PAIR1_W3): pair | step form, saturated shapes
+  O=$R/gpurun_out/r05_run31; mkdir -p $O; rm -f $O/w3.txt
+  for lib in libtrx2fold.so libtrx2fold_w3.so; do for half in 0 1; do
+    echo "== $lib TRX2_ENGINE_HALF=$half" >> $O/w3.txt
+    ( export TRX2FOLD_LIB=$R/trrosettax2-dynamics_amd/$lib TRX2_ENGINE_HALF=$half
+      SCALING_WAVES=1 timeout -k 10 300 python3 tools/shared_scaling.py $R 150 1500 28 64 2>&1 | grep '^{' | cut -c60-330
+      timeout -k 10 400 python3 tools/e2e_batch.py $R 150 32 20 32 2>&1 | grep '^{' | cut -c1-170
+      timeout -k 10 400 python3 tools/e2e_batch.py $R 150 16 40 16 2>&1 | grep '^{' | cut -c1-170 ) >> $O/w3.txt 2>&1 || return $?
+  done; done
+  cat $O/w3.txt
+}
 "$@"
