@@ -1,6 +1,6 @@
 """Measurement of the rows SURVEY.md section 8(f) marks "next" and this tree has built on the device: each device path timed on an MI355X with the package's own
-host mirror of the same arithmetic timed beside it on the box's CPU (the mirrors are what the parity tests pin bit for bit to the reference: tests/test_feedback*.py,
-tests/test_cluster*.py, tests/test_evaluate*.py) -- never the oracle, which is test infrastructure.  One JSON line per row.
+host mirror of the same arithmetic timed beside it on the box's CPU (the mirrors are what the parity tests pin to the reference and compare the device output with: tests/test_oracle_golden.py,
+tests/test_gpu_feedback.py, tests/test_host_boundary.py) -- never the oracle, which is test infrastructure.  One JSON line per row.
   f1  the feedback step between two folds of a chain (utils_trX2dy/utils.py:294-403, run_inference.py:75-131): realised bins of the new decoy, re-weighting of the four
       maps, cumulative tmp array, convergence number, restraint tables rebuilt -- on the maps resident in the context (trx2_feedback_step)
   f1b the reference's ranking of the initial decoys (utils.py:352-372), n decoys at once (trx2_reliability_scores)
