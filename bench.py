@@ -1,32 +1,25 @@
 #!/usr/bin/env python
-"""bench.py -- decoys/sec of the MI355X-native fold, with kernel rooflines, a CPU baseline and the end-to-end job.
+"""bench.py -- decoys/sec of the MI355X-native fold, with kernel rooflines, a CPU baseline and sub-records of the other configs.
 
 Contract:  python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run, one rank per GPU)
 prints ONE JSON line on rank 0.
 
-A "step" = one pass of the hot path over one batch AS BASELINE.json WRITES IT: ONE call of the drop-in boundary for init_num
-decoys of one distogram -- `trx2_fold_batch(B = init_num)` on a context with the library's defaults (what
-`folding_with_pred_npz(repeat=init_num)` makes: two lanes, one slot per decoy, default tail compaction) -- folded through the
-full staged protocol (folding/folding.py:118-171 mode 2), timed from tables-resident-in-HBM to the last coordinates on the
-host.  The K steps are K such calls, one after the other; every call ends with its slowest decoy, so `value` does not depend
-on K.  Workload at N=1 = BASELINE.json configs[1]: L=150 single target, init_num=64, dist-only restraints (synthetic map,
-SURVEY.md 8d -- the reference ships data for L=90 only).
+`value` (default, --config 0) = the job BASELINE.json's metric is quoted on: "decoys/sec (L=150, init_num=10)" = run_inference.py on one
+target end to end (run_inference.py:280-337): 10 initial decoys per model as one batch, the best one fed back, then one decoy per feedback
+iteration up to Nmax = 300, both models, all channels, default protocol (-m 2 --fastrelax), PDB files written; distograms resident in HBM
+as float32 tensors when the clock starts.  The timed region is that ONE job (metric_job); a step is a K-th of it.  N > 1: one target per
+GPU (weak scaling, no data-path collective).  `roofline` = the job's pair-energy kernel (one decoy per launch), `roofline_step` = its
+dominant kernel by time (the fused minimiser step), both from HIP events around live launches; `cpu_baseline` = the same job on the CPU
+port (a bounded sample run end to end + the figure for the whole job derived from its seconds per iteration).
 
-Named legs beside `value` (N=1 only; none of them is `value`):
-  pooled_queue   ONE call over a queue of 1280 decoys on 2 lanes x 640 decoy slots (every decoy in flight; a longer queue refills on the device)
-                 (trx2_ctx_set_pool): the throughput mode of a job that has that many independent decoys (round 2's headline)
-  in_flight_B    a queue of 320 decoys with init_num in flight: two lanes of init_num/2 slots
-  single_stream  the same queue on ONE stream of init_num slots
-  e2e            the job the reference actually runs: run_inference.py end to end (pipeline.run_single: init_num initial decoys
-                 per model, then the SEQUENTIAL chain of single-decoy folds + feedback until convergence or Nmax, both models,
-                 PDB files written), at init_num = 10 (BASELINE's metric) and 64, with the split initial / iteration phase
-Other configs: --config 3 (all channels, two models), --config 4 (L=400, B=32), --config 5 (eight targets L=100..400, 32 decoys
-each, assigned to ranks longest-first: strong scaling).  N>1: every rank folds its own calls of the same target (independent
-units, no data-path collective): weak scaling; the same line then also carries the config-5 batch-mode record ("batch_mode",
-strong scaling, with per-rank seconds and the plan), which is the north star's multi-GPU mode.  At N=1 the line carries compact
-sub-records for configs 3 and 4 ("sub_records").
+Sub-records on the same line (N=1): config2 = BASELINE.json configs[1] (ONE trx2_fold_batch call of 64 decoys, distances only: rounds 1-5's
+`value`) with its legs (pooled_queue: 1280 decoys in one call on 2 x 640 slots; in_flight_B; single_stream; no_fastrelax) and its OpenMP CPU
+figure; config3 (all channels, two models), config4 (L=400, 32 decoys), config5_one_gpu; e2e: the same job on the reference's own L=90
+example, run_inference's batch mode on one GPU (16 and 8 targets in flight); shared_launches; multi_gpu_plan (a prediction, unmeasured).
+N>1 sub-records: config2 weak-scaling calls, config 5 (eight targets, strong scaling), batch mode over 16 N targets pulled from the shared queue.
+--config 2..5 make that config `value` (what tools/ and the profiles use).
 
-Nothing here reads /root/reference.  The oracle is imported ONLY for the cpu_baseline leg (rank 0, N=1).
+Nothing here reads /root/reference.  The oracle is imported ONLY for the cpu_baseline legs (rank 0, N=1).
 """
 import argparse
 import hashlib
@@ -236,6 +229,125 @@ def sampled_fold(ctx, B, runs, seed, decoy0):
         return ctx.last_fold_kernel_times()
     finally:
         ctx.set_profiling(0)
+
+
+def metric_job(args, T, synth, rank, local_rank, world, dist, forced, L=150, init_num=10):
+    """`value`: the job BASELINE.json's metric is quoted on -- "decoys/sec (L=150, init_num=10)" = run_inference.py on ONE target, end to end
+    (/root/reference/run_inference.py:280-337 -> pipeline.run_single): init_num = 10 initial decoys per model as one batch, the best one fed back,
+    then ONE decoy per feedback iteration until the cumulative array converges or Nmax = 300 (the CLI default; the synthetic maps never take the
+    convergence exit), both models (--mult_two_models), all four channels, the reference's default protocol (-m 2 --fastrelax), every decoy written
+    as a PDB file, final renaming included.  The distograms are float32 CUDA tensors -- what the trX2 front-end holds when it is done
+    (utils_trX2dy/utils.py:783-796) -- so the inputs are resident in HBM when the clock starts (pointers go into the table build).
+    The TIMED REGION IS THAT ONE JOB, run once; --steps K reports it as K equal slices (a step = Nmax / K feedback iterations of both chains plus a
+    K-th of the initial batches: ms_per_step x K = the job's wall), --warmup W runs W such slices as a shorter job of the same shape beforehand (same
+    kernels, buffers and code paths; untimed).  N > 1: every rank folds its OWN target on its own GPU (independent targets one per GPU, no data-path
+    collective): weak scaling, value = decoys written by all ranks / the slowest rank's wall."""
+    import contextlib
+    import io
+    import torch
+    pipe_mod = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
+    K, W, nmax = max(1, args.steps), max(0, args.warmup), int(args.nmax)
+    dev = torch.device("cuda", local_rank)
+    maps = [synth.make_map(L, seed=L + c) for c in range(2)]
+    seq = maps[0]["seq"]
+    work = tempfile.mkdtemp(prefix=f"trx2_metric_r{rank}_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    fasta = os.path.join(work, "t.fasta")
+    with open(fasta, "w") as f:
+        f.write(f">t\n{seq}\n")
+    arrays = {tag: {k: torch.from_numpy(np.ascontiguousarray(m[k], np.float32)).to(dev) for k in ("dist", "omega", "theta", "phi")}
+              for tag, m in zip(("NMR", "Xray"), maps)}
+    torch.cuda.synchronize(dev)
+
+    def job(tag, n_iter, seed, phases=None, profile_every=0):
+        out_dir = os.path.join(work, tag)
+        with contextlib.redirect_stdout(io.StringIO()):     # the pipeline prints the reference's progress lines
+            n = pipe_mod.run_single("t", fasta, out_dir, init_num=init_num, Nmax=n_iter, angle=True, mult_two_models=True, arrays=arrays,
+                                    device=local_rank, seed=seed, phase_times=phases, profile_every=profile_every)
+        files = len([f for f in os.listdir(os.path.join(out_dir, "t", "pred_pdb")) if f.endswith(".pdb")])
+        shutil.rmtree(out_dir, ignore_errors=True)
+        return n, files
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    try:
+        if W:
+            job("warm", max(1, (W * nmax) // K), 900 + rank)
+        sync()
+        phases = {}
+        t0 = time.perf_counter()
+        n_out, n_files = job("timed", nmax, 7 + 1000 * rank, phases)
+        sync()
+        elapsed = time.perf_counter() - t0
+        per_rank, decoys = [elapsed], n_out
+        if dist is not None:
+            tt = torch.tensor([elapsed, float(n_out)], dtype=torch.float64, device="cpu" if forced is not None else dev)
+            gathered = [torch.zeros_like(tt) for _ in range(world)]
+            dist.all_gather(gathered, tt)
+            per_rank = [float(g[0].item()) for g in gathered]
+            decoys = int(sum(float(g[1].item()) for g in gathered))
+            elapsed = max(per_rank)
+        # kernel records: one more, UNTIMED, shorter job of the same shape with every 4th evaluation of the iteration folds bracketed by HIP events
+        # on the fold's own stream (rank 0)
+        kern = {}
+        if rank == 0:
+            ph2 = {}
+            job("prof", min(nmax, 16), 7, ph2, profile_every=4)
+            kern = {k: v.get("kernel") for k, v in ph2.items() if v.get("kernel")}
+        if dist is not None:
+            dist.barrier()
+        if rank != 0:
+            return None
+        n_iter = sum(v["iterations"] for v in phases.values())
+        t_init = max(v["initial_s"] for v in phases.values())
+        roof, roof_step = None, None
+        if kern:
+            ks = list(kern.values())
+            n = sum(k["samples"] for k in ks)
+            pair_ms = sum(k["pair_ms"] * k["samples"] for k in ks) / max(n, 1)
+            step_ms = sum(k["step_ms"] * k["samples"] for k in ks) / max(n, 1)
+            terms = float(np.mean([k["selected_terms"] for k in ks]))
+            abytes = algorithmic_bytes(1, terms, L)
+            tr = traffic_record("e2e_single", 1, "k_pair")
+            roof = {"bound": "hbm", "kernel": f"k_pair_c<all channels, segment cache> -- ONE decoy per launch, four waves per row, {ks[0]['pair_workgroups']} workgroups; "
+                                              "the pair-energy kernel of the job's iteration phase (99 % of its wall)",
+                    "achieved": abytes / (pair_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "traffic": tr["hbm_bytes_per_launch"] if tr else None, "traffic_source": (tr or {}).get("method"),
+                    "avg_launch_ms": pair_ms, "avg_launch_source": f"HIP events on the fold's own stream around every 4th live launch of {min(nmax, 16)} iteration folds per chain ({n} samples), untimed job of the same shape",
+                    "replay_launch_ms": float(np.mean([k["replay_pair_ms"] for k in ks])), "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": terms,
+                    "share_of_kernel_time": pair_ms / (pair_ms + step_ms),
+                    "binding_limit": "one decoy per launch: a few hundred waves on 256 CUs for ~9 us; dependent-load latency, not HBM bandwidth (DESIGN.md section 5)"}
+            sb = step_algorithmic_bytes(1, L, ks[0]["record_bytes"], ks[0]["history_pairs"])
+            trs = traffic_record("e2e_single", 1, "k_step")
+            roof_step = {"bound": "hbm", "kernel": "k_step<1,256,256> -- one decoy: one workgroup in the slot's current role (torsion or Cartesian); the job's DOMINANT kernel by time",
+                         "achieved": sb / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sb / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": trs["hbm_bytes_per_launch"] if trs else None, "traffic_source": (trs or {}).get("method"),
+                         "avg_launch_ms": step_ms, "algorithmic_bytes_per_launch": sb, "samples": n, "share_of_kernel_time": step_ms / (pair_ms + step_ms),
+                         "binding_limit": "latency of ~25 dependent phases on ONE workgroup (DESIGN.md section 4), not bandwidth"}
+        evals = sum(k["evals"] for k in kern.values()) / max(1, sum(min(nmax, 16) for _ in kern)) if kern else None
+        return {
+            "metric": "decoys/sec", "value": decoys / elapsed, "unit": "decoys/sec", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json's metric job: run_inference end to end on one target per GPU -- L={L}, init_num={init_num} per model, two models (synthetic maps seed {L}, {L + 1}, "
+                                   f"resident in HBM as float32 tensors), dist+omega+theta+phi, Nmax={nmax}" + ("" if nmax == 300 else " (NOT the CLI default 300: --nmax)") +
+                                   ", default protocol (-m 2 --fastrelax), PDB files written and renamed",
+                       "L": L, "init_num": init_num, "Nmax": nmax, "decoys_per_job": n_out, "pdb_files": n_files,
+                       "step": f"a step is 1/{K} of the ONE timed job ({nmax}/{K} feedback iterations of both chains + 1/{K} of the initial batches); the job is run once, unsliced",
+                       "warmup": f"{W} such slices as a shorter job of the same shape (Nmax={max(1, (W * nmax) // K) if W else 0}), untimed",
+                       "parallelism": f"one target per GPU over {world} rank(s), no collective on the data path"},
+            "roofline": roof, "roofline_step": roof_step,
+            "job": {"wall_s": elapsed, "initial_phase_s": t_init, "iteration_phase_s": max(v["iteration_s"] for v in phases.values()),
+                    "iterations": {k: v["iterations"] for k, v in phases.items()}, "converged": {k: bool(v.get("converged")) for k, v in phases.items()},
+                    "ms_per_iteration": 1e3 * sum(v["iteration_s"] for v in phases.values()) / max(n_iter, 1),
+                    "ms_per_iteration_fold": 1e3 * sum(v["iteration_fold_s"] for v in phases.values()) / max(n_iter, 1),
+                    "evaluations_per_iteration_fold": evals,
+                    "note": "the two chains (models) run concurrently on two streams; within a chain the iterations are sequential single-decoy folds, each from a fresh random start"},
+            "per_rank_seconds": per_rank,
+        }
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def e2e_leg(pipe_mod, synth, L, init_num, seed=7, candidates=1, real=False, nmax=300):
@@ -754,8 +866,9 @@ def batch_mode_multi(args, T, synth, rank, local_rank, world, dist, forced, L=15
     the summaries at the end).  Sixteen targets per GPU -- 32 chains in flight -- is where a GPU's shared launches fill the chip (one GPU: 8 / 16 / 32
     targets in flight 95 / 162 / 179 decoys/s).  A step = one such job: 16 N targets of L = 150, init_num = 10, both models, all channels, the default protocol,
     Nmax shortened to `nmax` feedback iterations per chain so that W + K steps fit the driver's run (stated in `config.workload`), PDB files
-    written.  Total work is fixed as N grows: `scaling: strong`.  UNMEASURED until a multi-GPU node runs it: no such node has been available
-    to the builder in five rounds; the two-rank rehearsal on one GPU (tests/test_gpu_bench.py) exercises the control flow only."""
+    written.  Sixteen targets PER GPU: the work grows with N, so the record says `scaling: weak`.  A sub-record of the N > 1 line since
+    round 6 (`value` is the metric's job, one target per GPU).  UNMEASURED until a multi-GPU node runs it: no such node has been available
+    to the builder in six rounds; the two-rank rehearsal on one GPU (tests/test_gpu_bench.py) exercises the control flow only."""
     import contextlib
     import io
     import torch
@@ -808,12 +921,12 @@ def batch_mode_multi(args, T, synth, rank, local_rank, world, dist, forced, L=15
             return None
         return {
             "metric": "decoys/sec", "value": decoys / elapsed, "unit": "decoys/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"run_inference batch mode: {n_targets} independent targets of L={L} ({targets_per_gpu} per GPU), init_num=10, both models, all channels, default protocol "
                                    f"(-m 2 --fastrelax), Nmax={nmax} feedback iterations per chain (the CLI's default is 300: shortened so that warm-up + timed steps fit the run), PDB files written",
                        "L": L, "decoys_per_step": decoys // max(1, args.steps),
                        "parallelism": f"targets pulled from a shared counter by {world} rank(s), one process per GPU; no collective on the data path; one summary gather per job",
-                       "measured_on_hardware": "this line is the first measurement of the multi-GPU path whenever the driver produces it: the builder has had no multi-GPU node in five rounds"},
+                       "measured_on_hardware": "this record is the first measurement of the queue's multi-GPU path whenever the driver produces it: the builder has had no multi-GPU node in six rounds"},
             "all_targets_folded": all(r["failed"] == 0 for r in res), "per_rank_seconds": per_rank,
             "per_rank_decoys_last_step": [p["decoys"] for p in res[-1]["per_rank"]] if res else None,
         }
@@ -844,14 +957,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--config", type=int, default=0, choices=[0] + sorted(CONFIGS),
+                    help="0 (default): the job BASELINE.json's metric is quoted on (run_inference end to end, L=150, init_num=10); 2-5: BASELINE.json's configs[1..4] as `value`")
+    ap.add_argument("--nmax", type=int, default=300, help="feedback iterations per chain of the metric's job (300 = the CLI default of run_inference.py; anything else is named in config.workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the pooled-queue / B-in-flight / single-stream legs (profiling: every launch in the trace then belongs to `value`'s calls)")
-    ap.add_argument("--no-sub-records", action="store_true", help="skip the config 3 / 4 sub-records (N=1) and the batch-mode record (N>1)")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end run_inference leg (N=1, config 2)")
+    ap.add_argument("--no-sub-records", action="store_true", help="skip the sub-records of the other configs")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end legs beside `value` (the L=90 example, batch mode on one GPU, shared launches)")
     ap.add_argument("--all-e2e", action="store_true", help="also run the init_num=64 and --candidates 8 end-to-end legs (another ~2 minutes)")
     args = ap.parse_args()
-    cfg = CONFIGS[args.config]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -879,69 +993,79 @@ def main():
     T = importlib.import_module("trrosettax2-dynamics_amd")
     synth = importlib.import_module("trrosettax2-dynamics_amd.synth")
     with_cpu = not multi and not args.no_cpu_baseline
-    if "targets" in cfg:
-        out = multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, with_cpu)
-    else:
-        out, m, runs = single_target(args, cfg, args.config, T, synth, rank, local_rank, world, dist, forced, args.steps, args.warmup, True)
+    k_sub = max(1, min(5, args.steps))
+    if args.config == 0:
+        out = metric_job(args, T, synth, rank, local_rank, world, dist, forced)
+        L = 150
+        runs = T.protocol.build_runs(L, 2, fastrelax=True)
         if rank == 0 and with_cpu:
-            out["cpu_baseline"] = cpu_baseline(m, cfg, runs)
-        if args.config == 2 and not multi and rank == 0 and not args.no_e2e and not args.no_legs:
+            # the same job on the CPU port: a bounded sample RUN end to end (both models, init_num = 2, Nmax = 2), and from its seconds per
+            # iteration the figure for the whole job (a chain's iterations are sequential: more cores do not shorten them)
+            its = max(out["job"]["iterations"].values())
+            ms = cpu_e2e_measured(synth, L, runs)
+            out["cpu_baseline"] = cpu_e2e_baseline(synth, L, 10, its, runs, t_iteration=ms["seconds_per_iteration"])
+            out["cpu_baseline"]["measured_sample"] = ms
+        sub = {}
+        if not args.no_sub_records:
+            a_sub = argparse.Namespace(**{**vars(args), "steps": k_sub, "warmup": 1})
+            # BASELINE.json configs[1]: one call of 64 decoys, distances only (rounds 1-5's `value`), with its legs and kernel records
+            r2, m2, runs2 = single_target(a_sub, CONFIGS[2], 2, T, synth, rank, local_rank, world, dist, forced, k_sub, 1, True)
+            if rank == 0:
+                sub["config2"] = compact(r2)
+                for k in ("no_fastrelax", "pooled_queue", "in_flight_B", "single_stream", "per_rank_seconds", "scaling", "n_gpus"):
+                    if k in r2:
+                        sub["config2"][k] = r2[k]
+                if with_cpu:
+                    sub["config2"]["cpu_baseline"] = cpu_baseline(m2, CONFIGS[2], runs2)
+            if not multi:
+                for c in (3, 4):
+                    r, _, _ = single_target(a_sub, CONFIGS[c], c, T, synth, rank, local_rank, world, dist, forced, k_sub, 1, False)
+                    sub[f"config{c}"] = compact(r)
+                a5 = argparse.Namespace(steps=1, warmup=1)
+                bm = multi_target(a5, CONFIGS[5], T, synth, rank, local_rank, world, dist, forced, False)
+                sub["config5_one_gpu"] = {"value": bm["value"], "unit": bm["unit"], "ms_per_step": bm["ms_per_step"], "workload": bm["config"]["workload"]}
+                out["multi_gpu_plan"] = multi_gpu_plan(T, synth, local_rank, bm["ms_per_step"] * 1e-3)
+            else:
+                # the other multi-GPU shapes: config 5 (eight targets of different length, strong scaling) and run_inference's batch mode with sixteen
+                # targets per GPU pulled from the shared queue (work grows with N: weak) -- one step each
+                bm = multi_target(argparse.Namespace(steps=1, warmup=0), CONFIGS[5], T, synth, rank, local_rank, world, dist, forced, False)
+                bq = batch_mode_multi(argparse.Namespace(steps=1, warmup=1), T, synth, rank, local_rank, world, dist, forced)
+                if rank == 0:
+                    sub["config5_batch_mode"] = {k: bm[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "all_decoys_converged", "per_rank")}
+                    sub["config5_batch_mode"]["workload"] = bm["config"]["workload"]
+                    sub["config5_batch_mode"]["parallelism"] = bm["config"]["parallelism"]
+                    sub["batch_mode_queue"] = {k: bq[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "all_targets_folded", "per_rank_seconds", "per_rank_decoys_last_step")}
+                    sub["batch_mode_queue"]["workload"] = bq["config"]["workload"]
+                    sub["batch_mode_queue"]["decoys_per_step"] = bq["config"]["decoys_per_step"]
+        if rank == 0:
+            out["sub_records"] = sub
+        if not multi and rank == 0 and not args.no_e2e:
             pipe_mod = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
             import contextlib
             import io
-            with contextlib.redirect_stdout(io.StringIO()):     # the pipeline prints the reference's progress lines
-                # BASELINE.json's metric is quoted at init_num=10: that job, on the synthetic L=150 pair and on the reference's own example
-                out["e2e"] = {"init_num_10": e2e_leg(pipe_mod, synth, cfg["L"], 10),
-                              "example_L90_init_num_10": e2e_leg(pipe_mod, synth, 90, 10, real=True)}
+            with contextlib.redirect_stdout(io.StringIO()):
+                # the same job on the reference's own example (L=90: the only real distograms there are; its chains take the convergence exit)
+                out["e2e"] = {"example_L90_init_num_10": e2e_leg(pipe_mod, synth, 90, 10, real=True)}
                 if args.all_e2e:
-                    out["e2e"]["init_num_64"] = e2e_leg(pipe_mod, synth, cfg["L"], 64)
-                    out["e2e"]["init_num_10_candidates_8"] = e2e_leg(pipe_mod, synth, cfg["L"], 10, candidates=8)
-                out["e2e"]["batch_mode_one_gpu"] = e2e_batch_leg(pipe_mod, synth, cfg["L"])
+                    out["e2e"]["init_num_64"] = e2e_leg(pipe_mod, synth, L, 64)
+                    out["e2e"]["init_num_10_candidates_8"] = e2e_leg(pipe_mod, synth, L, 10, candidates=8)
+                out["e2e"]["batch_mode_one_gpu"] = e2e_batch_leg(pipe_mod, synth, L)
                 # ... and the shape VERDICT r3 set its target on: 8 targets x 2 models, Nmax = 80, all eight in flight
-                out["e2e"]["batch_mode_8_targets_nmax80"] = e2e_batch_leg(pipe_mod, synth, cfg["L"], n_targets=8, nmax=80, in_flight=(8,))
-            out["shared_launches"] = shared_launch_leg(T, synth, cfg["L"])
-            if with_cpu:
-                its = max(out["e2e"]["init_num_10"]["iterations"].values())
-                ms = cpu_e2e_measured(synth, cfg["L"], T.protocol.build_runs(cfg["L"], 2, fastrelax=True))
-                out["e2e"]["cpu_baseline"] = cpu_e2e_baseline(synth, cfg["L"], 10, its, T.protocol.build_runs(cfg["L"], 2, fastrelax=True), t_iteration=ms["seconds_per_iteration"])
-                out["e2e"]["cpu_baseline"]["measured_sample"] = ms
-        if args.config == 2 and not args.no_sub_records:
-            if not multi:
-                # the other single-GPU configs of BASELINE.json, shorter legs of the same measurement
-                sub = {}
-                for c in (3, 4):
-                    r, _, _ = single_target(args, CONFIGS[c], c, T, synth, rank, local_rank, world, dist, forced, max(1, min(5, args.steps)), 1, False)
-                    sub[f"config{c}"] = compact(r)
-                out["sub_records"] = sub
-                # config 5 on this one GPU (three items in flight), and what 2 / 4 / 8 ranks would make of it (prediction, unmeasured)
-                a5 = argparse.Namespace(steps=1, warmup=1)
-                bm = multi_target(a5, CONFIGS[5], T, synth, rank, local_rank, world, dist, forced, False)
-                out["sub_records"]["config5_one_gpu"] = {"value": bm["value"], "unit": bm["unit"], "ms_per_step": bm["ms_per_step"], "workload": bm["config"]["workload"]}
-                out["multi_gpu_plan"] = multi_gpu_plan(T, synth, local_rank, bm["ms_per_step"] * 1e-3)
-            else:
-                # the north star's multi-GPU mode: independent targets sharded over the ranks (config 5, strong scaling)
-                a5 = argparse.Namespace(steps=1, warmup=0)
-                bm = multi_target(a5, CONFIGS[5], T, synth, rank, local_rank, world, dist, forced, False)
-                if rank == 0:
-                    out["batch_mode"] = {k: bm[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "all_decoys_converged", "per_rank")}
-                    out["batch_mode"]["workload"] = bm["config"]["workload"]
-                    out["batch_mode"]["parallelism"] = bm["config"]["parallelism"]
-        if args.config == 2 and multi:
-            # N > 1: `value` is batch mode over 16 N targets pulled from the shared queue (strong scaling); the weak-scaling calls of config 2
-            # (every rank its own 64-decoy calls) and the config-5 record stay on the line as sub-records
-            line = batch_mode_multi(args, T, synth, rank, local_rank, world, dist, forced)
-            if rank == 0:
-                line["sub_records"] = {"config2_weak_scaling": {k: out[k] for k in ("value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "all_decoys_converged", "per_rank_seconds") if k in out}}
-                line["sub_records"]["config2_weak_scaling"]["workload"] = out["config"]["workload"]
-                if "batch_mode" in out:
-                    line["sub_records"]["config5_batch_mode"] = out["batch_mode"]
-                out = line
+                out["e2e"]["batch_mode_8_targets_nmax80"] = e2e_batch_leg(pipe_mod, synth, L, n_targets=8, nmax=80, in_flight=(8,))
+            out["shared_launches"] = shared_launch_leg(T, synth, L)
+    else:
+        cfg = CONFIGS[args.config]
+        if "targets" in cfg:
+            out = multi_target(args, cfg, T, synth, rank, local_rank, world, dist, forced, with_cpu)
+        else:
+            out, m, runs = single_target(args, cfg, args.config, T, synth, rank, local_rank, world, dist, forced, args.steps, args.warmup, True)
+            if rank == 0 and with_cpu:
+                out["cpu_baseline"] = cpu_baseline(m, cfg, runs)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        # Short numeric copies of the other records inside `config` (the driver's parsed record keeps `config` whole): the job
-        # BASELINE.json's metric names (init_num=10, end to end), the pooled queue, the other single-GPU configs.  decoys/sec each.
+        # Short numeric copies of the other records inside `config` (the driver's parsed record keeps `config` whole).  decoys/sec each.
         def num(*path):
             d = out
             for k in path:
@@ -949,11 +1073,14 @@ def main():
                 if d is None:
                     return None
             return round(float(d), 2)
-        for key, path in (("e2e_init10", ("e2e", "init_num_10", "value")), ("e2e_example_L90_init10", ("e2e", "example_L90_init_num_10", "value")),
-                          ("e2e_cpu_init10", ("e2e", "cpu_baseline", "value")), ("batch_mode_one_gpu", ("e2e", "batch_mode_one_gpu", "best", "value")),
+        for key, path in (("e2e_example_L90_init10", ("e2e", "example_L90_init_num_10", "value")),
+                          ("cpu_same_job", ("cpu_baseline", "value")), ("batch_mode_one_gpu", ("e2e", "batch_mode_one_gpu", "best", "value")),
                           ("batch_8x2_nmax80", ("e2e", "batch_mode_8_targets_nmax80", "best", "value")),
-                          ("shared_fold_evals_per_s", ("shared_launches", "fold_evaluations_per_sec")), ("pooled_1280", ("pooled_queue", "value")), ("no_fastrelax", ("no_fastrelax", "value")),
+                          ("shared_fold_evals_per_s", ("shared_launches", "fold_evaluations_per_sec")),
+                          ("c2_call_of_64", ("sub_records", "config2", "value")), ("c2_pooled_1280", ("sub_records", "config2", "pooled_queue", "value")),
+                          ("c2_no_fastrelax", ("sub_records", "config2", "no_fastrelax", "value")),
                           ("c3", ("sub_records", "config3", "value")), ("c4", ("sub_records", "config4", "value")), ("c5_one_gpu", ("sub_records", "config5_one_gpu", "value")),
+                          ("batch_mode_queue", ("sub_records", "batch_mode_queue", "value")),
                           ("predicted_speedup_8gpu_unmeasured", ("multi_gpu_plan", "predicted", "8", "with_block_splits", "speedup_vs_three_in_flight"))):
             v = num(*path)
             if v is not None:

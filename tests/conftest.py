@@ -13,6 +13,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The red-by-design statements of tests/test_gpu_zz_open_findings.py run after EVERY other test, whatever the file names sort
+    like (round 5: `test_restraint_variants.py` sorts behind `test_gpu_zz...`, so `pytest -x` stopped before its three device tests)."""
+    last = [it for it in items if "test_gpu_zz_open_findings" in it.nodeid]
+    if last:
+        items[:] = [it for it in items if "test_gpu_zz_open_findings" not in it.nodeid] + last
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

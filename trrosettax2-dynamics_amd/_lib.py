@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # TRX2FOLD_LIB selects an alternative build of the SAME library (A/B timing of kernel variants); never a CPU path
 LIB_PATH = os.environ.get("TRX2FOLD_LIB") or os.path.join(_HERE, "libtrx2fold.so")
 NTERMS, NW = 9, 8
+ABI_VERSION = 2      # include/trx2fold.h: trx2_abi_version
 K = (35, 28, 28, 16)
 TERM_NAMES = ("dist", "omega", "theta", "phi", "vdw", "rama", "omega_bb", "cart", "hb")
 
@@ -69,6 +70,11 @@ def load():
     L = C.CDLL(LIB_PATH)
     vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
     L.trx2_abi_version.restype = C.c_int
+    if L.trx2_abi_version() != ABI_VERSION:
+        # ABI 2 made trx2_run.precheck a bit field (bit 1 = warm start): an older library would read every warm run as a guarded one
+        # and loop to max_evals without an error
+        raise RuntimeError(f"{LIB_PATH} has ABI version {L.trx2_abi_version()}, this package needs {ABI_VERSION}: rebuild it with "
+                           f"`make -C {_HERE}/csrc` (or __graft_entry__.build())")
     L.trx2_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.trx2_ctx_destroy.argtypes = [vp]
     L.trx2_ctx_destroy.restype = None
@@ -150,6 +156,7 @@ class Context:
         if rc != 0:
             raise RuntimeError(f"trx2_ctx_create(device={device}) failed with code {rc}: no usable GPU (no CPU fallback)")
         self._h = h
+        self.device = int(device)
         self.L = 0
         self.kd = 35
         self.use_orient = False

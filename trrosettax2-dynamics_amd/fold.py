@@ -131,7 +131,12 @@ def set_restraints(ctx, npz, seq, args, ang):
         for t in ts:
             if not (_on_device(t) and t.dtype == torch.float32 and t.is_contiguous()):
                 raise ValueError("device-resident distograms must be contiguous float32 CUDA tensors, all on one device")
-        torch.cuda.current_stream(ts[0].device).synchronize()      # the producer's stream has written them
+            if t.device != ts[0].device or t.device.index != int(ctx.device):
+                raise ValueError(f"device-resident distograms must all live on the fold context's device cuda:{int(ctx.device)} "
+                                 f"(got {t.device} beside {ts[0].device})")
+        # Every stream of the device, not the calling thread's current one: run_single folds the second chain on a worker thread whose
+        # current stream is the default stream, and the producer may have written the tensors on a side stream.
+        torch.cuda.synchronize(ts[0].device)
         ptrs = [int(t.data_ptr()) for t in ts] + [0] * (4 - len(ts))
         ctx.set_map_device(int(ts[0].shape[0]), *ptrs, seq=seq, pcut=args.pcut)
         return

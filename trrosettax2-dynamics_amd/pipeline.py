@@ -20,7 +20,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
-from . import sched
+from . import protocol, sched
 from .feedback import calculate_reliability_score, feedback_labels
 from .fold import FoldError, close_contexts, fold_arrays_to_pdb, fold_resident_to_pdb, get_context
 
@@ -34,7 +34,7 @@ def resident_ok(device_feedback, sigma):
 
 def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz, fasta, N=10, Nmax=500, begin_num=0,
                          sigma=1.0, tta_opt="-m 2 -r no-idp --orient ", angle=True, device=0, seed=None, lanes=2,
-                         write_tmp_npz=False, device_feedback=True, timing=None, candidates=1, single_decoy_waves=4):
+                         write_tmp_npz=False, device_feedback=True, timing=None, candidates=1, single_decoy_waves=4, profile_every=0):
     """N initial decoys as one GPU batch -> best by reliability -> feedback -> one decoy per iteration until the
     cumulative `tmp` array moves by < 0.01 or Nmax iterations (run_inference.py:97-139).  Returns the last index.
 
@@ -64,7 +64,12 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
 
     timing: a dict that receives initial_s (initial batch: table build, fold, files, ranking), iteration_s (everything after),
     iteration_fold_s (the single-decoy folds alone), iterations, tmp_change (the convergence measure after every iteration: max
-    |tmp_new - tmp_old|, run_inference.py:133) and converged (the chain took the < 0.01 exit) -- bench.py's e2e legs."""
+    |tmp_new - tmp_old|, run_inference.py:133) and converged (the chain took the < 0.01 exit) -- bench.py's e2e legs.
+
+    profile_every: n > 0 brackets every n-th evaluation of the iteration phase's folds by HIP events on the fold's own stream
+    (Context.set_profiling); `timing` then also receives kernel = dict(pair_ms, step_ms, samples: live averages over the sampled launches;
+    evals; selected_terms of the last fed-back map and replay_pair_ms, 200 replays of the pair kernel on the last decoy) -- bench.py's roofline
+    record of the metric's job.  Measurement only: a profiled job is never the timed one."""
     import time
     os.makedirs(processed_npz_dir, exist_ok=True)
     t_start = time.perf_counter()
@@ -114,6 +119,9 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
         # The initial batch left its map in this thread's context.  From here on the distograms never leave the device.
         ctx = get_context(device, lanes)
         ctx.set_single_decoy_waves(single_decoy_waves)
+        prof = dict(pair=0.0, step=0.0, n=0, evals=0)
+        if profile_every:
+            ctx.set_profiling(int(profile_every))
 
         def step(xyz_fold, k):
             # the decoy as the reference sees it -- through its PDB file -- without reading the file back
@@ -144,6 +152,9 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
                     shutil.copyfile(os.path.join(pred_pdb_dir, f"{pdb_name}{first}.pdb"), os.path.join(pred_pdb_dir, f"{pdb_name}{first + c}.pdb"))
                 print(f"warning: candidates {list(e.bad)} of iteration {iter_n} failed to fold; their files repeat candidate 0")
             tm["iteration_fold_s"] += time.perf_counter() - t_f
+            if profile_every:
+                a, b, n = ctx.last_fold_kernel_times()
+                prof["pair"] += a * n; prof["step"] += b * n; prof["n"] += n; prof["evals"] += int(r["n_evals"].sum())
             print("Done generating structure", iter_n)
             if iter_n - begin_num >= Nmax:
                 break
@@ -152,6 +163,14 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
             if delta < 0.01:
                 tm["converged"] = True
                 break
+        if profile_every:
+            ctx.set_profiling(0)
+            w = np.array(protocol.SF, np.float32)
+            ctx.eval_batch(r["tors"][:1], w)                      # lays the last decoy out for one slot
+            rep_ms, terms = ctx.time_pair_kernel(1, w, 1, len(seq), n_rep=200)
+            tm["kernel"] = dict(pair_ms=prof["pair"] / max(prof["n"], 1), step_ms=prof["step"] / max(prof["n"], 1), samples=prof["n"], evals=prof["evals"],
+                                selected_terms=float(terms), replay_pair_ms=float(rep_ms), record_bytes=ctx.info(1), history_pairs=int(ctx.info(2)),
+                                pair_workgroups=int(ctx.info(4)))
         done(iter_n)
         return begin_num + (iter_n - begin_num) * K
     base = {k: init[k] for k in (("dist", "theta", "omega", "phi") if angle else ("dist",))}   # no "tmp": falls back to dist
@@ -222,7 +241,7 @@ def flatten_and_rename(save_pdb_dir, num_conf1_others):
 
 def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mult_two_models=True, npz_nmr=None,
                npz_xray=None, device=0, seed=None, keep_tmp_npz=False, phase_times=None, candidates=1, single_decoy_waves=4, arrays=None,
-               write_pred_npz=True):
+               write_pred_npz=True, profile_every=0):
     """run_inference.py:280-337 without the network front-end: expects the distograms to exist -- as pred_npz files (npz_nmr / npz_xray or
     already in place) or IN MEMORY: arrays = {"NMR": {dist, omega, theta, phi}, "Xray": {...}} of numpy arrays or of float32 CUDA tensors, what
     pred_2d_geometry computes before it writes them (run_inference.py:301-310, utils_trX2dy/utils.py:783-796).  CUDA tensors are handed to the
@@ -271,7 +290,7 @@ def run_single(name, fasta_file, save_dir, init_num=10, Nmax=300, angle=True, mu
                                     N=init_num, Nmax=Nmax, begin_num=0, angle=angle, tta_opt=tta_opt, device=device,
                                     seed=None if seed is None else seed + 100000 * len(tag),
                                     lanes=1 if len(maps) == 2 else 2,   # two chains already occupy two streams
-                                    write_tmp_npz=keep_tmp_npz, candidates=candidates, single_decoy_waves=single_decoy_waves,
+                                    write_tmp_npz=keep_tmp_npz, candidates=candidates, single_decoy_waves=single_decoy_waves, profile_every=profile_every,
                                     timing=None if phase_times is None else phase_times.setdefault(tag, {}))
 
     if len(maps) == 2:
@@ -339,11 +358,15 @@ def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, 
     import zlib
     key = f"trx2_next_item/{_BATCH_CALLS}/{zlib.crc32(' '.join(it.target for it in items).encode()):08x}"
     shared = store if store is not None else (sched.queue_store(dist, group=group) if world > 1 else None)
+    static_split = False
     if world > 1 and shared is None:
         # No store to share a counter on (a library caller without an initialised process group): a process-local counter would hand
         # EVERY target to EVERY rank -- duplicated work and ranks racing on the same PDB files.  Static split instead: every
         # rank computes the same longest-first assignment from the same list and folds its own share.
-        items = sched.lpt_assign(items, world)[rank]
+        # Whole targets only: run_single folds a target with both its chains, so a decoy-block split (which lpt_assign makes when
+        # there are fewer targets than ranks or no iterations) would make two ranks fold the SAME target.
+        items = sched.lpt_assign(items, world, min_block=1 << 30)[rank]
+        static_split = True
     queue = sched.DynamicQueue(len(items), shared, key=key)
     local = dict(decoys=0, seconds=0.0, failed=0, targets=[], errors=[])
     if targets_in_flight is None:
@@ -377,7 +400,8 @@ def run_batch(names, fasta_dir, save_dir, rank=0, world=1, dist=None, device=0, 
 
     # never more workers than a rank's fair share of the list: with a list shorter than world x targets_in_flight the first ranks
     # to arrive would otherwise take every target and leave the others idle
-    n_workers = max(1, min(int(targets_in_flight), -(-len(items) // max(1, int(world)))))
+    # (after a static split `items` is already this rank's private share)
+    n_workers = max(1, min(int(targets_in_flight), len(items) if static_split else -(-len(items) // max(1, int(world)))))
     if n_workers == 1:
         worker()
     else:
