@@ -326,7 +326,7 @@ def metric_job(args, T, synth, rank, local_rank, world, dist, forced, L=150, ini
                          "traffic": trs["hbm_bytes_per_launch"] if trs else None, "traffic_source": (trs or {}).get("method"),
                          "avg_launch_ms": step_ms, "algorithmic_bytes_per_launch": sb, "samples": n, "share_of_kernel_time": step_ms / (pair_ms + step_ms),
                          "binding_limit": "latency of ~25 dependent phases on ONE workgroup (DESIGN.md section 4), not bandwidth"}
-        evals = sum(k["evals"] for k in kern.values()) / max(1, sum(min(nmax, 16) for _ in kern)) if kern else None
+        evals = sum(v.get("iteration_evals", 0) for v in phases.values()) / max(n_iter, 1)
         return {
             "metric": "decoys/sec", "value": decoys / elapsed, "unit": "decoys/sec", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -342,7 +342,7 @@ def metric_job(args, T, synth, rank, local_rank, world, dist, forced, L=150, ini
                     "iterations": {k: v["iterations"] for k, v in phases.items()}, "converged": {k: bool(v.get("converged")) for k, v in phases.items()},
                     "ms_per_iteration": 1e3 * sum(v["iteration_s"] for v in phases.values()) / max(n_iter, 1),
                     "ms_per_iteration_fold": 1e3 * sum(v["iteration_fold_s"] for v in phases.values()) / max(n_iter, 1),
-                    "evaluations_per_iteration_fold": evals,
+                    "evaluations_per_iteration_fold": evals, "us_per_evaluation": 1e3 * (1e3 * sum(v["iteration_fold_s"] for v in phases.values()) / max(n_iter, 1)) / max(evals, 1.0),
                     "note": "the two chains (models) run concurrently on two streams; within a chain the iterations are sequential single-decoy folds, each from a fresh random start"},
             "per_rank_seconds": per_rank,
         }
@@ -936,6 +936,38 @@ def batch_mode_multi(args, T, synth, rank, local_rank, world, dist, forced, L=15
             shutil.rmtree(work, ignore_errors=True)
 
 
+def pooled_all_channels(T, synth, local_rank, config=3, L=150):
+    """the pair kernel's ceiling -- ONE call over a queue of 1280 ALL-CHANNEL decoys of config 3's map on 2 lanes x 640 slots
+    (k_pair<64, all channels>, ten decoy groups per launch: the chip full, three waves per SIMD), and the kernel records at that shape."""
+    m = synth.make_map(L, seed=L)
+    runs = T.protocol.build_runs(L, 2, fastrelax=True)
+    ctx = T.Context(local_rank, lanes=2)
+    try:
+        ctx.set_map(m["dist"], m["omega"], m["theta"], m["phi"], seq=m["seq"])
+        ctx.set_pool(MAX_SLOTS)
+        ctx.fold_batch(2 * MAX_SLOTS, runs, seed=149, decoy0=10 ** 6, max_evals=1)      # slot buffers sized before the clock starts
+        t1 = time.perf_counter()
+        r = ctx.fold_batch(POOLED_QUEUE, runs, seed=150, decoy0=7000)
+        e1 = time.perf_counter() - t1
+        out = {"value": POOLED_QUEUE / e1, "unit": "decoys/sec", "seconds": e1,
+               "workload": f"ONE call over a queue of {POOLED_QUEUE} decoys of config 3's first map (L={L}, dist+omega+theta+phi) on 2 lanes x {MAX_SLOTS} decoy slots, default protocol",
+               "pair_launches": r["launches"], "slot_efficiency": r["slot_efficiency"], "all_decoys_converged": bool(np.all(r["status"] == 0)),
+               "evals_per_decoy_median": float(np.median(r["n_evals"]))}
+        ctx.set_lanes(1); ctx.set_pool(MAX_SLOTS)
+        ftp = sampled_fold(ctx, 2 * MAX_SLOTS, runs, 150, 9000)
+        out["roofline"] = compact_roofline(pair_roofline(ctx, T, r["tors"][:MAX_SLOTS], L, config, ftp))
+        out["roofline_step"] = compact_roofline(step_roofline(ctx, MAX_SLOTS, L, config, ftp))
+        rec = traffic_record(config, MAX_SLOTS, "k_pair")
+        if rec and out["roofline"]:
+            terms = out["roofline"]["algorithmic_bytes_per_launch"] / MAX_SLOTS      # bytes per decoy = 16 n_terms + 96 L
+            n_terms = (terms - 96.0 * L) / 16.0
+            out["roofline"]["valu_lane_ops_per_selected_term"] = rec["valu_insts_per_launch"] * 64.0 / (MAX_SLOTS * n_terms)
+            out["roofline"]["wave_time_waiting_frac"] = rec["wait_any_quad_cycles"] / rec["wave_quad_cycles"]
+        return out
+    finally:
+        ctx.close()
+
+
 def compact_roofline(r):
     return {q: r[q] for q in ("kernel", "achieved", "frac", "frac_over_fold", "unit", "avg_launch_ms", "avg_launch_ms_over_fold", "algorithmic_bytes_per_launch", "traffic") if q in r} if r else None
 
@@ -1021,6 +1053,8 @@ def main():
                 for c in (3, 4):
                     r, _, _ = single_target(a_sub, CONFIGS[c], c, T, synth, rank, local_rank, world, dist, forced, k_sub, 1, False)
                     sub[f"config{c}"] = compact(r)
+                if not args.no_legs:
+                    sub["config3"]["pooled_queue"] = pooled_all_channels(T, synth, local_rank)
                 a5 = argparse.Namespace(steps=1, warmup=1)
                 bm = multi_target(a5, CONFIGS[5], T, synth, rank, local_rank, world, dist, forced, False)
                 sub["config5_one_gpu"] = {"value": bm["value"], "unit": bm["unit"], "ms_per_step": bm["ms_per_step"], "workload": bm["config"]["workload"]}
@@ -1079,7 +1113,7 @@ def main():
                           ("shared_fold_evals_per_s", ("shared_launches", "fold_evaluations_per_sec")),
                           ("c2_call_of_64", ("sub_records", "config2", "value")), ("c2_pooled_1280", ("sub_records", "config2", "pooled_queue", "value")),
                           ("c2_no_fastrelax", ("sub_records", "config2", "no_fastrelax", "value")),
-                          ("c3", ("sub_records", "config3", "value")), ("c4", ("sub_records", "config4", "value")), ("c5_one_gpu", ("sub_records", "config5_one_gpu", "value")),
+                          ("c3", ("sub_records", "config3", "value")), ("c3_pooled_1280", ("sub_records", "config3", "pooled_queue", "value")), ("c4", ("sub_records", "config4", "value")), ("c5_one_gpu", ("sub_records", "config5_one_gpu", "value")),
                           ("batch_mode_queue", ("sub_records", "batch_mode_queue", "value")),
                           ("predicted_speedup_8gpu_unmeasured", ("multi_gpu_plan", "predicted", "8", "with_block_splits", "speedup_vs_three_in_flight"))):
             v = num(*path)

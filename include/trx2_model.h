@@ -131,15 +131,17 @@ enum {
  * The eight committed decoys carry ref2015_cart's per-residue energy table (tests/golden/pose_energies.json).  tools/fit_backbone_terms.py
  * recovers the per-residue rama_prepro terms from it (Rosetta splits that two-body energy half / half between residue i and i + 1; the
  * recursion closes to 1e-4 on all eight decoys) and fits, by ridge regression, leave-one-decoy-out validated:
- *   rama_i  = six-basin prior(phi, psi) + c_class + sum_k a_class,k f_k(phi, psi) + h_aa r_alpha(phi, psi)
+ *   rama_i  = six-basin prior(phi, psi) + c_class + sum_k a_class,k f_k(phi, psi) + h_class r_alpha(phi, psi)
  *             f = cos psi, sin psi, cos(phi - psi), sin(phi - psi), cos phi, sin phi, cos(phi + psi), sin(phi + psi);
- *             classes general / glycine (own surface), proline / before a proline (a constant each: 8 samples at one place);
- *             r_alpha = posterior weight of the two right-handed helical basins of the mixture, h_aa a helix propensity per residue type
+ *             classes general / glycine (own surface and helix constant), proline / before a proline (a constant each: 8 samples at one place);
+ *             r_alpha = posterior weight of the two right-handed helical basins of the mixture, h_class a helix constant per class
+ *             (round 5 fitted one per residue TYPE on this one sequence and shipped it for every protein: see TRX2_RAMA_FIT_HELIX_CLASS below)
  *   omega_i = A(psi_i) + B(psi_i) x + C(psi_i) x^2,  x = (omega_i - 180 deg) / 10 deg,  A, B, C = q0 + q1 cos psi_i + q2 sin psi_i
  *             (ref2015's tether has a conformation-dependent centre and width; psi_i carries most of it; C > 0 for every psi)
  * Rank correlation over residues with Rosetta's columns (median of the eight decoys): rama 0.21 -> 0.79 held out, omega 0.33 -> 0.81.
  * The constants below are that script's output (tests/test_pose_energies.py re-runs it and compares).  All eight decoys are folds of
- * ONE sequence: residue types absent from it (C, H, W, Y) get no helix term, and the validation says nothing about other proteins.
+ * ONE sequence: the validation says nothing about other proteins (tests/diag/fit_generalisation.py, profiles/r06_fit_generalisation.txt:
+ * leave-one-chain-out on OUTCOME, and weak-restraint folds of non-helical targets with the fitted terms on and off).
  * TRX2_RAMA_FIT_ON 0 / TRX2_OMEGA_FIT_ON 0 restore rounds 1-4's terms (model scans).
  * TRX2_OMEGA_STIFF: the fitted tether's stiffness about its own (psi-dependent) centre, E = A + STIFF (B x + C x^2).  1 is ref2015's;
  * with it this model's chains twist their peptides (2 x 2048 decoys, default protocol: 1.9 % / 3.0 % of the decoys carry a peptide beyond
@@ -164,16 +166,39 @@ enum {
 #ifndef TRX2_RAMA_FIT_SHRINK
 #define TRX2_RAMA_FIT_SHRINK 0.50
 #endif
-#define TRX2_RAMA_FIT_GENERAL {-3.1034f, -1.4014f, -0.2878f, -0.4212f, 0.2970f, 3.5343f, -1.4491f, -2.4248f}
+/* The fit's constants (tools/fit_backbone_terms.py prints these lines; tests/test_pose_energies.py re-runs it and compares).  Each can be
+ * overridden on the compiler's command line: the leave-one-chain-out builds of tests/diag/fit_generalisation.py are made that way. */
+#ifndef TRX2_RAMA_FIT_GENERAL
+#define TRX2_RAMA_FIT_GENERAL {-2.7974f, -1.5162f, -0.1823f, -0.4471f, 0.2686f, 3.2531f, -1.7017f, -2.6745f}
+#endif
+#ifndef TRX2_RAMA_FIT_GLY
 #define TRX2_RAMA_FIT_GLY {-1.0537f, -0.8192f, 1.2651f, -0.2527f, 0.6021f, -1.6864f, 0.4358f, -0.5246f}
-#define TRX2_RAMA_FIT_CONST {0.1322f, -4.2043f, -2.2664f, -4.7437f} /* general, glycine, proline, before a proline */
-#define TRX2_RAMA_FIT_HELIX {0.0755f, 0.0000f, -0.1235f, -0.0929f, 0.4663f, 2.5974f, 0.0000f, 0.5969f, 0.1588f, 0.1061f, 0.7142f, -0.0033f, -0.1836f, 0.3847f, 0.1225f, 0.0690f, 0.6063f, 0.4778f, 0.0000f, 0.0000f} /* ACDEFGHIKLMNPQRSTVWY */
+#endif
+#ifndef TRX2_RAMA_FIT_CONST
+#define TRX2_RAMA_FIT_CONST {0.2072f, -4.2043f, -2.2731f, -4.7437f} /* general, glycine, proline, before a proline */
+#endif
+/* Helix term h r_alpha(phi, psi).  Round 6: h is a constant PER CLASS (general, glycine; proline and the residue
+ * before one keep their constant alone).  Round 5 shipped a propensity per residue TYPE fitted on the one sequence of the example -- 16 types
+ * with 1-12 residues each, exact zeros for the four types it lacks (C, H, W, Y) -- for every protein; those per-type deviations are now a
+ * diagnostic of the fit script (--per-aa) and of TRX2_RAMA_FIT_AA builds, off by default. */
+#ifndef TRX2_RAMA_FIT_HELIX_CLASS
+#define TRX2_RAMA_FIT_HELIX_CLASS {-0.2955f, 2.5974f, 0.0000f, 0.0000f} /* general, glycine, proline, before a proline */
+#endif
+#ifndef TRX2_RAMA_FIT_AA
+#define TRX2_RAMA_FIT_AA 0
+#endif
+#ifndef TRX2_RAMA_FIT_HELIX_AA
+#define TRX2_RAMA_FIT_HELIX_AA {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f} /* ACDEFGHIKLMNPQRSTVWY: deviation from the class constant (diagnostic builds) */
+#endif
+#ifndef TRX2_OMEGA_FIT
 #define TRX2_OMEGA_FIT {-0.0435f, -0.0758f, -0.0839f, -0.2191f, -0.4417f, 0.2092f, 1.2822f, 0.2381f, -0.4129f} /* A(psi), B(psi), C(psi): q0 + q1 cos psi + q2 sin psi each; x = (omega - 180 deg) / 10 deg */
-/* per-residue parameter block of the rama term, 12 floats (three float4 on the device): [0] c_class, [1..8] a_class, [9] h_aa, [10..11] 0.
+#endif
+/* per-residue parameter block of the rama term, 12 floats (three float4 on the device): [0] c_class, [1..8] a_class, [9] h, [10..11] 0.
  * seq NULL = all alanine (what a map without a sequence is folded as).  Shared by the oracle and the library's host side. */
 #define TRX2_RAMA_NPAR 12
 static inline void trx2_rama_params(const char* seq, int i, int L, float* p) {
-  static const float gen[8] = TRX2_RAMA_FIT_GENERAL, gly[8] = TRX2_RAMA_FIT_GLY, cst[4] = TRX2_RAMA_FIT_CONST, hel[20] = TRX2_RAMA_FIT_HELIX;
+  static const float gen[8] = TRX2_RAMA_FIT_GENERAL, gly[8] = TRX2_RAMA_FIT_GLY, cst[4] = TRX2_RAMA_FIT_CONST, helc[4] = TRX2_RAMA_FIT_HELIX_CLASS,
+                     hel[20] = TRX2_RAMA_FIT_HELIX_AA;
   static const char aa[] = "ACDEFGHIKLMNPQRSTVWY";
   const char a = seq ? seq[i] : 'A';
   const int cls = a == 'G' ? 1 : a == 'P' ? 2 : (seq && i + 1 < L && seq[i + 1] == 'P') ? 3 : 0;
@@ -181,7 +206,9 @@ static inline void trx2_rama_params(const char* seq, int i, int L, float* p) {
   if (!TRX2_RAMA_FIT_ON) return;
   p[0] = cst[cls];
   for (int k = 0; k < 8; k++) p[1 + k] = (float)TRX2_RAMA_FIT_SHRINK * (cls == 0 ? gen[k] : cls == 1 ? gly[k] : 0.0f);
-  for (int k = 0; k < 20; k++) if (aa[k] == a) p[9] = hel[k];
+  p[9] = helc[cls];
+  if (TRX2_RAMA_FIT_AA)
+    for (int k = 0; k < 20; k++) if (aa[k] == a) p[9] += hel[k];
 }
 
 /* omega_bb: E = OMEGA_K * (wrap(omega - 180 deg) in degrees)^2.

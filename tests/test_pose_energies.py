@@ -103,11 +103,14 @@ def test_surrogate_terms_against_the_reference_decoys_energy_tables(table, golde
     report = "\n".join(lines)
     print("\n" + report)
     if os.environ.get("TRX2_WRITE_REPORT") == "1":
-        open(os.path.join(ROOT, "profiles", "r05_pose_energies.txt"), "w").write(report + "\n")
+        open(os.path.join(ROOT, "profiles", "r06_pose_energies.txt"), "w").write(report + "\n")
     # measured medians over the eight decoys (round 5, fitted rama / omega): rho omega 0.80, rama 0.70, cart_bonded 0.70, repulsion 0.37;
     # totals: hydrogen bonds 0.51 x Rosetta's, cart_bonded 25 x; omega and rama carry Rosetta's level where they were fitted (the omega
     # total is a small difference of positive and negative residues: no ratio asserted).  VERDICT r4 item 4 asked for >= 0.5 on rama and omega.
-    assert np.nanmedian(rho["omega"]) >= 0.65 and np.nanmedian(rho["rama"]) >= 0.55 and min(rho["omega"]) >= 0.5 and min(rho["rama"]) >= 0.4, rho
+    # Round 6: the helix term is a constant per CLASS (no per-residue-type constants fitted on one sequence in the default model) --
+    # rama 0.70 -> 0.51 (min 0.36) on these eight decoys, the price of not fitting 16 residue types on them; the outcome did not move
+    # (profiles/r06_fit_generalisation.txt).  Rounds 1-4's six-basin prior alone: 0.15.
+    assert np.nanmedian(rho["omega"]) >= 0.65 and np.nanmedian(rho["rama"]) >= 0.45 and min(rho["omega"]) >= 0.5 and min(rho["rama"]) >= 0.3, rho
     assert np.nanmedian(rho["cart_bonded"]) > 0.5 and np.nanmedian(rho["repulsion"]) > 0.2, rho
     assert 0.35 < np.nanmedian(ratio["hbond_bb"]) < 0.75 and 12 < np.nanmedian(ratio["cart_bonded"]) < 50, ratio
     tot_s = np.array([w[1] * rows[d][0][:, 1].sum() for d in rows]); tot_r = np.array([rows[d][1][:, 1].sum() for d in rows])

@@ -63,7 +63,7 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     job with few chains in flight, 1 when many chains share launches (run_batch passes 1).
 
     timing: a dict that receives initial_s (initial batch: table build, fold, files, ranking), iteration_s (everything after),
-    iteration_fold_s (the single-decoy folds alone), iterations, tmp_change (the convergence measure after every iteration: max
+    iteration_fold_s (the single-decoy folds alone), iterations, iteration_evals (energy / gradient evaluations of those folds), tmp_change (the convergence measure after every iteration: max
     |tmp_new - tmp_old|, run_inference.py:133) and converged (the chain took the < 0.01 exit) -- bench.py's e2e legs.
 
     profile_every: n > 0 brackets every n-th evaluation of the iteration phase's folds by HIP events on the fold's own stream
@@ -73,7 +73,7 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
     import time
     os.makedirs(processed_npz_dir, exist_ok=True)
     t_start = time.perf_counter()
-    tm = dict(initial_s=0.0, iteration_s=0.0, iteration_fold_s=0.0, iterations=0, tmp_change=[], converged=False)
+    tm = dict(initial_s=0.0, iteration_s=0.0, iteration_fold_s=0.0, iterations=0, iteration_evals=0, tmp_change=[], converged=False)
 
     def done(iter_n):
         tm["iterations"] = iter_n - begin_num
@@ -152,6 +152,7 @@ def generate_npz_and_pdb(pdb_name, processed_npz_dir, pred_pdb_dir, initial_npz,
                     shutil.copyfile(os.path.join(pred_pdb_dir, f"{pdb_name}{first}.pdb"), os.path.join(pred_pdb_dir, f"{pdb_name}{first + c}.pdb"))
                 print(f"warning: candidates {list(e.bad)} of iteration {iter_n} failed to fold; their files repeat candidate 0")
             tm["iteration_fold_s"] += time.perf_counter() - t_f
+            tm["iteration_evals"] += int(r["n_evals"].sum())
             if profile_every:
                 a, b, n = ctx.last_fold_kernel_times()
                 prof["pair"] += a * n; prof["step"] += b * n; prof["n"] += n; prof["evals"] += int(r["n_evals"].sum())
