@@ -13,7 +13,7 @@ two independent draws of 256.  Bounds (each written at its assert):
                       median within 0.06 A (sampling sd of a 256-decoy median on these maps: 0.02-0.03 A on the unimodal ones; the bimodal
                       X-ray maps are judged by their cluster populations instead, below);
                       fractions within 0.6 A / 1.0 A / 1.5 A within 0.09 = 3 sigma of a fraction near one half at n = 256
-                      (VERDICT r4 item 1d: this replaces round 4's +-0.17 on 64 decoys); decoys beyond 3 A (mirror topologies) within 0.05;
+                      (VERDICT r4 item 1d: this replaces round 4's +-0.17 on 64 decoys); decoys beyond 3 A (mirror topologies) within 0.065 (3 sigma of the difference of two fractions of ~6 % at n = 256; round 6 measured 0.039 against 0.090 on one cell);
                       two-sample Kolmogorov-Smirnov distance <= 0.17 (the 0.1 % critical value for n = m = 256)
   evaluations         median within -15 % .. +20 % (the float32 minimiser accepts 5-15 % fewer iterations per evaluation, DESIGN.md deviation 6)
 The --no-fastrelax protocol (14 runs) is held to the same bounds on the two committed maps.
@@ -97,6 +97,6 @@ def test_whole_protocol_outcome_distribution_matches_oracle(setup, key, proto):
         assert abs(np.median(rm_g) - np.median(rm_o)) <= 0.06, (np.median(rm_g), np.median(rm_o))
     for c in (0.6, 1.0, 1.5):
         assert abs((rm_g <= c).mean() - (rm_o <= c).mean()) <= 0.09, (c, (rm_g <= c).mean(), (rm_o <= c).mean())
-    assert abs((rm_g > 3.0).mean() - (rm_o > 3.0).mean()) <= 0.05, ((rm_g > 3.0).mean(), (rm_o > 3.0).mean())
+    assert abs((rm_g > 3.0).mean() - (rm_o > 3.0).mean()) <= 0.065, ((rm_g > 3.0).mean(), (rm_o > 3.0).mean())
     assert ks(rm_g, rm_o) <= 0.17, ks(rm_g, rm_o)
     assert 0.85 <= np.median(e_g) / np.median(e_o) <= 1.2, (np.median(e_g), np.median(e_o))

@@ -1,6 +1,6 @@
-"""GPU, collected LAST (the file name sorts behind every other test file): statements that are RED on purpose while the finding they express
-is open.  VERDICT r4 item 1c asked for the percentile assert of the iteration-phase decoys to get teeth and to stay red if it fails; it runs
-last so that `pytest -x` has every other result on record before it stops here."""
+"""GPU, run LAST (tests/conftest.py moves this file's items behind every other test, whatever the file names sort like): statements that are RED on
+purpose while the finding they express is open.  VERDICT r4 item 1c asked for the percentile assert of the iteration-phase decoys to get teeth and
+to stay red if it fails; it runs last so that `pytest -x` has every other result on record before it stops here."""
 import numpy as np
 import pytest
 
@@ -18,7 +18,17 @@ def test_the_four_iteration_decoys_are_jointly_typical_draws():
     maps; the stage-2 decoys and the four initial decoys (percentiles 32 / 82 / 81 / 38, asserted in tests/test_gpu_cartesian.py) do not.
     Device and oracle agree on these maps to a KS distance of 0.04 (tests/test_gpu_outcome_vs_oracle.py), so this is the ENERGY MODEL's
     response to the feedback step's perturbation (realised bins of low-confidence pairs halved), not the kernels': what PyRosetta's centroid
-    and full-atom potentials do with those softened restraints is not in the reference tree ('parity unpinned')."""
+    and full-atom potentials do with those softened restraints is not in the reference tree ('parity unpinned').
+    ROUND 6, MEASURED (tests/diag/iteration_drift.py, profiles/r06_iteration_drift.txt; 1024 draws per map, 80-residue core): the reference's stage-1
+    decoy is displaced from the mean of its two initial decoys by 0.715 A (NMR) / 0.344 A (X-ray); the same statistic on draws of this build has a
+    median of 0.424 / 0.200 A -- the reference's sits at percentile 98 / 86.  The DIRECTION is this build's (cosine with the shift of the ensemble
+    mean +0.51 / +0.47, inside the null band 0.36..0.75 / 0.19..0.86) and along it the reference moved 1.5 / 1.4 times as far (null 5-95 %: 0.63..1.41);
+    what is left over is spread: one reference draw of the fed-back map scatters ~1.7 x as far about the common response as a draw of this build
+    (0.34 / 0.23 A about its ensemble mean).  Stage 2 is unremarkable on both maps (percentile 42 / 26).  So the finding is the UNDER-DISPERSION of this
+    build's ensembles (deviation list), sharpest on the first fed-back map -- not a wrong response.  Variants scanned on the fed-back
+    folds: restraint weights x 0.5 .. 2 leave the four percentiles at 81-90 / 67-81; the only variants that broaden the cloud enough are looser
+    tolerances (1e-5: 78 / 59 / 88 / 70, mean 74; 1e-4, the reference's own number: 71 / 33 / 68 / 57, mean 57) and they pay with the distance to the
+    reference's decoys (1.11 -> 1.25 A, 0.79 -> 0.88 A on the stage-1 maps) and with every initial-map figure (DESIGN deviation 1): not shipped."""
     try:
         import test_gpu_iteration_parity as IP
     except ImportError:
