@@ -214,7 +214,7 @@ static inline void trx2_rama_params(const char* seq, int i, int L, float* p) {
 /* omega_bb: E = OMEGA_K * (wrap(omega - 180 deg) in degrees)^2.
  * The reference's decoys carry ref2015_cart's per-residue energies (tests/golden/pose_energies.json): on their coordinates this
  * tether is 13 x Rosetta's omega column and the bonded term below 25 x its cart_bonded column.  Round-4 scans on 2 x 1024 decoys
- * per map (profiles/README.md; tools/runs_r01_r04.sh.txt section r04_model_scan*.sh): softer constants HERE (0.02 with 0.4 x the bonded stiffness) improve
+ * per map (profiles/README.md; profiles/history/runs_r01_r04.sh.txt section r04_model_scan*.sh): softer constants HERE (0.02 with 0.4 x the bonded stiffness) improve
  * the default protocol's outcome a little (X-ray decoys within 1 A 83 -> 88 %) but let --no-fastrelax decoys twist (peptides beyond
  * 60 degrees 11 -> 24 % on the X-ray map); applied in the relax stage alone -- whose weights are ref2015_cart's, the score function
  * the comparison is about -- they give most of the gain and leave the centroid stage's calibration alone.  So the constants stay

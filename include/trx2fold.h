@@ -87,7 +87,7 @@ int trx2_ctx_set_tail_compaction(trx2_ctx* ctx, int mode);
 /* Shared launches (process-wide; TRX2_ENGINE_STREAMS=1..3 sets the engines per device, default 2).  Default: on as soon as five
  * contexts are alive in the process (second lanes not counted) -- up to four chains fold 3-28 % faster launching for themselves, one
  * hardware queue each; from the fifth on the queues are shared and the engines win (6 / 8 / 12 folds in flight: 6.3 / 5.3 / 4.5 us per
- * fold-evaluation against 9.7 / 7.3 / 7.1; MI355X, L=150, tools/runs_r01_r04.sh.txt section r04_run23.sh).  TRX2_SHARED_LAUNCH=0 / 1 or mode 0 / 1 below force either.  A fold of ONE decoy -- every feedback iteration of run_inference.py:97-139 is one -- leaves the chip idle: a launch pair
+ * fold-evaluation against 9.7 / 7.3 / 7.1; MI355X, L=150, profiles/history/runs_r01_r04.sh.txt section r04_run23.sh).  TRX2_SHARED_LAUNCH=0 / 1 or mode 0 / 1 below force either.  A fold of ONE decoy -- every feedback iteration of run_inference.py:97-139 is one -- leaves the chip idle: a launch pair
  * of ~24 us on a few workgroups, thousands of them in sequence.  With shared launches such a fold does not launch for itself: it hands
  * its argument blocks (its own map's tables, row lists and row plan; its own state and buffers) to an engine thread of the library,
  * whose launch pairs step the single-decoy folds of ALL contexts that are folding at that moment (k_pair1_multi: blockIdx.z = fold,

@@ -54,7 +54,7 @@ def test_non_bundle_targets_evaluate_like_the_oracle_and_fold(kind, L):
         ctx.close()
 
 
-# measured on MI355X (tools/runs_r01_r04.sh.txt section r04_run19.sh): meander median 0.40 A, 32 of 32 within 2 A (worst 1.61); mixed 0.32 A, 32 of 32
+# measured on MI355X (profiles/history/runs_r01_r04.sh.txt section r04_run19.sh): meander median 0.40 A, 32 of 32 within 2 A (worst 1.61); mixed 0.32 A, 32 of 32
 # (worst 1.01); no mirror images (all four channels).  Limits = measured + margin.
 RMSD_MEDIAN_MAX = {"meander": 0.7, "mixed": 0.6}
 WITHIN_2A_MIN = {"meander": 0.9, "mixed": 0.9}

@@ -14,13 +14,13 @@ def sha(files):
     return h.hexdigest()[:16]
 rec = {"kernel_src_sha": {k: sha(v) for k, v in SOURCES.items()}, "records": []}
 for p1 in sorted(glob.glob(os.path.join(src, "c*_*_B*_pass1.json"))):
-    m = re.match(r"c(\d)_(pair|step)_B(\d+)_pass1\.json", os.path.basename(p1))
+    m = re.match(r"c(\w)_(pair|step)_B(\d+)_pass1\.json", os.path.basename(p1))
     ps = [p1.replace("pass1", f"pass{i}") for i in (1, 2, 3, 4)]
     if not m or not all(os.path.exists(q) and os.path.getsize(q) for q in ps):
         continue
     a, b, f, w = (json.load(open(q)) for q in ps)
     rec["records"].append({
-        "config": int(m.group(1)), "kernel_family": "k_" + m.group(2), "kernel": a["kernel"], "decoys_per_launch": int(m.group(3)),
+        "config": "e2e_single" if m.group(1) == "e" else int(m.group(1)), "kernel_family": "k_" + m.group(2), "kernel": a["kernel"], "decoys_per_launch": int(m.group(3)),
         "fetch_bytes_raw": f["FETCH_SIZE"] * 1024.0, "write_bytes": w["WRITE_SIZE"] * 1024.0,
         "hbm_bytes_per_launch": 2.0 * f["FETCH_SIZE"] * 1024.0 + w["WRITE_SIZE"] * 1024.0,
         "method": "rocprofv3 --pmc in separate runs of tools/pmc_kernel.py (tools/pmc_run.sh: two SQ groups, FETCH_SIZE, WRITE_SIZE; mean of the last "
@@ -28,7 +28,7 @@ for p1 in sorted(glob.glob(os.path.join(src, "c*_*_B*_pass1.json"))):
         "valu_insts_per_launch": a["SQ_INSTS_VALU"], "valu_active_quad_cycles": b["SQ_ACTIVE_INST_VALU"], "waves": a["SQ_WAVES"],
         "wave_quad_cycles": b["SQ_WAVE_CYCLES"], "wait_any_quad_cycles": b["SQ_WAIT_ANY"], "sq_busy_cycles_sum": a["SQ_BUSY_CYCLES"],
         "lds_insts_per_launch": a["SQ_INSTS_LDS"], "vmem_rd_insts_per_launch": a["SQ_INSTS_VMEM_RD"]})
-# the shared-launch shape: sixteen single-decoy folds in one engine's launches (tools/runs_r01_r04.sh.txt section r04_profiles.sh: shared16_{pair,step}_<group>.json
+# the shared-launch shape: sixteen single-decoy folds in one engine's launches (profiles/history/runs_r01_r04.sh.txt section r04_profiles.sh: shared16_{pair,step}_<group>.json
 # beside the pmc directory), keyed config "shared16"
 up = os.path.dirname(os.path.abspath(src))
 for fam, kern in (("pair", "k_pair1_multi"), ("step", "k_step_multi"), ("half", "k_half_multi")):   # half: the same folds in half-evaluation form (eight per role and launch)

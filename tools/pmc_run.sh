@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes over ONE kernel at ONE launch shape of a bench config (separate rocprofv3 --pmc runs, kernel trace only;
 # MI355X_MICROARCH.md, HBM section):
-#   usage: tools/pmc_run.sh <config 2|3|4> <decoys per launch> <pair|step> <out dir under gpurun_out/> [replays]
+#   usage: tools/pmc_run.sh <config 2|3|4|e (the metric's job: one decoy on a fed-back map)> <decoys per launch> <pair|step> <out dir under gpurun_out/> [replays]
 # tools/pmc_kernel.py drives the launches; tools/pmc_report.py averages the last <replays> dispatches of the kernel.
 # Results: $GRAFT_REPO_ROOT/gpurun_out/<out dir>/c<config>_<kernel>_B<decoys>_pass<i>.json (assembled by tools/make_traffic_json.py).
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -92,7 +92,7 @@ static std::map<int, std::vector<LaunchEngine*>> g_engines;   // per device; nev
 // of contexts alive in the process (second lanes not counted): up to four chains fold fastest launching for themselves, each on one
 // of the library's four streams (hardware queues); from the fifth on the streams are shared and the engines win.  Measured on
 // MI355X, L=150, all channels, microseconds per fold-evaluation with 1 / 2 / 3 / 4 / 6 / 8 / 12 folds in flight
-// (tools/runs_r01_r04.sh.txt section r04_run23.sh): own launches 25.3 / 13.2 / 9.3 / 6.9 / 9.7 / 7.3 / 7.1, engines 26.0 / 13.5 / 10.2 / 8.8 / 6.3 / 5.3 / 4.5.
+// (profiles/history/runs_r01_r04.sh.txt section r04_run23.sh): own launches 25.3 / 13.2 / 9.3 / 6.9 / 9.7 / 7.3 / 7.1, engines 26.0 / 13.5 / 10.2 / 8.8 / 6.3 / 5.3 / 4.5.
 #ifndef TRX2_ENGINE_MIN_CONTEXTS
 #define TRX2_ENGINE_MIN_CONTEXTS 5
 #endif
