@@ -54,7 +54,8 @@ MAX_SLOTS = 640  # decoy slots per lane of the pooled leg = every decoy of its q
                  # tools/pool_sweep.py, round 3: 1280 decoys on 2 x 192 / 320 / 640 slots -> 1121 / 1425 / 1675 decoys/s)
 POOLED_QUEUE = 1280  # decoys of the pooled_queue leg (fixed: the leg does not depend on --steps)
 LEG_QUEUE = 320      # decoys of the in_flight_B / single_stream legs
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_traffic.json")
+TRACE_FILE = os.path.join(ROOT, "profiles", "r06_kernel_trace.json")   # rocprofv3 --kernel-trace --stats averages of the same commands (tools/make_kernel_trace_json.py)
 KERNEL_SOURCES = {"k_pair": ("kernel_pair.h", "trx2_device.h"), "k_step": ("kernel_step.h", "trx2_device.h")}
 
 
@@ -170,6 +171,21 @@ def traffic_record(config, decoys_per_launch, kernel="k_pair"):
     return None
 
 
+def trace_avg_ms(tag, kernel_prefix):
+    """average duration (ms) of the first kernel whose name starts with `kernel_prefix` in the committed rocprofv3 kernel trace of command `tag`
+    (metric_job, c2, c3, c4, batch16); None when the kernel sources changed since the trace was taken"""
+    if not os.path.exists(TRACE_FILE):
+        return None
+    rec = json.load(open(TRACE_FILE))
+    src = "k_step" if kernel_prefix.startswith("k_step") else "k_pair"
+    if rec.get("kernel_src_sha", {}).get(src) != kernel_source_sha(src):
+        return None
+    for k in rec.get("traces", {}).get(tag, {}).get("kernels", []):
+        if k["kernel"].startswith(kernel_prefix):
+            return k["avg_us"] * 1e-3
+    return None
+
+
 def pair_roofline(ctx, T, tors, L, config, fold_times=None):
     """k_pair on the FINAL coordinates of the timed decoys at the launch shape of the timed calls: one evaluation batch of their
     final torsions lays the coordinates out for exactly that many slots (full layout, nothing left over from a compacted fold:
@@ -196,6 +212,10 @@ def pair_roofline(ctx, T, tors, L, config, fold_times=None):
            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": (rec or {}).get("method"),
            "avg_launch_ms": ms, "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": n_terms, "valu": valu,
            "binding_limit": "vector-ALU issue + dependent-load latency, not HBM bandwidth (DESIGN.md section 5)"}
+    rp = trace_avg_ms(f"c{config}", f"k_pair<{bw},") if B <= 64 else None
+    if rp:
+        out["rocprof_avg_launch_ms"] = rp
+        out["frac_rocprof"] = abytes / (rp * 1e-3) / 1e9 / HBM_PEAK_GBS
     if fold_times and fold_times[2]:
         out["avg_launch_ms_over_fold"] = fold_times[0]
         # the conservative reading: the same bytes over the fold's own average launch, which includes the narrower launches of the tail
@@ -316,15 +336,19 @@ def metric_job(args, T, synth, rank, local_rank, world, dist, forced, L=150, ini
                     "achieved": abytes / (pair_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": abytes / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "traffic": tr["hbm_bytes_per_launch"] if tr else None, "traffic_source": (tr or {}).get("method"),
                     "avg_launch_ms": pair_ms, "avg_launch_source": f"HIP events on the fold's own stream around every 4th live launch of {min(nmax, 16)} iteration folds per chain ({n} samples), untimed job of the same shape",
-                    "replay_launch_ms": float(np.mean([k["replay_pair_ms"] for k in ks])), "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": terms,
+                    "replay_launch_ms": float(np.mean([k["replay_pair_ms"] for k in ks])), "rocprof_avg_launch_ms": trace_avg_ms("metric_job", "k_pair_c<"),
+                    "algorithmic_bytes_per_launch": abytes, "selected_terms_per_decoy": terms,
                     "share_of_kernel_time": pair_ms / (pair_ms + step_ms),
                     "binding_limit": "one decoy per launch: a few hundred waves on 256 CUs for ~9 us; dependent-load latency, not HBM bandwidth (DESIGN.md section 5)"}
+            if roof["rocprof_avg_launch_ms"]:      # the kernel's own duration (profiles/r06_metric_job_kernel_stats.csv): an event pair around ONE 9-us launch also spans its dispatch gaps
+                roof["frac_rocprof"] = abytes / (roof["rocprof_avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
             sb = step_algorithmic_bytes(1, L, ks[0]["record_bytes"], ks[0]["history_pairs"])
             trs = traffic_record("e2e_single", 1, "k_step")
             roof_step = {"bound": "hbm", "kernel": "k_step<1,256,256> -- one decoy: one workgroup in the slot's current role (torsion or Cartesian); the job's DOMINANT kernel by time",
                          "achieved": sb / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sb / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "traffic": trs["hbm_bytes_per_launch"] if trs else None, "traffic_source": (trs or {}).get("method"),
-                         "avg_launch_ms": step_ms, "algorithmic_bytes_per_launch": sb, "samples": n, "share_of_kernel_time": step_ms / (pair_ms + step_ms),
+                         "avg_launch_ms": step_ms, "rocprof_avg_launch_ms": trace_avg_ms("metric_job", "k_step<1, 256, 256, false>"),
+                         "algorithmic_bytes_per_launch": sb, "samples": n, "share_of_kernel_time": step_ms / (pair_ms + step_ms),
                          "binding_limit": "latency of ~25 dependent phases on ONE workgroup (DESIGN.md section 4), not bandwidth"}
         evals = sum(v.get("iteration_evals", 0) for v in phases.values()) / max(n_iter, 1)
         return {
@@ -969,7 +993,8 @@ def pooled_all_channels(T, synth, local_rank, config=3, L=150):
 
 
 def compact_roofline(r):
-    return {q: r[q] for q in ("kernel", "achieved", "frac", "frac_over_fold", "unit", "avg_launch_ms", "avg_launch_ms_over_fold", "algorithmic_bytes_per_launch", "traffic") if q in r} if r else None
+    return {q: r[q] for q in ("kernel", "achieved", "frac", "frac_over_fold", "frac_rocprof", "unit", "avg_launch_ms", "avg_launch_ms_over_fold", "rocprof_avg_launch_ms",
+                              "algorithmic_bytes_per_launch", "traffic") if q in r} if r else None
 
 
 def compact(rec):
