@@ -80,3 +80,21 @@ def test_tools_never_import_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_a_stale_library_is_refused_on_load(tmp_path):
+    """ABI 2 made trx2_run.precheck a bit field; an ABI-1 library would read every warm run as a guarded one and loop to max_evals
+    without an error.  load() must refuse it with a message that says what to do."""
+    import subprocess
+    src = tmp_path / "old.c"
+    src.write_text("int trx2_abi_version(void) { return 1; }\n")
+    so = tmp_path / "libold.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-o", str(so), str(src)])
+    L = importlib.import_module("trrosettax2-dynamics_amd._lib")
+    keep = (L.LIB_PATH, L._lib)
+    try:
+        L.LIB_PATH, L._lib = str(so), None
+        with pytest.raises(RuntimeError, match="ABI version 1.*needs 2.*rebuild"):
+            L.load()
+    finally:
+        L.LIB_PATH, L._lib = keep

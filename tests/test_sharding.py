@@ -225,3 +225,31 @@ def test_batch_mode_without_a_store_splits_statically(tmp_path):
     assert sorted(took[0] + took[1]) == sorted(names) and not set(took[0]) & set(took[1]), took
     assert took[0] and took[1] and all(o["failed"] == 0 for o in out)
     assert out[0]["decoys"] == 5 * len(took[0]) and out[1]["decoys"] == 5 * len(took[1])
+
+
+def test_static_split_never_cuts_a_target_in_two(tmp_path):
+    """the static-split fallback used sched.lpt_assign's default, which cuts a target into two decoy blocks when there are fewer targets
+    than ranks or no iterations (Nmax = 0) -- run_single folds a whole target, so both ranks folded the same one and raced on its files.  One target,
+    two ranks, Nmax = 0: exactly one rank runs it; and with several workers allowed a rank's private share is not divided by the world again."""
+    P = importlib.import_module("trrosettax2-dynamics_amd.pipeline")
+    with open(tmp_path / "t0.fasta", "w") as f:
+        f.write(">t0\n" + "A" * 80 + "\n")
+    took = {0: [], 1: []}
+
+    def fake_run_single(name, fasta_file, save_dir, device=0, **kw):
+        took[device].append(name)
+        return 20
+
+    out = [P.run_batch(["t0"], str(tmp_path), str(tmp_path), rank=r, world=2, dist=None, store=None, device=r, run=fake_run_single, init_num=10, Nmax=0)
+           for r in range(2)]
+    assert sorted(took[0] + took[1]) == ["t0"], took
+    assert sum(o["decoys"] for o in out) == 20 and all(o["failed"] == 0 for o in out)
+    # six targets, two ranks, four workers allowed: every target once, each rank its own three
+    names = [f"u{k}" for k in range(6)]
+    for nm in names:
+        with open(tmp_path / f"{nm}.fasta", "w") as f:
+            f.write(f">{nm}\n" + "A" * 60 + "\n")
+    took = {0: [], 1: []}
+    out = [P.run_batch(names, str(tmp_path), str(tmp_path), rank=r, world=2, dist=None, store=None, device=r, run=fake_run_single, init_num=10, Nmax=0,
+                       targets_in_flight=4) for r in range(2)]
+    assert sorted(took[0] + took[1]) == names and len(took[0]) == 3 and len(took[1]) == 3, took
