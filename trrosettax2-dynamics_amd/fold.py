@@ -15,6 +15,7 @@ Differences from the reference, all deliberate:
      run_inference.py:295 never disables it); --no-fastrelax skips it (measured effect: DESIGN.md section 2)
 """
 import argparse
+import functools
 import os
 import shlex
 import threading
@@ -35,6 +36,17 @@ _CTX_OWNER = {}   # (device, thread ident) -> the Thread object that made the ca
 
 def parse_options(options):
     """the flags of folding/utils_ros/arguments.py:5-25 that can appear in an `options` string or on the CLI"""
+    if isinstance(options, str):      # run_inference's loop hands the same string to every one of its hundreds of folds: parsed once
+        return argparse.Namespace(**vars(_parse_options_cached(options)))
+    return _parse_options(options)
+
+
+@functools.lru_cache(maxsize=64)
+def _parse_options_cached(options):
+    return _parse_options(options)
+
+
+def _parse_options(options):
     ap = argparse.ArgumentParser(add_help=False)
     ap.add_argument("-pd", type=float, dest="pcut", default=0.05)
     ap.add_argument("-m", type=int, dest="mode", default=2, choices=[0, 1, 2, 3])
