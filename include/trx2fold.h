@@ -226,8 +226,8 @@ int trx2_time_pair_kernel(trx2_ctx* ctx, int B, const float* w, int sep_lo, int 
 
 /* measurement helpers (bench.py): with every > 0, every `every`-th evaluation of a fold on this ctx is bracketed by HIP events
  * on the ctx stream (before the pair kernel | between | after the step kernel); trx2_last_fold_kernel_times returns the
- * averages over the sampled evaluations of the last fold -- the live launch durations of both kernels over a whole fold,
- * not only on final coordinates.  Sampling inserts event records into the stream: use it in an untimed fold.
+ * averages over the sampled evaluations of the last fold (samples beyond four medians of their kernel -- a host stall between an event
+ * and the launch behind it -- dropped) -- the live launch durations of both kernels over a whole fold, not only on final coordinates.  Sampling inserts event records into the stream: use it in an untimed fold.
  * trx2_ctx_info: layout facts the roofline arithmetic needs (key TRX2_INFO_*), valid after a fold/eval on the ctx. */
 #define TRX2_INFO_GROUP_WIDTH 0 /* decoys per wave of the pair kernel */
 #define TRX2_INFO_SLAB_BYTES 1  /* bytes of pair-kernel records the step kernel sums per residue (average over residues) */

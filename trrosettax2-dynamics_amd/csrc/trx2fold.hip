@@ -186,6 +186,7 @@ struct trx2_ctx {
   int lds_total = 160 * 1024;      // LDS of a CU
   std::vector<hipEvent_t> prof_ev;
   double prof_pair_ms = 0, prof_step_ms = 0; int prof_n = 0;
+  std::vector<float> prof_a, prof_b;   // the samples themselves: the accessor drops those beyond four medians (a host stall between an event and its launch)
   // second lane (trx2_ctx_set_lanes): a context of its own stream and batch buffers that BORROWS this one's tables, so that
   // one job can run as two half-batches whose pair and step kernels overlap
   trx2_ctx* child = nullptr;
@@ -1192,7 +1193,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
   HIPCHK(hipMemsetAsync(ctx->seq_ctr, 0, sizeof(int), ctx->stream));
   const int pe = ctx->prof_every;
   int prof_used = 0;
-  ctx->prof_pair_ms = ctx->prof_step_ms = 0; ctx->prof_n = 0;
+  ctx->prof_pair_ms = ctx->prof_step_ms = 0; ctx->prof_n = 0; ctx->prof_a.clear(); ctx->prof_b.clear();
   if (pe > 0 && ctx->prof_ev.empty()) {
     ctx->prof_ev.resize(3 * (size_t)chunk);
     for (auto& e : ctx->prof_ev) HIPCHK(hipEventCreate(&e));
@@ -1317,7 +1318,7 @@ static int fold_impl(trx2_ctx* ctx, int N, const trx2_run* runs, int nruns, uint
       float a = 0, b = 0;
       if (hipEventElapsedTime(&a, ctx->prof_ev[3 * k], ctx->prof_ev[3 * k + 1]) == hipSuccess &&
           hipEventElapsedTime(&b, ctx->prof_ev[3 * k + 1], ctx->prof_ev[3 * k + 2]) == hipSuccess) {
-        ctx->prof_pair_ms += a; ctx->prof_step_ms += b; ctx->prof_n++;
+        ctx->prof_pair_ms += a; ctx->prof_step_ms += b; ctx->prof_n++; ctx->prof_a.push_back(a); ctx->prof_b.push_back(b);
       }
     }
     prof_used = 0;
@@ -1790,9 +1791,24 @@ extern "C" int trx2_ctx_set_profiling(trx2_ctx* ctx, int every) {
 }
 extern "C" int trx2_last_fold_kernel_times(trx2_ctx* ctx, double* pair_ms_avg, double* step_ms_avg, int* n_samples) {
   if (!ctx) return 1;
-  const int n = ctx->prof_n;
-  if (pair_ms_avg) *pair_ms_avg = n ? ctx->prof_pair_ms / n : 0.0;
-  if (step_ms_avg) *step_ms_avg = n ? ctx->prof_step_ms / n : 0.0;
+  // An event pair spans whatever happens between its two records: when the host thread is descheduled between recording an event and
+  // launching the kernel behind it while the stream has run dry, the sample holds the stall (seen: one 15-ms sample in a fold of 300,
+  // which tripled the average).  Samples beyond four medians of their kernel are dropped; n_samples counts the kept ones.
+  auto robust = [](const std::vector<float>& v, const std::vector<float>& w, double& ma, double& mb) -> int {
+    if (v.empty()) { ma = mb = 0.0; return 0; }
+    std::vector<float> sa(v), sb(w);
+    std::nth_element(sa.begin(), sa.begin() + sa.size() / 2, sa.end());
+    std::nth_element(sb.begin(), sb.begin() + sb.size() / 2, sb.end());
+    const float la = 4.0f * sa[sa.size() / 2], lb = 4.0f * sb[sb.size() / 2];
+    double a = 0, b = 0; int n = 0;
+    for (size_t i = 0; i < v.size(); i++) if (v[i] <= la && w[i] <= lb) { a += v[i]; b += w[i]; n++; }
+    ma = n ? a / n : 0.0; mb = n ? b / n : 0.0;
+    return n;
+  };
+  double ma, mb;
+  const int n = robust(ctx->prof_a, ctx->prof_b, ma, mb);
+  if (pair_ms_avg) *pair_ms_avg = ma;
+  if (step_ms_avg) *step_ms_avg = mb;
   if (n_samples) *n_samples = n;
   return 0;
 }
